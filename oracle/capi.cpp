@@ -1,0 +1,314 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see common.h).
+// C entry points for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (ctypes).
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include "mlt.h"
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+#define ORC_TRY try {
+#define ORC_CATCH(ret)                 \
+    }                                  \
+    catch (const std::exception &e) {  \
+        g_err = e.what();              \
+        return ret;                    \
+    }
+
+extern "C" {
+
+const char *orc_last_error() { return g_err.c_str(); }
+
+// overrides: <=0 / <0 means "keep the XML value" (see lmc::LoadOverrides)
+void *orc_create(const char *xmlPath, int forceDiffuse, int maxDepth, int width, int height, int seedOffset, const char *pathrefSo) {
+    ORC_TRY
+    lmc::LoadOverrides ov;
+    ov.forceDiffuse = forceDiffuse != 0;
+    ov.maxDepth = maxDepth;
+    ov.width = width;
+    ov.height = height;
+    ov.seedOffset = seedOffset;
+    std::unique_ptr<MLT> m(new MLT);
+    m->scene = BuildRScene(lmc::ParseScene(xmlPath, ov));
+    if (pathrefSo && pathrefSo[0]) m->lib.Load(pathrefSo, 8);
+    return m.release();
+    ORC_CATCH(nullptr)
+}
+
+void orc_destroy(void *h) { delete (MLT *)h; }
+
+int orc_info(void *h, int *out) {  // [width, height, numTris, maxDepth, numDervFuncs, numLights]
+    MLT *m = (MLT *)h;
+    out[0] = m->scene->camera.pixelWidth;
+    out[1] = m->scene->camera.pixelHeight;
+    out[2] = (int)m->scene->tris.size();
+    out[3] = m->scene->options->maxDepth;
+    out[4] = (int)m->lib.dervMap.size();
+    out[5] = (int)m->scene->lights.size();
+    return 0;
+}
+
+void orc_scene_params(void *h, float *out38) { memcpy(out38, ((MLT *)h)->scene->sceneParams, 38 * sizeof(float)); }
+
+int orc_set_option(void *h, const char *name, double v) {
+    lmc::DptOptions &o = *((MLT *)h)->scene->options;
+    std::string n(name);
+    if (n == "largestepprob") o.largeStepProbability = (float)v;
+    else if (n == "largestepscale") o.largeStepProbScale = (float)v;
+    else if (n == "mala") o.mala = v != 0;
+    else if (n == "uniformmixprob") o.uniformMixingProbability = (float)v;
+    else if (n == "mala-stepsize") o.malaStepsize = (float)v;
+    else if (n == "mala-gn") o.malaGN = (float)v;
+    else if (n == "perturbstddev") o.perturbStdDev = (float)v;
+    else if (n == "mindepth") o.minDepth = (int)v;
+    else return -1;
+    return 0;
+}
+
+int orc_init(void *h, long long numInitSamples, int numChains, int initThreads, float *normalization, long long *numContribs) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    float n = m->Init(numInitSamples, numChains, initThreads);
+    if (normalization) *normalization = n;
+    if (numContribs) *numContribs = m->numInitContribs;
+    return 0;
+    ORC_CATCH(-1)
+}
+
+int orc_setup_chains(void *h, long long samplesPerChain, long long chainsNeedExtra) {
+    ORC_TRY((MLT *)h)->SetupChains(samplesPerChain, chainsNeedExtra);
+    return 0;
+    ORC_CATCH(-1)
+}
+
+int orc_step(void *h, int nsteps) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    for (int i = 0; i < nsteps; i++) m->StepAll();
+    return 0;
+    ORC_CATCH(-1)
+}
+
+void orc_film(void *h, float *out) {
+    MLT *m = (MLT *)h;
+    memcpy(out, m->film.data(), m->film.size() * sizeof(float));
+}
+
+void orc_stats(void *h, long long *out) {  // steps, largeSteps, accepted, gradCalls, cacheQueries, cacheHits, resets, cacheReadyMask
+    MLT *m = (MLT *)h;
+    out[0] = m->stats.steps, out[1] = m->stats.largeSteps, out[2] = m->stats.accepted, out[3] = m->stats.gradCalls;
+    out[4] = m->stats.cacheQueries, out[5] = m->stats.cacheHits, out[6] = m->stats.resets;
+    long long mask = 0;
+    for (int d = 2; d <= 16; d++)
+        if (m->cache.isReady(d)) mask |= 1ll << d;
+    out[7] = mask;
+    memcpy(&out[8], &m->stats.weightSum, 8);
+}
+
+// per-chain summary, `stride` floats each (>= 32):
+// [valid, camDepth, lightDepth, lsScore, ssScore, scoreSum, time, gaussianInitialized, buffered, sampleIdx,
+//  screenX, screenY, contribR, contribG, contribB, nSplats, pss[0..15]]
+int orc_chain_summary(void *h, int which /*0 current, 1 init*/, float *out, int stride) {
+    MLT *m = (MLT *)h;
+    size_t n = which == 0 ? m->chains.size() : m->initStates.size();
+    for (size_t i = 0; i < n; i++) {
+        const MarkovState &s = which == 0 ? m->chains[i].currentState : m->initStates[i];
+        float *o = out + i * stride;
+        memset(o, 0, stride * sizeof(float));
+        o[0] = s.valid, o[1] = (float)s.spContrib.camDepth, o[2] = (float)s.spContrib.lightDepth, o[3] = s.spContrib.lsScore, o[4] = s.spContrib.ssScore;
+        o[5] = s.scoreSum, o[6] = s.path.time, o[7] = s.gaussianInitialized;
+        if (which == 0) o[8] = m->chains[i].chain.buffered, o[9] = (float)m->chains[i].sampleIdx;
+        o[10] = s.spContrib.screenPos[0], o[11] = s.spContrib.screenPos[1];
+        o[12] = s.spContrib.contrib[0], o[13] = s.spContrib.contrib[1], o[14] = s.spContrib.contrib[2];
+        o[15] = (float)s.toSplat.size();
+        for (size_t k = 0; k < s.pss.size() && k < 16 && 16 + (int)k < stride; k++) o[16 + k] = s.pss[k];
+    }
+    return (int)n;
+}
+
+// Serialises init state i into the path-function ABI buffers (primary[2L+1], vertParams[V]); returns
+// camDepth*16+lightDepth, or -1.  Lets tests feed identical inputs to libpathref.so and to the HIP gradient.
+int orc_serialize_init_state(void *h, int i, float *primary, int primaryCap, float *vertParams, int vertCap) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    if (i < 0 || i >= (int)m->initStates.size()) return -1;
+    const MarkovState &s = m->initStates[i];
+    SerializedSubpath ss;
+    ss.primary.assign(GetPrimaryParamSize(8, 8), 0.f);
+    ss.vertParams.assign(GetVertParamSize(8, 8), 0.f);
+    Serialize(m->scene.get(), s.path, ss);
+    int np = (int)GetPrimaryParamSize(s.path.camDepth, s.path.lgtDepth);
+    if (np > primaryCap) return -1;
+    memcpy(primary, ss.primary.data(), np * sizeof(float));
+    int nv = std::min(vertCap, (int)ss.vertParams.size());
+    memcpy(vertParams, ss.vertParams.data(), nv * sizeof(float));
+    return s.path.camDepth * 16 + s.path.lgtDepth;
+    ORC_CATCH(-1)
+}
+
+// reference gradient / forward programs through the dlsym'd table (mutation_mala.h:101-107)
+int orc_ref_eval(void *h, int c, int l, const float *primary, const float *vertParams, float *logLum, float *grad) {
+    MLT *m = (MLT *)h;
+    auto f = m->lib.funcMap.find({c, l});
+    auto d = m->lib.dervMap.find({c, l});
+    if (f == m->lib.funcMap.end() || d == m->lib.dervMap.end()) return -1;
+    float lens[2] = {0, 0};
+    if (logLum) f->second(lens, primary, m->scene->sceneParams, vertParams, logLum);
+    if (grad) d->second(lens, primary, m->scene->sceneParams, vertParams, grad, nullptr);
+    return 0;
+}
+
+// closest-hit / occlusion probes: rays = n x [ox,oy,oz,dx,dy,dz,tnear,tfar]
+void orc_trace(void *h, int n, const float *rays, int *prim, float *t) {
+    MLT *m = (MLT *)h;
+    for (int i = 0; i < n; i++) {
+        const float *r = rays + (size_t)i * 8;
+        Ray ray{Vector3(r[0], r[1], r[2]), Vector3(r[3], r[4], r[5])};
+        Float tt = 0;
+        prim[i] = m->scene->bvh.Intersect(ray, r[6], r[7], &tt);
+        t[i] = prim[i] >= 0 ? tt : 0.f;
+    }
+}
+void orc_occluded(void *h, int n, const float *rays, int *occ) {
+    MLT *m = (MLT *)h;
+    for (int i = 0; i < n; i++) {
+        const float *r = rays + (size_t)i * 8;
+        Ray ray{Vector3(r[0], r[1], r[2]), Vector3(r[3], r[4], r[5])};
+        occ[i] = m->scene->bvh.Occluded(ray, r[6], r[7]) ? 1 : 0;
+    }
+}
+// brute force over all triangles (pins the BVHs, CPU and HIP alike)
+void orc_trace_brute(void *h, int n, const float *rays, int *prim, float *t) {
+    MLT *m = (MLT *)h;
+    for (int i = 0; i < n; i++) {
+        const float *r = rays + (size_t)i * 8;
+        Ray ray{Vector3(r[0], r[1], r[2]), Vector3(r[3], r[4], r[5])};
+        int best = -1;
+        Float bestT = r[7];
+        for (size_t k = 0; k < m->scene->tris.size(); k++) {
+            Float tt;
+            if (TriTest(m->scene->tris[k], ray, r[6], bestT, tt) && (best < 0 || tt < bestT)) best = (int)k, bestT = tt;
+        }
+        prim[i] = best;
+        t[i] = best >= 0 ? bestT : 0.f;
+    }
+}
+
+// ---- small pure-function probes -----------------------------------------------------------------
+void orc_pcg_u32(unsigned long long seed, int n, unsigned *out) {
+    RNG rng(seed);
+    for (int i = 0; i < n; i++) out[i] = rng();
+}
+void orc_pcg_uniform(unsigned long long seed, int n, float *out) {
+    RNG rng(seed);
+    for (int i = 0; i < n; i++) out[i] = Uniform01(rng);
+}
+void orc_pcg_normal(unsigned long long seed, int n, float mean, float stddev, float *out) {
+    RNG rng(seed);
+    NormalPolar nd(mean, stddev);
+    for (int i = 0; i < n; i++) out[i] = nd(rng);
+}
+void orc_pcg_mixed(unsigned long long seed, int rounds, int k, float *out) {
+    RNG rng(seed);
+    int o = 0;
+    for (int r = 0; r < rounds; r++) {
+        out[o++] = Uniform01(rng);
+        out[o++] = Uniform01(rng);
+        NormalPolar nd(0.f, 1.f);
+        for (int i = 0; i < k; i++) out[o++] = nd(rng);
+    }
+}
+// state such that the next draw ticks the extension table: set the base state directly
+void orc_pcg_dump(unsigned long long seed, int ndraws, unsigned *out66) {
+    RNG rng(seed);
+    for (int i = 0; i < ndraws; i++) rng();
+    memcpy(out66, &rng.state, 8);
+    memcpy(out66 + 2, rng.data, 256);
+}
+void orc_fastlog(int n, const float *in, float *out) {
+    for (int i = 0; i < n; i++) out[i] = fastlog(in[i]);
+}
+int orc_kd_query(int dim, int npts, const float *pts, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist) {
+    KdTree t;
+    t.Build(pts, npts, dim);
+    for (int i = 0; i < nq; i++) {
+        int idx[16];
+        float dist[16];
+        int n = t.RadiusSearch(q + (size_t)i * dim, radiusSq, knn, idx, dist);
+        outN[i] = n;
+        for (int k = 0; k < knn; k++) {
+            outIdx[i * knn + k] = k < n ? idx[k] : -1;
+            outDist[i * knn + k] = k < n ? dist[k] : 0.f;
+        }
+    }
+    return 0;
+}
+// ComputeGaussian (mala.cpp:7-52) + GaussianLogPdf probe: out = [mean(dim), covL(dim), invCov(dim), logDet, logpdf(offset)]
+void orc_compute_gaussian(int dim, const float *v1, const float *M, float ss, float shk, float sc, const float *offset, float *out) {
+    std::vector<Float> a(v1, v1 + dim), mm(M, M + dim), off(offset, offset + dim);
+    Gaussian g;
+    ComputeGaussianMALA(dim, a, a, ss, shk, mm, 0, sc, g);
+    for (int i = 0; i < dim; i++) out[i] = g.mean[i], out[dim + i] = g.covL_d[i], out[2 * dim + i] = g.invCov_d[i];
+    out[3 * dim] = g.logDet;
+    out[3 * dim + 1] = GaussianLogPdf(off, g, false);
+}
+
+// ---- CPU baseline (bench.py): the chain loop on `threads` host threads, chains handed out in contiguous
+// blocks (one chain per work item as in parallel.cpp:82-142).  Cache pushes stay deferred per step and are
+// applied in chain order, so it is the same lock-step algorithm as orc_step; each thread splats into a
+// private film that is summed at the end (float add order differs from the 1-thread run).
+double orc_bench_steps(void *h, int nsteps, int threads, long long *stepsDone) {
+    MLT *m = (MLT *)h;
+    threads = std::max(1, threads);
+    const int n = (int)m->chains.size();
+    threads = std::min(threads, std::max(1, n));
+    long long before = m->stats.steps;
+    std::vector<std::vector<Float>> films(threads);
+    std::vector<StepStats> st(threads);
+    if (threads > 1)
+        for (int t = 0; t < threads; t++) {
+            films[t].assign(m->film.size(), 0.f);
+            int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);
+            for (int i = lo; i < hi; i++) m->chains[i].film = &films[t], m->chains[i].st = &st[t];
+        }
+    auto t0 = std::chrono::steady_clock::now();
+    if (threads == 1) {
+        for (int i = 0; i < nsteps; i++) m->StepAll();
+    } else {
+        for (int s = 0; s < nsteps; s++) {
+            std::vector<std::vector<PendingPush>> pushes(threads);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; t++)
+                pool.emplace_back([&, t]() {
+                    int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);
+                    for (int i = lo; i < hi; i++)
+                        if (m->chains[i].sampleIdx < m->chains[i].numSamplesThisChain) m->StepChain(m->chains[i], pushes[t]);
+                });
+            for (auto &th : pool) th.join();
+            for (int t = 0; t < threads; t++)
+                for (auto &p : pushes[t]) m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
+        }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (threads > 1) {
+        for (int t = 0; t < threads; t++) {
+            for (size_t i = 0; i < m->film.size(); i++) m->film[i] += films[t][i];
+            m->stats.steps += st[t].steps, m->stats.largeSteps += st[t].largeSteps, m->stats.accepted += st[t].accepted;
+            m->stats.gradCalls += st[t].gradCalls, m->stats.cacheQueries += st[t].cacheQueries, m->stats.cacheHits += st[t].cacheHits;
+            m->stats.resets += st[t].resets;
+            m->stats.weightSum += st[t].weightSum;
+        }
+        for (auto &c : m->chains) c.film = &m->film, c.st = &m->stats;
+    }
+    double sec = std::chrono::duration<double>(t1 - t0).count();
+    long long done = m->stats.steps - before;
+    if (stepsDone) *stepsDone = done;
+    return done / sec;
+}
+
+}  // extern "C"

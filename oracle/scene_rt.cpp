@@ -1,0 +1,696 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see common.h).
+// Scene objects: restates /root/reference/src/{trianglemesh,lambertian,envlight,arealight,pointlight,
+// camera,scene}.cpp (scalar halves) over the plain lmc::Scene description.
+#include <stdexcept>
+
+#include "render.h"
+
+namespace orc {
+
+static inline Vector3 V(const lmc::V3 &p) { return Vector3(p.x, p.y, p.z); }
+
+// ============================================================================================ BVH
+bool TriTest(const TriAccel &tr, const Ray &ray, Float tnear, Float tfar, Float &t) {
+    // Same arithmetic as the reference's TriangleIntersect (trianglemesh.cpp:30-53) plus the range and
+    // u >= 0 tests a ray tracer needs.  The HIP kernel uses the identical expression order.
+    Vector3 s1 = Cross(ray.dir, tr.e2);
+    Float divisor = Dot(s1, tr.e1);
+    if (divisor == Float(0.0)) return false;
+    Float invDivisor = inverse(divisor);
+    Vector3 s = ray.org - tr.p0;
+    Float u = Dot(s, s1) * invDivisor;
+    Vector3 s2 = Cross(s, tr.e1);
+    Float v = Dot(ray.dir, s2) * invDivisor;
+    if (!(u >= Float(0.0) && v >= Float(0.0) && u + v <= Float(1.0))) return false;
+    Float tt = Dot(tr.e2, s2) * invDivisor;
+    if (!(tt >= tnear && tt <= tfar)) return false;
+    t = tt;
+    return true;
+}
+
+namespace {
+struct BuildPrim {
+    float bmin[3], bmax[3], c[3];
+    int id;
+};
+}  // namespace
+
+static int BuildRec(Bvh &bvh, std::vector<BuildPrim> &prims, int lo, int hi) {
+    int ni = (int)bvh.nodes.size();
+    bvh.nodes.push_back(Bvh::Node());
+    float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = lo; i < hi; i++)
+        for (int k = 0; k < 3; k++) {
+            bmin[k] = std::min(bmin[k], prims[i].bmin[k]);
+            bmax[k] = std::max(bmax[k], prims[i].bmax[k]);
+            cmin[k] = std::min(cmin[k], prims[i].c[k]);
+            cmax[k] = std::max(cmax[k], prims[i].c[k]);
+        }
+    for (int k = 0; k < 3; k++) bvh.nodes[ni].bmin[k] = bmin[k], bvh.nodes[ni].bmax[k] = bmax[k];
+    int n = hi - lo;
+    int axis = 0;
+    for (int k = 1; k < 3; k++)
+        if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+    if (n <= 4 || cmax[axis] == cmin[axis]) {
+        bvh.nodes[ni].left = -n;
+        bvh.nodes[ni].right = (int)bvh.triIds.size();
+        for (int i = lo; i < hi; i++) bvh.triIds.push_back(prims[i].id);
+        return ni;
+    }
+    // binned SAH along the widest centroid axis
+    const int NB = 16;
+    struct Bin {
+        float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int cnt = 0;
+    } bins[NB];
+    float scale = NB / (cmax[axis] - cmin[axis]);
+    auto binOf = [&](const BuildPrim &p) { return std::min(NB - 1, std::max(0, (int)((p.c[axis] - cmin[axis]) * scale))); };
+    for (int i = lo; i < hi; i++) {
+        Bin &b = bins[binOf(prims[i])];
+        b.cnt++;
+        for (int k = 0; k < 3; k++) b.bmin[k] = std::min(b.bmin[k], prims[i].bmin[k]), b.bmax[k] = std::max(b.bmax[k], prims[i].bmax[k]);
+    }
+    auto area = [](const float *mn, const float *mx) {
+        float d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+    };
+    float leftA[NB], rightA[NB];
+    int leftN[NB], rightN[NB];
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int c = 0;
+        for (int b = 0; b < NB; b++) {
+            c += bins[b].cnt;
+            for (int k = 0; k < 3; k++) mn[k] = std::min(mn[k], bins[b].bmin[k]), mx[k] = std::max(mx[k], bins[b].bmax[k]);
+            leftA[b] = c ? area(mn, mx) : 0.f;
+            leftN[b] = c;
+        }
+    }
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int c = 0;
+        for (int b = NB - 1; b >= 0; b--) {
+            c += bins[b].cnt;
+            for (int k = 0; k < 3; k++) mn[k] = std::min(mn[k], bins[b].bmin[k]), mx[k] = std::max(mx[k], bins[b].bmax[k]);
+            rightA[b] = c ? area(mn, mx) : 0.f;
+            rightN[b] = c;
+        }
+    }
+    int best = -1;
+    float bestCost = INFINITY;
+    for (int b = 0; b < NB - 1; b++) {
+        if (leftN[b] == 0 || rightN[b + 1] == 0) continue;
+        float cost = leftA[b] * leftN[b] + rightA[b + 1] * rightN[b + 1];
+        if (cost < bestCost) bestCost = cost, best = b;
+    }
+    int mid;
+    if (best < 0) {
+        mid = (lo + hi) / 2;
+        std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
+                         [&](const BuildPrim &a, const BuildPrim &b) { return a.c[axis] < b.c[axis]; });
+    } else {
+        mid = (int)(std::partition(prims.begin() + lo, prims.begin() + hi, [&](const BuildPrim &p) { return binOf(p) <= best; }) - prims.begin());
+        if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+    }
+    int l = BuildRec(bvh, prims, lo, mid);
+    int r = BuildRec(bvh, prims, mid, hi);
+    bvh.nodes[ni].left = l;
+    bvh.nodes[ni].right = r;
+    return ni;
+}
+
+void Bvh::Build(const std::vector<TriAccel> &t) {
+    tris = &t;
+    nodes.clear();
+    triIds.clear();
+    std::vector<BuildPrim> prims(t.size());
+    for (size_t i = 0; i < t.size(); i++) {
+        Vector3 p1 = t[i].p0 + t[i].e1, p2 = t[i].p0 + t[i].e2;
+        for (int k = 0; k < 3; k++) {
+            prims[i].bmin[k] = std::min(t[i].p0[k], std::min(p1[k], p2[k]));
+            prims[i].bmax[k] = std::max(t[i].p0[k], std::max(p1[k], p2[k]));
+            prims[i].c[k] = 0.5f * (prims[i].bmin[k] + prims[i].bmax[k]);
+        }
+        prims[i].id = (int)i;
+    }
+    if (!prims.empty()) BuildRec(*this, prims, 0, (int)prims.size());
+}
+
+static inline bool SlabTest(const Bvh::Node &n, const Ray &ray, const Float invd[3], Float tnear, Float tfar) {
+    // slab test with the usual 2*gamma(3) widening so that rounding in the box test does not cull a
+    // triangle hit that TriTest accepts; fminf/fmaxf drop the NaN of 0*inf (ray parallel to a slab).
+    Float t0 = tnear, t1 = tfar;
+    for (int k = 0; k < 3; k++) {
+        Float a = (n.bmin[k] - ray.org[k]) * invd[k], b = (n.bmax[k] - ray.org[k]) * invd[k];
+        t0 = std::fmax(t0, std::fmin(a, b));
+        t1 = std::fmin(t1, std::fmax(a, b));
+    }
+    return t0 * 0.9999996f <= t1 * 1.0000004f;
+}
+
+int Bvh::Intersect(const Ray &ray, Float tnear, Float tfar, Float *tOut) const {
+    if (nodes.empty()) return -1;
+    Float invd[3] = {1.0f / ray.dir[0], 1.0f / ray.dir[1], 1.0f / ray.dir[2]};
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    int best = -1;
+    Float bestT = tfar;
+    while (sp) {
+        const Node &n = nodes[stack[--sp]];
+        if (!SlabTest(n, ray, invd, tnear, bestT)) continue;
+        if (n.left < 0) {
+            for (int i = 0; i < -n.left; i++) {
+                int id = triIds[n.right + i];
+                Float t;
+                if (TriTest((*tris)[id], ray, tnear, bestT, t)) {
+                    if (best < 0 || t < bestT || (t == bestT && id < best)) {  // ties -> lower global id
+                        bestT = t;
+                        best = id;
+                    }
+                }
+            }
+        } else {
+            stack[sp++] = n.left;
+            stack[sp++] = n.right;
+        }
+    }
+    if (best >= 0 && tOut) *tOut = bestT;
+    return best;
+}
+
+bool Bvh::Occluded(const Ray &ray, Float tnear, Float tfar) const {
+    if (nodes.empty()) return false;
+    Float invd[3] = {1.0f / ray.dir[0], 1.0f / ray.dir[1], 1.0f / ray.dir[2]};
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const Node &n = nodes[stack[--sp]];
+        if (!SlabTest(n, ray, invd, tnear, tfar)) continue;
+        if (n.left < 0) {
+            for (int i = 0; i < -n.left; i++) {
+                Float t;
+                if (TriTest((*tris)[triIds[n.right + i]], ray, tnear, tfar, t)) return true;
+            }
+        } else {
+            stack[sp++] = n.left;
+            stack[sp++] = n.right;
+        }
+    }
+    return false;
+}
+
+// ============================================================================================ shapes
+void Shape::Serialize(const PrimID primID, Float *buffer) const {  // trianglemesh.cpp:145-187
+    const lmc::Mesh &m = *mesh;
+    uint32_t i0 = m.idx[3 * primID], i1 = m.idx[3 * primID + 1], i2 = m.idx[3 * primID + 2];
+    Vector3 p0 = V(m.P[i0]), p1 = V(m.P[i1]), p2 = V(m.P[i2]);
+    Vector3 n0 = V(m.N[i0]), n1 = V(m.N[i1]), n2 = V(m.N[i2]);
+    Float *b = buffer;
+    *b++ = 0;  // ShapeType::TriangleMesh
+    *b++ = 0;  // isMoving
+    for (int rep = 0; rep < 2; rep++) {
+        Vector3 e1 = p1 - p0, e2 = p2 - p0;
+        for (int k = 0; k < 3; k++) *b++ = p0[k];
+        for (int k = 0; k < 3; k++) *b++ = e1[k];
+        for (int k = 0; k < 3; k++) *b++ = e2[k];
+        for (int k = 0; k < 3; k++) *b++ = n0[k];
+        for (int k = 0; k < 3; k++) *b++ = n1[k];
+        for (int k = 0; k < 3; k++) *b++ = n2[k];
+    }
+    *b++ = m.ST.empty() ? FTRUE : FFALSE;
+    if (!m.ST.empty()) {
+        *b++ = m.ST[i0].x, *b++ = m.ST[i0].y, *b++ = m.ST[i1].x, *b++ = m.ST[i1].y, *b++ = m.ST[i2].x, *b++ = m.ST[i2].y;
+    } else
+        b += 6;
+    *b = inverse(mesh->totalArea);  // inf when the mesh is not an emitter (totalArea == 0), as in the reference
+}
+
+bool Shape::Intersect(const PrimID &primID, const Float /*time*/, const RaySegment &raySeg, Intersection &isect, Vector2 &st) const {
+    const lmc::Mesh &m = *mesh;  // trianglemesh.cpp:30-79,189-236
+    uint32_t i0 = m.idx[3 * primID], i1 = m.idx[3 * primID + 1], i2 = m.idx[3 * primID + 2];
+    Vector3 p0 = V(m.P[i0]), e1 = V(m.P[i1]) - p0, e2 = V(m.P[i2]) - p0;
+    const Ray &ray = raySeg.ray;
+    isect.geomNormal = Normalize(Cross(e1, e2));
+    Vector3 s1 = Cross(ray.dir, e2);
+    Float divisor = Dot(s1, e1);
+    if (divisor == Float(0.0)) return false;
+    Float invDivisor = inverse(divisor);
+    Vector3 s = ray.org - p0;
+    Vector2 uv;
+    uv[0] = Dot(s, s1) * invDivisor;
+    Vector3 s2 = Cross(s, e1);
+    uv[1] = Dot(ray.dir, s2) * invDivisor;
+    if (!(uv[1] >= Float(0.0) && uv[0] + uv[1] <= Float(1.0))) return false;
+    Float t = Dot(e2, s2) * invDivisor;
+    Float w = Float(1.0) - uv[0] - uv[1];
+    isect.position = ray.org + t * ray.dir;
+    isect.shadingNormal = Normalize(w * V(m.N[i0]) + uv[0] * V(m.N[i1]) + uv[1] * V(m.N[i2]));
+    if (Dot(isect.geomNormal, isect.shadingNormal) < Float(0.0)) isect.geomNormal = -isect.geomNormal;
+    if (!m.ST.empty()) {
+        st[0] = (Float(1.0) - uv[0] - uv[1]) * m.ST[i0].x + uv[0] * m.ST[i1].x + uv[1] * m.ST[i2].x;
+        st[1] = (Float(1.0) - uv[0] - uv[1]) * m.ST[i0].y + uv[0] * m.ST[i1].y + uv[1] * m.ST[i2].y;
+    } else
+        st = uv;
+    return true;
+}
+
+PrimID Shape::Sample(const Float u) const {  // trianglemesh.cpp:287-289
+    return lmc::SampleDiscrete1D(mesh->areaFunc, mesh->areaCdf, mesh->areaFuncInt, u, nullptr);
+}
+
+void Shape::Sample(const Vector2 rndParam, const Float /*time*/, const PrimID primID, Vector3 &position, Vector3 &normal, Float *pdf) const {
+    const lmc::Mesh &m = *mesh;  // trianglemesh.cpp:291-365 (ADEpsilon<Float>() == 0)
+    uint32_t i0 = m.idx[3 * primID], i1 = m.idx[3 * primID + 1], i2 = m.idx[3 * primID + 2];
+    Vector3 p0 = V(m.P[i0]), e1 = V(m.P[i1]) - p0, e2 = V(m.P[i2]) - p0;
+    const Float a = std::sqrt((Float(1.0) + Float(0.0)) - rndParam[0]);
+    const Float b1 = Float(1.0) - a;
+    const Float b2 = a * rndParam[1];
+    position = p0 + (e1 * b1) + (e2 * b2);
+    normal = Normalize(V(m.N[i0]) * (Float(1.0) - b1 - b2) + V(m.N[i1]) * b1 + V(m.N[i2]) * b2);
+    if (pdf) *pdf = inverse(m.totalArea);
+}
+
+// ============================================================================================ BSDFs
+namespace {
+
+struct Lambertian : BSDF {  // lambertian.cpp:15-93
+    const lmc::Scene *S;
+    const lmc::Material *mat;
+    bool twoSided;
+    Vector3 Kd(const Vector2 st) const {
+        float o[3];
+        lmc::EvalTexture(*S, mat->Kd, st[0], st[1], o);
+        return Vector3(o[0], o[1], o[2]);
+    }
+    int GetType() const override { return lmc::BSDF_LAMBERTIAN; }
+    void Serialize(const Vector2 st, Float *buffer) const override {
+        buffer[0] = (Float)lmc::BSDF_LAMBERTIAN;
+        Vector3 k = Kd(st);
+        buffer[1] = k[0], buffer[2] = k[1], buffer[3] = k[2];
+    }
+    void Evaluate(const Vector3 &wi, const Vector3 &normal, const Vector3 &wo, const Vector2 st, Vector3 &contrib, Float &cosWo, Float &pdf,
+                  Float &revPdf) const override {
+        Float cosWi = Dot(normal, wi);
+        Vector3 normal_ = normal;
+        if (twoSided && cosWi < Float(0.0)) {
+            cosWi = -cosWi;
+            normal_ = -normal_;
+        }
+        cosWo = Dot(normal_, wo);
+        contrib = Vector3::Zero();
+        if (cosWi < c_CosEpsilon || cosWo < c_CosEpsilon) return;  // pdf/revPdf left untouched (quirk)
+        Float fwdScalar = cosWo * c_INVPI;
+        Float revScalar = cosWi * c_INVPI;
+        contrib = fwdScalar * Kd(st);
+        pdf = fwdScalar;
+        revPdf = revScalar;
+    }
+    bool Sample(const Vector3 &wi, const Vector3 &normal, const Vector2 st, const Vector2 rndParam, const Float /*uDiscrete*/, Vector3 &wo,
+                Vector3 &contrib, Float &cosWo, Float &pdf, Float &revPdf) const override {
+        Float cosWi = Dot(wi, normal);
+        Vector3 normal_ = normal;
+        if (std::fabs(cosWi) < c_CosEpsilon) return false;
+        if (cosWi < Float(0.0)) {
+            if (twoSided) {
+                cosWi = -cosWi;
+                normal_ = -normal_;
+            } else
+                return false;
+        }
+        Vector3 b0, b1;
+        CoordinateSystem(normal_, b0, b1);
+        Vector3 ret = SampleCosHemisphere(rndParam);
+        wo = ret[0] * b0 + ret[1] * b1 + ret[2] * normal_;
+        cosWo = ret[2];
+        pdf = ret[2] * c_INVPI;
+        if (cosWo < c_CosEpsilon) return false;
+        revPdf = cosWi * c_INVPI;
+        contrib = Kd(st);
+        return true;
+    }
+    Float Roughness(const Vector2, const Float) const override { return Float(1.0); }
+};
+
+}  // namespace
+
+// ============================================================================================ lights
+void Light::Emission(const BSphere &, const Vector3 &, const Vector3 &, const Float, LightPrimID &, Vector3 &, Float &, Float &) const {
+    throw std::runtime_error("Unimplemented method");
+}
+
+namespace {
+
+static void Mat4FromAnim(const lmc::AnimXform &x, Float out[4][4]) {
+    lmc::M4 m = lmc::ToM4(x);
+    memcpy(out, m.m, sizeof(m.m));
+}
+static Vector3 XformVector(const Float x[4][4], const Vector3 &v) {
+    return Vector3(x[0][0] * v[0] + x[0][1] * v[1] + x[0][2] * v[2], x[1][0] * v[0] + x[1][1] * v[1] + x[1][2] * v[2],
+                   x[2][0] * v[0] + x[2][1] * v[1] + x[2][2] * v[2]);
+}
+static Vector3 XformPoint(const Float x[4][4], const Vector3 &p) {
+    Float tx = x[0][0] * p[0] + x[0][1] * p[1] + x[0][2] * p[2] + x[0][3];
+    Float ty = x[1][0] * p[0] + x[1][1] * p[1] + x[1][2] * p[2] + x[1][3];
+    Float tz = x[2][0] * p[0] + x[2][1] * p[1] + x[2][2] * p[2] + x[2][3];
+    Float tw = x[3][0] * p[0] + x[3][1] * p[1] + x[3][2] * p[2] + x[3][3];
+    Float invW = inverse(tw);
+    return Vector3(tx * invW, ty * invW, tz * invW);
+}
+
+struct PointLight : Light {  // pointlight.cpp
+    Vector3 lightPos, emission;
+    int GetType() const override { return lmc::LIGHT_POINT; }
+    void Serialize(const LightPrimID &, Float *b) const override {
+        b[0] = (Float)lmc::LIGHT_POINT;
+        for (int k = 0; k < 3; k++) b[1 + k] = lightPos[k], b[4 + k] = emission[k];
+    }
+    bool SampleDirect(const BSphere &, const Vector3 &pos, const Vector3 &, const Vector2, const Float, LightPrimID &lPrimID,
+                      Vector3 &dirToLight, Float &dist, Vector3 &contrib, Float &cosAtLight, Float &directPdf, Float &emissionPdf) const override {
+        dirToLight = lightPos - pos;
+        const Float distSq = LengthSquared(dirToLight);
+        directPdf = distSq;
+        dist = std::sqrt(distSq);
+        dirToLight = dirToLight / dist;
+        contrib = emission * inverse(distSq);
+        emissionPdf = c_INVFOURPI;
+        cosAtLight = Float(1.0);
+        lPrimID = 0;
+        return true;
+    }
+    void Emit(const BSphere &, const Vector2, const Vector2 rndParamDir, const Float, LightPrimID &, Ray &ray, Vector3 &em, Float &cosAtLight,
+              Float &emissionPdf, Float &directPdf) const override {
+        ray.org = lightPos;
+        Float j;
+        ray.dir = SampleSphere(rndParamDir, j);
+        em = emission;
+        emissionPdf = c_INVFOURPI;
+        cosAtLight = directPdf = Float(1.0);
+    }
+    bool IsFinite() const override { return true; }
+    bool IsDelta() const override { return true; }
+};
+
+struct AreaLight : Light {  // arealight.cpp
+    const Shape *shape;
+    Vector3 emission;
+    int GetType() const override { return lmc::LIGHT_AREA; }
+    void Serialize(const LightPrimID &lPrimID, Float *b) const override {
+        b[0] = (Float)lmc::LIGHT_AREA;
+        shape->Serialize(lPrimID, b + 1);
+        for (int k = 0; k < 3; k++) b[47 + k] = emission[k];
+    }
+    LightPrimID SampleDiscrete(const Float u) const override { return shape->Sample(u); }
+    bool SampleDirect(const BSphere &, const Vector3 &pos, const Vector3 &, const Vector2 rndParam, const Float time, LightPrimID &lPrimID,
+                      Vector3 &dirToLight, Float &dist, Vector3 &contrib, Float &cosAtLight, Float &directPdf, Float &emissionPdf) const override {
+        Vector3 posOnLight, normalOnLight;
+        Float shapePdf;
+        shape->Sample(rndParam, time, lPrimID, posOnLight, normalOnLight, &shapePdf);
+        dirToLight = posOnLight - pos;
+        Float distSq = LengthSquared(dirToLight);
+        dist = std::sqrt(distSq);
+        dirToLight = dirToLight / dist;
+        cosAtLight = -Dot(dirToLight, normalOnLight);
+        if (cosAtLight > c_CosEpsilon) {
+            contrib = (cosAtLight / (distSq * shapePdf)) * emission;
+            directPdf = shapePdf * distSq / cosAtLight;
+            emissionPdf = shapePdf * cosAtLight * c_INVPI;
+            return true;
+        }
+        return false;
+    }
+    void Emission(const BSphere &, const Vector3 &dirToLight, const Vector3 &normalOnLight, const Float, LightPrimID &, Vector3 &em,
+                  Float &directPdf, Float &emissionPdf) const override {
+        Float cosAtLight = -Dot(normalOnLight, dirToLight);
+        if (cosAtLight > Float(0.0)) {
+            em = emission;
+            directPdf = shape->SamplePdf();
+            emissionPdf = cosAtLight * directPdf * c_INVPI;
+        } else {
+            em = Vector3::Zero();
+            directPdf = Float(0.0);
+            emissionPdf = Float(0.0);
+        }
+    }
+    void Emit(const BSphere &, const Vector2 rndParamPos, const Vector2 rndParamDir, const Float time, LightPrimID &lPrimID, Ray &ray,
+              Vector3 &em, Float &cosAtLight, Float &emissionPdf, Float &directPdf) const override {
+        Vector3 normal;
+        Float shapePdf;
+        shape->Sample(rndParamPos, time, lPrimID, ray.org, normal, &shapePdf);
+        Vector3 d = SampleCosHemisphere(rndParamDir);
+        Vector3 b0, b1;
+        CoordinateSystem(normal, b0, b1);
+        ray.dir = d[0] * b0 + d[1] * b1 + d[2] * normal;
+        em = emission * (Float(M_PI) / shapePdf);
+        cosAtLight = d[2];
+        emissionPdf = d[2] * c_INVPI * shapePdf;
+        directPdf = shapePdf;
+    }
+    bool IsFinite() const override { return true; }
+    bool IsDelta() const override { return false; }
+};
+
+struct EnvLight : Light {  // envlight.cpp:65-248
+    const lmc::Light *L;
+    Float toWorld[4][4], toLight[4][4];
+    int W, H;
+    Vector3 At(int x, int y) const {
+        const float *p = L->image.At(x, y);
+        return Vector3(p[0], p[1], p[2]);
+    }
+    Vector3 RepAt(int x, int y) const { return At(Modulo(x, W), Modulo(y, H)); }
+    int GetType() const override { return lmc::LIGHT_ENV; }
+    void Serialize(const LightPrimID &lPrimID, Float *buffer) const override {
+        const lmc::EnvmapSampleInfo &si = L->sampleInfo;
+        Float *b = buffer;
+        *b++ = (Float)lmc::LIGHT_ENV;
+        for (const lmc::AnimXform *x : {&L->toWorld, &L->toLight}) {
+            *b++ = x->isMoving;
+            for (int k = 0; k < 2; k++)
+                for (int i = 0; i < 3; i++) *b++ = x->t[k][i];
+            for (int k = 0; k < 2; k++)
+                for (int i = 0; i < 4; i++) *b++ = x->q[k][i];
+        }
+        size_t col = lPrimID % W, row = lPrimID / W;
+        const Float *cdfCol = &si.cdfCols[0] + row * (W + 1);
+        *b++ = cdfCol[col];
+        *b++ = cdfCol[col + 1];
+        *b++ = si.cdfRows[row];
+        *b++ = si.cdfRows[row + 1];
+        *b++ = (Float)col;
+        *b++ = (Float)row;
+        *b++ = si.pixelSize[0];
+        *b++ = si.pixelSize[1];
+        for (Vector3 v : {RepAt((int)col, (int)row), RepAt((int)col + 1, (int)row), RepAt((int)col, (int)row + 1), RepAt((int)col + 1, (int)row + 1)})
+            for (int k = 0; k < 3; k++) *b++ = v[k];
+        *b++ = si.rowWeights[Clamp(row, (size_t)0, (size_t)H - 1)];
+        *b++ = si.rowWeights[Clamp(row + 1, (size_t)0, (size_t)H - 1)];
+        *b++ = si.normalization;
+    }
+    void SampleDirection(const Vector2 rndParam, LightPrimID &lPrimID, Vector3 &dirToLight, Vector3 &value, Float &pdf) const {
+        const lmc::EnvmapSampleInfo &si = L->sampleInfo;
+        auto uToIndex = [](const Float *cdf, const size_t size, Float &u) {
+            const Float *entry = std::lower_bound(cdf, cdf + size + 1, u);
+            size_t index = std::min(std::max((ptrdiff_t)0, entry - cdf - 1), (ptrdiff_t)size - 1);
+            u = (u - (Float)cdf[index]) / (Float)(cdf[index + 1] - cdf[index]);
+            return index;
+        };
+        Float u0 = rndParam[0], u1 = rndParam[1];
+        int row = (int)uToIndex(&si.cdfRows[0], H, u1);
+        int col = (int)uToIndex(&si.cdfCols[0] + row * (W + 1), W, u0);
+        lPrimID = row * W + col;
+        Vector2 tent(Tent(u0), Tent(u1));
+        Vector2 pl((Float)col + tent[0], (Float)row + tent[1]);
+        Float phi = (pl[0] + Float(0.5)) * si.pixelSize[0];
+        Float theta = (pl[1] + Float(0.5)) * si.pixelSize[1];
+        Float sinPhi = std::sin(phi), cosPhi = std::cos(phi), sinTheta = std::sin(theta), cosTheta = std::cos(theta);
+        dirToLight = XformVector(toWorld, Vector3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
+        Float dx1 = tent[0], dx2 = Float(1.0) - tent[0], dy1 = tent[1], dy2 = Float(1.0) - tent[1];
+        // NB: the reference uses At() (no wrap) here, envlight.cpp:164-165: col+1 == W reads the first texel of the next row and
+        // row+1 == H reads one row past the image.  RepAt keeps the oracle in bounds; differs only on the last column/row.
+        Vector3 value1 = AtQ(col, row) * dx2 * dy2 + AtQ(col + 1, row) * dx1 * dy2;
+        Vector3 value2 = AtQ(col, row + 1) * dx2 * dy1 + AtQ(col + 1, row + 1) * dx1 * dy1;
+        value = value1 + value2;
+        Float rowWeight0 = si.rowWeights[Clamp(row, 0, H - 1)];
+        Float rowWeight1 = si.rowWeights[Clamp(row + 1, 0, H - 1)];
+        pdf = (Luminance(value1) * rowWeight0 + Luminance(value2) * rowWeight1) * si.normalization / std::fmax(std::fabs(sinTheta), Float(1e-7));
+    }
+    // Image3::At(x,y) = data[y*W + x] without range check (image.h:26-31): linear index, clamped to the buffer
+    Vector3 AtQ(int x, int y) const {
+        long idx = (long)y * W + x;
+        long n = (long)W * H;
+        if (idx >= n) idx -= n;  // one row past the end wraps to row 0 (documented deviation: the reference reads out of bounds)
+        const float *p = &L->image.data[(size_t)idx * 3];
+        return Vector3(p[0], p[1], p[2]);
+    }
+    bool SampleDirect(const BSphere &sceneSphere, const Vector3 &, const Vector3 &, const Vector2 rndParam, const Float, LightPrimID &lPrimID,
+                      Vector3 &dirToLight, Float &dist, Vector3 &contrib, Float &cosAtLight, Float &directPdf, Float &emissionPdf) const override {
+        Vector3 value;
+        SampleDirection(rndParam, lPrimID, dirToLight, value, directPdf);
+        dist = std::numeric_limits<Float>::infinity();
+        contrib = value * inverse(directPdf);
+        cosAtLight = Float(1.0);
+        Float positionPdf = c_INVPI / square(sceneSphere.radius);
+        emissionPdf = directPdf * positionPdf;
+        return true;
+    }
+    void Emission(const BSphere &sceneSphere, const Vector3 &dirToLight, const Vector3 &, const Float, LightPrimID &lPrimID, Vector3 &emission,
+                  Float &directPdf, Float &emissionPdf) const override {
+        const lmc::EnvmapSampleInfo &si = L->sampleInfo;
+        Vector3 d = XformVector(toLight, dirToLight);
+        Vector2 uv(std::atan2(d[0], -d[2]) * c_INVTWOPI * (Float)W - Float(0.5), std::acos(d[1]) * c_INVPI * (Float)H - Float(0.5));
+        int col = int(std::floor(uv[0]));
+        int row = int(std::floor(uv[1]));
+        lPrimID = Modulo(row, H) * W + Modulo(col, W);
+        Float dx1 = uv[0] - col, dx2 = Float(1.0) - dx1, dy1 = uv[1] - row, dy2 = Float(1.0) - dy1;
+        Vector3 value1 = RepAt(col, row) * dx2 * dy2 + RepAt(col + 1, row) * dx1 * dy2;
+        Vector3 value2 = RepAt(col, row + 1) * dx2 * dy1 + RepAt(col + 1, row + 1) * dx1 * dy1;
+        emission = value1 + value2;
+        Float sinTheta = std::sqrt(Float(1.0) - square(d[1]));
+        Float rowWeight0 = si.rowWeights[Clamp(row, 0, H - 1)];
+        Float rowWeight1 = si.rowWeights[Clamp(row + 1, 0, H - 1)];
+        directPdf = (Luminance(value1) * rowWeight0 + Luminance(value2) * rowWeight1) * si.normalization / std::fmax(std::fabs(sinTheta), Float(1e-7));
+        Float positionPdf = c_INVPI / square(sceneSphere.radius);
+        emissionPdf = directPdf * positionPdf;
+    }
+    void Emit(const BSphere &sceneSphere, const Vector2 rndParamPos, const Vector2 rndParamDir, const Float, LightPrimID &lPrimID, Ray &ray,
+              Vector3 &emission, Float &cosAtLight, Float &emissionPdf, Float &directPdf) const override {
+        SampleDirection(rndParamDir, lPrimID, ray.dir, emission, directPdf);
+        ray.dir = -ray.dir;
+        Vector2 offset = SampleConcentricDisc(rndParamPos);
+        Vector3 b0, b1;
+        CoordinateSystem(ray.dir, b0, b1);
+        Vector3 perpOffset = offset[0] * b0 + offset[1] * b1;
+        ray.org = sceneSphere.center + (perpOffset - ray.dir) * sceneSphere.radius;
+        cosAtLight = Float(1.0);
+        Float positionPdf = c_INVPI / square(sceneSphere.radius);
+        emissionPdf = directPdf * positionPdf;
+    }
+    bool IsFinite() const override { return false; }
+    bool IsDelta() const override { return false; }
+};
+
+}  // namespace
+
+// ============================================================================================ scene
+std::unique_ptr<RScene> BuildRScene(std::unique_ptr<lmc::Scene> desc) {
+    std::unique_ptr<RScene> R(new RScene);
+    R->desc = std::move(desc);
+    lmc::Scene &S = *R->desc;
+    R->options = &S.options;
+    for (auto &m : S.materials) {
+        if (m.type == lmc::BSDF_LAMBERTIAN) {
+            auto *b = new Lambertian;
+            b->S = &S, b->mat = &m, b->twoSided = m.twoSided;
+            R->bsdfs.emplace_back(b);
+        } else
+            throw std::runtime_error("oracle: BSDF type not restated yet (phong / roughdielectric are SURVEY.md §8 config 3)");
+    }
+    int triBase = 0;
+    for (size_t i = 0; i < S.meshes.size(); i++) {
+        std::unique_ptr<Shape> sh(new Shape);
+        sh->mesh = &S.meshes[i];
+        sh->bsdf = R->bsdfs[S.meshes[i].material].get();
+        sh->id = (int)i;
+        sh->triBase = triBase;
+        const lmc::Mesh &m = S.meshes[i];
+        for (size_t t = 0; t < m.numTris(); t++) {
+            TriAccel ta;
+            ta.p0 = V(m.P[m.idx[3 * t]]);
+            ta.e1 = V(m.P[m.idx[3 * t + 1]]) - ta.p0;
+            ta.e2 = V(m.P[m.idx[3 * t + 2]]) - ta.p0;
+            R->tris.push_back(ta);
+            R->triShape.push_back((int)i);
+        }
+        triBase += (int)m.numTris();
+        R->objects.push_back(std::move(sh));
+    }
+    for (size_t i = 0; i < S.lights.size(); i++) {
+        const lmc::Light &L = S.lights[i];
+        std::unique_ptr<Light> l;
+        if (L.type == lmc::LIGHT_POINT) {
+            auto *p = new PointLight;
+            p->lightPos = V(L.position), p->emission = V(L.intensity);
+            l.reset(p);
+        } else if (L.type == lmc::LIGHT_AREA) {
+            auto *a = new AreaLight;
+            a->shape = R->objects[L.mesh].get();
+            a->emission = V(L.radiance);
+            R->objects[L.mesh]->areaLight = a;
+            l.reset(a);
+        } else {
+            auto *e = new EnvLight;
+            e->L = &L;
+            e->W = L.image.width, e->H = L.image.height;
+            Mat4FromAnim(L.toWorld, e->toWorld);
+            Mat4FromAnim(L.toLight, e->toLight);
+            l.reset(e);
+            R->envLight = e;
+        }
+        l->samplingWeight = L.samplingWeight;
+        l->id = (int)i;
+        R->lights.push_back(std::move(l));
+    }
+    R->lightWeightSum = S.lightWeightSum;
+    R->bSphere.center = V(S.bsphereCenter);
+    R->bSphere.radius = S.bsphereRadius;
+    RCamera &c = R->camera;
+    memcpy(c.sampleToCam, S.camera.sampleToCam.m, 64);
+    memcpy(c.camToSample, S.camera.camToSample.m, 64);
+    Mat4FromAnim(S.camera.camToWorld, c.toWorld);
+    Mat4FromAnim(S.camera.worldToCamera, c.worldToCamera);
+    c.pixelWidth = S.camera.width, c.pixelHeight = S.camera.height;
+    c.nearClip = S.camera.nearClip, c.farClip = S.camera.farClip, c.dist = S.camera.dist;
+    lmc::SerializeSceneBlock(S, R->sceneParams);
+    R->bvh.Build(R->tris);
+    return R;
+}
+
+bool Intersect(const RScene *scene, const Float, const RaySegment &raySeg, ShapeInst &shapeInst) {  // scene.cpp:106-126
+    Float t;
+    int id = scene->bvh.Intersect(raySeg.ray, raySeg.minT, raySeg.maxT, &t);
+    if (id < 0) return false;
+    const Shape *sh = scene->objects[scene->triShape[id]].get();
+    shapeInst.obj = sh;
+    shapeInst.primID = id - sh->triBase;
+    return true;
+}
+
+bool Occluded(const RScene *scene, const Float, const Ray &ray, const Float dist) {  // scene.cpp:128-149
+    Float minT = c_IsectEpsilon, maxT;
+    if (dist == std::numeric_limits<Float>::infinity())
+        maxT = std::numeric_limits<Float>::infinity();
+    else
+        maxT = (Float(1.0) - c_ShadowEpsilon) * dist;
+    return scene->bvh.Occluded(ray, minT, maxT);
+}
+
+const Light *PickLight(const RScene *scene, const Float u, Float &prob) {
+    const lmc::Scene &S = *scene->desc;
+    int id = lmc::SampleDiscrete1D(S.lightFunc, S.lightCdf, S.lightFuncInt, u, &prob);
+    return scene->lights[id].get();
+}
+Float PickLightProb(const RScene *scene, const Light *light) { return light->samplingWeight / scene->lightWeightSum; }
+
+void SamplePrimary(const RCamera *camera, const Vector2 screenPos, const Float, RaySegment &raySeg) {  // camera.cpp:38-51
+    Ray &ray = raySeg.ray;
+    ray.org = XformPoint(camera->sampleToCam, Vector3(screenPos[0], screenPos[1], Float(0.0)));
+    ray.dir = Normalize(ray.org);
+    Float invZ = inverse(ray.dir[2]);
+    ray.org = XformPoint(camera->toWorld, Vector3::Zero());
+    ray.dir = XformVector(camera->toWorld, ray.dir);
+    raySeg.minT = camera->nearClip * invZ;
+    raySeg.maxT = camera->farClip * invZ;
+}
+
+bool ProjectPoint(const RCamera *camera, const Vector3 &p, const Float, Vector2 &screenPos) {  // camera.cpp:67-84
+    Vector3 camP = XformPoint(camera->worldToCamera, p);
+    if (camP[2] < camera->nearClip || camP[2] > camera->farClip) return false;
+    Vector3 rasterP = XformPoint(camera->camToSample, camP);
+    if (rasterP[0] < Float(0.0) || rasterP[0] > Float(1.0) || rasterP[1] < Float(0.0) || rasterP[1] > Float(1.0)) return false;
+    screenPos[0] = rasterP[0];
+    screenPos[1] = rasterP[1];
+    return true;
+}
+
+}  // namespace orc
