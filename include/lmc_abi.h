@@ -1,0 +1,102 @@
+/* lmc_abi.h -- C ABI of the MI355X (gfx950) back end for the Langevin-MCMC chain loop.
+ *
+ * Drop-in boundary.  Two groups of entry points, all `extern "C"`, plain pointers and sizes:
+ *
+ * (1) The reference's own in-process plugin ABI: the shared object it dlopen()s as
+ *     $DPT_LIBPATH/pathlibbidir_mala.so and resolves by name with dlsym
+ *     (/root/reference/src/chad.cpp:884-895,1000-1016; names path.cpp:3404-3417; loop path.cpp:4028-4057):
+ *         void evaluate_path_bidir_mala_<c>_<l>_static     (lens[2], primary[2L+1], scene[38], vertParams[V], logLum[1])
+ *         void evaluate_path_bidir_mala_<c>_<l>_static_derv(lens[2], primary[2L+1], scene[38], vertParams[V], grad[2L])
+ *     for 1<=c<=9, 0<=l<=8, 3<=c+l<=9 (L = c+l-1, V = 238+59(c+l-3)).  Caller type: PathFunc / PathFuncDerv
+ *     (/root/reference/src/path.h:121-125); the caller passes a 6th NULL `hess` argument in MALA mode
+ *     (mutation_mala.h:102-107), which these symbols ignore.  Each call launches the HIP kernel on one path;
+ *     lmc_grad_batch is the entry point meant for throughput.
+ *
+ * (2) The batched / resident interface that replaces the per-chain loop of MLT() (mlt.cpp:20-214): scene
+ *     load (ParseScene, parsescene.cpp:627-639), MLTInit (mlt.h:41-154), the chain loop (mlt.cpp:60-196),
+ *     film read-back (mlt.cpp:203-207).
+ *
+ * Error convention: functions returning int give 0 on success, a negative value on failure with the message
+ * available from lmc_last_error(); nothing throws across the boundary.  All functions fail (never fall back
+ * to a CPU path) when no HIP device is usable.
+ */
+#ifndef LMC_ABI_H
+#define LMC_ABI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lmc_ctx lmc_ctx;
+
+/* Scene description: the reference's command line + <dpt> overrides (main.cpp:49-64, parsescene.cpp:535-590).
+ * Integer fields <= 0 (seed_offset < 0) keep the value from the XML. */
+typedef struct lmc_scene_desc {
+    const char *scene_xml;  /* path of the Mitsuba-0.5-subset scene file, as given to `dpt` */
+    int force_diffuse;      /* BASELINE.json config 2: every BSDF becomes `diffuse` */
+    int max_depth;          /* <dpt maxdepth> override */
+    int width, height;      /* film size override */
+    int seed_offset;        /* --seedoffset (main.cpp:57-58) */
+    int device;             /* HIP device ordinal */
+    int use_gradient;       /* 1: evaluate d log f / d pss in-kernel (derivative library present);
+                               0: behave like a missing pathlibbidir_mala.so (isotropic proposals, path.cpp:4042-4053) */
+} lmc_scene_desc;
+
+const char *lmc_last_error(void);
+
+lmc_ctx *lmc_create(const lmc_scene_desc *desc);
+void lmc_destroy(lmc_ctx *ctx);
+
+/* [width, height, numTriangles, maxDepth, numBvhNodes, bvhDepth, numLights, mala] */
+int lmc_info(lmc_ctx *ctx, int *out8);
+/* the 38-float scene block of the plugin ABI (scene.cpp:160-169) */
+int lmc_scene_params(lmc_ctx *ctx, float *out38);
+/* <dpt> float options by XML name: largestepprob, largestepscale, mala, uniformmixprob, mala-stepsize, mala-gn,
+ * perturbstddev, mindepth (parsescene.cpp:538-585) */
+int lmc_set_option(lmc_ctx *ctx, const char *name, double value);
+
+/* MLTInit (mlt.h:41-154) + chain set-up (mlt.cpp:60-90).  `init_threads` plays NumSystemCores(): init stream t is
+ * seeded RNG(t + seedOffset) (mlt.h:67).  The chains [chain_begin, chain_end) of the n_chains_total chains live on
+ * this device (multi-GPU: one range per rank; seeds are global chain ids, mlt.cpp:61-62).
+ * samples_per_chain / chains_need_extra as computed at mlt.cpp:36-40. */
+int lmc_chains_init(lmc_ctx *ctx, long long num_init_samples, int n_chains_total, int init_threads, int chain_begin, int chain_end,
+                    long long samples_per_chain, long long chains_need_extra);
+/* normalization = avgScore (mlt.cpp:46-47), number of init contributions */
+int lmc_init_result(lmc_ctx *ctx, float *normalization, long long *num_contribs);
+/* advances every resident chain by n_steps mutations (the loop body mlt.cpp:91-170), lock step */
+int lmc_chains_step(lmc_ctx *ctx, int n_steps);
+/* blocks until all queued work is done */
+int lmc_sync(lmc_ctx *ctx);
+/* indirect film buffer, W*H*3 floats, un-normalised like indirectBuffer (mlt.cpp:54) */
+int lmc_film_read(lmc_ctx *ctx, float *rgb);
+int lmc_film_clear(lmc_ctx *ctx);
+/* out[0..7] = steps, largeSteps, accepted, gradCalls, cacheQueries, cacheHits, resets, cacheReadyMask; *weight_sum =
+ * sum over steps of the splatted weight (film luminance == normalization * weight_sum) */
+int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);
+/* per-chain summary, `stride` floats each (>= 32), same layout as the oracle's orc_chain_summary:
+ * [valid, camDepth, lightDepth, lsScore, ssScore, scoreSum, time, gaussianInitialized, buffered, sampleIdx,
+ *  screenX, screenY, contribR, contribG, contribB, nSplats, pss[0..15]]; which = 0 current, 1 init states */
+int lmc_chain_summary(lmc_ctx *ctx, int which, float *out, int stride);
+/* kernel time (ms, HIP events on the launch stream) and launch count of the chain-step kernel since the last call */
+int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);
+
+/* Batched path program: n evaluations of technique (c,l); SoA, word-major: primary_soa[(2L+1)*n],
+ * vert_soa[V*n], grad_soa[2L*n] (word w of item i at [w*n + i]); scene38 as lmc_scene_params.  Host pointers.
+ * loglum and grad_soa may each be NULL. */
+int lmc_grad_batch(int c, int l, int n, const float *primary_soa, const float *scene38, const float *vert_soa, float *loglum, float *grad_soa);
+
+/* ---- probes used by the parity tests (tests/) ---- */
+/* rays: n x [ox,oy,oz,dx,dy,dz,tnear,tfar]; closest hit -> global triangle id (or -1) and t */
+int lmc_trace(lmc_ctx *ctx, int n, const float *rays, int *prim, float *t);
+int lmc_occluded(lmc_ctx *ctx, int n, const float *rays, int *occluded);
+/* mode 0 raw u32, 1 uniform01 bits, 2 one normal_distribution object, 3 mixed (u,u,7 normals per round);
+ * out: n_seeds x (n + 66) words, the last 66 = RNG state after the draws [lo, hi, table 64] */
+int lmc_rng_probe(int n_seeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, unsigned *out);
+int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, float radius_sq, int knn, int *out_n, int *out_idx, float *out_dist);
+/* ComputeGaussian (mala.cpp:7-52) + GaussianLogPdf (gaussian.cpp:24-36): out n x (3*dim+2) */
+int lmc_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

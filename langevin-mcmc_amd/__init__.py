@@ -1,0 +1,194 @@
+"""ctypes binding of the MI355X back end (liblmc_hip.so, C ABI in include/lmc_abi.h).
+
+The package is plumbing around the C ABI: it loads the HIP library (and fails loudly if it is missing or if no GPU is
+usable); it never computes anything on the CPU.  Import with importlib.import_module("langevin-mcmc_amd")."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "liblmc_hip.so")
+vp = ctypes.c_void_p
+c_ll = ctypes.c_longlong
+
+
+class SceneDesc(ctypes.Structure):
+    _fields_ = [
+        ("scene_xml", ctypes.c_char_p),
+        ("force_diffuse", ctypes.c_int),
+        ("max_depth", ctypes.c_int),
+        ("width", ctypes.c_int),
+        ("height", ctypes.c_int),
+        ("seed_offset", ctypes.c_int),
+        ("device", ctypes.c_int),
+        ("use_gradient", ctypes.c_int),
+    ]
+
+
+def P(a):
+    return a.ctypes.data_as(vp)
+
+
+_lib = None
+
+
+def lib():
+    """The loaded HIP library; raises if it has not been built (run `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP extension missing: %s (build with `python __graft_entry__.py`); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.lmc_last_error.restype = ctypes.c_char_p
+        L.lmc_create.restype = vp
+        L.lmc_create.argtypes = [ctypes.POINTER(SceneDesc)]
+        L.lmc_destroy.argtypes = [vp]
+        L.lmc_info.argtypes = [vp, vp]
+        L.lmc_scene_params.argtypes = [vp, vp]
+        L.lmc_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
+        L.lmc_chains_init.argtypes = [vp, c_ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_ll, c_ll]
+        L.lmc_init_result.argtypes = [vp, vp, vp]
+        L.lmc_chains_step.argtypes = [vp, ctypes.c_int]
+        L.lmc_sync.argtypes = [vp]
+        L.lmc_film_read.argtypes = [vp, vp]
+        L.lmc_film_clear.argtypes = [vp]
+        L.lmc_stats.argtypes = [vp, vp, vp]
+        L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
+        L.lmc_step_timing.argtypes = [vp, vp, vp]
+        L.lmc_grad_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
+        L.lmc_trace.argtypes = [vp, ctypes.c_int, vp, vp, vp]
+        L.lmc_occluded.argtypes = [vp, ctypes.c_int, vp, vp]
+        L.lmc_rng_probe.argtypes = [ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
+        L.lmc_kd_probe.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp]
+        L.lmc_gauss_probe.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _err():
+    return lib().lmc_last_error().decode()
+
+
+class Renderer:
+    """One scene resident on one GPU; mirrors MLT() of the reference (mlt.cpp:20-214) step by step."""
+
+    def __init__(self, xml, force_diffuse=0, max_depth=0, width=0, height=0, seed_offset=-1, device=0, use_gradient=1):
+        L = lib()
+        self._xml = os.fsencode(xml)
+        d = SceneDesc(self._xml, force_diffuse, max_depth, width, height, seed_offset, device, use_gradient)
+        h = L.lmc_create(ctypes.byref(d))
+        if not h:
+            raise RuntimeError("lmc_create failed: " + _err())
+        self.h = vp(h)
+        info = (ctypes.c_int * 8)()
+        L.lmc_info(self.h, info)
+        (self.width, self.height, self.num_tris, self.max_depth, self.num_nodes, self.bvh_depth, self.num_lights, self.mala) = list(info)
+        self.num_chains = 0
+
+    def close(self):
+        if self.h:
+            lib().lmc_destroy(self.h)
+            self.h = None
+
+    def set_option(self, name, value):
+        if lib().lmc_set_option(self.h, name.encode(), float(value)) != 0:
+            raise RuntimeError(_err())
+
+    def scene_params(self):
+        s = np.zeros(38, np.float32)
+        lib().lmc_scene_params(self.h, P(s))
+        return s
+
+    def init_chains(self, num_init, n_chains_total, init_threads, per_chain, extra=0, chain_begin=0, chain_end=None):
+        if chain_end is None:
+            chain_end = n_chains_total
+        if lib().lmc_chains_init(self.h, num_init, n_chains_total, init_threads, chain_begin, chain_end, per_chain, extra) != 0:
+            raise RuntimeError("lmc_chains_init failed: " + _err())
+        self.num_chains = chain_end - chain_begin
+        self.num_chains_total = n_chains_total
+        n = ctypes.c_float()
+        nc = c_ll()
+        lib().lmc_init_result(self.h, ctypes.byref(n), ctypes.byref(nc))
+        self.normalization = n.value
+        return n.value, nc.value
+
+    def step(self, n):
+        if lib().lmc_chains_step(self.h, n) != 0:
+            raise RuntimeError("lmc_chains_step failed: " + _err())
+
+    def sync(self):
+        if lib().lmc_sync(self.h) != 0:
+            raise RuntimeError(_err())
+
+    def film(self):
+        f = np.zeros((self.height, self.width, 3), np.float32)
+        if lib().lmc_film_read(self.h, P(f)) != 0:
+            raise RuntimeError(_err())
+        return f
+
+    def stats(self):
+        s = (c_ll * 8)()
+        w = ctypes.c_double()
+        if lib().lmc_stats(self.h, s, ctypes.byref(w)) != 0:
+            raise RuntimeError(_err())
+        keys = ["steps", "largeSteps", "accepted", "gradCalls", "cacheQueries", "cacheHits", "resets", "cacheReadyMask"]
+        d = dict(zip(keys, list(s)))
+        d["weightSum"] = w.value
+        return d
+
+    def summary(self, which=0):
+        n = self.num_chains if which == 0 else self.num_chains_total
+        out = np.zeros((n, 32), np.float32)
+        if lib().lmc_chain_summary(self.h, which, P(out), 32) < 0:
+            raise RuntimeError(_err())
+        return out
+
+    def step_timing(self):
+        ms = ctypes.c_double()
+        n = c_ll()
+        if lib().lmc_step_timing(self.h, ctypes.byref(ms), ctypes.byref(n)) != 0:
+            raise RuntimeError(_err())
+        return ms.value, n.value
+
+    def trace(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = len(rays)
+        prim = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float32)
+        if lib().lmc_trace(self.h, n, P(rays), P(prim), P(t)) != 0:
+            raise RuntimeError(_err())
+        return prim, t
+
+    def occluded(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        occ = np.zeros(len(rays), np.int32)
+        if lib().lmc_occluded(self.h, len(rays), P(rays), P(occ)) != 0:
+            raise RuntimeError(_err())
+        return occ
+
+
+def grad_batch(c, l, primary_soa, scene38, vert_soa, want_grad=True):
+    """n evaluations of the (c,l) path program on the GPU; SoA word-major inputs (see include/lmc_abi.h)."""
+    primary_soa = np.ascontiguousarray(primary_soa, np.float32)
+    vert_soa = np.ascontiguousarray(vert_soa, np.float32)
+    scene38 = np.ascontiguousarray(scene38, np.float32)
+    n = primary_soa.shape[1]
+    L = max(c + l - 1, 2)
+    ll = np.zeros(n, np.float32)
+    g = np.zeros((2 * L, n), np.float32)
+    r = lib().lmc_grad_batch(c, l, n, P(primary_soa), P(scene38), P(vert_soa), P(ll), P(g) if want_grad else None)
+    if r != 0:
+        raise RuntimeError("lmc_grad_batch failed: " + _err())
+    return ll, g
+
+
+def smoke():
+    """One small invocation of the hot path on cuda:0, checked against the CPU oracle (test infrastructure)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from tests import gpu_checks
+
+    gpu_checks.smoke()

@@ -1,0 +1,290 @@
+// Per-chain Markov state in HBM (SoA: word w of chain i lives at base[w * N + i], so a wave touching the
+// same field of 64 consecutive chains reads one or two cache lines) and the device side of
+// /root/reference/src/{mlt.cpp:91-170, mutation_large.h:31-128, mutation_small.h:16-56,
+// mutation_mala.h:35-278, mala.cpp:7-52, gaussian.cpp:4-55, global_cache.h:96-124}.
+#pragma once
+#include "dpath.h"
+
+namespace lmcd {
+
+constexpr int GAUSS_WORDS = 3 * MAXPSS + 1;  // mean, covL_d, invCov_d, logDet
+constexpr int CONTRIB_WORDS = 9;
+constexpr int SPLAT_WORDS = 5;
+
+enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16 };
+enum : int { KIND_SMALL = 0, KIND_LARGE = 1 };
+
+// global_cache.h:8-14, mala.h:9-13, mutation.h:5-8
+constexpr int PSS_MIN_LENGTH = 2, PSS_MAX_LENGTH = 12, PSS_MAX_SIZE = 3000;
+constexpr float PSS_QUERY_DIST = 0.01f, PSS_REUSE_DIST = 0.10f;
+constexpr float PCD_MIN = 0.01f, PCD_MAX = 100.f, MTM_MIN = -5.0f, MTM_MAX = 5.0f, LS_RATIO = 0.1f;
+constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
+constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
+
+struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly like nanoflann's divideTree)
+    int child1, child2;  // -1,-1 => leaf
+    int left, right;     // leaf: [left,right) into vind
+    int divfeat;
+    float divlow, divhigh;
+    int pad;
+};
+struct DCacheDim {
+    int ready;
+    const KdNode *nodes;
+    const int *vind;
+    const float *pts, *v1, *v2;  // PSS_MAX_SIZE x dim, row-major
+    float rootLow[MAXPSS], rootHigh[MAXPSS];
+};
+struct DCache {
+    DCacheDim d[PSS_MAX_LENGTH + 1];
+};
+
+struct ChainArrays {
+    int N;
+    uint64_t *rngState;
+    uint32_t *rngTab;  // N x 64 (AoS)
+    float *curPath;    // DPATH_WORDS x N
+    float *curContrib; // CONTRIB_WORDS x N
+    float *scoreSum;   // N
+    int *flags;        // N
+    float *gaussian;   // GAUSS_WORDS x N
+    float *curSplat;   // MAXCONTRIB*SPLAT_WORDS x N
+    int *curSplatCount;
+    float *chV1, *chV2, *chCurrNewV2, *chPropNewV1, *chPropNewV2, *chPss, *chLastPss;  // MAXPSS x N each
+    float *pathWeight, *lastScoreSum, *lastScore;
+    int *adjacentReject, *sampleIdx, *numSamples;
+    float *contribList;  // MAXCONTRIB*CONTRIB_WORDS x N (GeneratePathBidir scratch)
+    int *pushDim;        // N: dim of a pending global-cache push (0 = none)
+    float *pushData;     // (3*MAXPSS+1) x N: pss, v1, v2, weight snapshot for the push
+    // init states (outlier reset, mlt.cpp:147-169)
+    float *initPath, *initContrib, *initScoreSum;
+    // per-launch counters: [0] steps, [1] large, [2] accepted, [3] gradCalls, [4] cacheQueries, [5] cacheHits, [6] resets
+    unsigned long long *counters;
+    double *weightSum;
+};
+
+LMC_D void LoadWords(const float *base, int N, int i, float *dst, int n) {
+    for (int w = 0; w < n; w++) dst[w] = base[(size_t)w * N + i];
+}
+LMC_D void StoreWords(float *base, int N, int i, const float *src, int n) {
+    for (int w = 0; w < n; w++) base[(size_t)w * N + i] = src[w];
+}
+LMC_D void LoadPath(const float *base, int N, int i, DPath &p) {
+    float *w = reinterpret_cast<float *>(&p);
+    // only the used vertices are moved: head + camCount / lgtCount vertices
+    for (int k = 0; k < DPATH_HEAD_WORDS; k++) w[k] = base[(size_t)k * N + i];
+    for (int v = 0; v < p.camCount; v++)
+        for (int k = 0; k < DVERTEX_WORDS; k++) {
+            int o = DPATH_HEAD_WORDS + v * DVERTEX_WORDS + k;
+            w[o] = base[(size_t)o * N + i];
+        }
+    for (int v = 0; v < p.lgtCount; v++)
+        for (int k = 0; k < DVERTEX_WORDS; k++) {
+            int o = DPATH_HEAD_WORDS + (MAXD + v) * DVERTEX_WORDS + k;
+            w[o] = base[(size_t)o * N + i];
+        }
+}
+LMC_D void StorePath(float *base, int N, int i, const DPath &p) {
+    const float *w = reinterpret_cast<const float *>(&p);
+    for (int k = 0; k < DPATH_HEAD_WORDS; k++) base[(size_t)k * N + i] = w[k];
+    for (int v = 0; v < p.camCount; v++)
+        for (int k = 0; k < DVERTEX_WORDS; k++) {
+            int o = DPATH_HEAD_WORDS + v * DVERTEX_WORDS + k;
+            base[(size_t)o * N + i] = w[o];
+        }
+    for (int v = 0; v < p.lgtCount; v++)
+        for (int k = 0; k < DVERTEX_WORDS; k++) {
+            int o = DPATH_HEAD_WORDS + (MAXD + v) * DVERTEX_WORDS + k;
+            base[(size_t)o * N + i] = w[o];
+        }
+}
+LMC_D Contrib LoadContrib(const float *base, int N, int i) {
+    Contrib c;
+    c.camDepth = __float_as_int(base[0 * (size_t)N + i]);
+    c.lightDepth = __float_as_int(base[1 * (size_t)N + i]);
+    c.screenPos = V2{base[2 * (size_t)N + i], base[3 * (size_t)N + i]};
+    c.contrib = V3{base[4 * (size_t)N + i], base[5 * (size_t)N + i], base[6 * (size_t)N + i]};
+    c.lsScore = base[7 * (size_t)N + i];
+    c.ssScore = base[8 * (size_t)N + i];
+    return c;
+}
+LMC_D void StoreContrib(float *base, int N, int i, const Contrib &c) {
+    base[0 * (size_t)N + i] = __int_as_float(c.camDepth);
+    base[1 * (size_t)N + i] = __int_as_float(c.lightDepth);
+    base[2 * (size_t)N + i] = c.screenPos.x;
+    base[3 * (size_t)N + i] = c.screenPos.y;
+    base[4 * (size_t)N + i] = c.contrib.x;
+    base[5 * (size_t)N + i] = c.contrib.y;
+    base[6 * (size_t)N + i] = c.contrib.z;
+    base[7 * (size_t)N + i] = c.lsScore;
+    base[8 * (size_t)N + i] = c.ssScore;
+}
+
+struct Film {
+    float *rgb;  // W*H*3
+    int W, H;
+};
+// image.h:66-77: nearest pixel, drop non-finite, float atomics (hardware global_atomic_add_f32)
+LMC_D void Splat(const Film &film, V2 screenPos, V3 contrib) {
+    int ix = Clampi((int)(screenPos.x * film.W), 0, film.W - 1);
+    int iy = Clampi((int)(screenPos.y * film.H), 0, film.H - 1);
+    if (AllFinite(contrib)) {
+        float *px = film.rgb + ((size_t)iy * film.W + ix) * 3;
+        unsafeAtomicAdd(px + 0, contrib.x);
+        unsafeAtomicAdd(px + 1, contrib.y);
+        unsafeAtomicAdd(px + 2, contrib.z);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Gaussian
+struct Gauss {
+    float mean[MAXPSS], covL[MAXPSS], invCov[MAXPSS];
+    float logDet;
+};
+LMC_D void IsotropicGaussian(int dim, float sigma, Gauss &g) {  // gaussian.cpp:4-22
+    for (int i = 0; i < dim; i++) g.mean[i] = 0.0f, g.covL[i] = sigma, g.invCov[i] = 1.0f / (sigma * sigma);
+    g.logDet = dim * fastlog(1.0f / (sigma * sigma));
+}
+LMC_D float GaussianLogPdf(int dim, const float *offset, bool negate, const Gauss &g) {  // gaussian.cpp:24-36, summed left to right
+    float logPdf = dim * (-0.9189385332046727f);
+    logPdf += 0.5f * g.logDet;
+    float q = 0.f;
+    for (int i = 0; i < dim; i++) {
+        float d = (negate ? -offset[i] : offset[i]) - g.mean[i];
+        q += d * (g.invCov[i] * d);
+    }
+    logPdf -= 0.5f * q;
+    return logPdf;
+}
+// mala.cpp:7-52
+LMC_D void ComputeGaussianMALA(int dim, const float *v1, float ss, float shk, const float *M, float sc, Gauss &g) {
+    g.logDet = 0.0f;
+    const float shrk = inverse(shk * shk);
+    if (sc <= 1e-10f) {
+        for (int i = 0; i < dim; i++) g.mean[i] = 0.0f, g.invCov[i] = shrk, g.covL[i] = shk;
+        g.logDet = dim * fastlog(inverse(shk * shk));
+    } else {
+        for (int i = 0; i < dim; i++) {
+            float cov_t = ss * ss * (M[i] + 1.0f);
+            float invcov = inverse(cov_t) + shrk;
+            float cov = inverse(invcov);
+            g.invCov[i] = invcov;
+            g.covL[i] = sqrtf(cov);
+            g.mean[i] = Clampf(v1[i], MTM_MIN, MTM_MAX) * cov / 2;
+            g.logDet += fastlog(invcov);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- cache query
+// nanoflann searchLevel (nanoflann.hpp:1359-1422) unrolled onto an explicit stack; the reference-modified
+// RadiusResultSet stops the whole search after `knn` matches (nanoflann.hpp:256-262).  Matches are NOT
+// sorted (SearchParams::sorted defaults to false in the reference's copy, nanoflann.hpp:567).
+LMC_D int KdRadiusSearch(const DCacheDim &C, int dim, const float *q, float radiusSq, int knn, int *idx, float *dist) {
+    float dists[MAXPSS];
+    float distsq = 0.f;
+    for (int i = 0; i < dim; i++) {
+        dists[i] = 0.f;
+        if (q[i] < C.rootLow[i]) {
+            dists[i] = (q[i] - C.rootLow[i]) * (q[i] - C.rootLow[i]);
+            distsq += dists[i];
+        }
+        if (q[i] > C.rootHigh[i]) {
+            dists[i] = (q[i] - C.rootHigh[i]) * (q[i] - C.rootHigh[i]);
+            distsq += dists[i];
+        }
+    }
+    struct Frame {
+        int node, other, idx;
+        float mindistsq, cutDist, dst;
+        int phase;
+    };
+    Frame st[32];
+    int sp = 0;
+    int count = 0;
+    st[sp++] = Frame{0, -1, 0, distsq, 0.f, 0.f, 0};
+    while (sp > 0) {
+        Frame &f = st[sp - 1];
+        const KdNode nd = C.nodes[f.node];
+        if (f.phase == 0) {
+            if (nd.child1 < 0 && nd.child2 < 0) {
+                for (int i = nd.left; i < nd.right; ++i) {
+                    const int index = C.vind[i];
+                    float d = 0.f;
+                    for (int k = 0; k < dim; ++k) {
+                        const float diff = q[k] - C.pts[(size_t)index * dim + k];
+                        d += diff * diff;
+                    }
+                    if (d < radiusSq) {
+                        idx[count] = index;
+                        dist[count] = d;
+                        count++;
+                        if (count >= knn) return count;
+                    }
+                }
+                sp--;
+                continue;
+            }
+            int id = nd.divfeat;
+            float val = q[id];
+            float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+            int bestChild, otherChild;
+            float cut_dist;
+            if ((diff1 + diff2) < 0) {
+                bestChild = nd.child1, otherChild = nd.child2;
+                cut_dist = (val - nd.divhigh) * (val - nd.divhigh);
+            } else {
+                bestChild = nd.child2, otherChild = nd.child1;
+                cut_dist = (val - nd.divlow) * (val - nd.divlow);
+            }
+            f.other = otherChild, f.idx = id, f.cutDist = cut_dist, f.phase = 1;
+            float m = f.mindistsq;
+            if (sp < 32) st[sp++] = Frame{bestChild, -1, 0, m, 0.f, 0.f, 0};
+            continue;
+        } else if (f.phase == 1) {
+            float dst = dists[f.idx];
+            float mindistsq = f.mindistsq + f.cutDist - dst;
+            f.dst = dst;
+            dists[f.idx] = f.cutDist;
+            f.phase = 2;
+            if (mindistsq * 1.0f <= radiusSq) {
+                int other = f.other;
+                if (sp < 32) st[sp++] = Frame{other, -1, 0, mindistsq, 0.f, 0.f, 0};
+                continue;
+            }
+        }
+        // phase 2: restore and return
+        dists[f.idx] = f.dst;
+        sp--;
+    }
+    return count;
+}
+
+// global_cache.h:96-124
+LMC_D bool CacheQuery(const DCacheDim &C, int dim, const float *pss, float *v1, float *v2) {
+    if (!C.ready) return false;
+    const float radius = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
+    int idx[5];
+    float dist[5];
+    const int nMatches = KdRadiusSearch(C, dim, pss, radius, 5, idx, dist);
+    if (!nMatches) return false;
+    double sum_w = 0;
+    for (int i = 0; i < dim; i++) v1[i] = 0.f, v2[i] = 0.f;
+    for (int k = 0; k < nMatches; k++) {
+        int index = idx[k];
+        float d = dist[k];
+        float w = inverse(d * d + 1e-6f);
+        for (int i = 0; i < dim; i++) {
+            v1[i] += C.v1[(size_t)index * dim + i] * w;
+            v2[i] += C.v2[(size_t)index * dim + i] * w;
+        }
+        sum_w += w;
+    }
+    for (int i = 0; i < dim; i++) {
+        v1[i] = (float)((double)v1[i] / sum_w);
+        v2[i] = (float)((double)v2[i] / sum_w);
+    }
+    return true;
+}
+
+}  // namespace lmcd

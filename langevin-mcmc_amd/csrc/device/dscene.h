@@ -1,0 +1,220 @@
+// Flattened scene in HBM (read-only during rendering; ~a few MB, L2/MALL resident) and the LBVH
+// closest-hit / any-hit traversal that stands in for Embree's rtcIntersect1 / rtcOccluded1
+// (/root/reference/src/scene.cpp:106-149).  Built by host/context.cpp from lmc::Scene.
+#pragma once
+#include "dmath.h"
+
+namespace lmcd {
+
+enum { BSDF_LAMBERTIAN = 0, BSDF_PHONG = 1, BSDF_ROUGHDIELECTRIC = 2 };
+enum { LIGHT_POINT = 0, LIGHT_AREA = 1, LIGHT_ENV = 2 };
+
+// LBVH node, 64 B = one cache line: both children's boxes live in the parent so one fetch feeds two
+// slab tests.  child >= 0: inner node index; child < 0: leaf, ~child = (firstTri << 3) | (count - 1), count <= 4.
+struct alignas(16) BvhNode {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int left, right;
+    int pad[2];
+};
+// triangle in BVH leaf order, 48 B: Moeller-Trumbore operands + global triangle id
+struct alignas(16) LeafTri {
+    float p0[3];
+    int id;
+    float e1[3];
+    float pad0;
+    float e2[3];
+    float pad1;
+};
+// shading data by global triangle id, 112 B
+struct alignas(16) TriData {
+    float p0[3], e1[3], e2[3];
+    float n0[3], n1[3], n2[3];
+    float st[6];  // per-vertex st (valid iff mesh.hasST)
+    int mesh;
+    int pad[3];
+};
+struct DMesh {
+    int material, areaLight, hasST, triBase, numTris;
+    float totalArea, invTotalArea;
+    // PiecewiseConstant1D over triangle areas (area lights only): offsets into DScene::areaFunc / areaCdf
+    int areaOff, areaCdfOff;
+    float areaFuncInt;
+};
+struct DMaterial {
+    int type, twoSided;
+    float Kd[3], Ks[3], Kt[3];
+    float expOrAlpha, eta, invEta, KsWeight;
+    int KdTex;  // -1: constant (bitmap textures: SURVEY.md §8 config 3)
+};
+struct DLight {
+    int type;
+    float samplingWeight;
+    float pos[3], intensity[3];  // point
+    int mesh;                    // area
+    float radiance[3];
+};
+struct DEnv {
+    int W, H;
+    const float *image;  // W*H*3
+    const float *cdfRows, *cdfCols, *rowWeights;
+    float normalization, pixelSize[2];
+    float toWorld[16], toLight[16];
+    float xformBlocks[30];  // the two 15-float AnimatedTransform blocks, as Light::Serialize writes them
+};
+struct DCamera {
+    float sampleToCam[16], camToSample[16], toWorld[16], worldToCamera[16];
+    int width, height;
+    float nearClip, farClip, dist;
+};
+struct DOptions {
+    int minDepth, maxDepth, mala;
+    float roughnessThreshold, largeStepProbability, largeStepProbScale;
+    float malaGN, malaStepsize, malaStdDev, perturbStdDev, discreteStdDev, uniformMixingProbability;
+    int seedOffset;
+};
+
+struct DScene {
+    const BvhNode *nodes;
+    const LeafTri *leafTris;
+    const TriData *tris;
+    const DMesh *meshes;
+    const DMaterial *materials;
+    const DLight *lights;
+    const float *areaFunc, *areaCdf;
+    const float *lightFunc, *lightCdf;
+    float lightFuncInt, lightWeightSum;
+    int numTris, numNodes, numMeshes, numLights, envLight;
+    DEnv env;
+    DCamera cam;
+    DOptions opt;
+    float bsCenter[3], bsRadius;
+    float sceneParams[38];
+};
+
+// ---------------------------------------------------------------------------------------------- ray / tri
+// Same arithmetic, in the same order, as the oracle's TriTest (oracle/scene_rt.cpp) which restates the
+// reference's TriangleIntersect (trianglemesh.cpp:30-53): the build compiles with -ffp-contract=off so that
+// the accepted (id, t) pairs are bit-identical between CPU and GPU.
+LMC_HD bool TriTest(const float *p0, const float *e1, const float *e2, V3 org, V3 dir, float tnear, float tfar, float &t) {
+    V3 E1{e1[0], e1[1], e1[2]}, E2{e2[0], e2[1], e2[2]};
+    V3 s1 = Cross(dir, E2);
+    float divisor = Dot(s1, E1);
+    if (divisor == 0.0f) return false;
+    float invDivisor = inverse(divisor);
+    V3 s = org - V3{p0[0], p0[1], p0[2]};
+    float u = Dot(s, s1) * invDivisor;
+    V3 s2 = Cross(s, E1);
+    float v = Dot(dir, s2) * invDivisor;
+    if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) return false;
+    float tt = Dot(E2, s2) * invDivisor;
+    if (!(tt >= tnear && tt <= tfar)) return false;
+    t = tt;
+    return true;
+}
+
+LMC_D bool SlabTest(const float *bmin, const float *bmax, V3 org, V3 invd, float tnear, float tfar, float &tEntry) {
+    float ax = (bmin[0] - org.x) * invd.x, bx = (bmax[0] - org.x) * invd.x;
+    float ay = (bmin[1] - org.y) * invd.y, by = (bmax[1] - org.y) * invd.y;
+    float az = (bmin[2] - org.z) * invd.z, bz = (bmax[2] - org.z) * invd.z;
+    float t0 = fmaxf(fmaxf(tnear, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+    float t1 = fminf(fminf(tfar, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    tEntry = t0;
+    return t0 * 0.9999996f <= t1 * 1.0000004f;  // 2*gamma(3) widening, as in the oracle
+}
+
+constexpr int BVH_STACK = 64;
+
+// closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer)
+LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit) {
+    if (S.numNodes == 0) return -1;
+    V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    int stack[BVH_STACK];
+    int sp = 0;
+    int best = -1;
+    float bestT = tfar;
+    int cur = 0;  // root is an inner node (or a single-leaf wrapper)
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode nd = S.nodes[cur];
+            float tl, tr;
+            bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, bestT, tl);
+            bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, bestT, tr);
+            if (hl && hr) {
+                int nearC = nd.left, farC = nd.right;
+                if (tr < tl) nearC = nd.right, farC = nd.left;
+                if (sp < BVH_STACK) stack[sp++] = farC;
+                cur = nearC;
+                continue;
+            } else if (hl) {
+                cur = nd.left;
+                continue;
+            } else if (hr) {
+                cur = nd.right;
+                continue;
+            }
+        } else {
+            unsigned code = (unsigned)~cur;
+            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int i = 0; i < cnt; i++) {
+                const LeafTri tr = S.leafTris[first + i];
+                float t;
+                if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, bestT, t)) {
+                    if (best < 0 || t < bestT || (t == bestT && tr.id < best)) {
+                        bestT = t;
+                        best = tr.id;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    tHit = bestT;
+    return best;
+}
+
+LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar) {
+    if (S.numNodes == 0) return false;
+    V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    int stack[BVH_STACK];
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode nd = S.nodes[cur];
+            float tl, tr;
+            bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, tfar, tl);
+            bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, tfar, tr);
+            if (hl && hr) {
+                if (sp < BVH_STACK) stack[sp++] = nd.right;
+                cur = nd.left;
+                continue;
+            } else if (hl) {
+                cur = nd.left;
+                continue;
+            } else if (hr) {
+                cur = nd.right;
+                continue;
+            }
+        } else {
+            unsigned code = (unsigned)~cur;
+            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int i = 0; i < cnt; i++) {
+                const LeafTri tr = S.leafTris[first + i];
+                float t;
+                if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, tfar, t)) return true;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return false;
+}
+
+// scene.cpp:128-149
+LMC_D bool Occluded(const DScene &S, V3 org, V3 dir, float dist) {
+    float maxT = (dist == INFINITY) ? INFINITY : (1.0f - c_ShadowEpsilon) * dist;
+    return BvhOccluded(S, org, dir, c_IsectEpsilon, maxT);
+}
+
+}  // namespace lmcd

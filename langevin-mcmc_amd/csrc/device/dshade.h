@@ -1,0 +1,337 @@
+// Surface hit reconstruction, BSDFs, lights and the camera on the device.
+// Scalar semantics of /root/reference/src/{trianglemesh.cpp:30-79,189-236,291-365, lambertian.cpp:15-93,
+// envlight.cpp:120-248, arealight.cpp:28-104, pointlight.cpp:20-80, camera.cpp:38-84, scene.cpp:151-158,
+// distribution.h:38-46}; every early-out of the reference is kept.
+#pragma once
+#include "dscene.h"
+
+namespace lmcd {
+
+struct Isect {
+    V3 position, shadingNormal, geomNormal;
+};
+struct SurfHit {
+    int tri;  // global triangle id
+    V2 st;
+};
+
+// path.cpp:91-103 = scene.cpp:106-126 (BVH) + TriangleMesh::Intersect (recompute from primID)
+LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float tfar, SurfHit &hit, Isect &isect) {
+    float tB;
+    int id = BvhIntersect(S, org, dir, tnear, tfar, tB);
+    if (id < 0) return false;
+    const TriData &T = S.tris[id];
+    V3 p0{T.p0[0], T.p0[1], T.p0[2]}, e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
+    isect.geomNormal = Normalize(Cross(e1, e2));
+    V3 s1 = Cross(dir, e2);
+    float divisor = Dot(s1, e1);
+    if (divisor == 0.0f) return false;
+    float invDivisor = inverse(divisor);
+    V3 s = org - p0;
+    float u = Dot(s, s1) * invDivisor;
+    V3 s2 = Cross(s, e1);
+    float v = Dot(dir, s2) * invDivisor;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    float t = Dot(e2, s2) * invDivisor;
+    float w = 1.0f - u - v;
+    isect.position = org + t * dir;
+    V3 n0{T.n0[0], T.n0[1], T.n0[2]}, n1{T.n1[0], T.n1[1], T.n1[2]}, n2{T.n2[0], T.n2[1], T.n2[2]};
+    isect.shadingNormal = Normalize(w * n0 + u * n1 + v * n2);
+    if (Dot(isect.geomNormal, isect.shadingNormal) < 0.0f) isect.geomNormal = -isect.geomNormal;
+    hit.tri = id;
+    if (S.meshes[T.mesh].hasST) {
+        hit.st.x = (1.0f - u - v) * T.st[0] + u * T.st[2] + v * T.st[4];
+        hit.st.y = (1.0f - u - v) * T.st[1] + u * T.st[3] + v * T.st[5];
+    } else {
+        hit.st = V2{u, v};
+    }
+    return true;
+}
+
+// PiecewiseConstant1D::SampleDiscrete (distribution.h:38-46): std::upper_bound over cdf[0..count]
+LMC_D int SampleDiscrete1D(const float *func, const float *cdf, int count, float funcInt, float u, float *pdf) {
+    int lo = 0, len = count + 1;
+    while (len > 0) {
+        int half = len >> 1;
+        if (!(u < cdf[lo + half])) {
+            lo += half + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    int offset = Clampi(lo - 1, 0, count - 1);
+    if (pdf) *pdf = func[offset] / (funcInt * count);
+    return offset;
+}
+
+LMC_D int PickLight(const DScene &S, float u, float &prob) { return SampleDiscrete1D(S.lightFunc, S.lightCdf, S.numLights, S.lightFuncInt, u, &prob); }
+LMC_D float PickLightProb(const DScene &S, int light) { return S.lights[light].samplingWeight / S.lightWeightSum; }
+
+// ---------------------------------------------------------------------------------------------- BSDF
+LMC_D const DMaterial &MaterialOfTri(const DScene &S, int tri) { return S.materials[S.meshes[S.tris[tri].mesh].material]; }
+
+LMC_D V3 EvalKd(const DScene &, const DMaterial &m, V2) { return V3{m.Kd[0], m.Kd[1], m.Kd[2]}; }
+
+LMC_D float BsdfRoughness(const DScene &, const DMaterial &m, V2, float) {
+    if (m.type == BSDF_ROUGHDIELECTRIC) return m.expOrAlpha;  // roughdielectric.h:61-63
+    return 1.0f;                                             // lambertian.h, phong.cpp:155-157
+}
+
+// lambertian.cpp:15-43 (pdf / revPdf are left untouched on the early-out, as in the reference)
+LMC_D void BsdfEvaluate(const DScene &S, const DMaterial &m, bool /*adjoint*/, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo,
+                        float &pdf, float &revPdf) {
+    float cosWi = Dot(normal, wi);
+    V3 normal_ = normal;
+    if (m.twoSided && cosWi < 0.0f) {
+        cosWi = -cosWi;
+        normal_ = -normal_;
+    }
+    cosWo = Dot(normal_, wo);
+    contrib = V3{0, 0, 0};
+    if (cosWi < c_CosEpsilon || cosWo < c_CosEpsilon) return;
+    float fwdScalar = cosWo * c_INVPI;
+    float revScalar = cosWi * c_INVPI;
+    contrib = fwdScalar * EvalKd(S, m, st);
+    pdf = fwdScalar;
+    revPdf = revScalar;
+}
+
+// lambertian.cpp:45-93
+LMC_D bool BsdfSample(const DScene &S, const DMaterial &m, bool /*adjoint*/, V3 wi, V3 normal, V2 st, V2 rnd, float /*uDiscrete*/, V3 &wo,
+                      V3 &contrib, float &cosWo, float &pdf, float &revPdf) {
+    float cosWi = Dot(wi, normal);
+    V3 normal_ = normal;
+    if (fabsf(cosWi) < c_CosEpsilon) return false;
+    if (cosWi < 0.0f) {
+        if (m.twoSided) {
+            cosWi = -cosWi;
+            normal_ = -normal_;
+        } else
+            return false;
+    }
+    V3 b0, b1;
+    CoordinateSystem(normal_, b0, b1);
+    V3 ret = SampleCosHemisphere(rnd);
+    wo = ret.x * b0 + ret.y * b1 + ret.z * normal_;
+    cosWo = ret.z;
+    pdf = ret.z * c_INVPI;
+    if (cosWo < c_CosEpsilon) return false;
+    revPdf = cosWi * c_INVPI;
+    contrib = EvalKd(S, m, st);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- shapes
+// TriangleMesh::Sample (trianglemesh.cpp:291-365, ADEpsilon<Float>() == 0)
+LMC_D void SampleTriangle(const DScene &S, int tri, V2 rnd, V3 &position, V3 &normal, float &pdf) {
+    const TriData &T = S.tris[tri];
+    V3 p0{T.p0[0], T.p0[1], T.p0[2]}, e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
+    const float a = sqrtf((1.0f + 0.0f) - rnd.x);
+    const float b1 = 1.0f - a;
+    const float b2 = a * rnd.y;
+    position = p0 + (e1 * b1) + (e2 * b2);
+    V3 n0{T.n0[0], T.n0[1], T.n0[2]}, n1{T.n1[0], T.n1[1], T.n1[2]}, n2{T.n2[0], T.n2[1], T.n2[2]};
+    normal = Normalize(n0 * (1.0f - b1 - b2) + n1 * b1 + n2 * b2);
+    pdf = S.meshes[T.mesh].invTotalArea;
+}
+
+// ---------------------------------------------------------------------------------------------- lights
+LMC_D V3 EnvAtLinear(const DEnv &E, int x, int y) {  // Image3::At without range check; one-past-the-end wraps (oracle AtQ)
+    long idx = (long)y * E.W + x;
+    long n = (long)E.W * E.H;
+    if (idx >= n) idx -= n;
+    const float *p = E.image + idx * 3;
+    return V3{p[0], p[1], p[2]};
+}
+LMC_D V3 EnvRepAt(const DEnv &E, int x, int y) {
+    const float *p = E.image + ((long)Moduloi(y, E.H) * E.W + Moduloi(x, E.W)) * 3;
+    return V3{p[0], p[1], p[2]};
+}
+LMC_D int EnvUToIndex(const float *cdf, int size, float &u) {  // std::lower_bound, envlight.cpp:128-133
+    int lo = 0, len = size + 1;
+    while (len > 0) {
+        int half = len >> 1;
+        if (cdf[lo + half] < u) {
+            lo += half + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    int index = lo - 1;
+    if (index < 0) index = 0;
+    if (index > size - 1) index = size - 1;
+    u = (u - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+// envlight.cpp:120-171
+LMC_D void EnvSampleDirection(const DScene &S, V2 rnd, int &lPrimID, V3 &dirToLight, V3 &value, float &pdf) {
+    const DEnv &E = S.env;
+    float u0 = rnd.x, u1 = rnd.y;
+    int row = EnvUToIndex(E.cdfRows, E.H, u1);
+    int col = EnvUToIndex(E.cdfCols + (long)row * (E.W + 1), E.W, u0);
+    lPrimID = row * E.W + col;
+    V2 tent{Tent(u0), Tent(u1)};
+    float phi = (((float)col + tent.x) + 0.5f) * E.pixelSize[0];
+    float theta = (((float)row + tent.y) + 0.5f) * E.pixelSize[1];
+    float sinPhi = sinf(phi), cosPhi = cosf(phi), sinTheta = sinf(theta), cosTheta = cosf(theta);
+    dirToLight = XformVector(E.toWorld, V3{sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta});
+    float dx1 = tent.x, dx2 = 1.0f - tent.x, dy1 = tent.y, dy2 = 1.0f - tent.y;
+    V3 value1 = EnvAtLinear(E, col, row) * dx2 * dy2 + EnvAtLinear(E, col + 1, row) * dx1 * dy2;
+    V3 value2 = EnvAtLinear(E, col, row + 1) * dx2 * dy1 + EnvAtLinear(E, col + 1, row + 1) * dx1 * dy1;
+    value = value1 + value2;
+    float rowWeight0 = E.rowWeights[Clampi(row, 0, E.H - 1)];
+    float rowWeight1 = E.rowWeights[Clampi(row + 1, 0, E.H - 1)];
+    pdf = (Luminance(value1) * rowWeight0 + Luminance(value2) * rowWeight1) * E.normalization / fmaxf(fabsf(sinTheta), 1e-7f);
+}
+
+// Light::SampleDirect
+LMC_D bool LightSampleDirect(const DScene &S, int light, V3 pos, V2 rnd, int &lPrimID, V3 &dirToLight, float &dist, V3 &contrib,
+                             float &cosAtLight, float &directPdf, float &emissionPdf) {
+    const DLight &L = S.lights[light];
+    if (L.type == LIGHT_ENV) {  // envlight.cpp:173-193
+        V3 value;
+        EnvSampleDirection(S, rnd, lPrimID, dirToLight, value, directPdf);
+        dist = INFINITY;
+        contrib = value * inverse(directPdf);
+        cosAtLight = 1.0f;
+        float positionPdf = c_INVPI / square(S.bsRadius);
+        emissionPdf = directPdf * positionPdf;
+        return true;
+    } else if (L.type == LIGHT_AREA) {  // arealight.cpp:28-60
+        V3 posOnLight, normalOnLight;
+        float shapePdf;
+        SampleTriangle(S, S.meshes[L.mesh].triBase + lPrimID, rnd, posOnLight, normalOnLight, shapePdf);
+        dirToLight = posOnLight - pos;
+        float distSq = LengthSquared(dirToLight);
+        dist = sqrtf(distSq);
+        dirToLight = dirToLight / dist;
+        cosAtLight = -Dot(dirToLight, normalOnLight);
+        if (cosAtLight > c_CosEpsilon) {
+            V3 em{L.radiance[0], L.radiance[1], L.radiance[2]};
+            contrib = (cosAtLight / (distSq * shapePdf)) * em;
+            directPdf = shapePdf * distSq / cosAtLight;
+            emissionPdf = shapePdf * cosAtLight * c_INVPI;
+            return true;
+        }
+        return false;
+    } else {  // pointlight.cpp:20-55
+        V3 lp{L.pos[0], L.pos[1], L.pos[2]};
+        dirToLight = lp - pos;
+        const float distSq = LengthSquared(dirToLight);
+        directPdf = distSq;
+        dist = sqrtf(distSq);
+        dirToLight = dirToLight / dist;
+        contrib = V3{L.intensity[0], L.intensity[1], L.intensity[2]} * inverse(distSq);
+        emissionPdf = c_INVFOURPI;
+        cosAtLight = 1.0f;
+        lPrimID = 0;
+        return true;
+    }
+}
+
+// Light::Emission (env: envlight.cpp:195-222; area: arealight.cpp:62-79)
+LMC_D void LightEmission(const DScene &S, int light, V3 dirToLight, V3 normalOnLight, int &lPrimID, V3 &emission, float &directPdf,
+                         float &emissionPdf) {
+    const DLight &L = S.lights[light];
+    if (L.type == LIGHT_ENV) {
+        const DEnv &E = S.env;
+        V3 d = XformVector(E.toLight, dirToLight);
+        float uvx = atan2f(d.x, -d.z) * c_INVTWOPI * (float)E.W - 0.5f;
+        float uvy = acosf(d.y) * c_INVPI * (float)E.H - 0.5f;
+        int col = (int)floorf(uvx), row = (int)floorf(uvy);
+        lPrimID = Moduloi(row, E.H) * E.W + Moduloi(col, E.W);
+        float dx1 = uvx - col, dx2 = 1.0f - dx1, dy1 = uvy - row, dy2 = 1.0f - dy1;
+        V3 value1 = EnvRepAt(E, col, row) * dx2 * dy2 + EnvRepAt(E, col + 1, row) * dx1 * dy2;
+        V3 value2 = EnvRepAt(E, col, row + 1) * dx2 * dy1 + EnvRepAt(E, col + 1, row + 1) * dx1 * dy1;
+        emission = value1 + value2;
+        float sinTheta = sqrtf(1.0f - square(d.y));
+        float rowWeight0 = E.rowWeights[Clampi(row, 0, E.H - 1)];
+        float rowWeight1 = E.rowWeights[Clampi(row + 1, 0, E.H - 1)];
+        directPdf = (Luminance(value1) * rowWeight0 + Luminance(value2) * rowWeight1) * E.normalization / fmaxf(fabsf(sinTheta), 1e-7f);
+        float positionPdf = c_INVPI / square(S.bsRadius);
+        emissionPdf = directPdf * positionPdf;
+    } else {  // area
+        float cosAtLight = -Dot(normalOnLight, dirToLight);
+        if (cosAtLight > 0.0f) {
+            emission = V3{L.radiance[0], L.radiance[1], L.radiance[2]};
+            directPdf = S.meshes[L.mesh].invTotalArea;
+            emissionPdf = cosAtLight * directPdf * c_INVPI;
+        } else {
+            emission = V3{0, 0, 0};
+            directPdf = 0.0f;
+            emissionPdf = 0.0f;
+        }
+    }
+}
+
+// Light::Emit (env: envlight.cpp:224-248; area: arealight.cpp:81-104; point: pointlight.cpp:57-72)
+LMC_D void LightEmit(const DScene &S, int light, V2 rndPos, V2 rndDir, int &lPrimID, V3 &org, V3 &dir, V3 &emission, float &cosAtLight,
+                     float &emissionPdf, float &directPdf) {
+    const DLight &L = S.lights[light];
+    if (L.type == LIGHT_ENV) {
+        EnvSampleDirection(S, rndDir, lPrimID, dir, emission, directPdf);
+        dir = -dir;
+        V2 offset = SampleConcentricDisc(rndPos);
+        V3 b0, b1;
+        CoordinateSystem(dir, b0, b1);
+        V3 perpOffset = offset.x * b0 + offset.y * b1;
+        org = V3{S.bsCenter[0], S.bsCenter[1], S.bsCenter[2]} + (perpOffset - dir) * S.bsRadius;
+        cosAtLight = 1.0f;
+        float positionPdf = c_INVPI / square(S.bsRadius);
+        emissionPdf = directPdf * positionPdf;
+    } else if (L.type == LIGHT_AREA) {
+        V3 normal;
+        float shapePdf;
+        SampleTriangle(S, S.meshes[L.mesh].triBase + lPrimID, rndPos, org, normal, shapePdf);
+        V3 d = SampleCosHemisphere(rndDir);
+        V3 b0, b1;
+        CoordinateSystem(normal, b0, b1);
+        dir = d.x * b0 + d.y * b1 + d.z * normal;
+        emission = V3{L.radiance[0], L.radiance[1], L.radiance[2]} * (c_PI / shapePdf);
+        cosAtLight = d.z;
+        emissionPdf = d.z * c_INVPI * shapePdf;
+        directPdf = shapePdf;
+    } else {
+        org = V3{L.pos[0], L.pos[1], L.pos[2]};
+        float j;
+        dir = SampleSphere(rndDir, j);
+        emission = V3{L.intensity[0], L.intensity[1], L.intensity[2]};
+        emissionPdf = c_INVFOURPI;
+        cosAtLight = directPdf = 1.0f;
+    }
+}
+
+// Light::SampleDiscrete: area lights pick a triangle by area (arealight.cpp:24-26), others INVALID (-1)
+LMC_D int LightSampleDiscrete(const DScene &S, int light, float u) {
+    const DLight &L = S.lights[light];
+    if (L.type != LIGHT_AREA) return -1;
+    const DMesh &M = S.meshes[L.mesh];
+    return SampleDiscrete1D(S.areaFunc + M.areaOff, S.areaCdf + M.areaCdfOff, M.numTris, M.areaFuncInt, u, nullptr);
+}
+LMC_D bool LightIsDelta(const DScene &S, int light) { return S.lights[light].type == LIGHT_POINT; }
+LMC_D bool LightIsFinite(const DScene &S, int light) { return S.lights[light].type != LIGHT_ENV; }
+
+// ---------------------------------------------------------------------------------------------- camera
+LMC_D void SamplePrimary(const DScene &S, V2 screenPos, V3 &org, V3 &dir) {  // camera.cpp:38-51
+    V3 o = XformPoint(S.cam.sampleToCam, V3{screenPos.x, screenPos.y, 0.0f});
+    V3 d = Normalize(o);
+    org = XformPoint(S.cam.toWorld, V3{0, 0, 0});
+    dir = XformVector(S.cam.toWorld, d);
+}
+LMC_D float PrimaryMinT(const DScene &S, V2 screenPos, float &maxT) {
+    V3 o = XformPoint(S.cam.sampleToCam, V3{screenPos.x, screenPos.y, 0.0f});
+    V3 d = Normalize(o);
+    float invZ = inverse(d.z);
+    maxT = S.cam.farClip * invZ;
+    return S.cam.nearClip * invZ;
+}
+LMC_D bool ProjectPoint(const DScene &S, V3 p, V2 &screenPos) {  // camera.cpp:67-84
+    V3 camP = XformPoint(S.cam.worldToCamera, p);
+    if (camP.z < S.cam.nearClip || camP.z > S.cam.farClip) return false;
+    V3 r = XformPoint(S.cam.camToSample, camP);
+    if (r.x < 0.0f || r.x > 1.0f || r.y < 0.0f || r.y > 1.0f) return false;
+    screenPos = V2{r.x, r.y};
+    return true;
+}
+
+}  // namespace lmcd

@@ -1,0 +1,323 @@
+// One Markov-chain step per thread: mlt.cpp:91-170 with LargeStep / SmallStep / MALASmallStep inlined.
+// Scheduling contract: all chains advance in lock step; global-cache readiness and contents are
+// frozen for the duration of a step and the step's pushes are applied afterwards in chain-id order.
+#pragma once
+#include "dchain.h"
+#include "dgrad.h"
+#include "dstep_params.h"
+
+namespace lmcd {
+
+struct StepStats {  // per-thread increments, block-reduced by the kernel
+    int steps = 0, large = 0, accepted = 0, gradCalls = 0, cacheQueries = 0, cacheHits = 0, resets = 0;
+    float wsum = 0.f;
+};
+
+LMC_D void LoadGauss(const ChainArrays &A, int i, int dim, Gauss &g) {
+    const size_t N = A.N;
+    for (int k = 0; k < dim; k++) {
+        g.mean[k] = A.gaussian[(size_t)k * N + i];
+        g.covL[k] = A.gaussian[(size_t)(MAXPSS + k) * N + i];
+        g.invCov[k] = A.gaussian[(size_t)(2 * MAXPSS + k) * N + i];
+    }
+    g.logDet = A.gaussian[(size_t)(3 * MAXPSS) * N + i];
+}
+LMC_D void StoreGauss(const ChainArrays &A, int i, int dim, const Gauss &g) {
+    const size_t N = A.N;
+    for (int k = 0; k < dim; k++) {
+        A.gaussian[(size_t)k * N + i] = g.mean[k];
+        A.gaussian[(size_t)(MAXPSS + k) * N + i] = g.covL[k];
+        A.gaussian[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov[k];
+    }
+    A.gaussian[(size_t)(3 * MAXPSS) * N + i] = g.logDet;
+}
+
+// The twin blocks of MALASmallStep::Mutate (mutation_mala.h:83-166 current, :174-260 proposal).
+// Persistent Chain vectors (mutation.h:28-43) live in HBM: v1, v2, curr_new_v2, prop_new_v1, prop_new_v2, pss,
+// last_pss (g / curr_new_v1 / curr_new_g / prop_new_g / M are write-only or recomputed in the reference).
+LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, const DPath &path,
+                           const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st) {
+    const size_t N = A.N;
+    const int dim = PathDimension(path.camDepth, path.lgtDepth);
+    float pss[MAXPSS];
+    for (int k = 0; k < MAXPSS; k++) pss[k] = 0.f;
+    GetPathPss(path, pss);
+    for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = pss[k];  // GetPathPss(path, chain->pss)
+    A.pathWeight[i] = sp.lsScore;
+    const bool inRange = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH;
+    const bool ready = inRange && cache.d[dim].ready;
+    const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth);
+    const float ss = S.opt.malaStepsize, shk = S.opt.malaStdDev;
+    float M[MAXPSS];
+    if (inRange && !ready && haveDerv) {
+        float vGrad[MAXPSS];
+        for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
+        if (sp.ssScore > 1e-10f) {
+            ComputeGradient(S, path, sp, vGrad, gw);
+            st.gradCalls++;
+            bool finite = true;
+            for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);
+            if (!finite)
+                for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
+        }
+        float norm = 0.f, drift = S.opt.malaGN;
+        for (int k = 0; k < dim; k++) norm += vGrad[k] * vGrad[k];
+        norm = sqrtf(norm);
+        for (int k = 0; k < dim; k++) vGrad[k] *= drift / fmaxf(drift, norm);
+        float *newV2 = isProposal ? A.chPropNewV2 : A.chCurrNewV2;
+        bool first = true;
+        for (int k = 0; k < dim; k++)
+            if (newV2[(size_t)k * N + i] > 1e-10f) {
+                first = false;
+                break;
+            }
+        float nv1[MAXPSS];
+        for (int k = 0; k < dim; k++) {
+            float gk = vGrad[k];
+            float v1 = A.chV1[(size_t)k * N + i], v2 = A.chV2[(size_t)k * N + i];
+            nv1[k] = first ? gk : 0.9f * v1 + 0.1f * gk;
+            float nv2 = first ? gk * gk : 0.999f * v2 + 0.001f * gk * gk;
+            newV2[(size_t)k * N + i] = nv2;
+            if (isProposal) A.chPropNewV1[(size_t)k * N + i] = nv1[k];
+            M[k] = Clampf(1.0f / (1e-3f + sqrtf(nv2)), PCD_MIN, PCD_MAX);
+        }
+        ComputeGaussianMALA(dim, nv1, ss, shk, M, sp.ssScore, g);
+    } else if (ready) {
+        bool reuse = false;
+        if (flags & F_QUERIED) {
+            float dist_sqr = 0.f;
+            for (int k = 0; k < dim; k++) {
+                float diff = pss[k] - A.chLastPss[(size_t)k * N + i];
+                dist_sqr += diff * diff;
+            }
+            if (dist_sqr < dim * (PSS_REUSE_DIST * PSS_REUSE_DIST)) reuse = true;
+        }
+        float v1[MAXPSS], v2[MAXPSS];
+        bool fromV = false;
+        if (reuse) {
+            for (int k = 0; k < dim; k++) v1[k] = A.chV1[(size_t)k * N + i], v2[k] = A.chV2[(size_t)k * N + i];
+            fromV = true;
+        } else {
+            st.cacheQueries++;
+            if (CacheQuery(cache.d[dim], dim, pss, v1, v2)) {
+                st.cacheHits++;
+                // query() zero-fills the whole 2*maxDepth vectors before accumulating (global_cache.h:107-108)
+                for (int k = 0; k < MAXPSS; k++) {
+                    A.chV1[(size_t)k * N + i] = k < dim ? v1[k] : 0.f;
+                    A.chV2[(size_t)k * N + i] = k < dim ? v2[k] : 0.f;
+                }
+                flags |= F_QUERIED;
+                for (int k = 0; k < MAXPSS; k++) A.chLastPss[(size_t)k * N + i] = A.chPss[(size_t)k * N + i];  // last_pss = pss
+                fromV = true;
+            }
+        }
+        if (fromV) {
+            for (int k = 0; k < dim; k++) M[k] = Clampf(1.0f / (1e-3f + sqrtf(v2[k])), PCD_MIN, PCD_MAX);
+            ComputeGaussianMALA(dim, v1, ss, shk, M, sp.ssScore, g);
+        } else {
+            IsotropicGaussian(dim, shk, g);
+        }
+    } else {
+        IsotropicGaussian(dim, shk, g);
+    }
+}
+
+// mlt.cpp:96-97.  Drawn by the launch that precedes the step so that large and small steps can be
+// dispatched as separate, divergence-free launches (the RNG order is unchanged: nothing draws in between).
+LMC_D int DecideKind(const DScene &S, const ChainArrays &A, int i, Rng &rng) {
+    if (!(A.flags[i] & F_VALID)) return KIND_LARGE;
+    const int sampleIdx = A.sampleIdx[i];
+    const float lsScale = ((float)sampleIdx > (float)A.numSamples[i] * LS_RATIO) ? S.opt.largeStepProbScale : 1.0f;
+    return (rng.Uniform() < S.opt.largeStepProbability * lsScale) ? KIND_LARGE : KIND_SMALL;
+}
+
+LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
+                     GradWork &gw, StepStats &st) {
+    const size_t N = A.N;
+    int flags = A.flags[i];
+    const bool curValid = flags & F_VALID;
+    const Contrib cur = LoadContrib(A.curContrib, A.N, i);
+    DPath prop;
+    Contrib pc;
+    pc.camDepth = pc.lightDepth = 0;
+    pc.lsScore = pc.ssScore = 0.f;
+    float a = 1.0f;
+    float propScoreSum = 0.f;
+    bool lastMala = false;
+    Gauss pg;
+    ContribSink sink{A.contribList, N, (size_t)i, 0};
+    st.steps++;
+
+    if (kind == KIND_LARGE) {  // LargeStep::Mutate, mutation_large.h:31-128 (largeStepMultiplexed = false)
+        st.large++;
+        GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng);
+        if (sink.count > 0) {
+            float scoreSum = 0.f;
+            for (int k = 0; k < sink.count; k++) scoreSum += sink.LsScore(k);  // contribCdf.back()
+            const float invSc = inverse(scoreSum);
+            const float u = rng.Uniform();
+            // std::upper_bound(cdf*invSc, u): first element > u; contribId = clamp(pos - 1, 0, n - 1)
+            int pos = sink.count + 1;
+            float cdf = 0.f;
+            if (u < cdf * invSc) pos = 0;
+            for (int k = 0; k < sink.count && pos > sink.count; k++) {
+                cdf += sink.LsScore(k);
+                if (u < cdf * invSc) pos = k + 1;
+            }
+            int contribId = Clampi(pos - 1, 0, sink.count - 1);
+            pc = sink.Get(contribId);
+            propScoreSum = scoreSum;
+            if (curValid) {
+                const float probProposal = pc.lsScore / scoreSum;
+                const float probLast = A.lastScore[i] / A.lastScoreSum[i];
+                a = Clampf((pc.lsScore * probLast) / (cur.lsScore * probProposal), 0.0f, 1.0f);
+            }
+        } else {
+            a = 0.0f;
+        }
+    } else {
+        LoadPath(A.curPath, A.N, i, prop);  // proposalState.path = currentState.path
+        const int dim = PathDimension(prop.camDepth, prop.lgtDepth);
+        float offset[MAXPSS];
+        const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51
+        Gauss cg;
+        if (!mala) {  // SmallStep::Mutate, mutation_small.h:16-56
+            NormalDist nd(0.0f, S.opt.perturbStdDev);
+            for (int k = 0; k < dim; k++) offset[k] = nd(rng);
+        } else {
+            lastMala = true;
+            if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81
+                for (int k = 0; k < MAXPSS; k++) {
+                    size_t o = (size_t)k * N + i;
+                    A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
+                }
+                flags |= F_BUFFERED;
+                flags &= ~F_QUERIED;
+            }
+            if (!(flags & F_GAUSS)) {
+                InitGaussianFor(S, cache, A, P, i, prop, cur, false, flags, cg, gw, st);
+                StoreGauss(A, i, dim, cg);
+                flags |= F_GAUSS;
+            } else {
+                LoadGauss(A, i, dim, cg);
+            }
+            NormalDist nd(0.0f, 1.0f);  // GenerateSample, gaussian.cpp:38-55
+            for (int k = 0; k < dim; k++) offset[k] = nd(rng);
+            for (int k = 0; k < dim; k++) offset[k] = cg.covL[k] * offset[k] + cg.mean[k];
+        }
+        if (PerturbPathBidir(S, offset, prop, pc, rng)) {
+            if (mala) {
+                InitGaussianFor(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st);
+                float py = GaussianLogPdf(dim, offset, false, cg);
+                float px = GaussianLogPdf(dim, offset, true, pg);
+                a = Clampf(expf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+            } else {
+                a = Clampf(pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+            }
+        } else {
+            a = 0.0f;
+        }
+    }
+
+    // ---- splats, mlt.cpp:103-112
+    if (curValid && a < 1.0f) {
+        const int n = A.curSplatCount[i];
+        for (int k = 0; k < n; k++) {
+            const float *p = A.curSplat + ((size_t)k * SPLAT_WORDS) * N + i;
+            Splat(film, V2{p[0], p[N]}, (1.0f - a) * V3{p[2 * N], p[3 * N], p[4 * N]});
+        }
+    }
+    // small-step splat value: mutation_small.h:48 `contrib * (normalization / lsScore)` vs mutation_mala.h:271
+    // `contrib * normalization / lsScore` (different rounding, kept)
+    V3 smallSplat{0, 0, 0};
+    if (kind == KIND_SMALL) smallSplat = lastMala ? (pc.contrib * P.normalization) / pc.lsScore : pc.contrib * (P.normalization / pc.lsScore);
+    if (a > 0.0f) {
+        if (kind == KIND_LARGE) {
+            const float scale = P.normalization / propScoreSum;
+            for (int k = 0; k < sink.count; k++) {
+                Contrib c = sink.Get(k);
+                Splat(film, c.screenPos, a * (c.contrib * scale));
+            }
+        } else {
+            Splat(film, pc.screenPos, a * smallSplat);
+        }
+    }
+    st.wsum += curValid ? 1.0f : (a > 0.0f ? a : 0.0f);
+
+    // ---- accept / reject, mlt.cpp:113-170
+    const int sampleIdx = A.sampleIdx[i];
+    A.pushDim[i] = 0;
+    if (a > 0.0f && rng.Uniform() <= a) {
+        st.accepted++;
+        const int oldDim = PathDimension(cur.camDepth, cur.lightDepth);  // GetDimension(proposalState.path) after the swap, mlt.cpp:121
+        ToSubpath(pc.camDepth, pc.lightDepth, prop);
+        StorePath(A.curPath, A.N, i, prop);
+        StoreContrib(A.curContrib, A.N, i, pc);
+        A.adjacentReject[i] = 0;
+        if (kind == KIND_LARGE) {
+            A.scoreSum[i] = propScoreSum;
+            const float scale = P.normalization / propScoreSum;
+            for (int k = 0; k < sink.count; k++) {
+                Contrib c = sink.Get(k);
+                float *p = A.curSplat + ((size_t)k * SPLAT_WORDS) * N + i;
+                V3 v = c.contrib * scale;
+                p[0] = c.screenPos.x, p[N] = c.screenPos.y, p[2 * N] = v.x, p[3 * N] = v.y, p[4 * N] = v.z;
+            }
+            A.curSplatCount[i] = sink.count;
+            // the old current state was valid iff the chain had run a MALA step since (chain.buffered)
+            if ((flags & F_BUFFERED) && A.pathWeight[i] > 1e-10f) {
+                if (oldDim >= PSS_MIN_LENGTH && oldDim <= PSS_MAX_LENGTH && !cache.d[oldDim].ready) {
+                    A.pushDim[i] = oldDim;
+                    for (int k = 0; k < oldDim; k++) {
+                        A.pushData[(size_t)k * N + i] = A.chPss[(size_t)k * N + i];
+                        A.pushData[(size_t)(MAXPSS + k) * N + i] = A.chV1[(size_t)k * N + i];
+                        A.pushData[(size_t)(2 * MAXPSS + k) * N + i] = A.chV2[(size_t)k * N + i];
+                    }
+                    A.pushData[(size_t)(3 * MAXPSS) * N + i] = A.pathWeight[i];
+                }
+            }
+            A.lastScoreSum[i] = propScoreSum;
+            A.lastScore[i] = pc.lsScore;
+            flags &= ~(F_GAUSS | F_BUFFERED);
+        } else {
+            float *p = A.curSplat + i;
+            p[0] = pc.screenPos.x, p[N] = pc.screenPos.y, p[2 * N] = smallSplat.x, p[3 * N] = smallSplat.y, p[4 * N] = smallSplat.z;
+            A.curSplatCount[i] = 1;
+            if (lastMala) {  // mlt.cpp:133-142: chain.v1/v2 = prop_new_v1/v2 (whole vectors, whichever branch filled them last)
+                for (int k = 0; k < MAXPSS; k++) {
+                    A.chV1[(size_t)k * N + i] = A.chPropNewV1[(size_t)k * N + i];
+                    A.chV2[(size_t)k * N + i] = A.chPropNewV2[(size_t)k * N + i];
+                }
+                flags |= F_BUFFERED | F_GAUSS;
+                StoreGauss(A, i, PathDimension(pc.camDepth, pc.lightDepth), pg);
+            } else {
+                flags &= ~F_GAUSS;  // proposalState.gaussianInitialized = false, mutation_small.h:39
+            }
+        }
+        flags |= F_VALID;
+    } else {
+        int rej = A.adjacentReject[i] + 1;  // REMOVE_OUTLIERS, mlt.cpp:147-169
+        A.adjacentReject[i] = rej;
+        const bool strongReject = cur.lsScore > OUTLIER_RATIO_THRESHOLD * P.normalization;
+        if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
+            int chainId = i, cnt = 0;
+            for (;;) {
+                const float ls = A.initContrib[7 * N + chainId];
+                if (ls < OUTLIER_RATIO_THRESHOLD * P.normalization) break;
+                chainId = (int)(((long long)chainId + sampleIdx + cnt++) % P.numChains);
+            }
+            DPath ip;
+            LoadPath(A.initPath, A.N, chainId, ip);
+            StorePath(A.curPath, A.N, i, ip);
+            StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, A.N, chainId));
+            A.scoreSum[i] = A.initScoreSum[chainId];
+            A.curSplatCount[i] = 0;
+            flags &= ~(F_VALID | F_GAUSS | F_BUFFERED);
+            st.resets++;
+        }
+    }
+    A.flags[i] = flags;
+    A.sampleIdx[i] = sampleIdx + 1;
+}
+
+}  // namespace lmcd

@@ -1,0 +1,25 @@
+// Launch entry points of kernels.hip (compiled by hipcc for gfx950); called from host/context.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dchain.h"
+#include "dstep_params.h"
+
+void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s);
+void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out, hipStream_t s);
+void LaunchTrace(const lmcd::DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s);
+void LaunchKdProbe(const lmcd::DCacheDim &C, int dim, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist, hipStream_t s);
+void LaunchGaussProbe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out, hipStream_t s);
+void LaunchGradBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, int wantGrad,
+                     hipStream_t s);
+void LaunchInitPass1(const lmcd::DScene &S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
+                     uint32_t *ckTicks, unsigned char *count, hipStream_t s);
+void LaunchInitPass2(const lmcd::DScene &S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
+                     const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs, hipStream_t s);
+void LaunchInitRegen(const lmcd::DScene &S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
+                     uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
+                     float *initScoreSum, hipStream_t s);
+void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s);
+void LaunchStep(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, int chainBegin,
+                const int *list, const int *listCount, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+void LaunchCachePush(const lmcd::ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s);

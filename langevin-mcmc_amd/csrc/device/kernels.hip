@@ -1,0 +1,373 @@
+// gfx950 kernels of the LMC hot path.  One thread = one Markov chain (or one MLT-init stream / sample);
+// launches are grid-stride ("persistent thread") loops over index lists so that large steps and small
+// steps run in separate, divergence-free launches.  Launch glue is in host/context.cpp.
+#include "kernels.h"
+
+#include "dstep.h"
+
+namespace lmcd {
+
+// ---------------------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum) {
+    __shared__ int sInt[7];
+    __shared__ float sW;
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; k++) sInt[k] = 0;
+        sW = 0.f;
+    }
+    __syncthreads();
+    // wave reduction first (64 lanes), then one LDS atomic per wave
+    int v[7] = {st.steps, st.large, st.accepted, st.gradCalls, st.cacheQueries, st.cacheHits, st.resets};
+    float w = st.wsum;
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 7; k++) v[k] += __shfl_down(v[k], off);
+        w += __shfl_down(w, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 7; k++)
+            if (v[k]) atomicAdd(&sInt[k], v[k]);
+        atomicAdd(&sW, w);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; k++)
+            if (sInt[k]) atomicAdd(&counters[k], (unsigned long long)sInt[k]);
+        if (sW != 0.f) atomicAdd(weightSum, (double)sW);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- RNG
+__global__ void k_seed_rng(int n, long long firstSeed, uint64_t *state, uint32_t *tab) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        state[i] = PcgSeed((uint64_t)(firstSeed + i), tab + (size_t)i * 64);
+}
+
+// test probe: draws from RNG(seed): mode 0 raw u32, 1 uniform, 2 one normal object (mean, stddev), 3 mixed rounds
+__global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nSeeds) return;
+    Rng rng;
+    rng.tab = tabScratch + (size_t)i * 64;
+    rng.state = PcgSeed(seeds[i], rng.tab);
+    rng.ticks = 0;
+    uint32_t *o = out + (size_t)i * (n + 66);
+    if (mode == 0) {
+        for (int k = 0; k < n; k++) o[k] = rng.Next();
+    } else if (mode == 1) {
+        for (int k = 0; k < n; k++) o[k] = __float_as_uint(rng.Uniform());
+    } else if (mode == 2) {
+        NormalDist nd(mean, stddev);
+        for (int k = 0; k < n; k++) o[k] = __float_as_uint(nd(rng));
+    } else {
+        int k = 0;
+        while (k + 9 <= n) {
+            o[k++] = __float_as_uint(rng.Uniform());
+            o[k++] = __float_as_uint(rng.Uniform());
+            NormalDist nd(0.f, 1.f);
+            for (int j = 0; j < 7; j++) o[k++] = __float_as_uint(nd(rng));
+        }
+    }
+    // state dump after the draws: [lo, hi, table 64]
+    o[n] = (uint32_t)rng.state, o[n + 1] = (uint32_t)(rng.state >> 32);
+    for (int k = 0; k < 64; k++) o[n + 2 + k] = rng.tab[k];
+}
+
+// ---------------------------------------------------------------------------------------------- probes
+__global__ void k_trace(DScene S, int n, const float *rays, int *prim, float *t, int anyHit) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *r = rays + (size_t)i * 8;
+        V3 org{r[0], r[1], r[2]}, dir{r[3], r[4], r[5]};
+        if (anyHit) {
+            prim[i] = BvhOccluded(S, org, dir, r[6], r[7]) ? 1 : 0;
+        } else {
+            float tt = 0.f;
+            int id = BvhIntersect(S, org, dir, r[6], r[7], tt);
+            prim[i] = id;
+            t[i] = id >= 0 ? tt : 0.f;
+        }
+    }
+}
+
+__global__ void k_kd_probe(DCacheDim C, int dim, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int idx[8];
+    float dist[8];
+    float qq[MAXPSS];
+    for (int k = 0; k < dim; k++) qq[k] = q[(size_t)i * dim + k];
+    int n = KdRadiusSearch(C, dim, qq, radiusSq, knn, idx, dist);
+    outN[i] = n;
+    for (int k = 0; k < knn; k++) {
+        outIdx[i * knn + k] = k < n ? idx[k] : -1;
+        outDist[i * knn + k] = k < n ? dist[k] : 0.f;
+    }
+}
+
+__global__ void k_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[MAXPSS], m[MAXPSS], off[MAXPSS];
+    for (int k = 0; k < dim; k++) a[k] = v1[(size_t)i * dim + k], m[k] = M[(size_t)i * dim + k], off[k] = offset[(size_t)i * dim + k];
+    Gauss g;
+    ComputeGaussianMALA(dim, a, ss, shk, m, sc[i], g);
+    float *o = out + (size_t)i * (3 * dim + 2);
+    for (int k = 0; k < dim; k++) o[k] = g.mean[k], o[dim + k] = g.covL[k], o[2 * dim + k] = g.invCov[k];
+    o[3 * dim] = g.logDet;
+    o[3 * dim + 1] = GaussianLogPdf(dim, off, false, g);
+}
+
+// ---------------------------------------------------------------------------------------------- gradient batch
+// lmc_grad_batch: n independent evaluations of the (c,l) path program, inputs/outputs SoA (word-major)
+__global__ void k_grad_batch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA,
+                             int wantGrad) {
+    __shared__ float sScene[38];
+    if (threadIdx.x < 38) sScene[threadIdx.x] = scene[threadIdx.x];
+    __syncthreads();
+    const int L = c + l - 1 > 2 ? c + l - 1 : 2;
+    const int dim = 2 * L;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float primary[2 * MAXD + 1];
+        for (int k = 0; k < dim + 1; k++) primary[k] = primarySoA[(size_t)k * n + i];
+        StridedIn vin{vertSoA + i, (size_t)n};
+        if (wantGrad) {
+            float ll, g[MAXPSS];
+            PathFuncGrad(c, l, primary, sScene, vin, &ll, g);
+            if (logLum) logLum[i] = ll;
+            for (int k = 0; k < dim; k++) gradSoA[(size_t)k * n + i] = g[k];
+        } else {
+            logLum[i] = PathFuncValue(c, l, primary, sScene, vin);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- MLT init
+// pass 1: one thread per virtual init thread (mlt.h:66-98 with NumSystemCores() := V): RNG(threadId + seedOffset),
+// samples drawn back to back; records the per-sample RNG checkpoint and the number of contributions.
+__global__ void k_init_pass1(DScene S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
+                             uint32_t *ckTicks, unsigned char *count) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= V) return;
+    Rng rng;
+    rng.tab = tabScratch + (size_t)t * 64;
+    rng.state = PcgSeed((uint64_t)(t + S.opt.seedOffset), rng.tab);
+    rng.ticks = 0;
+    long long n = perThread + (t < extra ? 1 : 0);
+    long long base = (long long)t * perThread + (t < extra ? t : extra);
+    const int minPathLength = max(S.opt.minDepth, 3);
+    DPath path;
+    for (long long s = 0; s < n; s++) {
+        ckState[base + s] = rng.state;
+        ckTicks[base + s] = rng.ticks;
+        ContribSink sink{contribScratch, (size_t)V, (size_t)t, 0};
+        GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng);
+        count[base + s] = (unsigned char)sink.count;
+    }
+}
+
+LMC_D int InitThreadOfSample(long long g, long long perThread, long long extra) {
+    long long head = extra * (perThread + 1);
+    if (g < head) return (int)(g / (perThread + 1));
+    return (int)(extra + (g - head) / perThread);
+}
+
+LMC_D void RngFromCheckpoint(Rng &rng, uint64_t seed, uint64_t state, uint32_t ticks) {
+    PcgSeed(seed, rng.tab);
+    for (uint32_t k = 0; k < ticks; k++) PcgAdvanceTable(rng.tab);
+    rng.state = state;
+    rng.ticks = ticks;
+}
+
+// pass 2: one grid-stride thread per sample; re-runs the sample from its checkpoint and writes (c,l,lsScore) compactly
+__global__ void k_init_pass2(DScene S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
+                             const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs) {
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nSlots) return;
+    const int minPathLength = max(S.opt.minDepth, 3);
+    DPath path;
+    for (long long g = slot; g < numSamples; g += nSlots) {
+        Rng rng;
+        rng.tab = tabScratch + (size_t)slot * 64;
+        int t = InitThreadOfSample(g, perThread, extra);
+        RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
+        ContribSink sink{contribScratch, (size_t)nSlots, (size_t)slot, 0};
+        GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng);
+        unsigned long long o = offset[g];
+        for (int k = 0; k < sink.count; k++) {
+            Contrib c = sink.Get(k);
+            outCL[o + k] = (unsigned char)(c.camDepth * 16 + c.lightDepth);
+            outLs[o + k] = c.lsScore;
+        }
+    }
+}
+
+// regenerate the selected seed paths (mlt.h:121-148) into the init-state arrays (size = total number of chains)
+__global__ void k_init_regen(DScene S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
+                             uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath,
+                             float *initContrib, float *initScoreSum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numChains) return;
+    const long long g = seedSample[i];
+    Rng rng;
+    rng.tab = tabScratch + (size_t)i * 64;
+    int t = InitThreadOfSample(g, perThread, extra);
+    RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
+    DPath path;
+    ContribSink sink{contribScratch, (size_t)numChains, (size_t)i, 0};
+    GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, path, sink, rng);
+    float scoreSum = 0.f;
+    Contrib sel;
+    sel.camDepth = sel.lightDepth = 0;
+    sel.screenPos = V2{0, 0};
+    sel.contrib = V3{0, 0, 0};
+    sel.lsScore = sel.ssScore = 0.f;
+    const int wantC = seedCL[i] >> 4, wantL = seedCL[i] & 15;
+    for (int k = 0; k < sink.count; k++) {
+        Contrib c = sink.Get(k);
+        scoreSum += c.lsScore;
+        if (c.camDepth == wantC && c.lightDepth == wantL) sel = c;
+    }
+    ToSubpath(sel.camDepth, sel.lightDepth, path);
+    StorePath(initPath, numChains, i, path);
+    StoreContrib(initContrib, numChains, i, sel);
+    initScoreSum[i] = scoreSum;
+}
+
+// chain set-up (mlt.cpp:60-90): current state = init state of the chain's GLOBAL id, everything else cleared
+__global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.N) return;
+    const int gid = chainBegin + i;
+    DPath p;
+    LoadPath(A.initPath, numChainsTotal, gid, p);
+    StorePath(A.curPath, A.N, i, p);
+    StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, numChainsTotal, gid));
+    A.scoreSum[i] = A.initScoreSum[gid];
+    A.flags[i] = 0;
+    A.curSplatCount[i] = 0;
+    A.pathWeight[i] = 0.f;
+    A.lastScoreSum[i] = 1.0f;
+    A.lastScore[i] = 1.0f;
+    A.adjacentReject[i] = 0;
+    A.sampleIdx[i] = 0;
+    A.numSamples[i] = (int)(perChain + (gid < chainsNeedExtra ? 1 : 0));
+    A.pushDim[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------- the step
+// mode 0: every chain decides and steps in this launch (reference order, used for small runs / tests)
+// mode 1: only chains whose pre-drawn kind == wantKind (list-driven launches)
+__global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, int chainBegin, const int *list,
+                                              const int *listCount, float *gradBuf, int gradStride) {
+    StepStats st;
+    const int total = list ? *listCount : A.N;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int i = list ? list[j] : j;
+        if (A.sampleIdx[i] >= A.numSamples[i]) continue;
+        Rng rng;
+        rng.state = A.rngState[i];
+        rng.tab = A.rngTab + (size_t)i * 64;
+        rng.ticks = 0;
+        GradWork gw{gradBuf, (size_t)gradStride, (size_t)(blockIdx.x * blockDim.x + threadIdx.x)};
+        const int kind = DecideKind(S, A, i, rng);
+        StepParams Pl = P;
+        StepChain(S, *cache, A, film, Pl, i, kind, rng, gw, st);
+        A.rngState[i] = rng.state;
+    }
+    (void)chainBegin;
+    BlockReduceStats(st, A.counters, A.weightSum);
+}
+
+// applies the pending global-cache pushes of the step in chain order (one block per dim; deterministic)
+__global__ void k_cache_push(ChainArrays A, int dim, float *pss, float *v1, float *v2, float *weight, int *count) {
+    __shared__ int sBase;
+    __shared__ int sWave[16];
+    if (threadIdx.x == 0) sBase = *count;
+    __syncthreads();
+    const int N = A.N;
+    for (int start = 0; start < N; start += blockDim.x) {
+        if (sBase >= PSS_MAX_SIZE) break;
+        const int i = start + threadIdx.x;
+        const int want = (i < N && A.pushDim[i] == dim) ? 1 : 0;
+        // block-wide exclusive scan of `want`
+        unsigned long long ballot = __ballot(want);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int inWave = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) sWave[wave] = __popcll(ballot);
+        __syncthreads();
+        int before = 0, totalWant = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+            if (w < wave) before += sWave[w];
+            totalWant += sWave[w];
+        }
+        const int slot = sBase + before + inWave;
+        if (want && slot < PSS_MAX_SIZE) {
+            for (int k = 0; k < dim; k++) {
+                pss[(size_t)slot * dim + k] = A.pushData[(size_t)k * N + i];
+                v1[(size_t)slot * dim + k] = A.pushData[(size_t)(MAXPSS + k) * N + i];
+                v2[(size_t)slot * dim + k] = A.pushData[(size_t)(2 * MAXPSS + k) * N + i];
+            }
+            weight[slot] = A.pushData[(size_t)(3 * MAXPSS) * N + i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sBase = min(sBase + totalWant, PSS_MAX_SIZE);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = sBase;
+}
+
+}  // namespace lmcd
+
+// ================================================================================================ launch glue
+using namespace lmcd;
+
+static inline int GridFor(long long n, int block, int maxBlocks = 2048) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > maxBlocks) g = maxBlocks;
+    return (int)g;
+}
+
+void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s) {
+    hipLaunchKernelGGL(k_seed_rng, dim3(GridFor(n, 256)), dim3(256), 0, s, n, firstSeed, state, tab);
+}
+void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_rng_probe, dim3((nSeeds + 63) / 64), dim3(64), 0, s, nSeeds, seeds, mode, n, mean, stddev, tabScratch, out);
+}
+void LaunchTrace(const DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s) {
+    hipLaunchKernelGGL(k_trace, dim3(GridFor(n, 256)), dim3(256), 0, s, S, n, rays, prim, t, anyHit);
+}
+void LaunchKdProbe(const DCacheDim &C, int dim, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist, hipStream_t s) {
+    hipLaunchKernelGGL(k_kd_probe, dim3((nq + 63) / 64), dim3(64), 0, s, C, dim, nq, q, radiusSq, knn, outN, outIdx, outDist);
+}
+void LaunchGaussProbe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gauss_probe, dim3((n + 63) / 64), dim3(64), 0, s, n, dim, v1, M, ss, shk, sc, offset, out);
+}
+void LaunchGradBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, int wantGrad,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_grad_batch, dim3(GridFor(n, 128, 4096)), dim3(128), 0, s, c, l, n, primarySoA, scene, vertSoA, logLum, gradSoA, wantGrad);
+}
+void LaunchInitPass1(const DScene &S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
+                     uint32_t *ckTicks, unsigned char *count, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_pass1, dim3((V + 127) / 128), dim3(128), 0, s, S, V, perThread, extra, tabScratch, contribScratch, ckState, ckTicks, count);
+}
+void LaunchInitPass2(const DScene &S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
+                     const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_pass2, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, numSamples, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
+                       ckTicks, offset, outCL, outLs);
+}
+void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
+                     uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
+                     float *initScoreSum, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_regen, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
+                       contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
+}
+void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s) {
+    hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, numChainsTotal, perChain, chainsNeedExtra);
+}
+void LaunchStep(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, int chainBegin, const int *list,
+                const int *listCount, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_step, dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, chainBegin, list, listCount, gradBuf, gradStride);
+}
+void LaunchCachePush(const ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s) {
+    hipLaunchKernelGGL(k_cache_push, dim3(1), dim3(1024), 0, s, A, dim, pss, v1, v2, weight, count);
+}

@@ -1,0 +1,746 @@
+// The path program of the reference's plugin ABI, as ONE generic function:
+//   logLum = log Luminance(contribution of the (c,l) technique)   as a function of primary[1..2L]
+// and its gradient by forward-mode dual numbers.  It restates, for PathFuncMode::Static, the program that
+// RegisterPathFuncBidirMALA builds with chad (/root/reference/src/path.cpp:3664-3911) out of the AD twins
+// path.cpp:2789-3417, camera.cpp:53-65, trianglemesh.cpp:55-77,291-365,367-473, bsdf.cpp:13-171,
+// lambertian.cpp:95-151, light.cpp:12-324, envlight.cpp:250-400, arealight.cpp:106-208,
+// pointlight.cpp:57-116, sampling.h, utils.h -- including their deviations from the scalar sampler
+// (no rejection tests, ADEpsilon, the PointLight/!IsDelta swap in EmitFromLight,
+// frozen env-map texel).  Inputs use the reference's serialized layout: `scene[38]`,
+// `primary[2L+1]`, `vertParams[V]`; the latter is read through an accessor so the same code runs on a
+// contiguous host buffer (C-ABI symbols, CPU tests) and on a strided per-thread slice in HBM (kernels).
+// Host- and device-compilable; no reference code is generated or copied: this is hand-written.
+#pragma once
+#include "dmath.h"
+
+namespace lmcd {
+
+struct ContigIn {
+    const float *p;
+    LMC_HD float operator[](int k) const { return p[k]; }
+};
+struct StridedIn {
+    const float *p;
+    size_t stride;
+    LMC_HD float operator[](int k) const { return p[(size_t)k * stride]; }
+};
+
+// ------------------------------------------------------------------------------------------ dual numbers
+template <int N>
+struct Dual {
+    float v;
+    float d[N];
+};
+template <int N>
+LMC_HD Dual<N> MakeDual(float v) {
+    Dual<N> r;
+    r.v = v;
+    for (int i = 0; i < N; i++) r.d[i] = 0.f;
+    return r;
+}
+template <int N>
+LMC_HD Dual<N> Chain1(const Dual<N> &a, float v, float dv) {  // f(a) with f' = dv
+    Dual<N> r;
+    r.v = v;
+    for (int i = 0; i < N; i++) r.d[i] = dv * a.d[i];
+    return r;
+}
+#define LMC_DUAL_T template <int N> LMC_HD Dual<N>
+LMC_DUAL_T operator+(const Dual<N> &a, const Dual<N> &b) {
+    Dual<N> r;
+    r.v = a.v + b.v;
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+LMC_DUAL_T operator-(const Dual<N> &a, const Dual<N> &b) {
+    Dual<N> r;
+    r.v = a.v - b.v;
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+LMC_DUAL_T operator*(const Dual<N> &a, const Dual<N> &b) {
+    Dual<N> r;
+    r.v = a.v * b.v;
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+LMC_DUAL_T operator/(const Dual<N> &a, const Dual<N> &b) {
+    Dual<N> r;
+    float inv = 1.0f / b.v;
+    r.v = a.v * inv;
+    for (int i = 0; i < N; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+LMC_DUAL_T operator-(const Dual<N> &a) {
+    Dual<N> r;
+    r.v = -a.v;
+    for (int i = 0; i < N; i++) r.d[i] = -a.d[i];
+    return r;
+}
+LMC_DUAL_T operator+(const Dual<N> &a, float b) { Dual<N> r = a; r.v += b; return r; }
+LMC_DUAL_T operator+(float b, const Dual<N> &a) { Dual<N> r = a; r.v += b; return r; }
+LMC_DUAL_T operator-(const Dual<N> &a, float b) { Dual<N> r = a; r.v -= b; return r; }
+LMC_DUAL_T operator-(float b, const Dual<N> &a) { Dual<N> r = -a; r.v += b; return r; }
+LMC_DUAL_T operator*(const Dual<N> &a, float b) { return Chain1(a, a.v * b, b); }
+LMC_DUAL_T operator*(float b, const Dual<N> &a) { return Chain1(a, a.v * b, b); }
+LMC_DUAL_T operator/(const Dual<N> &a, float b) { float inv = 1.0f / b; return Chain1(a, a.v * inv, inv); }
+LMC_DUAL_T operator/(float b, const Dual<N> &a) { float inv = 1.0f / a.v; return Chain1(a, b * inv, -b * inv * inv); }
+template <int N> LMC_HD bool operator<(const Dual<N> &a, float b) { return a.v < b; }
+template <int N> LMC_HD bool operator>(const Dual<N> &a, float b) { return a.v > b; }
+template <int N> LMC_HD bool operator<(const Dual<N> &a, const Dual<N> &b) { return a.v < b.v; }
+template <int N> LMC_HD bool operator>(const Dual<N> &a, const Dual<N> &b) { return a.v > b.v; }
+
+LMC_HD float Val(float x) { return x; }
+template <int N> LMC_HD float Val(const Dual<N> &x) { return x.v; }
+
+LMC_HD float Sqrt(float x) { return sqrtf(x); }
+LMC_HD float Sin(float x) { return sinf(x); }
+LMC_HD float Cos(float x) { return cosf(x); }
+LMC_HD float Acos(float x) { return acosf(x); }
+LMC_HD float Atan2(float y, float x) { return atan2f(y, x); }
+LMC_HD float Fabs(float x) { return fabsf(x); }
+LMC_HD float Log(float x) { return logf(x); }
+LMC_HD float Exp(float x) { return expf(x); }
+LMC_HD float Fmax(float a, float b) { return fmaxf(a, b); }
+LMC_DUAL_T Sqrt(const Dual<N> &a) { float s = sqrtf(a.v); return Chain1(a, s, 0.5f / s); }
+LMC_DUAL_T Sin(const Dual<N> &a) { return Chain1(a, sinf(a.v), cosf(a.v)); }
+LMC_DUAL_T Cos(const Dual<N> &a) { return Chain1(a, cosf(a.v), -sinf(a.v)); }
+LMC_DUAL_T Acos(const Dual<N> &a) { return Chain1(a, acosf(a.v), -1.0f / sqrtf(1.0f - a.v * a.v)); }
+LMC_DUAL_T Atan2(const Dual<N> &y, const Dual<N> &x) {
+    Dual<N> r;
+    r.v = atan2f(y.v, x.v);
+    float inv = 1.0f / (x.v * x.v + y.v * y.v);
+    for (int i = 0; i < N; i++) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * inv;
+    return r;
+}
+LMC_DUAL_T Fabs(const Dual<N> &a) { return a.v >= 0.f ? a : -a; }  // chad.h:1226-1234: x >= 0 ? x : -x
+LMC_DUAL_T Log(const Dual<N> &a) { return Chain1(a, logf(a.v), 1.0f / a.v); }
+LMC_DUAL_T Exp(const Dual<N> &a) { float e = expf(a.v); return Chain1(a, e, e); }
+LMC_DUAL_T Fmax(const Dual<N> &a, float b) { return a.v >= b ? a : MakeDual<N>(b); }  // chad.h:1236-1244: a >= b ? a : b
+
+// ------------------------------------------------------------------------------------------ small vectors
+template <class T>
+struct V3T {
+    T x, y, z;
+};
+template <class T> LMC_HD V3T<T> operator+(const V3T<T> &a, const V3T<T> &b) { return V3T<T>{a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> LMC_HD V3T<T> operator-(const V3T<T> &a, const V3T<T> &b) { return V3T<T>{a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> LMC_HD V3T<T> operator-(const V3T<T> &a) { return V3T<T>{-a.x, -a.y, -a.z}; }
+template <class T> LMC_HD V3T<T> operator*(const V3T<T> &a, const T &s) { return V3T<T>{a.x * s, a.y * s, a.z * s}; }
+template <class T> LMC_HD V3T<T> operator*(const T &s, const V3T<T> &a) { return V3T<T>{a.x * s, a.y * s, a.z * s}; }
+template <class T> LMC_HD V3T<T> Cmul(const V3T<T> &a, const V3T<T> &b) { return V3T<T>{a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <class T> LMC_HD T DotT(const V3T<T> &a, const V3T<T> &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> LMC_HD T LenSqT(const V3T<T> &a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+template <class T> LMC_HD T DistSqT(const V3T<T> &a, const V3T<T> &b) { return LenSqT(a - b); }
+template <class T> LMC_HD V3T<T> NormalizeT(const V3T<T> &a) {
+    T invLen = 1.0f / Sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return a * invLen;
+}
+template <class T> LMC_HD V3T<T> CrossT(const V3T<T> &a, const V3T<T> &b) {
+    return V3T<T>{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class T> LMC_HD T LumT(const V3T<T> &v) { return v.x * 0.212671f + v.y * 0.715160f + v.z * 0.072169f; }
+
+template <class T> struct Lift;  // constant -> T
+template <> struct Lift<float> { static LMC_HD float Of(float v) { return v; } };
+template <int N> struct Lift<Dual<N>> { static LMC_HD Dual<N> Of(float v) { return MakeDual<N>(v); } };
+template <class T> LMC_HD V3T<T> C3(float a, float b, float c) { return V3T<T>{Lift<T>::Of(a), Lift<T>::Of(b), Lift<T>::Of(c)}; }
+template <class T> LMC_HD T MISq(const T &p) { return p * p; }
+
+template <class T>
+struct PState {  // ADBidirPathState, path.cpp:2789-2797 (lensContrib only feeds PathFuncMode::Lens)
+    V3T<T> position, shadingNormal, geomNormal, wi;
+    T accMISWPrev, accMISWThis;
+    V3T<T> throughput;
+};
+
+// rotation part of ToMatrix4x4(AnimatedTransform) for isStatic (animatedtransform.cpp:57-59, quaternion.h:13-40)
+struct Rot3 {
+    float m[3][3];
+    float t[3];
+};
+template <class In>
+LMC_HD Rot3 ReadXform(const In &b, int off) {  // 15-float block [isMoving, t0(3), t1(3), q0(4), q1(4)]
+    Rot3 r;
+    r.t[0] = b[off + 1], r.t[1] = b[off + 2], r.t[2] = b[off + 3];
+    float q0 = b[off + 7], q1 = b[off + 8], q2 = b[off + 9], q3 = b[off + 10];
+    float xx = q0 * q0, yy = q1 * q1, zz = q2 * q2, xy = q0 * q1, xz = q0 * q2, yz = q1 * q2, wx = q0 * q3, wy = q1 * q3, wz = q2 * q3;
+    r.m[0][0] = 1.f - 2.f * (yy + zz), r.m[0][1] = 2.f * (xy - wz), r.m[0][2] = 2.f * (xz + wy);
+    r.m[1][0] = 2.f * (xy + wz), r.m[1][1] = 1.f - 2.f * (xx + zz), r.m[1][2] = 2.f * (yz - wx);
+    r.m[2][0] = 2.f * (xz - wy), r.m[2][1] = 2.f * (yz + wx), r.m[2][2] = 1.f - 2.f * (xx + yy);
+    return r;
+}
+template <class T>
+LMC_HD V3T<T> RotVec(const Rot3 &r, const V3T<T> &v) {
+    return V3T<T>{v.x * r.m[0][0] + v.y * r.m[0][1] + v.z * r.m[0][2], v.x * r.m[1][0] + v.y * r.m[1][1] + v.z * r.m[1][2],
+                  v.x * r.m[2][0] + v.y * r.m[2][1] + v.z * r.m[2][2]};
+}
+
+struct SceneBlk {  // scene.cpp:164-169
+    float useLightCoord;
+    float s2c[4][4];  // sampleToCam, row-major here
+    Rot3 camToWorld;
+    float pixelCount, camDist, bsCenter[3], bsRadius;
+};
+LMC_HD SceneBlk ReadScene(const float *s) {
+    SceneBlk b;
+    b.useLightCoord = s[0];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) b.s2c[j][i] = s[1 + i * 4 + j];  // column-major stream (utils.h:331-348)
+    b.camToWorld = ReadXform(ContigIn{s}, 17);
+    b.pixelCount = s[32], b.camDist = s[33];
+    b.bsCenter[0] = s[34], b.bsCenter[1] = s[35], b.bsCenter[2] = s[36], b.bsRadius = s[37];
+    return b;
+}
+
+// camera.cpp:53-65 (isStatic)
+template <class T>
+LMC_HD void SamplePrimaryT(const SceneBlk &sc, const T &sx, const T &sy, V3T<T> &org, V3T<T> &dir) {
+    T tx = sx * sc.s2c[0][0] + sy * sc.s2c[0][1] + sc.s2c[0][3];
+    T ty = sx * sc.s2c[1][0] + sy * sc.s2c[1][1] + sc.s2c[1][3];
+    T tz = sx * sc.s2c[2][0] + sy * sc.s2c[2][1] + sc.s2c[2][3];
+    T tw = sx * sc.s2c[3][0] + sy * sc.s2c[3][1] + sc.s2c[3][3];
+    T invW = 1.0f / tw;
+    V3T<T> o{tx * invW, ty * invW, tz * invW};
+    V3T<T> d = NormalizeT(o);
+    org = C3<T>(sc.camToWorld.t[0], sc.camToWorld.t[1], sc.camToWorld.t[2]);  // XformPoint(toWorld, 0) = translation (w = 1)
+    dir = RotVec(sc.camToWorld, d);
+}
+
+// trianglemesh.cpp:55-77 + IntersectTriangleMesh :367-473 (isStatic); consumes the 46-float shape slot
+template <class T, class In>
+LMC_HD void IntersectT(const In &b, int off, const V3T<T> &org, const V3T<T> &dir, PState<T> &ps, T &st0, T &st1) {
+    // [type, isMoving, p0, e1, e2, n0, n1, n2, (same at t=1), noST, st0, st1, st2, invTotalArea]
+    V3T<T> p0 = C3<T>(b[off + 2], b[off + 3], b[off + 4]), e1 = C3<T>(b[off + 5], b[off + 6], b[off + 7]), e2 = C3<T>(b[off + 8], b[off + 9], b[off + 10]);
+    V3T<T> n0 = C3<T>(b[off + 11], b[off + 12], b[off + 13]), n1 = C3<T>(b[off + 14], b[off + 15], b[off + 16]), n2 = C3<T>(b[off + 17], b[off + 18], b[off + 19]);
+    ps.geomNormal = NormalizeT(CrossT(e1, e2));
+    V3T<T> s1 = CrossT(dir, e2);
+    T divisor = DotT(s1, e1);
+    T invDivisor = 1.0f / divisor;
+    V3T<T> s = org - p0;
+    T u = DotT(s, s1) * invDivisor;
+    V3T<T> s2 = CrossT(s, e1);
+    T v = DotT(dir, s2) * invDivisor;
+    T t = DotT(e2, s2) * invDivisor;
+    T w = 1.0f - u - v;
+    ps.position = org + dir * t;
+    ps.shadingNormal = NormalizeT(n0 * w + n1 * u + n2 * v);
+    const float noST = b[off + 38];
+    if (noST == 0.0f) {  // AD reads the flag as "hasST" and uses barycentrics when it is 0 (trianglemesh.cpp:462); st is not used afterwards
+        st0 = u, st1 = v;
+    } else {
+        st0 = (1.0f - u - v) * b[off + 39] + u * b[off + 41] + v * b[off + 43];
+        st1 = (1.0f - u - v) * b[off + 40] + u * b[off + 42] + v * b[off + 44];
+    }
+}
+
+// SampleDirect on a triangle, trianglemesh.cpp:291-305 with ADEpsilon = 1e-6
+template <class T, class In>
+LMC_HD void SampleShapeT(const In &b, int off, const T &r0, const T &r1, V3T<T> &pos, V3T<T> &nrm, float &pdf) {
+    V3T<T> p0 = C3<T>(b[off + 2], b[off + 3], b[off + 4]), e1 = C3<T>(b[off + 5], b[off + 6], b[off + 7]), e2 = C3<T>(b[off + 8], b[off + 9], b[off + 10]);
+    V3T<T> n0 = C3<T>(b[off + 11], b[off + 12], b[off + 13]), n1 = C3<T>(b[off + 14], b[off + 15], b[off + 16]), n2 = C3<T>(b[off + 17], b[off + 18], b[off + 19]);
+    T a = Sqrt((1.0f + 1e-6f) - r0);
+    T b1 = 1.0f - a;
+    T b2 = a * r1;
+    pos = p0 + e1 * b1 + e2 * b2;
+    nrm = NormalizeT(n0 * (1.0f - b1 - b2) + n1 * b1 + n2 * b2);
+    pdf = b[off + 45];
+}
+
+template <class T>
+LMC_HD void CoordinateSystemT(const V3T<T> &n, V3T<T> &b1, V3T<T> &b2) {  // utils.h:249-273
+    if (Val(n.z) < float(-1.0 + 1e-6)) {
+        b1 = C3<T>(0.f, -1.f, 0.f);
+        b2 = C3<T>(-1.f, 0.f, 0.f);
+        return;
+    }
+    T a = 1.0f / (1.0f + n.z);
+    T b = -n.x * n.y * a;
+    b1 = V3T<T>{1.0f - n.x * n.x * a, b, -n.x};
+    b2 = V3T<T>{b, 1.0f - n.y * n.y * a, -n.y};
+}
+
+template <class T>
+LMC_HD V3T<T> SampleCosHemisphereT(const T &r0, const T &r1) {  // sampling.h:104-110 with ADEpsilon
+    T phi = c_TWOPI * r0;
+    T tmp = Sqrt(Fmax(1.0f - r1, 1e-6f));
+    return V3T<T>{Cos(phi) * tmp, Sin(phi) * tmp, Sqrt(Fmax(r1, 1e-6f))};
+}
+template <class T>
+LMC_HD V3T<T> SampleSphereT(const T &c0, const T &c1, T &jacobian) {  // sampling.h:6-16
+    T scaledTheta = c_TWOPI * c0;
+    T scaledPhi = c_PI * c1;
+    T sinPhi = Sin(scaledPhi), cosPhi = Cos(scaledPhi);
+    jacobian = Fabs(sinPhi) * (c_TWOPI * c_PI);
+    return V3T<T>{sinPhi * Cos(scaledTheta), sinPhi * Sin(scaledTheta), cosPhi};
+}
+template <class T>
+LMC_HD T TentT(const T &s) {  // utils.h:283-291
+    if (Val(s) < 0.5f) return 1.0f - Sqrt(2.0f * s);
+    return Sqrt(2.0f * (s - 0.5f)) - 1.0f;
+}
+
+template <class T>
+LMC_HD T ShadingNormalCorrectionAdj(const V3T<T> &wi, const PState<T> &ps, const V3T<T> &wo) {  // path.cpp:56-70, adjoint = true
+    T cosWi = DotT(ps.shadingNormal, wi), cosWo = DotT(ps.shadingNormal, wo);
+    T wiDotGeoN = DotT(ps.geomNormal, wi), woDotGeoN = DotT(ps.geomNormal, wo);
+    return Fabs((woDotGeoN * cosWi) / (wiDotGeoN * cosWo));
+}
+
+// ------------------------------------------------------------------------------------------ BSDFs (10-float slot)
+// EvaluateBSDF, bsdf.cpp:13-63.  Unknown types produce zeros like the generated else-branch.
+template <class T, class In>
+LMC_HD void EvaluateBSDFT(bool /*adjoint*/, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
+                          T &pdf, T &revPdf) {
+    const float type = b[off];
+    if (type == (float)0 /*Lambertian*/) {  // lambertian.cpp:95-122
+        T cosWi = DotT(normal, wi);
+        V3T<T> n = normal;
+        if (!(Val(cosWi) > 0.0f)) {
+            n = -normal;
+            cosWi = -cosWi;
+        }
+        cosWo = DotT(n, wo);
+        T fwdScalar = cosWo * c_INVPI;
+        contrib = C3<T>(b[off + 1], b[off + 2], b[off + 3]) * fwdScalar;
+        pdf = fwdScalar;
+        revPdf = cosWi * c_INVPI;
+    } else {
+        // Phong / RoughDielectric twins (phong.cpp:171-393, roughdielectric.cpp:332-528): SURVEY.md §8 config 3, not built yet
+        contrib = C3<T>(NAN, NAN, NAN);
+        cosWo = pdf = revPdf = Lift<T>::Of(NAN);
+    }
+}
+// SampleBSDF, bsdf.cpp:65-171 (fixDiscrete = false)
+template <class T, class In>
+LMC_HD void SampleBSDFT(bool /*adjoint*/, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const T &r0, const T &r1, float /*uDiscrete*/,
+                        V3T<T> &wo, V3T<T> &contrib, T &cosWo, T &pdf, T &revPdf) {
+    const float type = b[off];
+    if (type == (float)0) {  // lambertian.cpp:124-151
+        T cosWi = DotT(wi, normal);
+        V3T<T> n = normal;
+        if (!(Val(cosWi) > 0.0f)) {
+            n = -normal;
+            cosWi = -cosWi;
+        }
+        V3T<T> b0, b1;
+        CoordinateSystemT(n, b0, b1);
+        V3T<T> ret = SampleCosHemisphereT(r0, r1);
+        wo = b0 * ret.x + b1 * ret.y + n * ret.z;
+        cosWo = ret.z;
+        pdf = ret.z * c_INVPI;
+        contrib = C3<T>(b[off + 1], b[off + 2], b[off + 3]);
+        revPdf = cosWi * c_INVPI;
+    } else {
+        wo = contrib = C3<T>(NAN, NAN, NAN);
+        cosWo = pdf = revPdf = Lift<T>::Of(NAN);
+    }
+}
+
+// BSDFSampling<adjoint, fixedDiscrete=false>, path.cpp:2962-3135 (doLightCoordinateSampling branch: the
+// reference only takes it when scene[0] == 1, i.e. uselightcoordinatesampling, SURVEY.md §8f.4 -- not built)
+template <bool adjoint, class T, class In>
+LMC_HD void BSDFSamplingT(const In &b, int off, const T &r0, const T &r1, float bsdfDiscrete, float useAbs, PState<T> &ps, V3T<T> &dir) {
+    V3T<T> bsdfContrib;
+    T cosWo, bsdfPdf, bsdfRevPdf, jacobian;
+    if (useAbs == 0.0f) {
+        SampleBSDFT(adjoint, b, off, ps.wi, ps.shadingNormal, r0, r1, bsdfDiscrete, dir, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+        jacobian = Lift<T>::Of(1.0f);
+    } else {
+        dir = SampleSphereT(r0, r1, jacobian);
+        EvaluateBSDFT(adjoint, b, off, ps.wi, ps.shadingNormal, dir, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+    }
+    if (adjoint) {
+        T factor = ShadingNormalCorrectionAdj(ps.wi, ps, dir);
+        bsdfContrib = bsdfContrib * factor;
+    }
+    bsdfContrib = bsdfContrib * jacobian;
+    ps.accMISWThis = MISq(cosWo / bsdfPdf) * (ps.accMISWThis * MISq(bsdfRevPdf) + ps.accMISWPrev);
+    ps.accMISWPrev = MISq(1.0f / bsdfPdf);
+    ps.throughput = Cmul(ps.throughput, bsdfContrib);
+}
+
+// ------------------------------------------------------------------------------------------ lights (56-float slot)
+struct EnvBlk {
+    Rot3 toWorld, toLight;
+    float cdfCol0, cdfCol1, cdfRow0, cdfRow1, col, row, pix0, pix1;
+    float img[4][3];
+    float rowWeight0, rowWeight1, normalization;
+};
+template <class In>
+LMC_HD EnvBlk ReadEnv(const In &b, int off) {  // after the type float: 15 + 15 + 8 + 12 + 3 (envlight.cpp:270-288)
+    EnvBlk e;
+    e.toWorld = ReadXform(b, off + 1);
+    e.toLight = ReadXform(b, off + 16);
+    int o = off + 31;
+    e.cdfCol0 = b[o + 0], e.cdfCol1 = b[o + 1], e.cdfRow0 = b[o + 2], e.cdfRow1 = b[o + 3], e.col = b[o + 4], e.row = b[o + 5], e.pix0 = b[o + 6], e.pix1 = b[o + 7];
+    for (int k = 0; k < 4; k++)
+        for (int c = 0; c < 3; c++) e.img[k][c] = b[o + 8 + k * 3 + c];
+    e.rowWeight0 = b[o + 20], e.rowWeight1 = b[o + 21], e.normalization = b[o + 22];
+    return e;
+}
+template <class T>
+LMC_HD void EnvSampleDirectionT(const EnvBlk &e, const T &r0, const T &r1, V3T<T> &dirToLight, V3T<T> &value, T &pdf) {  // envlight.cpp:290-322
+    T u0 = (r0 - e.cdfCol0) / (e.cdfCol1 - e.cdfCol0);
+    T u1 = (r1 - e.cdfRow0) / (e.cdfRow1 - e.cdfRow0);
+    T tent0 = TentT(u0), tent1 = TentT(u1);
+    T phi = ((e.col + tent0) + 0.5f) * e.pix0;
+    T theta = ((e.row + tent1) + 0.5f) * e.pix1;
+    T sinPhi = Sin(phi), cosPhi = Cos(phi), sinTheta = Sin(theta), cosTheta = Cos(theta);
+    dirToLight = RotVec(e.toWorld, V3T<T>{sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta});
+    T dx1 = tent0, dx2 = 1.0f - tent0, dy1 = tent1, dy2 = 1.0f - tent1;
+    V3T<T> value1 = C3<T>(e.img[0][0], e.img[0][1], e.img[0][2]) * dx2 * dy2 + C3<T>(e.img[1][0], e.img[1][1], e.img[1][2]) * dx1 * dy2;
+    V3T<T> value2 = C3<T>(e.img[2][0], e.img[2][1], e.img[2][2]) * dx2 * dy1 + C3<T>(e.img[3][0], e.img[3][1], e.img[3][2]) * dx1 * dy1;
+    value = value1 + value2;
+    pdf = (LumT(value1) * e.rowWeight0 + LumT(value2) * e.rowWeight1) * e.normalization / Fmax(Fabs(sinTheta), 1e-7f);
+}
+
+// SampleDirect dispatcher, light.cpp:12-138
+template <class T, class In>
+LMC_HD void SampleDirectT(const In &b, int off, const SceneBlk &sc, const V3T<T> &pos, const T &r0, const T &r1, V3T<T> &dirToLight, V3T<T> &lightContrib,
+                          T &cosAtLight, T &directPdf, T &emissionPdf) {
+    const float type = b[off];
+    if (type == 0.0f) {  // point, pointlight.cpp:20-31,74-93
+        V3T<T> lightPos = C3<T>(b[off + 1], b[off + 2], b[off + 3]), emission = C3<T>(b[off + 4], b[off + 5], b[off + 6]);
+        dirToLight = lightPos - pos;
+        T distSq = LenSqT(dirToLight);
+        directPdf = distSq;
+        T dist = Sqrt(distSq);
+        dirToLight = dirToLight * (1.0f / dist);
+        lightContrib = emission * (1.0f / distSq);
+        emissionPdf = Lift<T>::Of(c_INVFOURPI);
+        cosAtLight = Lift<T>::Of(1.0f);
+    } else if (type == 1.0f) {  // area, arealight.cpp:106-135
+        V3T<T> posOnLight, normalOnLight;
+        float shapePdf;
+        SampleShapeT(b, off + 1, r0, r1, posOnLight, normalOnLight, shapePdf);
+        V3T<T> emission = C3<T>(b[off + 47], b[off + 48], b[off + 49]);
+        dirToLight = posOnLight - pos;
+        T distSq = LenSqT(dirToLight);
+        T dist = Sqrt(distSq);
+        dirToLight = dirToLight * (1.0f / dist);
+        cosAtLight = -DotT(dirToLight, normalOnLight);
+        directPdf = shapePdf * distSq / cosAtLight;
+        lightContrib = emission * (1.0f / directPdf);
+        emissionPdf = shapePdf * cosAtLight * c_INVPI;
+    } else if (type == 2.0f) {  // env, envlight.cpp:324-346
+        EnvBlk e = ReadEnv(b, off);
+        V3T<T> value;
+        EnvSampleDirectionT(e, r0, r1, dirToLight, value, directPdf);
+        lightContrib = value * (1.0f / directPdf);
+        cosAtLight = Lift<T>::Of(1.0f);
+        float positionPdf = c_INVPI / (sc.bsRadius * sc.bsRadius);
+        emissionPdf = directPdf * positionPdf;
+    } else {
+        dirToLight = lightContrib = C3<T>(0, 0, 0);
+        cosAtLight = directPdf = emissionPdf = Lift<T>::Of(0.f);
+    }
+}
+
+// Emission dispatcher, light.cpp:140-185
+template <class T, class In>
+LMC_HD void EmissionT(const In &b, int off, const SceneBlk &sc, const V3T<T> &dirToLight, const V3T<T> &normalOnLight, V3T<T> &emission, T &directPdf,
+                      T &emissionPdf) {
+    const float type = b[off];
+    if (type == 1.0f) {  // arealight.cpp:157-174
+        float shapePdf = b[off + 1 + 45];
+        emission = C3<T>(b[off + 47], b[off + 48], b[off + 49]);
+        T cosAtLight = -DotT(normalOnLight, dirToLight);
+        directPdf = Lift<T>::Of(shapePdf);
+        emissionPdf = cosAtLight * shapePdf * c_INVPI;
+    } else if (type == 2.0f) {  // envlight.cpp:348-377
+        EnvBlk e = ReadEnv(b, off);
+        V3T<T> d = RotVec(e.toLight, dirToLight);
+        T uv0 = Atan2(d.x, -d.z) / e.pix0 - 0.5f;
+        T uv1 = Acos(d.y) / e.pix1 - 0.5f;
+        T dx1 = uv0 - e.col, dx2 = 1.0f - dx1, dy1 = uv1 - e.row, dy2 = 1.0f - dy1;
+        V3T<T> value1 = C3<T>(e.img[0][0], e.img[0][1], e.img[0][2]) * dx2 * dy2 + C3<T>(e.img[1][0], e.img[1][1], e.img[1][2]) * dx1 * dy2;
+        V3T<T> value2 = C3<T>(e.img[2][0], e.img[2][1], e.img[2][2]) * dx2 * dy1 + C3<T>(e.img[3][0], e.img[3][1], e.img[3][2]) * dx1 * dy1;
+        emission = value1 + value2;
+        T sinTheta = Sqrt(Fmax(1.0f - d.y * d.y, 1e-6f));
+        directPdf = (LumT(value1) * e.rowWeight0 + LumT(value2) * e.rowWeight1) * e.normalization / Fmax(Fabs(sinTheta), 1e-7f);
+        float positionPdf = c_INVPI / (sc.bsRadius * sc.bsRadius);
+        emissionPdf = directPdf * positionPdf;
+    } else {
+        emission = C3<T>(0, 0, 0);
+        directPdf = emissionPdf = Lift<T>::Of(0.f);
+    }
+}
+
+template <class T>
+LMC_HD void SampleConcentricDiscT(const T &p0, const T &p1, T &ox, T &oy) {  // sampling.h:65-97
+    T r1 = 2.0f * p0 - 1.0f, r2 = 2.0f * p1 - 1.0f;
+    T r, phi;
+    if (Val(r1) == 0.0f || Val(r2) == 0.0f) {
+        r = Lift<T>::Of(0.f), phi = Lift<T>::Of(0.f);
+    } else if (Val(r1) * Val(r1) > Val(r2) * Val(r2)) {
+        r = r1;
+        phi = c_PIOVERFOUR * (r2 / r1);
+    } else {
+        r = r2;
+        phi = c_PIOVERTWO - (r1 / r2) * c_PIOVERFOUR;
+    }
+    ox = r * Cos(phi), oy = r * Sin(phi);
+}
+
+// Emit dispatcher, light.cpp:187-324
+template <class T, class In>
+LMC_HD void EmitT(const In &b, int off, const SceneBlk &sc, const T &p0, const T &p1, const T &d0, const T &d1, V3T<T> &org, V3T<T> &dir, V3T<T> &emission,
+                  T &cosAtLight, T &emissionPdf, T &directPdf) {
+    const float type = b[off];
+    if (type == 0.0f) {  // pointlight.cpp:95-116
+        org = C3<T>(b[off + 1], b[off + 2], b[off + 3]);
+        T j;
+        dir = SampleSphereT(d0, d1, j);
+        emission = C3<T>(b[off + 4], b[off + 5], b[off + 6]);
+        emissionPdf = Lift<T>::Of(c_INVFOURPI);
+        cosAtLight = directPdf = Lift<T>::Of(1.0f);
+    } else if (type == 1.0f) {  // arealight.cpp:176-208
+        V3T<T> normalOnLight;
+        float shapePdf;
+        SampleShapeT(b, off + 1, p0, p1, org, normalOnLight, shapePdf);
+        V3T<T> d = SampleCosHemisphereT(d0, d1);
+        V3T<T> b0, b1;
+        CoordinateSystemT(normalOnLight, b0, b1);
+        dir = b0 * d.x + b1 * d.y + normalOnLight * d.z;
+        emission = C3<T>(b[off + 47], b[off + 48], b[off + 49]) * Lift<T>::Of(c_PI / shapePdf);
+        cosAtLight = d.z;
+        emissionPdf = d.z * c_INVPI * shapePdf;
+        directPdf = Lift<T>::Of(shapePdf);
+    } else if (type == 2.0f) {  // envlight.cpp:379-400
+        EnvBlk e = ReadEnv(b, off);
+        EnvSampleDirectionT(e, d0, d1, dir, emission, directPdf);
+        dir = -dir;
+        T ox, oy;
+        SampleConcentricDiscT(p0, p1, ox, oy);
+        V3T<T> b0, b1;
+        CoordinateSystemT(dir, b0, b1);
+        V3T<T> perp = b0 * ox + b1 * oy;
+        org = C3<T>(sc.bsCenter[0], sc.bsCenter[1], sc.bsCenter[2]) + (perp - dir) * Lift<T>::Of(sc.bsRadius);
+        cosAtLight = Lift<T>::Of(1.0f);
+        float positionPdf = c_INVPI / (sc.bsRadius * sc.bsRadius);
+        emissionPdf = directPdf * positionPdf;
+    } else {
+        org = dir = emission = C3<T>(0, 0, 0);
+        cosAtLight = emissionPdf = directPdf = Lift<T>::Of(0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ the program
+// RegisterPathFuncBidirMALA, PathFuncMode::Static (path.cpp:3664-3911).  Returns log Luminance(contrib).
+template <class T, class In>
+LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L+1], [0] = time (inactive) */, const float *scene, const In &vp) {
+    const SceneBlk sc = ReadScene(scene);
+    int buf = 3;  // lensVertexPos
+    int pi = 1;
+    int lgtBSDFOff = -1;
+    PState<T> lps, cps;
+    V3T<T> contrib = C3<T>(0, 0, 0);
+    if (maxLightDepth > 1) {
+        const float lightPickProb = vp[buf++];
+        const int lightOff = buf;
+        const float lightType = vp[lightOff];
+        V3T<T> org, dir;
+        T rp0 = primary[pi++], rp1 = primary[pi++], rd0 = primary[pi++], rd1 = primary[pi++];
+        {  // EmitFromLight, path.cpp:2799-2841
+            T cosLight, emissionPdf, directPdf;
+            EmitT(vp, lightOff, sc, rp0, rp1, rd0, rd1, org, dir, lps.throughput, cosLight, emissionPdf, directPdf);
+            buf += 56;
+            emissionPdf = emissionPdf * lightPickProb;
+            directPdf = directPdf * lightPickProb;
+            lps.throughput = lps.throughput * Lift<T>::Of(1.0f / lightPickProb);
+            lps.accMISWPrev = MISq(directPdf / emissionPdf);
+            // NB: the generated program has the IsDelta test inverted w.r.t. path.cpp:611-615 (path.cpp:2833-2838)
+            lps.accMISWThis = (lightType == 0.0f) ? MISq(cosLight / emissionPdf) : Lift<T>::Of(0.0f);
+        }
+        for (int lgtDepth = 0; lgtDepth < maxLightDepth - 1; lgtDepth++) {
+            T st0, st1;
+            IntersectT(vp, buf, org, dir, lps, st0, st1);
+            buf += 46;
+            const float bsdfDiscrete = vp[buf++], useAbs = vp[buf++];
+            lps.wi = -dir;
+            if (lgtDepth == 0) {  // ConvertMISLightEmit, path.cpp:2843-2856
+                T invCosTheta = 1.0f / MISq(Fabs(DotT(dir, lps.shadingNormal)));
+                if (lightType == 2.0f) {
+                    lps.accMISWPrev = lps.accMISWPrev * invCosTheta;
+                } else {
+                    lps.accMISWPrev = lps.accMISWPrev * (invCosTheta * MISq(DistSqT(org, lps.position)));
+                }
+                lps.accMISWThis = lps.accMISWThis * invCosTheta;
+            } else {  // ConvertMIS, path.cpp:2876-2882
+                lps.accMISWPrev = lps.accMISWPrev * MISq(DistSqT(org, lps.position));
+                T invCosTheta = 1.0f / MISq(Fabs(DotT(dir, lps.shadingNormal)));
+                lps.accMISWPrev = lps.accMISWPrev * invCosTheta;
+                lps.accMISWThis = lps.accMISWThis * invCosTheta;
+            }
+            if (lgtDepth == maxLightDepth - 2) {
+                if (maxCamDepth == 1) {  // ConnectToCamera, path.cpp:2884-2960
+                    V3T<T> camOrg, camDir;
+                    SamplePrimaryT(sc, Lift<T>::Of(0.5f), Lift<T>::Of(0.5f), camOrg, camDir);
+                    V3T<T> dirToCamera = camOrg - lps.position;
+                    T distSq = LenSqT(dirToCamera);
+                    T dist = Sqrt(distSq);
+                    dirToCamera = dirToCamera * (1.0f / dist);
+                    V3T<T> bsdfContrib;
+                    T cosToCamera, bsdfPdf, bsdfRevPdf;
+                    EvaluateBSDFT(true, vp, buf, lps.wi, lps.shadingNormal, dirToCamera, bsdfContrib, cosToCamera, bsdfPdf, bsdfRevPdf);
+                    T factor = ShadingNormalCorrectionAdj(lps.wi, lps, dirToCamera);
+                    bsdfContrib = bsdfContrib * factor;
+                    T invCosAtCamera = -(1.0f / DotT(camDir, dirToCamera));
+                    T imagePointToCameraDist = sc.camDist * invCosAtCamera;
+                    T imageToSolidAngleFactor = imagePointToCameraDist * imagePointToCameraDist * invCosAtCamera;
+                    T imageToSurfaceFactor = imageToSolidAngleFactor * Fabs(cosToCamera) / distSq;
+                    T wLight = MISq(imageToSurfaceFactor / sc.pixelCount) * (lps.accMISWPrev + lps.accMISWThis * MISq(bsdfRevPdf));
+                    T misWeight = 1.0f / (wLight + 1.0f);
+                    T surfaceToImageFactor = cosToCamera / imageToSurfaceFactor;
+                    V3T<T> c = bsdfContrib * (misWeight / (sc.pixelCount * surfaceToImageFactor));
+                    lps.throughput = Cmul(c, lps.throughput);
+                    contrib = lps.throughput;
+                }
+                lgtBSDFOff = buf;
+                buf += 10;
+                break;
+            }
+            T r0 = primary[pi++], r1 = primary[pi++];
+            BSDFSamplingT<true>(vp, buf, r0, r1, bsdfDiscrete, useAbs, lps, dir);
+            buf += 10;
+            const float rrWeight = vp[buf++];
+            lps.throughput = lps.throughput * Lift<T>::Of(rrWeight);
+            org = lps.position;
+        }
+    }
+    if (maxCamDepth > 1) {
+        T sx = primary[pi++], sy = primary[pi++];
+        V3T<T> org, dir;
+        {  // EmitFromCamera, path.cpp:3138-3170
+            V3T<T> cOrg, camDir;
+            SamplePrimaryT(sc, Lift<T>::Of(0.5f), Lift<T>::Of(0.5f), cOrg, camDir);
+            SamplePrimaryT(sc, sx, sy, org, dir);
+            T cosAtCamera = DotT(camDir, dir);
+            T imagePointToCameraDist = sc.camDist / cosAtCamera;
+            T cameraPdf = imagePointToCameraDist * imagePointToCameraDist / cosAtCamera;
+            cps.throughput = C3<T>(1, 1, 1);
+            cps.accMISWPrev = MISq(sc.pixelCount / cameraPdf);
+            cps.accMISWThis = Lift<T>::Of(0.0f);
+        }
+        for (int camDepth = 0; camDepth < maxCamDepth - 1; camDepth++) {
+            T st0, st1;
+            IntersectT(vp, buf, org, dir, cps, st0, st1);
+            buf += 46;
+            cps.wi = -dir;
+            if (camDepth == maxCamDepth - 2 && maxLightDepth == 0) {
+                const float lightType = vp[buf];
+                {  // ConvertMISLightHit, path.cpp:2858-2874
+                    if (lightType != 2.0f) {
+                        T distSq = MISq(DistSqT(org, cps.position));
+                        T invCosTheta = 1.0f / MISq(Fabs(DotT(dir, cps.shadingNormal)));
+                        cps.accMISWPrev = cps.accMISWPrev * (invCosTheta * distSq);
+                        cps.accMISWThis = cps.accMISWThis * invCosTheta;
+                    }
+                }
+                {  // HandleHitLight, path.cpp:3172-3200
+                    V3T<T> emission;
+                    T directPdf, emissionPdf;
+                    EmissionT(vp, buf, sc, dir, cps.shadingNormal, emission, directPdf, emissionPdf);
+                    cps.throughput = Cmul(cps.throughput, emission);
+                    const float lightPickProb = vp[buf + 56];
+                    directPdf = directPdf * lightPickProb;
+                    emissionPdf = emissionPdf * lightPickProb;
+                    T wCamera = MISq(directPdf) * cps.accMISWPrev + MISq(emissionPdf) * cps.accMISWThis;
+                    T misWeight = 1.0f / (1.0f + wCamera);
+                    cps.throughput = cps.throughput * misWeight;
+                }
+                contrib = cps.throughput;
+                break;
+            }
+            {  // ConvertMIS
+                cps.accMISWPrev = cps.accMISWPrev * MISq(DistSqT(org, cps.position));
+                T invCosTheta = 1.0f / MISq(Fabs(DotT(dir, cps.shadingNormal)));
+                cps.accMISWPrev = cps.accMISWPrev * invCosTheta;
+                cps.accMISWThis = cps.accMISWThis * invCosTheta;
+            }
+            if (camDepth == maxCamDepth - 2) {
+                if (maxLightDepth == 1) {  // DirectLighting, path.cpp:3202-3290
+                    T r0 = primary[pi++], r1 = primary[pi++];
+                    const float lightType = vp[buf];
+                    V3T<T> dirToLight, lightContrib;
+                    T cosAtLight, directPdf, emissionPdf;
+                    SampleDirectT(vp, buf, sc, cps.position, r0, r1, dirToLight, lightContrib, cosAtLight, directPdf, emissionPdf);
+                    buf += 56;
+                    V3T<T> bsdfContrib;
+                    T cosToLight, bsdfPdf, bsdfRevPdf;
+                    EvaluateBSDFT(false, vp, buf, cps.wi, cps.shadingNormal, dirToLight, bsdfContrib, cosToLight, bsdfPdf, bsdfRevPdf);
+                    buf += 10;
+                    const float lightPickProb = vp[buf++];
+                    cps.throughput = Cmul(cps.throughput, bsdfContrib);
+                    cps.throughput = Cmul(cps.throughput, lightContrib) * Lift<T>::Of(1.0f / lightPickProb);
+                    T wLight = (lightType == 0.0f) ? Lift<T>::Of(0.0f) : MISq(bsdfPdf / (lightPickProb * directPdf));
+                    T wCamera = MISq(emissionPdf * cosToLight / (directPdf * cosAtLight)) * (cps.accMISWPrev + cps.accMISWThis * MISq(bsdfRevPdf));
+                    T misWeight = 1.0f / (wLight + 1.0f + wCamera);
+                    cps.throughput = cps.throughput * misWeight;
+                } else {  // ConnectVertex, path.cpp:3292-3379
+                    V3T<T> dirToLight = lps.position - cps.position;
+                    T distSq = LenSqT(dirToLight);
+                    T dist = Sqrt(distSq);
+                    dirToLight = dirToLight * (1.0f / dist);
+                    V3T<T> camBsdfFactor, lgtBsdfFactor;
+                    T cosCamera, camBsdfPdf, camBsdfRevPdf, cosLight, lgtBsdfPdf, lgtBsdfRevPdf;
+                    EvaluateBSDFT(false, vp, buf, cps.wi, cps.shadingNormal, dirToLight, camBsdfFactor, cosCamera, camBsdfPdf, camBsdfRevPdf);
+                    EvaluateBSDFT(true, vp, lgtBSDFOff, lps.wi, lps.shadingNormal, -dirToLight, lgtBsdfFactor, cosLight, lgtBsdfPdf, lgtBsdfRevPdf);
+                    T lgtFactor = ShadingNormalCorrectionAdj(lps.wi, lps, -dirToLight);
+                    lgtBsdfFactor = lgtBsdfFactor * lgtFactor;
+                    T geometryTerm = 1.0f / distSq;
+                    T camBsdfDirPdfA = camBsdfPdf * cosLight * geometryTerm;
+                    T lgtBsdfDirPdfA = lgtBsdfPdf * cosCamera * geometryTerm;
+                    T wLight = MISq(camBsdfDirPdfA) * (lps.accMISWPrev + lps.accMISWThis * MISq(lgtBsdfRevPdf));
+                    T wCamera = MISq(lgtBsdfDirPdfA) * (cps.accMISWPrev + cps.accMISWThis * MISq(camBsdfRevPdf));
+                    T misWeight = 1.0f / (wLight + 1.0f + wCamera);
+                    cps.throughput = Cmul(lps.throughput, cps.throughput);
+                    cps.throughput = Cmul(cps.throughput, camBsdfFactor);
+                    cps.throughput = Cmul(cps.throughput, lgtBsdfFactor) * (geometryTerm * misWeight);
+                }
+                contrib = cps.throughput;
+                break;
+            }
+            T r0 = primary[pi++], r1 = primary[pi++];
+            const float bsdfDiscrete = vp[buf++], useAbs = vp[buf++];
+            BSDFSamplingT<false>(vp, buf, r0, r1, bsdfDiscrete, useAbs, cps, dir);
+            buf += 10;
+            const float rrWeight = vp[buf++];
+            cps.throughput = cps.throughput * Lift<T>::Of(rrWeight);
+            org = cps.position;
+        }
+    }
+    return Log(LumT(contrib));
+}
+
+// value only: evaluate_path_bidir_mala_<c>_<l>_static
+template <class In>
+LMC_HD float PathFuncValue(int c, int l, const float *primary, const float *scene, const In &vp) {
+    return PathProgram<float, In>(c, l, primary, scene, vp);
+}
+
+template <int N, class In>
+LMC_HD void PathFuncGradN(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    Dual<N> p[2 * 8 + 1];
+    p[0] = MakeDual<N>(primary[0]);
+    for (int k = 0; k < dim; k++) {
+        p[k + 1] = MakeDual<N>(primary[k + 1]);
+        if (k < N) p[k + 1].d[k] = 1.0f;
+    }
+    Dual<N> r = PathProgram<Dual<N>, In>(c, l, p, scene, vp);
+    if (logLum) *logLum = r.v;
+    for (int k = 0; k < dim && k < N; k++) grad[k] = r.d[k];
+}
+
+// evaluate_path_bidir_mala_<c>_<l>_static_derv: d logLum / d primary[1..2L]
+template <class In>
+LMC_HD void PathFuncGrad(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    if (dim <= 8) PathFuncGradN<8>(c, l, primary, scene, vp, logLum, grad);
+    else if (dim <= 12) PathFuncGradN<12>(c, l, primary, scene, vp, logLum, grad);
+    else PathFuncGradN<16>(c, l, primary, scene, vp, logLum, grad);
+}
+
+}  // namespace lmcd

@@ -1,0 +1,245 @@
+// See accel.h.
+#include "accel.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace lmc {
+
+// ------------------------------------------------------------------------------------------------ LBVH
+static inline uint64_t ExpandBits21(uint32_t v) {  // 21 bits -> every third bit of 63
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+namespace {
+struct Prim {
+    uint64_t code;
+    int id;
+    float bmin[3], bmax[3];
+};
+struct Builder {
+    std::vector<Prim> prims;
+    LbvhResult out;
+    const std::vector<lmcd::TriData> *tris;
+
+    // returns encoded child (>= 0 inner node index, < 0 leaf) and its box
+    int Build(int lo, int hi, float *bmin, float *bmax, int depth) {
+        out.depth = std::max(out.depth, depth);
+        const int n = hi - lo;
+        if (n <= 4) {
+            int first = (int)out.leafTris.size();
+            for (int k = 0; k < 3; k++) bmin[k] = INFINITY, bmax[k] = -INFINITY;
+            for (int i = lo; i < hi; i++) {
+                const lmcd::TriData &T = (*tris)[prims[i].id];
+                lmcd::LeafTri lt;
+                memset(&lt, 0, sizeof(lt));
+                memcpy(lt.p0, T.p0, 12), memcpy(lt.e1, T.e1, 12), memcpy(lt.e2, T.e2, 12);
+                lt.id = prims[i].id;
+                out.leafTris.push_back(lt);
+                for (int k = 0; k < 3; k++) bmin[k] = std::min(bmin[k], prims[i].bmin[k]), bmax[k] = std::max(bmax[k], prims[i].bmax[k]);
+            }
+            return ~((first << 3) | (n - 1));
+        }
+        // split at the highest bit in which the first and last Morton code differ (binary radix tree)
+        uint64_t a = prims[lo].code, b = prims[hi - 1].code;
+        int mid;
+        if (a == b) {
+            mid = (lo + hi) / 2;
+        } else {
+            int bit = 63 - __builtin_clzll(a ^ b);
+            uint64_t mask = 1ull << bit;
+            // first index whose code has `bit` set (codes are sorted, prefix above `bit` is common)
+            int l = lo, r = hi - 1;
+            while (l < r) {
+                int m = (l + r) / 2;
+                if (prims[m].code & mask) r = m;
+                else l = m + 1;
+            }
+            mid = l;
+        }
+        int ni = (int)out.nodes.size();
+        out.nodes.push_back(lmcd::BvhNode());
+        float lmin[3], lmax[3], rmin[3], rmax[3];
+        int left = Build(lo, mid, lmin, lmax, depth + 1);
+        int right = Build(mid, hi, rmin, rmax, depth + 1);
+        lmcd::BvhNode &nd = out.nodes[ni];
+        memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 3; k++) {
+            nd.lmin[k] = lmin[k], nd.lmax[k] = lmax[k], nd.rmin[k] = rmin[k], nd.rmax[k] = rmax[k];
+            bmin[k] = std::min(lmin[k], rmin[k]), bmax[k] = std::max(lmax[k], rmax[k]);
+        }
+        nd.left = left, nd.right = right;
+        return ni;
+    }
+};
+}  // namespace
+
+LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris) {
+    Builder B;
+    B.tris = &tris;
+    const int n = (int)tris.size();
+    if (n == 0) return B.out;
+    B.prims.resize(n);
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<float> cen((size_t)n * 3);
+    for (int i = 0; i < n; i++) {
+        const lmcd::TriData &T = tris[i];
+        for (int k = 0; k < 3; k++) {
+            float p0 = T.p0[k], p1 = T.p0[k] + T.e1[k], p2 = T.p0[k] + T.e2[k];
+            B.prims[i].bmin[k] = std::min(p0, std::min(p1, p2));
+            B.prims[i].bmax[k] = std::max(p0, std::max(p1, p2));
+            cen[(size_t)i * 3 + k] = 0.5f * (B.prims[i].bmin[k] + B.prims[i].bmax[k]);
+            cmin[k] = std::min(cmin[k], cen[(size_t)i * 3 + k]);
+            cmax[k] = std::max(cmax[k], cen[(size_t)i * 3 + k]);
+        }
+        B.prims[i].id = i;
+    }
+    for (int i = 0; i < n; i++) {
+        uint64_t code = 0;
+        for (int k = 0; k < 3; k++) {
+            float ext = cmax[k] - cmin[k];
+            double f = ext > 0 ? (double)(cen[(size_t)i * 3 + k] - cmin[k]) / ext : 0.0;
+            uint32_t q = (uint32_t)std::min(2097151.0, std::max(0.0, f * 2097152.0));
+            code |= ExpandBits21(q) << (2 - k);
+        }
+        B.prims[i].code = code;
+    }
+    std::sort(B.prims.begin(), B.prims.end(), [](const Prim &a, const Prim &b) { return a.code != b.code ? a.code < b.code : a.id < b.id; });
+    float bmin[3], bmax[3];
+    int root = B.Build(0, n, bmin, bmax, 1);
+    if (root < 0) {  // the whole scene is one leaf: wrap it so that node 0 is an inner node
+        lmcd::BvhNode nd;
+        memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 3; k++) nd.lmin[k] = bmin[k], nd.lmax[k] = bmax[k], nd.rmin[k] = INFINITY, nd.rmax[k] = -INFINITY;
+        nd.left = root;
+        nd.right = root;
+        B.out.nodes.push_back(nd);
+    }
+    if (B.out.depth > lmcd::BVH_STACK) throw std::runtime_error("LBVH deeper than the traversal stack");
+    return B.out;
+}
+
+// ------------------------------------------------------------------------------------------------ kd-tree
+namespace {
+struct Interval {
+    float low, high;
+};
+struct KdBuilder {
+    const float *pts;
+    int dim;
+    KdTreeResult out;
+
+    float Get(int idx, int d) const { return pts[(size_t)idx * dim + d]; }
+    void MinMax(const int *ind, int count, int element, float &mn, float &mx) const {
+        mn = mx = Get(ind[0], element);
+        for (int i = 1; i < count; ++i) {
+            float v = Get(ind[i], element);
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+    }
+    void PlaneSplit(int *ind, int count, int cutfeat, float cutval, int &lim1, int &lim2) const {  // nanoflann.hpp:976-1011
+        int left = 0, right = count - 1;
+        for (;;) {
+            while (left <= right && Get(ind[left], cutfeat) < cutval) ++left;
+            while (right && left <= right && Get(ind[right], cutfeat) >= cutval) --right;
+            if (left > right || !right) break;
+            std::swap(ind[left], ind[right]);
+            ++left;
+            --right;
+        }
+        lim1 = left;
+        right = count - 1;
+        for (;;) {
+            while (left <= right && Get(ind[left], cutfeat) <= cutval) ++left;
+            while (right && left <= right && Get(ind[right], cutfeat) > cutval) --right;
+            if (left > right || !right) break;
+            std::swap(ind[left], ind[right]);
+            ++left;
+            --right;
+        }
+        lim2 = left;
+    }
+    int Divide(int left, int right, std::vector<Interval> &bbox) {  // nanoflann.hpp:867-917
+        int ni = (int)out.nodes.size();
+        lmcd::KdNode nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.child1 = nd.child2 = -1;
+        out.nodes.push_back(nd);
+        if ((right - left) <= 10) {
+            out.nodes[ni].left = left, out.nodes[ni].right = right;
+            for (int i = 0; i < dim; ++i) bbox[i].low = bbox[i].high = Get(out.vind[left], i);
+            for (int k = left + 1; k < right; ++k)
+                for (int i = 0; i < dim; ++i) {
+                    float v = Get(out.vind[k], i);
+                    if (bbox[i].low > v) bbox[i].low = v;
+                    if (bbox[i].high < v) bbox[i].high = v;
+                }
+            return ni;
+        }
+        int *ind = &out.vind[0] + left;
+        const int count = right - left;
+        const float EPS = 0.00001f;  // middleSplit_, nanoflann.hpp:919-966
+        float max_span = bbox[0].high - bbox[0].low;
+        for (int i = 1; i < dim; ++i) max_span = std::max(max_span, bbox[i].high - bbox[i].low);
+        float max_spread = -1;
+        int cutfeat = 0;
+        for (int i = 0; i < dim; ++i) {
+            float span = bbox[i].high - bbox[i].low;
+            if (span > (1 - EPS) * max_span) {
+                float mn, mx;
+                MinMax(ind, count, i, mn, mx);
+                float spread = mx - mn;
+                if (spread > max_spread) cutfeat = i, max_spread = spread;
+            }
+        }
+        float split_val = (bbox[cutfeat].low + bbox[cutfeat].high) / 2;
+        float mn, mx;
+        MinMax(ind, count, cutfeat, mn, mx);
+        float cutval = split_val < mn ? mn : (split_val > mx ? mx : split_val);
+        int lim1, lim2;
+        PlaneSplit(ind, count, cutfeat, cutval, lim1, lim2);
+        int idx = lim1 > count / 2 ? lim1 : (lim2 < count / 2 ? lim2 : count / 2);
+        out.nodes[ni].divfeat = cutfeat;
+        std::vector<Interval> lb(bbox), rb(bbox);
+        lb[cutfeat].high = cutval;
+        int c1 = Divide(left, left + idx, lb);
+        rb[cutfeat].low = cutval;
+        int c2 = Divide(left + idx, right, rb);
+        out.nodes[ni].child1 = c1, out.nodes[ni].child2 = c2;
+        out.nodes[ni].divlow = lb[cutfeat].high;
+        out.nodes[ni].divhigh = rb[cutfeat].low;
+        for (int i = 0; i < dim; ++i) bbox[i].low = std::min(lb[i].low, rb[i].low), bbox[i].high = std::max(lb[i].high, rb[i].high);
+        return ni;
+    }
+};
+}  // namespace
+
+KdTreeResult BuildKdTree(const float *pts, int n, int dim) {
+    KdBuilder B;
+    B.pts = pts, B.dim = dim;
+    B.out.vind.resize(n);
+    for (int i = 0; i < n; i++) B.out.vind[i] = i;
+    std::vector<Interval> bbox(dim);
+    for (int i = 0; i < dim; ++i) bbox[i].low = bbox[i].high = pts[i];
+    for (int k = 1; k < n; ++k)
+        for (int i = 0; i < dim; ++i) {
+            float v = pts[(size_t)k * dim + i];
+            if (v < bbox[i].low) bbox[i].low = v;
+            if (v > bbox[i].high) bbox[i].high = v;
+        }
+    B.Divide(0, n, bbox);
+    B.out.rootLow.resize(dim), B.out.rootHigh.resize(dim);
+    for (int i = 0; i < dim; i++) B.out.rootLow[i] = bbox[i].low, B.out.rootHigh[i] = bbox[i].high;
+    return B.out;
+}
+
+}  // namespace lmc

@@ -1,0 +1,29 @@
+// Host-side builders for the two search structures the kernels traverse:
+//   * LBVH over all scene triangles (Morton-ordered, binary radix split, leaves of <= 4 triangles), the
+//     stand-in for Embree's BVH (/root/reference/src/scene.cpp:8-46, trianglemesh.cpp:107-143);
+//   * the kd-tree of the global gradient cache, built exactly like nanoflann's KDTreeSingleIndexAdaptor
+//     with leaf size 10 (/root/reference/src/global_cache.h:85-92; nanoflann.hpp:867-1007) so that the
+//     reference's traversal-order-dependent "first 5 matches" query returns the same points.
+#pragma once
+#include <vector>
+
+#include "../device/dchain.h"
+#include "scene.h"
+
+namespace lmc {
+
+struct LbvhResult {
+    std::vector<lmcd::BvhNode> nodes;
+    std::vector<lmcd::LeafTri> leafTris;
+    int depth = 0;
+};
+LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris);
+
+struct KdTreeResult {
+    std::vector<lmcd::KdNode> nodes;
+    std::vector<int> vind;
+    std::vector<float> rootLow, rootHigh;
+};
+KdTreeResult BuildKdTree(const float *pts, int n, int dim);
+
+}  // namespace lmc

@@ -1,0 +1,733 @@
+// C-ABI implementation (include/lmc_abi.h): scene upload, MLT initialisation, the chain-step loop and the
+// global-cache maintenance around the gfx950 kernels.  Host logic only -- every numeric result returned by this
+// library is produced by the HIP kernels in device/kernels.hip; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/lmc_abi.h"
+#include "../device/drng.h"
+#include "../device/kernels.h"
+#include "accel.h"
+#include "scene.h"
+
+using namespace lmcd;
+
+static thread_local std::string g_err;
+
+#define HIP_CHECK(x)                                                                                                  \
+    do {                                                                                                              \
+        hipError_t e_ = (x);                                                                                          \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x); \
+    } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { Free(); }
+    void Free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void Alloc(size_t count, bool zero = true) {
+        Free();
+        n = count;
+        if (count == 0) return;
+        HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        if (zero) HIP_CHECK(hipMemset(p, 0, count * sizeof(T)));
+    }
+    void Upload(const std::vector<T> &v) {
+        Alloc(v.size(), false);
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void Upload(const T *v, size_t count) {
+        Alloc(count, false);
+        if (count) HIP_CHECK(hipMemcpy(p, v, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+    std::vector<T> Download() const {
+        std::vector<T> v(n);
+        if (n) HIP_CHECK(hipMemcpy(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+        return v;
+    }
+};
+
+void EnsureDevice(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw std::runtime_error("no HIP device available: the MI355X back end has no CPU fallback");
+    if (device < 0 || device >= count) throw std::runtime_error("HIP device ordinal out of range");
+    HIP_CHECK(hipSetDevice(device));
+}
+
+struct CacheDimHost {
+    DevBuf<float> pss, v1, v2, weight;
+    DevBuf<int> count;
+    DevBuf<KdNode> nodes;
+    DevBuf<int> vind;
+    bool ready = false;
+    bool relevant = false;
+};
+
+}  // namespace
+
+struct lmc_ctx {
+    std::unique_ptr<lmc::Scene> scene;
+    int device = 0;
+    int useGradient = 1;
+    hipStream_t stream = nullptr;
+    // scene buffers
+    DevBuf<BvhNode> nodes;
+    DevBuf<LeafTri> leafTris;
+    DevBuf<TriData> tris;
+    DevBuf<DMesh> meshes;
+    DevBuf<DMaterial> materials;
+    DevBuf<DLight> lights;
+    DevBuf<float> areaFunc, areaCdf, lightFunc, lightCdf, envImage, envCdfRows, envCdfCols, envRowWeights;
+    DScene S;
+    int bvhDepth = 0;
+    // film
+    DevBuf<float> film;
+    // chains
+    int N = 0, numChainsTotal = 0, chainBegin = 0;
+    ChainArrays A;
+    DevBuf<uint64_t> rngState;
+    DevBuf<uint32_t> rngTab;
+    DevBuf<float> curPath, curContrib, scoreSum, gaussian, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
+        lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum;
+    DevBuf<int> flags, curSplatCount, adjacentReject, sampleIdx, numSamples, pushDim;
+    DevBuf<unsigned long long> counters;
+    DevBuf<double> weightSum;
+    DevBuf<float> gradBuf;
+    int gradStride = 0, stepGrid = 0;
+    // cache
+    CacheDimHost cacheDims[PSS_MAX_LENGTH + 1];
+    DCache cacheHost;
+    DevBuf<DCache> cacheDev;
+    bool allCachesReady = false;
+    // init results
+    float normalization = 0.f;
+    long long numInitContribs = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double kernelMs = 0;
+    long long launches = 0;
+    ~lmc_ctx() {
+        for (auto &e : events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ scene upload
+static void UploadScene(lmc_ctx *c) {
+    const lmc::Scene &sc = *c->scene;
+    std::vector<TriData> tris;
+    std::vector<DMesh> meshes;
+    std::vector<float> areaFunc, areaCdf;
+    int triBase = 0;
+    for (size_t mi = 0; mi < sc.meshes.size(); mi++) {
+        const lmc::Mesh &m = sc.meshes[mi];
+        DMesh dm;
+        memset(&dm, 0, sizeof(dm));
+        dm.material = m.material;
+        dm.areaLight = m.areaLight;
+        dm.hasST = m.ST.empty() ? 0 : 1;
+        dm.triBase = triBase;
+        dm.numTris = (int)m.numTris();
+        dm.totalArea = m.totalArea;
+        dm.invTotalArea = 1.0f / m.totalArea;  // inf when the mesh is no emitter, like inverse(totalArea) in trianglemesh.cpp:186
+        dm.areaOff = (int)areaFunc.size();
+        dm.areaCdfOff = (int)areaCdf.size();
+        dm.areaFuncInt = m.areaFuncInt;
+        areaFunc.insert(areaFunc.end(), m.areaFunc.begin(), m.areaFunc.end());
+        areaCdf.insert(areaCdf.end(), m.areaCdf.begin(), m.areaCdf.end());
+        for (size_t t = 0; t < m.numTris(); t++) {
+            TriData T;
+            memset(&T, 0, sizeof(T));
+            uint32_t i0 = m.idx[3 * t], i1 = m.idx[3 * t + 1], i2 = m.idx[3 * t + 2];
+            for (int k = 0; k < 3; k++) {
+                T.p0[k] = m.P[i0][k];
+                T.e1[k] = m.P[i1][k] - m.P[i0][k];
+                T.e2[k] = m.P[i2][k] - m.P[i0][k];
+                T.n0[k] = m.N[i0][k], T.n1[k] = m.N[i1][k], T.n2[k] = m.N[i2][k];
+            }
+            if (dm.hasST) {
+                T.st[0] = m.ST[i0].x, T.st[1] = m.ST[i0].y, T.st[2] = m.ST[i1].x, T.st[3] = m.ST[i1].y, T.st[4] = m.ST[i2].x, T.st[5] = m.ST[i2].y;
+            }
+            T.mesh = (int)mi;
+            tris.push_back(T);
+        }
+        triBase += dm.numTris;
+        meshes.push_back(dm);
+    }
+    lmc::LbvhResult bvh = lmc::BuildLbvh(tris);
+    c->bvhDepth = bvh.depth;
+    std::vector<DMaterial> mats;
+    for (const lmc::Material &m : sc.materials) {
+        DMaterial d;
+        memset(&d, 0, sizeof(d));
+        d.type = m.type, d.twoSided = m.twoSided ? 1 : 0;
+        memcpy(d.Kd, m.Kd.value, 12), memcpy(d.Ks, m.Ks.value, 12), memcpy(d.Kt, m.Kt.value, 12);
+        d.expOrAlpha = m.expOrAlpha.value[0], d.eta = m.eta, d.invEta = m.invEta, d.KsWeight = m.KsWeight;
+        d.KdTex = m.Kd.bitmap;
+        if (m.type != lmc::BSDF_LAMBERTIAN)
+            throw std::runtime_error("BSDF type not available on the MI355X back end yet (phong / roughdielectric: SURVEY.md §8 config 3); load with force_diffuse");
+        if (m.Kd.bitmap >= 0) throw std::runtime_error("bitmap textures are not available on the MI355X back end yet (SURVEY.md §8 config 3)");
+        mats.push_back(d);
+    }
+    std::vector<DLight> lights;
+    for (const lmc::Light &L : sc.lights) {
+        DLight d;
+        memset(&d, 0, sizeof(d));
+        d.type = L.type, d.samplingWeight = L.samplingWeight, d.mesh = L.mesh;
+        for (int k = 0; k < 3; k++) d.pos[k] = L.position[k], d.intensity[k] = L.intensity[k], d.radiance[k] = L.radiance[k];
+        lights.push_back(d);
+    }
+    c->nodes.Upload(bvh.nodes), c->leafTris.Upload(bvh.leafTris), c->tris.Upload(tris), c->meshes.Upload(meshes), c->materials.Upload(mats),
+        c->lights.Upload(lights);
+    c->areaFunc.Upload(areaFunc), c->areaCdf.Upload(areaCdf), c->lightFunc.Upload(sc.lightFunc), c->lightCdf.Upload(sc.lightCdf);
+    DScene &S = c->S;
+    memset(&S, 0, sizeof(S));
+    S.nodes = c->nodes.p, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.lights = c->lights.p;
+    S.areaFunc = c->areaFunc.p, S.areaCdf = c->areaCdf.p, S.lightFunc = c->lightFunc.p, S.lightCdf = c->lightCdf.p;
+    S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
+    S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size();
+    S.envLight = sc.envLight;
+    if (sc.envLight >= 0) {
+        const lmc::Light &L = sc.lights[sc.envLight];
+        c->envImage.Upload(L.image.data), c->envCdfRows.Upload(L.sampleInfo.cdfRows), c->envCdfCols.Upload(L.sampleInfo.cdfCols),
+            c->envRowWeights.Upload(L.sampleInfo.rowWeights);
+        DEnv &E = S.env;
+        E.W = L.image.width, E.H = L.image.height;
+        E.image = c->envImage.p, E.cdfRows = c->envCdfRows.p, E.cdfCols = c->envCdfCols.p, E.rowWeights = c->envRowWeights.p;
+        E.normalization = L.sampleInfo.normalization, E.pixelSize[0] = L.sampleInfo.pixelSize[0], E.pixelSize[1] = L.sampleInfo.pixelSize[1];
+        lmc::M4 tw = lmc::ToM4(L.toWorld), tl = lmc::ToM4(L.toLight);
+        memcpy(E.toWorld, tw.m, 64), memcpy(E.toLight, tl.m, 64);
+        int o = 0;
+        for (const lmc::AnimXform *x : {&L.toWorld, &L.toLight}) {
+            E.xformBlocks[o++] = x->isMoving;
+            for (int k = 0; k < 2; k++)
+                for (int i = 0; i < 3; i++) E.xformBlocks[o++] = x->t[k][i];
+            for (int k = 0; k < 2; k++)
+                for (int i = 0; i < 4; i++) E.xformBlocks[o++] = x->q[k][i];
+        }
+    }
+    const lmc::Camera &cam = sc.camera;
+    memcpy(S.cam.sampleToCam, cam.sampleToCam.m, 64), memcpy(S.cam.camToSample, cam.camToSample.m, 64);
+    lmc::M4 tw = lmc::ToM4(cam.camToWorld), wc = lmc::ToM4(cam.worldToCamera);
+    memcpy(S.cam.toWorld, tw.m, 64), memcpy(S.cam.worldToCamera, wc.m, 64);
+    S.cam.width = cam.width, S.cam.height = cam.height, S.cam.nearClip = cam.nearClip, S.cam.farClip = cam.farClip, S.cam.dist = cam.dist;
+    for (int k = 0; k < 3; k++) S.bsCenter[k] = sc.bsphereCenter[k];
+    S.bsRadius = sc.bsphereRadius;
+    lmc::SerializeSceneBlock(sc, S.sceneParams);
+    c->film.Alloc((size_t)cam.width * cam.height * 3);
+}
+
+static void SyncOptions(lmc_ctx *c) {
+    const lmc::DptOptions &o = c->scene->options;
+    DOptions &d = c->S.opt;
+    d.minDepth = o.minDepth, d.maxDepth = o.maxDepth, d.mala = o.mala ? 1 : 0;
+    d.roughnessThreshold = o.roughnessThreshold, d.largeStepProbability = o.largeStepProbability, d.largeStepProbScale = o.largeStepProbScale;
+    d.malaGN = o.malaGN, d.malaStepsize = o.malaStepsize, d.malaStdDev = o.malaStdDev, d.perturbStdDev = o.perturbStdDev;
+    d.discreteStdDev = o.discreteStdDev, d.uniformMixingProbability = o.uniformMixingProbability, d.seedOffset = o.seedOffset;
+    if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 8] on the MI355X back end");
+    if (o.largeStepMultiplexed || o.sampleFromGlobalCache || o.useLightCoordinateSampling || o.h2mc)
+        throw std::runtime_error("largestepmultiplexed / samplecache / uselightcoordinatesampling / h2mc are out of scope (SURVEY.md §8f)");
+}
+
+static void UploadCacheStruct(lmc_ctx *c) {
+    c->cacheDev.Upload(&c->cacheHost, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ ABI
+extern "C" {
+
+const char *lmc_last_error(void) { return g_err.c_str(); }
+
+#define LMC_TRY try {
+#define LMC_CATCH(ret)                \
+    }                                 \
+    catch (const std::exception &e) { \
+        g_err = e.what();             \
+        return ret;                   \
+    }
+
+lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
+    LMC_TRY
+    if (!desc || !desc->scene_xml) throw std::runtime_error("lmc_create: null scene description");
+    EnsureDevice(desc->device);
+    std::unique_ptr<lmc_ctx> c(new lmc_ctx);
+    c->device = desc->device;
+    c->useGradient = desc->use_gradient;
+    lmc::LoadOverrides ov;
+    ov.forceDiffuse = desc->force_diffuse != 0;
+    ov.maxDepth = desc->max_depth, ov.width = desc->width, ov.height = desc->height, ov.seedOffset = desc->seed_offset;
+    c->scene = lmc::ParseScene(desc->scene_xml, ov);
+    HIP_CHECK(hipStreamCreate(&c->stream));
+    UploadScene(c.get());
+    SyncOptions(c.get());
+    memset(&c->cacheHost, 0, sizeof(c->cacheHost));
+    UploadCacheStruct(c.get());
+    return c.release();
+    LMC_CATCH(nullptr)
+}
+
+void lmc_destroy(lmc_ctx *ctx) { delete ctx; }
+
+int lmc_info(lmc_ctx *c, int *out) {
+    out[0] = c->S.cam.width, out[1] = c->S.cam.height, out[2] = c->S.numTris, out[3] = c->S.opt.maxDepth, out[4] = c->S.numNodes, out[5] = c->bvhDepth;
+    out[6] = c->S.numLights, out[7] = c->S.opt.mala;
+    return 0;
+}
+
+int lmc_scene_params(lmc_ctx *c, float *out38) {
+    memcpy(out38, c->S.sceneParams, 38 * sizeof(float));
+    return 0;
+}
+
+int lmc_set_option(lmc_ctx *c, const char *name, double v) {
+    LMC_TRY
+    lmc::DptOptions &o = c->scene->options;
+    std::string n(name);
+    if (n == "largestepprob") o.largeStepProbability = (float)v;
+    else if (n == "largestepscale") o.largeStepProbScale = (float)v;
+    else if (n == "mala") o.mala = v != 0;
+    else if (n == "uniformmixprob") o.uniformMixingProbability = (float)v;
+    else if (n == "mala-stepsize") o.malaStepsize = (float)v;
+    else if (n == "mala-gn") o.malaGN = (float)v;
+    else if (n == "perturbstddev") o.perturbStdDev = (float)v;
+    else if (n == "mindepth") o.minDepth = (int)v;
+    else throw std::runtime_error("Unknown dpt option:" + n);
+    SyncOptions(c);
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, int initThreads, int chainBegin, int chainEnd, long long perChain,
+                    long long chainsNeedExtra) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (numChainsTotal <= 0 || chainBegin < 0 || chainEnd > numChainsTotal || chainEnd <= chainBegin) throw std::runtime_error("bad chain range");
+    const int V = std::max(1, initThreads);
+    const long long perThread = numInitSamples / V, extra = numInitSamples % V;
+    hipStream_t s = c->stream;
+    // ---- MLTInit pass 1: checkpoints + contribution counts
+    DevBuf<uint64_t> ckState;
+    DevBuf<uint32_t> ckTicks, tab1;
+    DevBuf<unsigned char> count;
+    DevBuf<float> contrib1;
+    ckState.Alloc(numInitSamples), ckTicks.Alloc(numInitSamples), count.Alloc(numInitSamples);
+    tab1.Alloc((size_t)V * 64, false), contrib1.Alloc((size_t)V * MAXCONTRIB * CONTRIB_WORDS, false);
+    LaunchInitPass1(c->S, V, perThread, extra, tab1.p, contrib1.p, ckState.p, ckTicks.p, count.p, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<unsigned char> hCount = count.Download();
+    std::vector<unsigned long long> hOff(numInitSamples);
+    unsigned long long total = 0;
+    for (long long g = 0; g < numInitSamples; g++) {
+        hOff[g] = total;
+        total += hCount[g];
+    }
+    c->numInitContribs = (long long)total;
+    if ((long long)total < numChainsTotal)
+        throw std::runtime_error("MLT initialization failed, consider using a larger number of initial samples or smaller number of chains");
+    // ---- pass 2: (c,l,lsScore) of every contribution, in (thread, sample, contribution) order
+    DevBuf<unsigned long long> dOff;
+    dOff.Upload(hOff);
+    DevBuf<unsigned char> outCL;
+    DevBuf<float> outLs;
+    outCL.Alloc(total), outLs.Alloc(total);
+    const int nSlots = (int)std::min<long long>(numInitSamples, 1 << 18);
+    DevBuf<uint32_t> tab2;
+    DevBuf<float> contrib2;
+    tab2.Alloc((size_t)nSlots * 64, false), contrib2.Alloc((size_t)nSlots * MAXCONTRIB * CONTRIB_WORDS, false);
+    LaunchInitPass2(c->S, numInitSamples, perThread, extra, nSlots, tab2.p, contrib2.p, ckState.p, ckTicks.p, dOff.p, outCL.p, outLs.p, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<unsigned char> hCL = outCL.Download();
+    std::vector<float> hLs = outLs.Download();
+    // ---- equal-spaced seeding (mlt.h:107-148), sequential float arithmetic on the host like the reference
+    float totalScore = 0.f;
+    for (unsigned long long i = 0; i < total; i++) totalScore += hLs[i];
+    std::vector<float> cdf(total + 1);
+    cdf[0] = 0.f;
+    for (unsigned long long i = 0; i < total; i++) cdf[i + 1] = cdf[i] + hLs[i];
+    const float interval = cdf.back() / float(numChainsTotal);
+    std::vector<uint32_t> hostTab(64);
+    Rng hr;
+    hr.tab = hostTab.data();
+    hr.state = PcgSeed((uint64_t)total, hr.tab);  // RNG rng(mStates.size()), mlt.h:115
+    hr.ticks = 0;
+    float pos = hr.Uniform() * (interval - 0.f) + 0.f;  // uniform_real_distribution<Float>(0, interval)
+    // contribution index -> sample index
+    std::vector<long long> seedSample(numChainsTotal);
+    std::vector<unsigned char> seedCL(numChainsTotal);
+    long long cdfPos = 0, g = 0;
+    for (int i = 0; i < numChainsTotal; i++) {
+        // mlt.h:118-120; the reference's clamp inside the loop never terminates once pos > cdf[size-1]: stop at size-1
+        while (pos > cdf[cdfPos] && cdfPos < (long long)total - 1) cdfPos++;
+        long long m = std::max<long long>(cdfPos - 1, 0);
+        while (g + 1 < numInitSamples && hOff[g + 1] <= (unsigned long long)m) g++;  // monotone: sample owning contribution m
+        while (g > 0 && hOff[g] > (unsigned long long)m) g--;
+        seedSample[i] = g;
+        seedCL[i] = hCL[m];
+        pos += interval;
+    }
+    c->normalization = totalScore * (1.0f / float(numInitSamples));
+    // ---- regenerate the seed paths into the (global-size) init arrays
+    c->numChainsTotal = numChainsTotal;
+    c->chainBegin = chainBegin;
+    c->N = chainEnd - chainBegin;
+    const size_t NT = numChainsTotal, N = c->N;
+    c->initPath.Alloc(NT * DPATH_WORDS), c->initContrib.Alloc(NT * CONTRIB_WORDS), c->initScoreSum.Alloc(NT);
+    {
+        DevBuf<long long> dSeedSample;
+        DevBuf<unsigned char> dSeedCL;
+        DevBuf<uint32_t> tab3;
+        DevBuf<float> contrib3;
+        dSeedSample.Upload(seedSample), dSeedCL.Upload(seedCL);
+        tab3.Alloc(NT * 64, false), contrib3.Alloc(NT * MAXCONTRIB * CONTRIB_WORDS, false);
+        LaunchInitRegen(c->S, numChainsTotal, perThread, extra, dSeedSample.p, dSeedCL.p, tab3.p, contrib3.p, ckState.p, ckTicks.p, c->initPath.p,
+                        c->initContrib.p, c->initScoreSum.p, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    // ---- chain arrays
+    c->rngState.Alloc(N), c->rngTab.Alloc(N * 64, false);
+    c->curPath.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS);
+    c->curSplat.Alloc(N * MAXCONTRIB * SPLAT_WORDS), c->curSplatCount.Alloc(N);
+    c->chV1.Alloc(N * MAXPSS), c->chV2.Alloc(N * MAXPSS), c->chCurrNewV2.Alloc(N * MAXPSS), c->chPropNewV1.Alloc(N * MAXPSS),
+        c->chPropNewV2.Alloc(N * MAXPSS), c->chPss.Alloc(N * MAXPSS), c->chLastPss.Alloc(N * MAXPSS);
+    c->pathWeight.Alloc(N), c->lastScoreSum.Alloc(N), c->lastScore.Alloc(N), c->contribList.Alloc(N * MAXCONTRIB * CONTRIB_WORDS, false);
+    c->pushData.Alloc(N * GAUSS_WORDS), c->flags.Alloc(N), c->adjacentReject.Alloc(N), c->sampleIdx.Alloc(N), c->numSamples.Alloc(N), c->pushDim.Alloc(N);
+    c->counters.Alloc(8), c->weightSum.Alloc(1);
+    ChainArrays &A = c->A;
+    A.N = (int)N;
+    A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
+    A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
+    A.chV1 = c->chV1.p, A.chV2 = c->chV2.p, A.chCurrNewV2 = c->chCurrNewV2.p, A.chPropNewV1 = c->chPropNewV1.p, A.chPropNewV2 = c->chPropNewV2.p,
+    A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
+    A.pathWeight = c->pathWeight.p, A.lastScoreSum = c->lastScoreSum.p, A.lastScore = c->lastScore.p;
+    A.adjacentReject = c->adjacentReject.p, A.sampleIdx = c->sampleIdx.p, A.numSamples = c->numSamples.p;
+    A.contribList = c->contribList.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
+    A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p;
+    A.counters = c->counters.p, A.weightSum = c->weightSum.p;
+    LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
+    LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, s);
+    // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
+    c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
+    c->gradStride = c->stepGrid * 256;
+    c->gradBuf.Alloc(c->useGradient ? (size_t)c->gradStride * 640 : 1, false);  // V <= 238 + 59*6 = 592 words for c+l <= 9
+    // global cache: dims 2L for L in [3, maxDepth], capped by PSS_MAX_LENGTH
+    for (int d = 0; d <= PSS_MAX_LENGTH; d++) {
+        CacheDimHost &cd = c->cacheDims[d];
+        cd.ready = false;
+        cd.relevant = (d % 2 == 0) && d >= 2 * std::max(c->S.opt.minDepth, 3) && d <= 2 * c->S.opt.maxDepth;
+        if (cd.relevant) {
+            cd.pss.Alloc((size_t)PSS_MAX_SIZE * d), cd.v1.Alloc((size_t)PSS_MAX_SIZE * d), cd.v2.Alloc((size_t)PSS_MAX_SIZE * d);
+            cd.weight.Alloc(PSS_MAX_SIZE), cd.count.Alloc(1);
+        }
+    }
+    memset(&c->cacheHost, 0, sizeof(c->cacheHost));
+    UploadCacheStruct(c);
+    c->allCachesReady = false;
+    HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_init_result(lmc_ctx *c, float *normalization, long long *numContribs) {
+    if (normalization) *normalization = c->normalization;
+    if (numContribs) *numContribs = c->numInitContribs;
+    return 0;
+}
+
+static void MaintainCache(lmc_ctx *c) {
+    hipStream_t s = c->stream;
+    bool anyPending = false;
+    for (int d = 2; d <= PSS_MAX_LENGTH; d++) {
+        CacheDimHost &cd = c->cacheDims[d];
+        if (!cd.relevant || cd.ready) continue;
+        anyPending = true;
+        LaunchCachePush(c->A, d, cd.pss.p, cd.v1.p, cd.v2.p, cd.weight.p, cd.count.p, s);
+    }
+    if (!anyPending) {
+        c->allCachesReady = true;
+        return;
+    }
+    bool changed = false;
+    for (int d = 2; d <= PSS_MAX_LENGTH; d++) {
+        CacheDimHost &cd = c->cacheDims[d];
+        if (!cd.relevant || cd.ready) continue;
+        int cnt = 0;
+        HIP_CHECK(hipMemcpyAsync(&cnt, cd.count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (cnt >= PSS_MAX_SIZE) {  // global_cache.h:85-92: build the kd-tree once full
+            std::vector<float> pts = cd.pss.Download();
+            lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
+            cd.nodes.Upload(t.nodes), cd.vind.Upload(t.vind);
+            DCacheDim &D = c->cacheHost.d[d];
+            D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
+            for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
+            cd.ready = true;
+            changed = true;
+        }
+    }
+    if (changed) UploadCacheStruct(c);
+}
+
+int lmc_chains_step(lmc_ctx *c, int nSteps) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (c->N <= 0) throw std::runtime_error("lmc_chains_step before lmc_chains_init");
+    hipStream_t s = c->stream;
+    Film film{c->film.p, c->S.cam.width, c->S.cam.height};
+    StepParams P;
+    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.useGradient = c->useGradient;
+    for (int it = 0; it < nSteps; it++) {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, s));
+        LaunchStep(c->S, c->cacheDev.p, c->A, film, P, c->chainBegin, nullptr, nullptr, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        HIP_CHECK(hipEventRecord(e1, s));
+        c->events.emplace_back(e0, e1);
+        if (!c->allCachesReady) MaintainCache(c);
+    }
+    HIP_CHECK(hipGetLastError());
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_sync(lmc_ctx *c) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_step_timing(lmc_ctx *c, double *kernelMs, long long *launches) {
+    LMC_TRY
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    double ms = 0;
+    for (auto &e : c->events) {
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
+        ms += t;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (kernelMs) *kernelMs = ms;
+    if (launches) *launches = (long long)c->events.size();
+    c->events.clear();
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_film_read(lmc_ctx *c, float *rgb) {
+    LMC_TRY
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpy(rgb, c->film.p, c->film.n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_film_clear(lmc_ctx *c) {
+    LMC_TRY
+    HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), c->stream));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_stats(lmc_ctx *c, long long *out8, double *weightSum) {
+    LMC_TRY
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> h = c->counters.Download();
+    for (int k = 0; k < 7; k++) out8[k] = (long long)h[k];
+    long long mask = 0;
+    for (int d = 2; d <= PSS_MAX_LENGTH; d++)
+        if (c->cacheDims[d].ready) mask |= 1ll << d;
+    out8[7] = mask;
+    if (weightSum) *weightSum = c->weightSum.Download()[0];
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
+    LMC_TRY
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    const size_t N = which == 0 ? c->N : c->numChainsTotal;
+    std::vector<float> path = (which == 0 ? c->curPath : c->initPath).Download();
+    std::vector<float> con = (which == 0 ? c->curContrib : c->initContrib).Download();
+    std::vector<float> ss = (which == 0 ? c->scoreSum : c->initScoreSum).Download();
+    std::vector<int> fl, sidx, nspl;
+    if (which == 0) fl = c->flags.Download(), sidx = c->sampleIdx.Download(), nspl = c->curSplatCount.Download();
+    for (size_t i = 0; i < N; i++) {
+        float *o = out + i * stride;
+        memset(o, 0, stride * sizeof(float));
+        DPath p;
+        float *w = reinterpret_cast<float *>(&p);
+        for (int k = 0; k < DPATH_WORDS; k++) w[k] = path[(size_t)k * N + i];
+        int cc, ll;
+        memcpy(&cc, &con[0 * N + i], 4), memcpy(&ll, &con[1 * N + i], 4);
+        o[0] = which == 0 ? float(fl[i] & F_VALID ? 1 : 0) : 0.f;
+        o[1] = (float)cc, o[2] = (float)ll, o[3] = con[7 * N + i], o[4] = con[8 * N + i], o[5] = ss[i], o[6] = p.time;
+        if (which == 0) o[7] = (fl[i] & F_GAUSS) ? 1.f : 0.f, o[8] = (fl[i] & F_BUFFERED) ? 1.f : 0.f, o[9] = (float)sidx[i], o[15] = (float)nspl[i];
+        o[10] = con[2 * N + i], o[11] = con[3 * N + i], o[12] = con[4 * N + i], o[13] = con[5 * N + i], o[14] = con[6 * N + i];
+        // GetPathPss on the host copy (same ordering as device/dpath.h)
+        int k = 0;
+        float *pss = o + 16;
+        if (p.lgtDepth > 1) {
+            pss[k++] = p.lgtPos0, pss[k++] = p.lgtPos1, pss[k++] = p.lgtDir0, pss[k++] = p.lgtDir1;
+            for (int d = 0; d < p.lgtCount - 1; d++) pss[k++] = p.lgt[d].rnd0, pss[k++] = p.lgt[d].rnd1;
+        }
+        if (!(p.lgtDepth > 1 && p.camDepth == 1)) {
+            pss[k++] = p.screen0, pss[k++] = p.screen1;
+            for (int d = 0; d < p.camCount; d++) {
+                if (d == p.camCount - 1) {
+                    if (p.lgtDepth == 1) pss[k++] = p.cam[d].dirRnd0, pss[k++] = p.cam[d].dirRnd1;
+                    break;
+                }
+                pss[k++] = p.cam[d].rnd0, pss[k++] = p.cam[d].rnd1;
+            }
+        }
+    }
+    return (int)N;
+    LMC_CATCH(-1)
+}
+
+// ---- batched path program (context-free)
+int lmc_grad_batch(int c, int l, int n, const float *primarySoA, const float *scene38, const float *vertSoA, float *loglum, float *gradSoA) {
+    LMC_TRY
+    if (!(c >= 1 && l >= 0 && c + l >= 3 && c + l - 1 <= 8)) throw std::runtime_error("lmc_grad_batch: technique (c,l) out of range");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) EnsureDevice(0);
+    else EnsureDevice(dev);
+    const int L = std::max(c + l - 1, 2), V = 238 + 59 * (c + l - 3);
+    DevBuf<float> dPrim, dScene, dVert, dLL, dGrad;
+    dPrim.Upload(primarySoA, (size_t)(2 * L + 1) * n), dScene.Upload(scene38, 38), dVert.Upload(vertSoA, (size_t)V * n);
+    dLL.Alloc(n), dGrad.Alloc((size_t)2 * L * n);
+    LaunchGradBatch(c, l, n, dPrim.p, dScene.p, dVert.p, dLL.p, dGrad.p, gradSoA ? 1 : 0, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (loglum) HIP_CHECK(hipMemcpy(loglum, dLL.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (gradSoA) HIP_CHECK(hipMemcpy(gradSoA, dGrad.p, (size_t)2 * L * n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// ---- probes
+int lmc_trace(lmc_ctx *c, int n, const float *rays, int *prim, float *t) {
+    LMC_TRY
+    DevBuf<float> dR, dT;
+    DevBuf<int> dP;
+    dR.Upload(rays, (size_t)n * 8), dT.Alloc(n), dP.Alloc(n);
+    LaunchTrace(c->S, n, dR.p, dP.p, dT.p, 0, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpy(prim, dP.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(t, dT.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_occluded(lmc_ctx *c, int n, const float *rays, int *occ) {
+    LMC_TRY
+    DevBuf<float> dR, dT;
+    DevBuf<int> dP;
+    dR.Upload(rays, (size_t)n * 8), dT.Alloc(n), dP.Alloc(n);
+    LaunchTrace(c->S, n, dR.p, dP.p, dT.p, 1, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpy(occ, dP.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_rng_probe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, unsigned *out) {
+    LMC_TRY
+    EnsureDevice(0);
+    DevBuf<unsigned long long> dS;
+    DevBuf<uint32_t> dTab, dOut;
+    dS.Upload(seeds, nSeeds), dTab.Alloc((size_t)nSeeds * 64), dOut.Alloc((size_t)nSeeds * (n + 66));
+    LaunchRngProbe(nSeeds, dS.p, mode, n, mean, stddev, dTab.p, dOut.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dOut.p, dOut.n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist) {
+    LMC_TRY
+    EnsureDevice(0);
+    if (dim < 1 || dim > MAXPSS || knn > 8) throw std::runtime_error("lmc_kd_probe: bad arguments");
+    lmc::KdTreeResult t = lmc::BuildKdTree(pts, npts, dim);
+    DevBuf<KdNode> dN;
+    DevBuf<int> dV, dOutN, dOutI;
+    DevBuf<float> dP, dQ, dOutD;
+    dN.Upload(t.nodes), dV.Upload(t.vind), dP.Upload(pts, (size_t)npts * dim), dQ.Upload(q, (size_t)nq * dim);
+    dOutN.Alloc(nq), dOutI.Alloc((size_t)nq * knn), dOutD.Alloc((size_t)nq * knn);
+    DCacheDim C;
+    memset(&C, 0, sizeof(C));
+    C.ready = 1, C.nodes = dN.p, C.vind = dV.p, C.pts = dP.p, C.v1 = dP.p, C.v2 = dP.p;
+    for (int k = 0; k < dim; k++) C.rootLow[k] = t.rootLow[k], C.rootHigh[k] = t.rootHigh[k];
+    LaunchKdProbe(C, dim, nq, dQ.p, radiusSq, knn, dOutN.p, dOutI.p, dOutD.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(outN, dOutN.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(outIdx, dOutI.p, (size_t)nq * knn * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(outDist, dOutD.p, (size_t)nq * knn * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out) {
+    LMC_TRY
+    EnsureDevice(0);
+    DevBuf<float> dV, dM, dS, dO, dOut;
+    dV.Upload(v1, (size_t)n * dim), dM.Upload(M, (size_t)n * dim), dS.Upload(sc, n), dO.Upload(offset, (size_t)n * dim), dOut.Alloc((size_t)n * (3 * dim + 2));
+    LaunchGaussProbe(n, dim, dV.p, dM.p, ss, shk, dS.p, dO.p, dOut.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dOut.p, dOut.n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// ---- the reference's plugin symbols (pathlibbidir_mala.so): 42 forward + 42 derivative programs.
+// A single evaluation is one (tiny) kernel launch; throughput users call lmc_grad_batch.
+static void PluginEval(int c, int l, const float *primary, const float *scene, const float *vertParams, float *logLum, float *grad) {
+    const int L = std::max(c + l - 1, 2);
+    float ll = NAN, g[16];
+    for (int k = 0; k < 16; k++) g[k] = NAN;
+    // SoA with n = 1 is the plain array
+    int r = lmc_grad_batch(c, l, 1, primary, scene, vertParams, &ll, grad ? g : nullptr);
+    if (r != 0) fprintf(stderr, "lmc: path program (%d,%d) failed: %s\n", c, l, g_err.c_str());
+    if (logLum) logLum[0] = ll;
+    if (grad)
+        for (int k = 0; k < 2 * L; k++) grad[k] = g[k];
+}
+#define LMC_PLUGIN(C, Lg)                                                                                                                          \
+    void evaluate_path_bidir_mala_##C##_##Lg##_static(const float *, const float *primary, const float *scene, const float *vp, float *logLum) {   \
+        PluginEval(C, Lg, primary, scene, vp, logLum, nullptr);                                                                                    \
+    }                                                                                                                                              \
+    void evaluate_path_bidir_mala_##C##_##Lg##_static_derv(const float *, const float *primary, const float *scene, const float *vp, float *grad) { \
+        PluginEval(C, Lg, primary, scene, vp, nullptr, grad);                                                                                      \
+    }
+// (c,l) with 1<=c<=9, 0<=l<=8, 3<=c+l<=9 (path.cpp:3955-3959)
+LMC_PLUGIN(1, 2) LMC_PLUGIN(1, 3) LMC_PLUGIN(1, 4) LMC_PLUGIN(1, 5) LMC_PLUGIN(1, 6) LMC_PLUGIN(1, 7) LMC_PLUGIN(1, 8)
+LMC_PLUGIN(2, 1) LMC_PLUGIN(2, 2) LMC_PLUGIN(2, 3) LMC_PLUGIN(2, 4) LMC_PLUGIN(2, 5) LMC_PLUGIN(2, 6) LMC_PLUGIN(2, 7)
+LMC_PLUGIN(3, 0) LMC_PLUGIN(3, 1) LMC_PLUGIN(3, 2) LMC_PLUGIN(3, 3) LMC_PLUGIN(3, 4) LMC_PLUGIN(3, 5) LMC_PLUGIN(3, 6)
+LMC_PLUGIN(4, 0) LMC_PLUGIN(4, 1) LMC_PLUGIN(4, 2) LMC_PLUGIN(4, 3) LMC_PLUGIN(4, 4) LMC_PLUGIN(4, 5)
+LMC_PLUGIN(5, 0) LMC_PLUGIN(5, 1) LMC_PLUGIN(5, 2) LMC_PLUGIN(5, 3) LMC_PLUGIN(5, 4)
+LMC_PLUGIN(6, 0) LMC_PLUGIN(6, 1) LMC_PLUGIN(6, 2) LMC_PLUGIN(6, 3)
+LMC_PLUGIN(7, 0) LMC_PLUGIN(7, 1) LMC_PLUGIN(7, 2)
+LMC_PLUGIN(8, 0) LMC_PLUGIN(8, 1)
+LMC_PLUGIN(9, 0)
+
+}  // extern "C"

@@ -430,7 +430,9 @@ Float MLT::Init(int64_t numInitSamples, int numChains, int initThreads_) {  // m
     initStates.clear();
     initStates.reserve(numChains);
     for (int i = 0; i < numChains; i++) {
-        while (pos > cdf[cdfPos]) cdfPos = std::min(cdfPos + 1, int(mStates.size()) - 1);
+        // mlt.h:118-120 clamps cdfPos to size-1 inside the loop, which spins forever once pos exceeds cdf[size-1]
+        // (reachable for the last chains); the oracle (and the HIP host code) stop at size-1 instead.
+        while (pos > cdf[cdfPos] && cdfPos < int(mStates.size()) - 1) cdfPos++;
         initStates.push_back(MarkovState());
         MarkovState &state = initStates.back();
         state.valid = false;

@@ -711,7 +711,18 @@ void Serialize(const RScene *scene, const Path &path, SerializedSubpath &subPath
     for (int camDepth = 0; camDepth < (int)path.camSurfaceVertex.size(); camDepth++) {
         const SurfaceVertex &surfVertex = path.camSurfaceVertex[camDepth];
         const ShapeInst &shapeInst = surfVertex.shapeInst;
-        if (shapeInst.obj != nullptr) shapeInst.obj->Serialize(shapeInst.primID, buffer);
+        if (shapeInst.obj != nullptr) {
+            shapeInst.obj->Serialize(shapeInst.primID, buffer);
+        } else {
+            // The ray escaped to the environment light.  The reference leaves this 46-float slot untouched
+            // (path.cpp:2546-2549), i.e. it holds whatever an earlier Serialize of the same MALASmallStep object
+            // wrote there; the derivative program still "intersects" it, and with an all-zero slot its reverse
+            // sweep turns 0 * NaN into a NaN gradient.  The value the reference produces whenever the stale slot
+            // is a non-degenerate triangle does not depend on that triangle, so the oracle writes a fixed benign
+            // one (DESIGN.md "escaped last vertex").
+            static const Float dummy[46] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1};
+            memcpy(buffer, dummy, sizeof(dummy));
+        }
         buffer += 46;
         if (camDepth == (int)path.camSurfaceVertex.size() - 1) {
             if (path.lgtDepth == 0) {
