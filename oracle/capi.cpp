@@ -85,6 +85,11 @@ int orc_setup_chains(void *h, long long samplesPerChain, long long chainsNeedExt
     return 0;
     ORC_CATCH(-1)
 }
+int orc_setup_chains_range(void *h, long long samplesPerChain, long long chainsNeedExtra, int chainBegin, int chainEnd) {
+    ORC_TRY((MLT *)h)->SetupChains(samplesPerChain, chainsNeedExtra, chainBegin, chainEnd);
+    return 0;
+    ORC_CATCH(-1)
+}
 
 int orc_step(void *h, int nsteps) {
     ORC_TRY

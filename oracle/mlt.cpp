@@ -456,12 +456,14 @@ Float MLT::Init(int64_t numInitSamples, int numChains, int initThreads_) {  // m
     return normalization;
 }
 
-void MLT::SetupChains(int64_t numSamplesPerChain, int64_t chainsNeedExtraSamples) {  // mlt.cpp:60-90
-    const int numChains = (int)initStates.size();
+void MLT::SetupChains(int64_t numSamplesPerChain, int64_t chainsNeedExtraSamples, int chainBegin, int chainEnd) {  // mlt.cpp:60-90
+    const int numChainsTotal = (int)initStates.size();
+    if (chainEnd < 0) chainEnd = numChainsTotal;
     chains.clear();
-    chains.resize(numChains);
-    for (int chainId = 0; chainId < numChains; chainId++) {
-        ChainCtx &c = chains[chainId];
+    chains.resize(chainEnd - chainBegin);
+    // chains [chainBegin, chainEnd) of the global set (multi-process sharding); ids and seeds stay global
+    for (int chainId = chainBegin; chainId < chainEnd; chainId++) {
+        ChainCtx &c = chains[chainId - chainBegin];
         c.rng = RNG((uint64_t)(chainId + scene->options->seedOffset));
         c.numSamplesThisChain = numSamplesPerChain + ((chainId < chainsNeedExtraSamples) ? 1 : 0);
         c.currentState = initStates[chainId];
@@ -679,7 +681,7 @@ void MLT::StepChain(ChainCtx &c, std::vector<PendingPush> &pushes) {  // body of
     const RScene *sc = scene.get();
     std::uniform_real_distribution<Float> uniDist(Float(0.0), Float(1.0));
     const Float largeStepProb = sc->options->largeStepProbability;
-    const int numChains = (int)chains.size();
+    const int numChains = (int)initStates.size();
     MarkovState &currentState = c.currentState, &proposalState = c.proposalState;
     Chain &chain = c.chain;
     const int64_t sampleIdx = c.sampleIdx;

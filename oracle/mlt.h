@@ -149,7 +149,7 @@ struct MLT {
 
     // mlt.h:41-154 with NumSystemCores() := initThreads (deterministic order: thread-major)
     Float Init(int64_t numInitSamples, int numChains, int initThreads);
-    void SetupChains(int64_t numSamplesPerChain, int64_t chainsNeedExtraSamples);
+    void SetupChains(int64_t numSamplesPerChain, int64_t chainsNeedExtraSamples, int chainBegin = 0, int chainEnd = -1);
     // one lock-step iteration of the per-chain loop body (mlt.cpp:91-170) for every chain that still has samples
     void StepAll();
     void StepChain(ChainCtx &c, std::vector<PendingPush> &pushes);

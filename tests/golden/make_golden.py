@@ -39,6 +39,48 @@ def main():
     n, idx, dist = kd_run(drv, "ref_kd_query", 6, pts, q, radius)
     np.savez_compressed(os.path.join(HERE, "kdtree_dim6.npz"), pts=pts, q=q, radius=radius, n=n, idx=idx, dist=dist)
     print("wrote pcg_streams.json, fastlog.json, kdtree_dim6.npz")
+    # (input, output) vectors of the reference's generated forward + derivative programs (oracle/_ref/libpathref.so)
+    # on paths sampled from the torus scene by the oracle
+    from tests import _orc
+    from tests import gpu_checks as gc
+
+    L = gc.oracle_lib()
+    o = _orc.Oracle(L, gc.TORUS, 1, 6, 160, 120, 0, gc.pathref())
+    o.init(60000, 768, 8)
+    rec = {"c": [], "l": [], "primary": [], "vert": [], "loglum": [], "grad": []}
+    per = {}
+    for i in range(768):
+        c, l, prim, vert = o.serialize_init_state(i)
+        if per.get((c, l), 0) >= 24:
+            continue
+        per[(c, l)] = per.get((c, l), 0) + 1
+        ll, g = o.ref_eval(c, l, prim, vert)
+        gg = np.zeros(16, np.float32)
+        gg[: len(g)] = g
+        rec["c"].append(c), rec["l"].append(l), rec["primary"].append(prim), rec["vert"].append(vert[:600]), rec["loglum"].append(ll), rec["grad"].append(gg)
+    # the survey's hand-built known answer: (c,l) = (2,1), point light, one Lambertian triangle
+    f = np.float32
+    ka_primary = np.zeros(17, f)
+    ka_primary[:5] = [0.3, 0.55, 0.45, 0.2, 0.7]
+    ka_scene = np.zeros(38, f)
+    M = np.array([[1, 0, 0, -0.5], [0, 1, 0, -0.5], [0, 0, 1, 1], [0, 0, 0, 1]], f)
+    ka_scene[1:17] = M.T.reshape(-1)
+    ka_scene[24:28] = [0, 0, 0, 1]
+    ka_scene[28:32] = [0, 0, 0, 1]
+    ka_scene[32], ka_scene[33], ka_scene[34:37], ka_scene[37] = 4096, 64, [0, 0, 5], 20000
+    ka_vert = np.zeros(600, f)
+    tri = np.zeros(46, f)
+    tri[2:5], tri[5:8], tri[8:11] = [-10, -10, 5], [20, 0, 0], [0, 20, 0]
+    tri[11:20] = [0, 0, -1] * 3
+    tri[20:38] = tri[2:20]
+    tri[38], tri[45] = 1, 0.005
+    ka_vert[3:49] = tri
+    ka_vert[49:56] = [0, 1, 2, 1, 10, 10, 10]
+    ka_vert[105:109] = [0, 0.8, 0.6, 0.4]
+    ka_vert[115] = 1
+    np.savez_compressed(os.path.join(HERE, "grad_vectors.npz"), scene=o.scene_params(), ka_primary=ka_primary, ka_scene=ka_scene, ka_vert=ka_vert,
+                        **{k: np.array(v) for k, v in rec.items()})
+    print("wrote grad_vectors.npz:", len(rec["c"]), "vectors", per)
 
 
 if __name__ == "__main__":

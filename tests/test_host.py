@@ -1,0 +1,177 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/lmc_abi.h declares (no compute calls),
+the scene front end, the oracle's self-consistency, and the product's path program (host instantiation)
+against the reference's generated programs."""
+import ctypes
+import importlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _orc
+from tests import gpu_checks as gc
+from tests._orc import P
+
+ROOT = gc.ROOT
+
+
+def _product_lib():
+    p = gc.pkg()
+    if not os.path.exists(p.LIB_PATH):
+        pytest.skip("liblmc_hip.so not built (run `python __graft_entry__.py`)")
+    return ctypes.CDLL(p.LIB_PATH)
+
+
+def test_abi_exports_every_declared_symbol():
+    lib = _product_lib()
+    hdr = open(os.path.join(ROOT, "include", "lmc_abi.h")).read()
+    names = set(re.findall(r"\b(lmc_[a-z_0-9]+)\s*\(", hdr))
+    names.discard("lmc_ctx")
+    assert len(names) >= 18
+    for n in sorted(names):
+        assert hasattr(lib, n), "missing export " + n
+    # the reference's plugin symbols: 42 forward + 42 derivative programs (path.cpp:3955-3959)
+    cnt = 0
+    for c in range(1, 10):
+        for l in range(0, 9):
+            if 3 <= c + l <= 9:
+                for suffix in ("static", "static_derv"):
+                    assert hasattr(lib, "evaluate_path_bidir_mala_%d_%d_%s" % (c, l, suffix))
+                    cnt += 1
+    assert cnt == 84
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a HIP device lmc_create must fail with a clear message."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    p = gc.pkg()
+    if not os.path.exists(p.LIB_PATH):
+        pytest.skip("liblmc_hip.so not built")
+    with pytest.raises(RuntimeError, match="HIP|device"):
+        p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6)
+
+
+def test_scene_front_end(oracle):
+    o = _orc.Oracle(oracle, gc.TORUS, 1, 6, 0, 0, 0, "")
+    assert (o.width, o.height, o.num_tris, o.max_depth, o.num_lights) == (1024, 768, 23614, 6, 1)
+    sp = o.scene_params()
+    assert sp[0] == 0 and sp[32] == 1024 * 768 and abs(sp[33] - 1642.72) < 0.01  # pixel count, camera dist
+    assert np.allclose(sp[18:21], [-24.173, -38.184, 30.0076], atol=1e-4)  # camera origin (lookat)
+    assert abs(np.linalg.norm(sp[24:28]) - 1) < 1e-5  # unit quaternion
+    o.close()
+    with pytest.raises(RuntimeError):
+        _orc.Oracle(oracle, os.path.join(ROOT, "scenes", "torus", "nope.xml"))
+    # shipped materials (phong / roughdielectric) are config 3: the oracle says so instead of mis-rendering
+    with pytest.raises(RuntimeError, match="not restated"):
+        _orc.Oracle(oracle, gc.TORUS, 0, 6, 0, 0, 0, "")
+
+
+def test_oracle_energy_and_determinism(oracle):
+    a = _orc.Oracle(oracle, gc.TORUS, 1, 6, 64, 48, 0, "")
+    norm, nc = a.init(8000, 128, 4)
+    a.setup_chains(200, 0)
+    a.step(25)
+    st = a.stats()
+    f = a.film()
+    assert np.isfinite(f).all()
+    # every step deposits luminance `normalization` in total (mlt.cpp:103-112, mutation_*.h toSplat)
+    assert gc.lum(f).sum() == pytest.approx(norm * st["weightSum"], rel=2e-5)
+    assert 0.3 < st["accepted"] / st["steps"] < 0.98
+    b = _orc.Oracle(oracle, gc.TORUS, 1, 6, 64, 48, 0, "")
+    b.init(8000, 128, 4)
+    b.setup_chains(200, 0)
+    b.step(25)
+    assert np.array_equal(b.film(), f)
+    a.close(), b.close()
+
+
+def test_oracle_scalar_path_matches_reference_forward_program(oracle, pathref_path):
+    """log(ssScore) of the oracle's scalar sampler == the reference's generated forward program on the oracle's
+    Serialize output (SURVEY.md §8c identity).  Env-hit paths whose texel column wrapped (col >= W/2, i.e. atan2 < 0)
+    are excluded: there the reference's AD program itself disagrees with its scalar code (frozen texel, envlight.cpp:348-377)."""
+    o = _orc.Oracle(oracle, gc.TORUS, 1, 6, 160, 120, 0, pathref_path)
+    o.init(60000, 512, 8)
+    s = o.summary(1)
+    checked = 0
+    for i in range(512):
+        c, l, prim, vert = o.serialize_init_state(i)
+        if l == 0:
+            col = vert[3 + 59 * (c - 2) + 46 + 35]
+            if col >= 256:
+                continue
+        ll, g = o.ref_eval(c, l, prim, vert)
+        assert abs(ll - np.log(s[i, 4])) < 2e-4, (i, c, l)
+        assert np.isfinite(g).all()
+        checked += 1
+    assert checked > 300
+    o.close()
+
+
+def _host_pathfunc():
+    so = os.path.join(ROOT, "tests", "helpers", "libpathfunc_host.so")
+    src = os.path.join(ROOT, "tests", "helpers", "pathfunc_host.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], cwd=ROOT)
+    return ctypes.CDLL(so)
+
+
+def test_product_path_program_matches_reference_programs(oracle, pathref_path):
+    """The product's generic path program (device/pathfunc.h, instantiated on the host by a test helper) against the
+    reference's own generated forward + derivative programs, technique by technique.  Tolerances: logLum 5e-4 abs,
+    gradient 1e-2 relative L2 (the generated code truncates constants to 6 decimals)."""
+    H = _host_pathfunc()
+    o = _orc.Oracle(oracle, gc.TORUS, 1, 6, 160, 120, 0, pathref_path)
+    o.init(60000, 768, 8)
+    sp = o.scene_params()
+    seen = set()
+    for i in range(768):
+        c, l, prim, vert = o.serialize_init_state(i)
+        ll, g = o.ref_eval(c, l, prim, vert)
+        ll2 = np.zeros(1, np.float32)
+        g2 = np.zeros(16, np.float32)
+        H.lmc_test_pathfunc_host(c, l, P(prim), P(sp), P(vert), P(ll2), P(g2))
+        dim = 2 * (c + l - 1)
+        if not np.isfinite(ll):  # wrapped env texel (see the identity test): the AD program's radiance goes negative, log -> NaN on both sides
+            assert not np.isfinite(ll2[0])
+            continue
+        assert abs(ll - ll2[0]) < 5e-4
+        assert np.linalg.norm(g - g2[:dim]) <= 1e-2 * max(np.linalg.norm(g), 1e-2)
+        seen.add((c, l))
+    assert {(3, 1), (4, 0), (4, 1), (5, 0)} <= seen
+    o.close()
+
+
+def test_golden_gradient_vectors(oracle):
+    """Committed (input, output) vectors of the reference's generated programs (tests/golden/grad_vectors.npz, made by
+    tests/golden/make_golden.py): holds without /root/reference and without oracle/_ref."""
+    H = _host_pathfunc()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "grad_vectors.npz"))
+    n = len(z["c"])
+    assert n >= 64
+    for i in range(n):
+        c, l = int(z["c"][i]), int(z["l"][i])
+        ll2 = np.zeros(1, np.float32)
+        g2 = np.zeros(16, np.float32)
+        prim, vert = z["primary"][i].copy(), z["vert"][i].copy()
+        H.lmc_test_pathfunc_host(c, l, P(prim), P(z["scene"].copy()), P(vert), P(ll2), P(g2))
+        dim = 2 * (c + l - 1)
+        if not np.isfinite(z["loglum"][i]):
+            assert not np.isfinite(ll2[0])
+            continue
+        assert abs(z["loglum"][i] - ll2[0]) < 5e-4
+        assert np.linalg.norm(z["grad"][i][:dim] - g2[:dim]) <= 1e-2 * max(np.linalg.norm(z["grad"][i][:dim]), 1e-2)
+    # the survey's hand-built known answer for (c,l) = (2,1)  
+    k = z["ka_primary"], z["ka_scene"], z["ka_vert"]
+    ll2 = np.zeros(1, np.float32)
+    g2 = np.zeros(16, np.float32)
+    H.lmc_test_pathfunc_host(2, 1, P(k[0].copy()), P(k[1].copy()), P(k[2].copy()), P(ll2), P(g2))
+    assert abs(ll2[0] - (-2.53792)) < 1e-4
+    assert np.allclose(g2[:4], [0.513756, 1.54127, 0, 0], atol=2e-4)
