@@ -21,6 +21,8 @@ constexpr float PCD_MIN = 0.01f, PCD_MAX = 100.f, MTM_MIN = -5.0f, MTM_MAX = 5.0
 constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
 constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
 
+constexpr int KD_STACK = 160;  // deepest kd-tree the in-kernel search accepts (the host refuses deeper ones)
+
 struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly like nanoflann's divideTree)
     int child1, child2;  // -1,-1 => leaf
     int left, right;     // leaf: [left,right) into vind
@@ -194,67 +196,68 @@ LMC_D int KdRadiusSearch(const DCacheDim &C, int dim, const float *q, float radi
             distsq += dists[i];
         }
     }
+    // frame = one activation of searchLevel; divfeat / cut_dist / the two children are recomputed from the node
     struct Frame {
-        int node, other, idx;
-        float mindistsq, cutDist, dst;
-        int phase;
+        int node, phase;
+        float mindistsq, dst;
     };
-    Frame st[32];
+    Frame st[KD_STACK];
     int sp = 0;
     int count = 0;
-    st[sp++] = Frame{0, -1, 0, distsq, 0.f, 0.f, 0};
+    st[sp++] = Frame{0, 0, distsq, 0.f};
     while (sp > 0) {
         Frame &f = st[sp - 1];
         const KdNode nd = C.nodes[f.node];
-        if (f.phase == 0) {
-            if (nd.child1 < 0 && nd.child2 < 0) {
-                for (int i = nd.left; i < nd.right; ++i) {
-                    const int index = C.vind[i];
-                    float d = 0.f;
-                    for (int k = 0; k < dim; ++k) {
-                        const float diff = q[k] - C.pts[(size_t)index * dim + k];
-                        d += diff * diff;
-                    }
-                    if (d < radiusSq) {
-                        idx[count] = index;
-                        dist[count] = d;
-                        count++;
-                        if (count >= knn) return count;
-                    }
+        if (nd.child1 < 0 && nd.child2 < 0) {
+            for (int i = nd.left; i < nd.right; ++i) {
+                const int index = C.vind[i];
+                float d = 0.f;
+                for (int k = 0; k < dim; ++k) {
+                    const float diff = q[k] - C.pts[(size_t)index * dim + k];
+                    d += diff * diff;
                 }
-                sp--;
-                continue;
+                if (d < radiusSq) {
+                    idx[count] = index;
+                    dist[count] = d;
+                    count++;
+                    if (count >= knn) return count;
+                }
             }
-            int id = nd.divfeat;
-            float val = q[id];
-            float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
-            int bestChild, otherChild;
-            float cut_dist;
-            if ((diff1 + diff2) < 0) {
-                bestChild = nd.child1, otherChild = nd.child2;
-                cut_dist = (val - nd.divhigh) * (val - nd.divhigh);
-            } else {
-                bestChild = nd.child2, otherChild = nd.child1;
-                cut_dist = (val - nd.divlow) * (val - nd.divlow);
-            }
-            f.other = otherChild, f.idx = id, f.cutDist = cut_dist, f.phase = 1;
-            float m = f.mindistsq;
-            if (sp < 32) st[sp++] = Frame{bestChild, -1, 0, m, 0.f, 0.f, 0};
+            sp--;
             continue;
-        } else if (f.phase == 1) {
-            float dst = dists[f.idx];
-            float mindistsq = f.mindistsq + f.cutDist - dst;
+        }
+        const int id = nd.divfeat;
+        const float val = q[id];
+        const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int bestChild, otherChild;
+        float cut_dist;
+        if ((diff1 + diff2) < 0) {
+            bestChild = nd.child1, otherChild = nd.child2;
+            cut_dist = (val - nd.divhigh) * (val - nd.divhigh);
+        } else {
+            bestChild = nd.child2, otherChild = nd.child1;
+            cut_dist = (val - nd.divlow) * (val - nd.divlow);
+        }
+        if (f.phase == 0) {
+            f.phase = 1;
+            const float m = f.mindistsq;
+            if (sp >= KD_STACK) return -1;  // deeper than the host-checked bound: cannot happen (host/context.cpp refuses such trees)
+            st[sp++] = Frame{bestChild, 0, m, 0.f};
+            continue;
+        }
+        if (f.phase == 1) {
+            const float dst = dists[id];
+            const float mindistsq = f.mindistsq + cut_dist - dst;
             f.dst = dst;
-            dists[f.idx] = f.cutDist;
+            dists[id] = cut_dist;
             f.phase = 2;
-            if (mindistsq * 1.0f <= radiusSq) {
-                int other = f.other;
-                if (sp < 32) st[sp++] = Frame{other, -1, 0, mindistsq, 0.f, 0.f, 0};
+            if (mindistsq * 1.0f <= radiusSq) {  // epsError = 1 + eps, eps = 0
+                if (sp >= KD_STACK) return -1;
+                st[sp++] = Frame{otherChild, 0, mindistsq, 0.f};
                 continue;
             }
         }
-        // phase 2: restore and return
-        dists[f.idx] = f.dst;
+        dists[id] = f.dst;  // phase 2: restore and return to the caller
         sp--;
     }
     return count;

@@ -35,6 +35,7 @@ LMC_D void StoreGauss(const ChainArrays &A, int i, int dim, const Gauss &g) {
 // The twin blocks of MALASmallStep::Mutate (mutation_mala.h:83-166 current, :174-260 proposal).
 // Persistent Chain vectors (mutation.h:28-43) live in HBM: v1, v2, curr_new_v2, prop_new_v1, prop_new_v2, pss,
 // last_pss (g / curr_new_v1 / curr_new_g / prop_new_g / M are write-only or recomputed in the reference).
+template <bool WITH_GRAD>
 LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, const DPath &path,
                            const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st) {
     const size_t N = A.N;
@@ -53,7 +54,11 @@ LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArra
         float vGrad[MAXPSS];
         for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
         if (sp.ssScore > 1e-10f) {
-            ComputeGradient(S, path, sp, vGrad, gw);
+            // chains are only dispatched to a launch without the gradient code once the cache of their dim is
+            // ready (NeedsGradient below), so this branch is unreachable there; NaN -> zeroed keeps it defined
+            if (WITH_GRAD) ComputeGradient(S, path, sp, vGrad, gw);
+            else
+                for (int k = 0; k < dim; k++) vGrad[k] = NAN;
             st.gradCalls++;
             bool finite = true;
             for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);
@@ -131,6 +136,25 @@ LMC_D int DecideKind(const DScene &S, const ChainArrays &A, int i, Rng &rng) {
     return (rng.Uniform() < S.opt.largeStepProbability * lsScale) ? KIND_LARGE : KIND_SMALL;
 }
 
+// Will the next small step of a chain whose state has dimension `dim` evaluate a gradient?  (mutation_mala.h:94-96)
+LMC_D bool NeedsGradient(const DCache &cache, const StepParams &P, int camDepth, int lgtDepth) {
+    const int dim = PathDimension(camDepth, lgtDepth);
+    return P.useGradient && dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH && !cache.d[dim].ready && GradAvailable(camDepth, lgtDepth);
+}
+
+LMC_D void AppendToList(int *list, int *counter, int value, bool pred) {
+    // wave-aggregated append: one atomic per wave
+    const unsigned long long m = __ballot(pred);
+    if (!pred) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD>
 LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
                      GradWork &gw, StepStats &st) {
     const size_t N = A.N;
@@ -148,7 +172,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
     ContribSink sink{A.contribList, N, (size_t)i, 0};
     st.steps++;
 
-    if (kind == KIND_LARGE) {  // LargeStep::Mutate, mutation_large.h:31-128 (largeStepMultiplexed = false)
+    if (WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL)) {  // LargeStep::Mutate, mutation_large.h:31-128 (largeStepMultiplexed = false)
         st.large++;
         GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng);
         if (sink.count > 0) {
@@ -175,7 +199,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         } else {
             a = 0.0f;
         }
-    } else {
+    } else if (WITH_SMALL) {
         LoadPath(A.curPath, A.N, i, prop);  // proposalState.path = currentState.path
         const int dim = PathDimension(prop.camDepth, prop.lgtDepth);
         float offset[MAXPSS];
@@ -195,7 +219,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
                 flags &= ~F_QUERIED;
             }
             if (!(flags & F_GAUSS)) {
-                InitGaussianFor(S, cache, A, P, i, prop, cur, false, flags, cg, gw, st);
+                InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, cur, false, flags, cg, gw, st);
                 StoreGauss(A, i, dim, cg);
                 flags |= F_GAUSS;
             } else {
@@ -207,7 +231,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         }
         if (PerturbPathBidir(S, offset, prop, pc, rng)) {
             if (mala) {
-                InitGaussianFor(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st);
+                InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st);
                 float py = GaussianLogPdf(dim, offset, false, cg);
                 float px = GaussianLogPdf(dim, offset, true, pg);
                 a = Clampf(expf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
@@ -230,9 +254,10 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
     // small-step splat value: mutation_small.h:48 `contrib * (normalization / lsScore)` vs mutation_mala.h:271
     // `contrib * normalization / lsScore` (different rounding, kept)
     V3 smallSplat{0, 0, 0};
-    if (kind == KIND_SMALL) smallSplat = lastMala ? (pc.contrib * P.normalization) / pc.lsScore : pc.contrib * (P.normalization / pc.lsScore);
+    if (WITH_SMALL && kind == KIND_SMALL) smallSplat = lastMala ? (pc.contrib * P.normalization) / pc.lsScore : pc.contrib * (P.normalization / pc.lsScore);
+    const bool isLarge = WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL);
     if (a > 0.0f) {
-        if (kind == KIND_LARGE) {
+        if (isLarge) {
             const float scale = P.normalization / propScoreSum;
             for (int k = 0; k < sink.count; k++) {
                 Contrib c = sink.Get(k);
@@ -254,7 +279,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         StorePath(A.curPath, A.N, i, prop);
         StoreContrib(A.curContrib, A.N, i, pc);
         A.adjacentReject[i] = 0;
-        if (kind == KIND_LARGE) {
+        if (isLarge) {
             A.scoreSum[i] = propScoreSum;
             const float scale = P.normalization / propScoreSum;
             for (int k = 0; k < sink.count; k++) {

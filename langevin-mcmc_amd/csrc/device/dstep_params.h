@@ -8,4 +8,12 @@ struct StepParams {
     int useGradient;  // 0: derivative library "absent" (isotropic until the cache is ready, path.cpp:4042-4053), 1: in-kernel gradient
 };
 
+// Work lists of the next step: chains are appended by the launch that finishes their current step.
+struct NextLists {
+    int *large, *smallGrad, *smallPlain;  // chain indices
+    int *counts;                          // [0] large, [1] smallGrad, [2] smallPlain
+};
+
+enum StepKernelKind { STEP_LARGE = 0, STEP_SMALL_GRAD = 1, STEP_SMALL_PLAIN = 2 };
+
 }  // namespace lmcd

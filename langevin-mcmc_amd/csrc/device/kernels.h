@@ -20,6 +20,13 @@ void LaunchInitRegen(const lmcd::DScene &S, int numChains, long long perThread, 
                      uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
                      float *initScoreSum, hipStream_t s);
 void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s);
-void LaunchStep(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, int chainBegin,
-                const int *list, const int *listCount, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+// one of the three step launches (device/step_*.hip): chains of `list` (count read on the device) run one mutation and
+// append themselves to the lists of the next step
+void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
+                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
+                         const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
+                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 void LaunchCachePush(const lmcd::ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s);

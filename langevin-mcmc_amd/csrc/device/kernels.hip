@@ -8,7 +8,7 @@
 namespace lmcd {
 
 // ---------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum) {
+__device__ __forceinline__ void BlockReduceStatsUnused(const StepStats &st, unsigned long long *counters, double *weightSum) {
     __shared__ int sInt[7];
     __shared__ float sW;
     if (threadIdx.x == 0) {
@@ -253,28 +253,10 @@ __global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal
     A.pushDim[i] = 0;
 }
 
-// ---------------------------------------------------------------------------------------------- the step
-// mode 0: every chain decides and steps in this launch (reference order, used for small runs / tests)
-// mode 1: only chains whose pre-drawn kind == wantKind (list-driven launches)
-__global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, int chainBegin, const int *list,
-                                              const int *listCount, float *gradBuf, int gradStride) {
-    StepStats st;
-    const int total = list ? *listCount : A.N;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
-        const int i = list ? list[j] : j;
-        if (A.sampleIdx[i] >= A.numSamples[i]) continue;
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
-        GradWork gw{gradBuf, (size_t)gradStride, (size_t)(blockIdx.x * blockDim.x + threadIdx.x)};
-        const int kind = DecideKind(S, A, i, rng);
-        StepParams Pl = P;
-        StepChain(S, *cache, A, film, Pl, i, kind, rng, gw, st);
-        A.rngState[i] = rng.state;
-    }
-    (void)chainBegin;
-    BlockReduceStats(st, A.counters, A.weightSum);
+// first step: every chain starts invalid -> large step (mlt.cpp:97)
+__global__ void k_init_lists(int n, int *large, int *counts) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) large[i] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n, counts[1] = 0, counts[2] = 0;
 }
 
 // applies the pending global-cache pushes of the step in chain order (one block per dim; deterministic)
@@ -364,10 +346,10 @@ void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long l
 void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s) {
     hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, numChainsTotal, perChain, chainsNeedExtra);
 }
-void LaunchStep(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, int chainBegin, const int *list,
-                const int *listCount, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_step, dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, chainBegin, list, listCount, gradBuf, gradStride);
-}
 void LaunchCachePush(const ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s) {
     hipLaunchKernelGGL(k_cache_push, dim3(1), dim3(1024), 0, s, A, dim, pss, v1, v2, weight, count);
+}
+
+void LaunchInitLists(int n, int *large, int *counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_lists, dim3(GridFor(n, 256)), dim3(256), 0, s, n, large, counts);
 }

@@ -1,0 +1,73 @@
+// The chain-step kernel template; instantiated three times (step_large.hip, step_small_grad.hip,
+// step_small_plain.hip) so that large steps, gradient-evaluating small steps and plain small steps run as
+// separate launches: no large/small divergence inside a wave, and the common case (plain small step) does not
+// carry the registers and scratch of the other two.
+#pragma once
+#include "dstep.h"
+#include "kernels.h"
+
+namespace lmcd {
+
+__device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum) {
+    __shared__ int sInt[7];
+    __shared__ float sW;
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; k++) sInt[k] = 0;
+        sW = 0.f;
+    }
+    __syncthreads();
+    int v[7] = {st.steps, st.large, st.accepted, st.gradCalls, st.cacheQueries, st.cacheHits, st.resets};
+    float w = st.wsum;
+    for (int off = 32; off > 0; off >>= 1) {  // wave reduction (64 lanes), then one LDS atomic per wave
+        for (int k = 0; k < 7; k++) v[k] += __shfl_down(v[k], off);
+        w += __shfl_down(w, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 7; k++)
+            if (v[k]) atomicAdd(&sInt[k], v[k]);
+        atomicAdd(&sW, w);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; k++)
+            if (sInt[k]) atomicAdd(&counters[k], (unsigned long long)sInt[k]);
+        if (sW != 0.f) atomicAdd(weightSum, (double)sW);
+    }
+}
+
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD>
+__global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
+                                              NextLists next, float *gradBuf, int gradStride) {
+    StepStats st;
+    const int total = *listCount;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
+        const int i = list[j];
+        Rng rng;
+        rng.state = A.rngState[i];
+        rng.tab = A.rngTab + (size_t)i * 64;
+        rng.ticks = 0;
+        GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
+        const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
+        StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st);
+        // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
+        bool toLarge = false, toGrad = false, toPlain = false;
+        if (A.sampleIdx[i] < A.numSamples[i]) {
+            const int nk = DecideKind(S, A, i, rng);
+            if (nk == KIND_LARGE) {
+                toLarge = true;
+            } else {
+                const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
+                if (S.opt.mala && NeedsGradient(*cache, P, c, l)) toGrad = true;
+                else toPlain = true;
+            }
+        }
+        AppendToList(next.large, &next.counts[0], i, toLarge);
+        AppendToList(next.smallGrad, &next.counts[1], i, toGrad);
+        AppendToList(next.smallPlain, &next.counts[2], i, toPlain);
+        A.rngState[i] = rng.state;
+    }
+    BlockReduceStats(st, A.counters, A.weightSum);
+}
+
+}  // namespace lmcd

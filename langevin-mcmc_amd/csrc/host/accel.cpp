@@ -168,7 +168,8 @@ struct KdBuilder {
         }
         lim2 = left;
     }
-    int Divide(int left, int right, std::vector<Interval> &bbox) {  // nanoflann.hpp:867-917
+    int Divide(int left, int right, std::vector<Interval> &bbox, int depth = 1) {  // nanoflann.hpp:867-917
+        out.depth = std::max(out.depth, depth);
         int ni = (int)out.nodes.size();
         lmcd::KdNode nd;
         memset(&nd, 0, sizeof(nd));
@@ -211,9 +212,9 @@ struct KdBuilder {
         out.nodes[ni].divfeat = cutfeat;
         std::vector<Interval> lb(bbox), rb(bbox);
         lb[cutfeat].high = cutval;
-        int c1 = Divide(left, left + idx, lb);
+        int c1 = Divide(left, left + idx, lb, depth + 1);
         rb[cutfeat].low = cutval;
-        int c2 = Divide(left + idx, right, rb);
+        int c2 = Divide(left + idx, right, rb, depth + 1);
         out.nodes[ni].child1 = c1, out.nodes[ni].child2 = c2;
         out.nodes[ni].divlow = lb[cutfeat].high;
         out.nodes[ni].divhigh = rb[cutfeat].low;
@@ -237,6 +238,7 @@ KdTreeResult BuildKdTree(const float *pts, int n, int dim) {
             if (v > bbox[i].high) bbox[i].high = v;
         }
     B.Divide(0, n, bbox);
+    if (B.out.depth + 1 > lmcd::KD_STACK) throw std::runtime_error("global-cache kd-tree deeper than the in-kernel search stack");
     B.out.rootLow.resize(dim), B.out.rootHigh.resize(dim);
     for (int i = 0; i < dim; i++) B.out.rootLow[i] = bbox[i].low, B.out.rootHigh[i] = bbox[i].high;
     return B.out;

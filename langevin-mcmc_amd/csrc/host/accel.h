@@ -23,6 +23,7 @@ struct KdTreeResult {
     std::vector<lmcd::KdNode> nodes;
     std::vector<int> vind;
     std::vector<float> rootLow, rootHigh;
+    int depth = 0;
 };
 KdTreeResult BuildKdTree(const float *pts, int n, int dim);
 

@@ -112,6 +112,9 @@ struct lmc_ctx {
     DevBuf<double> weightSum;
     DevBuf<float> gradBuf;
     int gradStride = 0, stepGrid = 0;
+    // work lists (double buffered): [parity][large | smallGrad | smallPlain]
+    DevBuf<int> lists[2][3], listCounts[2];
+    int parity = 0;
     // cache
     CacheDimHost cacheDims[PSS_MAX_LENGTH + 1];
     DCache cacheHost;
@@ -443,6 +446,12 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
     UploadCacheStruct(c);
     c->allCachesReady = false;
+    for (int b = 0; b < 2; b++) {
+        for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
+        c->listCounts[b].Alloc(4);
+    }
+    c->parity = 0;
+    LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
     HIP_CHECK(hipStreamSynchronize(s));
     return 0;
@@ -502,7 +511,15 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, s));
-        LaunchStep(c->S, c->cacheDev.p, c->A, film, P, c->chainBegin, nullptr, nullptr, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        const int cur = c->parity, nxt = 1 - c->parity;
+        NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
+        HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
+        const int *cnt = c->listCounts[cur].p;
+        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        if (c->useGradient && !c->allCachesReady)
+            LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        c->parity = nxt;
         HIP_CHECK(hipEventRecord(e1, s));
         c->events.emplace_back(e0, e1);
         if (!c->allCachesReady) MaintainCache(c);

@@ -1,5 +1,6 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see common.h).
 // C entry points for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (ctypes).
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -285,19 +286,38 @@ double orc_bench_steps(void *h, int nsteps, int threads, long long *stepsDone) {
     if (threads == 1) {
         for (int i = 0; i < nsteps; i++) m->StepAll();
     } else {
-        for (int s = 0; s < nsteps; s++) {
-            std::vector<std::vector<PendingPush>> pushes(threads);
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; t++)
-                pool.emplace_back([&, t]() {
-                    int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);
+        // persistent worker threads (like the reference's pool, parallel.cpp:82-142) meeting at a barrier after every
+        // lock-step iteration; thread 0 applies the step's cache pushes in chain order between two barriers
+        std::vector<std::vector<PendingPush>> pushes(threads);
+        std::atomic<int> arrived{0};
+        std::atomic<int> phase{0};
+        auto barrier = [&]() {
+            int ph = phase.load(std::memory_order_acquire);
+            if (arrived.fetch_add(1, std::memory_order_acq_rel) == threads - 1) {
+                arrived.store(0, std::memory_order_relaxed);
+                phase.store(ph + 1, std::memory_order_release);
+            } else {
+                int spins = 0;
+                while (phase.load(std::memory_order_acquire) == ph)
+                    if (++spins > 2000) std::this_thread::yield();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&, t]() {
+                int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);
+                for (int s = 0; s < nsteps; s++) {
+                    pushes[t].clear();
                     for (int i = lo; i < hi; i++)
                         if (m->chains[i].sampleIdx < m->chains[i].numSamplesThisChain) m->StepChain(m->chains[i], pushes[t]);
-                });
-            for (auto &th : pool) th.join();
-            for (int t = 0; t < threads; t++)
-                for (auto &p : pushes[t]) m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
-        }
+                    barrier();
+                    if (t == 0)
+                        for (int tt = 0; tt < threads; tt++)
+                            for (auto &p : pushes[tt]) m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
+                    barrier();
+                }
+            });
+        for (auto &th : pool) th.join();
     }
     auto t1 = std::chrono::steady_clock::now();
     if (threads > 1) {

@@ -115,7 +115,7 @@ struct PendingPush {
     Float weight;
 };
 
-struct StepStats {
+struct alignas(128) StepStats {  // padded: one instance per worker thread in the MT baseline (no false sharing)
     int64_t steps = 0, largeSteps = 0, accepted = 0, gradCalls = 0, cacheQueries = 0, cacheHits = 0, resets = 0;
     double weightSum = 0;  // sum over steps of the total splat weight (1 if the current state is valid, else a): film luminance = normalization * weightSum
 };
