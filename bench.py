@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--init-threads", type=int, default=65536)
     ap.add_argument("--samples-per-chain", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chains", type=int, default=2048)
+    ap.add_argument("--cpu-chains", type=int, default=32768)
     ap.add_argument("--cpu-steps", type=int, default=48)
     return ap.parse_args()
 
@@ -43,6 +43,7 @@ def cpu_baseline(args):
 
     L = gc.oracle_lib()
     cores = os.cpu_count() or 1
+    cores = max(1, min(cores, args.cpu_chains // 64))  # at least 64 chains per worker thread between barriers
     orc = _orc.Oracle(L, gc.TORUS, 1, 6, 0, 0, 0, gc.pathref())
     n = args.cpu_chains
     orc.init(max(8 * n, 20000), n, 64)

@@ -174,7 +174,7 @@ def test_cache_phase_parity():
     """Enough chains and steps for the global gradient cache to fill (3000 entries per dim) and be queried:
     exercises the deferred, chain-ordered push, the host kd-tree build and the in-kernel radius search."""
     ug = 1 if gc.pathref() else 0
-    r = gc.run_pair(128, 96, 200000, 8192, 64, 120, 24, use_gradient=ug, opts={"largestepprob": 0.3})
+    r = gc.run_pair(128, 96, 200000, 8192, 64, 120, 24, use_gradient=ug, opts={"largestepprob": 0.3, "largestepscale": 1.0})
     so, sg = r["stats_oracle"], r["stats_gpu"]
     assert so["cacheReadyMask"] != 0, "test set-up: the cache never filled"
     assert sg["cacheReadyMask"] == so["cacheReadyMask"]
