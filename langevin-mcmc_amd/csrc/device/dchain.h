@@ -11,7 +11,9 @@ constexpr int GAUSS_WORDS = 3 * MAXPSS + 1;  // mean, covL_d, invCov_d, logDet
 constexpr int CONTRIB_WORDS = 9;
 constexpr int SPLAT_WORDS = 5;
 
-enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16 };
+// F_SEL: which of the two path buffers holds the chain's current path (the other receives the proposal; acceptance
+// flips the bit instead of copying the path)
+enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32 };
 enum : int { KIND_SMALL = 0, KIND_LARGE = 1 };
 
 // global_cache.h:8-14, mala.h:9-13, mutation.h:5-8
@@ -21,6 +23,7 @@ constexpr float PCD_MIN = 0.01f, PCD_MAX = 100.f, MTM_MIN = -5.0f, MTM_MAX = 5.0
 constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
 constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
 
+constexpr int KD_LDS_DEPTH = 24;  // deepest tree the lean small-step kernel searches with its frames in LDS (dsmall.h)
 constexpr int KD_STACK = 160;  // deepest kd-tree the in-kernel search accepts (the host refuses deeper ones)
 
 struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly like nanoflann's divideTree)
@@ -32,6 +35,7 @@ struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly 
 };
 struct DCacheDim {
     int ready;
+    int deep;  // tree deeper than the LDS search of the lean small-step kernel accepts: chains of this dim use the generic kernel
     const KdNode *nodes;
     const int *vind;
     const float *pts, *v1, *v2;  // PSS_MAX_SIZE x dim, row-major
@@ -45,7 +49,8 @@ struct ChainArrays {
     int N;
     uint64_t *rngState;
     uint32_t *rngTab;  // N x 64 (AoS)
-    float *curPath;    // DPATH_WORDS x N
+    float *curPath;    // DPATH_WORDS x N: path buffer 0
+    float *pathBuf1;   // DPATH_WORDS x N: path buffer 1 (see F_SEL)
     float *curContrib; // CONTRIB_WORDS x N
     float *scoreSum;   // N
     int *flags;        // N
@@ -100,6 +105,8 @@ LMC_D void StorePath(float *base, int N, int i, const DPath &p) {
             base[(size_t)o * N + i] = w[o];
         }
 }
+LMC_D float *CurPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.pathBuf1 : A.curPath; }
+LMC_D float *PropPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.curPath : A.pathBuf1; }
 LMC_D Contrib LoadContrib(const float *base, int N, int i) {
     Contrib c;
     c.camDepth = __float_as_int(base[0 * (size_t)N + i]);

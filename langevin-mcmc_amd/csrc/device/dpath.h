@@ -142,7 +142,8 @@ LMC_D void ConvertMIS(const DScene &S, int depth, int light, V3 rayOrg, V3 rayDi
 }
 
 // path.cpp:633-745; returns true and fills `out` when a contribution is produced
-LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const DVertex &lgtVertex, Contrib &out) {
+template <class Stk>
+LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const DVertex &lgtVertex, Contrib &out, Stk &stk) {
     V3 camOrg, camDir;
     SamplePrimary(S, V2{0.5f, 0.5f}, camOrg, camDir);
     V3 dirToCamera = camOrg - ps.isect.position;
@@ -152,7 +153,7 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
     const float distSq = LengthSquared(dirToCamera);
     const float dist = sqrtf(distSq);
     dirToCamera = dirToCamera * inverse(dist);
-    if (Occluded(S, ps.isect.position, dirToCamera, dist)) return false;
+    if (Occluded(S, ps.isect.position, dirToCamera, dist, stk)) return false;
     const DMaterial &m = MaterialOfTri(S, lgtVertex.tri);
     V2 st{lgtVertex.st0, lgtVertex.st1};
     V3 bsdfContrib;
@@ -247,7 +248,8 @@ LMC_D bool HandleHitLight(const DScene &S, int camDepth, int light, bool hitSurf
 }
 
 // path.cpp:969-1089 (doOcclusion = true, bidirMIS = true)
-LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out) {
+template <class Stk>
+LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk) {
     const DMaterial &m = MaterialOfTri(S, camVertex.tri);
     const int light = camVertex.dirLight;
     V3 dirToLight, lightContrib;
@@ -255,7 +257,7 @@ LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 scree
     if (!LightSampleDirect(S, light, ps.isect.position, V2{camVertex.dirRnd0, camVertex.dirRnd1}, camVertex.dirPrim, dirToLight, dist, lightContrib,
                            cosAtLight, directPdf, emissionPdf))
         return false;
-    if (Occluded(S, ps.isect.position, dirToLight, dist)) return false;
+    if (Occluded(S, ps.isect.position, dirToLight, dist, stk)) return false;
     V3 bsdfContrib;
     float cosToLight, bsdfPdf, bsdfRevPdf;
     BsdfEvaluate(S, m, false, ps.wi, ps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, bsdfContrib, cosToLight, bsdfPdf, bsdfRevPdf);
@@ -278,13 +280,14 @@ LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 scree
 }
 
 // path.cpp:1091-1235 (doOcclusion = true)
+template <class Stk>
 LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS &lps, const DVertex &lgtVertex, const BPS &cps,
-                         const DVertex &camVertex, V2 screenPos, Contrib &out) {
+                         const DVertex &camVertex, V2 screenPos, Contrib &out, Stk &stk) {
     V3 dirToLight = lps.isect.position - cps.isect.position;
     const float distSq = LengthSquared(dirToLight);
     const float dist = sqrtf(distSq);
     dirToLight = dirToLight * inverse(dist);
-    if (Occluded(S, cps.isect.position, dirToLight, dist)) return false;
+    if (Occluded(S, cps.isect.position, dirToLight, dist, stk)) return false;
     V3 camBsdfFactor;
     float cosCamera, camBsdfPdf, camBsdfRevPdf;
     BsdfEvaluate(S, MaterialOfTri(S, camVertex.tri), false, cps.wi, cps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, camBsdfFactor,
@@ -335,7 +338,8 @@ LMC_D int HitLightOf(const DScene &S, bool hitSurface, int tri) {  // GetHitLigh
 }
 
 // GeneratePathBidir, path.cpp:1237-1449 with screenPosi = (-1,-1)
-LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath &path, ContribSink &sink, Rng &rng) {
+template <class Stk>
+LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath &path, ContribSink &sink, Rng &rng, Stk &stk) {
     path.camCount = path.lgtCount = 0;
     path.envPrim = -1;
     path.time = rng.Uniform();
@@ -353,7 +357,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
     for (int lgtDepth = 0;; lgtDepth++) {
         DVertex &sv = path.lgt[lgtDepth];
         SurfHit hit;
-        bool hitSurface = IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lightStates[lgtDepth].isect);
+        bool hitSurface = IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lightStates[lgtDepth].isect, stk);
         if (!hitSurface) {
             numLightStates--;
             break;
@@ -365,7 +369,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         ConvertMIS(S, lgtDepth, path.lgtLight, org, dir, lightStates[lgtDepth]);
         if (lgtDepth + 2 >= minDepth) {
             Contrib c;
-            if (ConnectToCamera(S, lgtDepth, lightStates[lgtDepth], sv, c)) sink.Push(c);
+            if (ConnectToCamera(S, lgtDepth, lightStates[lgtDepth], sv, c, stk)) sink.Push(c);
         }
         if (maxDepth != -1 && lgtDepth + 2 >= maxDepth) break;
         if (lgtDepth + 1 >= MAXD) break;  // storage bound (never reached for maxDepth <= MAXD)
@@ -401,7 +405,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         path.camCount = camDepth + 1;
         SurfHit hit;
         hit.tri = -1;
-        bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect);
+        bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect, stk);
         sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
@@ -422,13 +426,13 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
             sv.dirRnd0 = r.x, sv.dirRnd1 = r.y;
             sv.dirPrim = LightSampleDiscrete(S, sv.dirLight, rng.Uniform());
             Contrib c;
-            if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c)) sink.Push(c);
+            if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk)) sink.Push(c);
         }
         int maxLgtDepth = maxDepth == -1 ? (numLightStates - 1) : min(maxDepth - camDepth - 3, numLightStates - 1);
         for (int lgtDepth = 0; lgtDepth <= maxLgtDepth; lgtDepth++) {
             if (camDepth + lgtDepth + 3 >= minDepth) {
                 Contrib c;
-                if (ConnectVertex(S, camDepth, lgtDepth, lightStates[lgtDepth], path.lgt[lgtDepth], cps, sv, screenPos, c)) sink.Push(c);
+                if (ConnectVertex(S, camDepth, lgtDepth, lightStates[lgtDepth], path.lgt[lgtDepth], cps, sv, screenPos, c, stk)) sink.Push(c);
             }
         }
         V2 r = RndVec2(rng);
@@ -475,7 +479,8 @@ LMC_D int GetPathPss(const DPath &path, float *pss) {
 }
 
 // PerturbPathBidir, path.cpp:1953-2160.  Returns true and fills `out` when the perturbed path carries light.
-LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, Contrib &out, Rng &rng) {
+template <class Stk>
+LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, Contrib &out, Rng &rng, Stk &stk) {
     NormalDist normDist(0.0f, S.opt.discreteStdDev);
     int offsetId = 0;
     path.time = Modulo1(path.time + normDist(rng));
@@ -491,12 +496,12 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         for (int lgtDepth = 0; lgtDepth < path.lgtCount; lgtDepth++) {
             DVertex &sv = path.lgt[lgtDepth];
             SurfHit hit;
-            if (!IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lps.isect)) return false;
+            if (!IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lps.isect, stk)) return false;
             sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
             lps.wi = -dir;
             sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
             ConvertMIS(S, lgtDepth, path.lgtLight, org, dir, lps);
-            if (lgtDepth == path.lgtCount - 1 && path.camDepth == 1) return ConnectToCamera(S, lgtDepth, lps, sv, out);
+            if (lgtDepth == path.lgtCount - 1 && path.camDepth == 1) return ConnectToCamera(S, lgtDepth, lps, sv, out, stk);
             if (lgtDepth == path.lgtCount - 1) break;
             sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
             sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);
@@ -517,7 +522,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         DVertex &sv = path.cam[camDepth];
         SurfHit hit;
         hit.tri = -1;
-        bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect);
+        bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect, stk);
         sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
@@ -533,9 +538,9 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
                 const float directLightPickProb = PickLightProb(S, sv.dirLight);
                 sv.dirRnd0 = Modulo1(sv.dirRnd0 + offset[offsetId++]);
                 sv.dirRnd1 = Modulo1(sv.dirRnd1 + offset[offsetId++]);
-                return DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, out);
+                return DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, out, stk);
             }
-            return ConnectVertex(S, camDepth, path.lgtCount - 1, lps, path.lgt[path.lgtCount - 1], cps, sv, screenPos, out);
+            return ConnectVertex(S, camDepth, path.lgtCount - 1, lps, path.lgt[path.lgtCount - 1], cps, sv, screenPos, out, stk);
         }
         sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
         sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);

@@ -122,14 +122,43 @@ LMC_D bool SlabTest(const float *bmin, const float *bmax, V3 org, V3 invd, float
     return t0 * 0.9999996f <= t1 * 1.0000004f;  // 2*gamma(3) widening, as in the oracle
 }
 
-constexpr int BVH_STACK = 64;
+constexpr int BVH_STACK = 64;      // host-checked bound on the LBVH depth
+constexpr int BVH_LDS_STACK = 32;  // entries of the per-thread LDS stack (the host refuses deeper trees for LDS kernels)
+
+// Traversal stack policies.  Private arrays indexed at run time live in scratch memory, which on gfx950 is HBM-backed
+// and was the bottleneck of the first version of the step kernel (profiles/r01_a_*): the hot kernels keep the stack
+// in LDS instead, laid out [entry][thread] so that a wave's accesses are conflict-free.
+struct LocalStack {
+    int s[BVH_STACK];
+    int sp = 0;
+    LMC_D void Reset() { sp = 0; }
+    LMC_D bool Empty() const { return sp == 0; }
+    LMC_D void Push(int v) {
+        if (sp < BVH_STACK) s[sp++] = v;
+    }
+    LMC_D int Pop() { return s[--sp]; }
+};
+struct LdsStack {
+    int *base;   // &lds[threadIdx.x]
+    int stride;  // blockDim.x
+    int sp;
+    LMC_D void Reset() { sp = 0; }
+    LMC_D bool Empty() const { return sp == 0; }
+    LMC_D void Push(int v) {
+        if (sp < BVH_LDS_STACK) base[sp * stride] = v, sp++;
+    }
+    LMC_D int Pop() {
+        --sp;
+        return base[sp * stride];
+    }
+};
 
 // closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer)
-LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit) {
+template <class Stk>
+LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stk &stk) {
     if (S.numNodes == 0) return -1;
     V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-    int stack[BVH_STACK];
-    int sp = 0;
+    stk.Reset();
     int best = -1;
     float bestT = tfar;
     int cur = 0;  // root is an inner node (or a single-leaf wrapper)
@@ -142,7 +171,7 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
             if (hl && hr) {
                 int nearC = nd.left, farC = nd.right;
                 if (tr < tl) nearC = nd.right, farC = nd.left;
-                if (sp < BVH_STACK) stack[sp++] = farC;
+                stk.Push(farC);
                 cur = nearC;
                 continue;
             } else if (hl) {
@@ -166,18 +195,18 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
                 }
             }
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
+        if (stk.Empty()) break;
+        cur = stk.Pop();
     }
     tHit = bestT;
     return best;
 }
 
-LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar) {
+template <class Stk>
+LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar, Stk &stk) {
     if (S.numNodes == 0) return false;
     V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-    int stack[BVH_STACK];
-    int sp = 0;
+    stk.Reset();
     int cur = 0;
     for (;;) {
         if (cur >= 0) {
@@ -186,7 +215,7 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar)
             bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, tfar, tl);
             bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, tfar, tr);
             if (hl && hr) {
-                if (sp < BVH_STACK) stack[sp++] = nd.right;
+                stk.Push(nd.right);
                 cur = nd.left;
                 continue;
             } else if (hl) {
@@ -205,16 +234,17 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar)
                 if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, tfar, t)) return true;
             }
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
+        if (stk.Empty()) break;
+        cur = stk.Pop();
     }
     return false;
 }
 
 // scene.cpp:128-149
-LMC_D bool Occluded(const DScene &S, V3 org, V3 dir, float dist) {
+template <class Stk>
+LMC_D bool Occluded(const DScene &S, V3 org, V3 dir, float dist, Stk &stk) {
     float maxT = (dist == INFINITY) ? INFINITY : (1.0f - c_ShadowEpsilon) * dist;
-    return BvhOccluded(S, org, dir, c_IsectEpsilon, maxT);
+    return BvhOccluded(S, org, dir, c_IsectEpsilon, maxT, stk);
 }
 
 }  // namespace lmcd

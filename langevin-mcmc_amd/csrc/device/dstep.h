@@ -142,6 +142,13 @@ LMC_D bool NeedsGradient(const DCache &cache, const StepParams &P, int camDepth,
     return P.useGradient && dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH && !cache.d[dim].ready && GradAvailable(camDepth, lgtDepth);
 }
 
+// ... or query a cache tree too deep for the lean kernel's LDS search (dsmall.h)?  Such chains run the generic kernel.
+LMC_D bool NeedsGeneric(const DCache &cache, const StepParams &P, int camDepth, int lgtDepth) {
+    const int dim = PathDimension(camDepth, lgtDepth);
+    const bool deep = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH && cache.d[dim].ready && cache.d[dim].deep;
+    return deep || NeedsGradient(cache, P, camDepth, lgtDepth);
+}
+
 LMC_D void AppendToList(int *list, int *counter, int value, bool pred) {
     // wave-aggregated append: one atomic per wave
     const unsigned long long m = __ballot(pred);
@@ -154,9 +161,9 @@ LMC_D void AppendToList(int *list, int *counter, int value, bool pred) {
     list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD>
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, class Stk>
 LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
-                     GradWork &gw, StepStats &st) {
+                     GradWork &gw, StepStats &st, Stk &stk) {
     const size_t N = A.N;
     int flags = A.flags[i];
     const bool curValid = flags & F_VALID;
@@ -174,7 +181,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
 
     if (WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL)) {  // LargeStep::Mutate, mutation_large.h:31-128 (largeStepMultiplexed = false)
         st.large++;
-        GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng);
+        GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng, stk);
         if (sink.count > 0) {
             float scoreSum = 0.f;
             for (int k = 0; k < sink.count; k++) scoreSum += sink.LsScore(k);  // contribCdf.back()
@@ -200,7 +207,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             a = 0.0f;
         }
     } else if (WITH_SMALL) {
-        LoadPath(A.curPath, A.N, i, prop);  // proposalState.path = currentState.path
+        LoadPath(CurPathBuf(A, flags), A.N, i, prop);  // proposalState.path = currentState.path
         const int dim = PathDimension(prop.camDepth, prop.lgtDepth);
         float offset[MAXPSS];
         const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51
@@ -229,7 +236,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             for (int k = 0; k < dim; k++) offset[k] = nd(rng);
             for (int k = 0; k < dim; k++) offset[k] = cg.covL[k] * offset[k] + cg.mean[k];
         }
-        if (PerturbPathBidir(S, offset, prop, pc, rng)) {
+        if (PerturbPathBidir(S, offset, prop, pc, rng, stk)) {
             if (mala) {
                 InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st);
                 float py = GaussianLogPdf(dim, offset, false, cg);
@@ -276,7 +283,8 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         st.accepted++;
         const int oldDim = PathDimension(cur.camDepth, cur.lightDepth);  // GetDimension(proposalState.path) after the swap, mlt.cpp:121
         ToSubpath(pc.camDepth, pc.lightDepth, prop);
-        StorePath(A.curPath, A.N, i, prop);
+        StorePath(PropPathBuf(A, flags), A.N, i, prop);  // the proposal buffer becomes the current one
+        flags ^= F_SEL;
         StoreContrib(A.curContrib, A.N, i, pc);
         A.adjacentReject[i] = 0;
         if (isLarge) {
@@ -325,16 +333,16 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         A.adjacentReject[i] = rej;
         const bool strongReject = cur.lsScore > OUTLIER_RATIO_THRESHOLD * P.normalization;
         if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
-            int chainId = i, cnt = 0;
+            int chainId = P.chainBegin + i, cnt = 0;  // init states are indexed by global chain id
             for (;;) {
-                const float ls = A.initContrib[7 * N + chainId];
+                const float ls = A.initContrib[7 * (size_t)P.numChains + chainId];
                 if (ls < OUTLIER_RATIO_THRESHOLD * P.normalization) break;
                 chainId = (int)(((long long)chainId + sampleIdx + cnt++) % P.numChains);
             }
             DPath ip;
-            LoadPath(A.initPath, A.N, chainId, ip);
-            StorePath(A.curPath, A.N, i, ip);
-            StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, A.N, chainId));
+            LoadPath(A.initPath, P.numChains, chainId, ip);
+            StorePath(CurPathBuf(A, flags), A.N, i, ip);
+            StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, P.numChains, chainId));
             A.scoreSum[i] = A.initScoreSum[chainId];
             A.curSplatCount[i] = 0;
             flags &= ~(F_VALID | F_GAUSS | F_BUFFERED);

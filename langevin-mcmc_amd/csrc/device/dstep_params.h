@@ -4,7 +4,8 @@ namespace lmcd {
 
 struct StepParams {
     float normalization;
-    int numChains;
+    int numChains;   // all chains of the job (stride of the init-state arrays)
+    int chainBegin;  // global id of this rank's chain 0
     int useGradient;  // 0: derivative library "absent" (isotropic until the cache is ready, path.cpp:4042-4053), 1: in-kernel gradient
 };
 

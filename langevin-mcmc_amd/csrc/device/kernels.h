@@ -27,6 +27,6 @@ void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+                          const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, int gridBlocks, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 void LaunchCachePush(const lmcd::ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s);

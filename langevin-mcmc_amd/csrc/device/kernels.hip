@@ -7,35 +7,6 @@
 
 namespace lmcd {
 
-// ---------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ void BlockReduceStatsUnused(const StepStats &st, unsigned long long *counters, double *weightSum) {
-    __shared__ int sInt[7];
-    __shared__ float sW;
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 7; k++) sInt[k] = 0;
-        sW = 0.f;
-    }
-    __syncthreads();
-    // wave reduction first (64 lanes), then one LDS atomic per wave
-    int v[7] = {st.steps, st.large, st.accepted, st.gradCalls, st.cacheQueries, st.cacheHits, st.resets};
-    float w = st.wsum;
-    for (int off = 32; off > 0; off >>= 1) {
-        for (int k = 0; k < 7; k++) v[k] += __shfl_down(v[k], off);
-        w += __shfl_down(w, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 7; k++)
-            if (v[k]) atomicAdd(&sInt[k], v[k]);
-        atomicAdd(&sW, w);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 7; k++)
-            if (sInt[k]) atomicAdd(&counters[k], (unsigned long long)sInt[k]);
-        if (sW != 0.f) atomicAdd(weightSum, (double)sW);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- RNG
 __global__ void k_seed_rng(int n, long long firstSeed, uint64_t *state, uint32_t *tab) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -77,11 +48,12 @@ __global__ void k_trace(DScene S, int n, const float *rays, int *prim, float *t,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *r = rays + (size_t)i * 8;
         V3 org{r[0], r[1], r[2]}, dir{r[3], r[4], r[5]};
+        LocalStack stk;
         if (anyHit) {
-            prim[i] = BvhOccluded(S, org, dir, r[6], r[7]) ? 1 : 0;
+            prim[i] = BvhOccluded(S, org, dir, r[6], r[7], stk) ? 1 : 0;
         } else {
             float tt = 0.f;
-            int id = BvhIntersect(S, org, dir, r[6], r[7], tt);
+            int id = BvhIntersect(S, org, dir, r[6], r[7], tt, stk);
             prim[i] = id;
             t[i] = id >= 0 ? tt : 0.f;
         }
@@ -155,11 +127,12 @@ __global__ void k_init_pass1(DScene S, int V, long long perThread, long long ext
     long long base = (long long)t * perThread + (t < extra ? t : extra);
     const int minPathLength = max(S.opt.minDepth, 3);
     DPath path;
+    LocalStack stk;
     for (long long s = 0; s < n; s++) {
         ckState[base + s] = rng.state;
         ckTicks[base + s] = rng.ticks;
         ContribSink sink{contribScratch, (size_t)V, (size_t)t, 0};
-        GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng);
+        GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng, stk);
         count[base + s] = (unsigned char)sink.count;
     }
 }
@@ -184,13 +157,14 @@ __global__ void k_init_pass2(DScene S, long long numSamples, long long perThread
     if (slot >= nSlots) return;
     const int minPathLength = max(S.opt.minDepth, 3);
     DPath path;
+    LocalStack stk;
     for (long long g = slot; g < numSamples; g += nSlots) {
         Rng rng;
         rng.tab = tabScratch + (size_t)slot * 64;
         int t = InitThreadOfSample(g, perThread, extra);
         RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
         ContribSink sink{contribScratch, (size_t)nSlots, (size_t)slot, 0};
-        GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng);
+        GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng, stk);
         unsigned long long o = offset[g];
         for (int k = 0; k < sink.count; k++) {
             Contrib c = sink.Get(k);
@@ -213,7 +187,8 @@ __global__ void k_init_regen(DScene S, int numChains, long long perThread, long 
     RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
     DPath path;
     ContribSink sink{contribScratch, (size_t)numChains, (size_t)i, 0};
-    GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, path, sink, rng);
+    LocalStack stk;
+    GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, path, sink, rng, stk);
     float scoreSum = 0.f;
     Contrib sel;
     sel.camDepth = sel.lightDepth = 0;

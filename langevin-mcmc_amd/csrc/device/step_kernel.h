@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
         rng.ticks = 0;
         GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
         const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
-        StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st);
+        LocalStack stk;
+        StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
         // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
         bool toLarge = false, toGrad = false, toPlain = false;
         if (A.sampleIdx[i] < A.numSamples[i]) {
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
                 toLarge = true;
             } else {
                 const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
-                if (S.opt.mala && NeedsGradient(*cache, P, c, l)) toGrad = true;
+                if (S.opt.mala && NeedsGeneric(*cache, P, c, l)) toGrad = true;
                 else toPlain = true;
             }
         }

@@ -1,9 +1,57 @@
-// k_step<false, true, false>: see step_kernel.h
+// The hot launch: plain small steps (dsmall.h) of the chains on the smallPlain list.  Everything indexed at run time
+// lives in LDS (80 words per thread), the path is streamed through registers: no scratch memory.
+// USE_LDS_STACK = false is the fallback for scenes whose LBVH is deeper than the 32-entry LDS traversal stack.
+#include "dsmall.h"
 #include "step_kernel.h"
 
 using namespace lmcd;
 
+template <bool USE_LDS_STACK>
+__global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
+                                                    const int *listCount, NextLists next) {
+    extern __shared__ float lds[];
+    StepStats st;
+    const int total = *listCount;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const LdsView L{lds + threadIdx.x, (int)blockDim.x};
+    for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
+        const int i = list[j];
+        Rng rng;
+        rng.state = A.rngState[i];
+        rng.tab = A.rngTab + (size_t)i * 64;
+        rng.ticks = 0;
+        if (USE_LDS_STACK) {
+            LdsStack stk{reinterpret_cast<int *>(L.base), L.stride, 0};
+            SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
+        } else {
+            LocalStack stk;
+            SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
+        }
+        // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
+        bool toLarge = false, toGrad = false, toPlain = false;
+        if (A.sampleIdx[i] < A.numSamples[i]) {
+            const int nk = DecideKind(S, A, i, rng);
+            if (nk == KIND_LARGE) {
+                toLarge = true;
+            } else {
+                const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
+                if (S.opt.mala && NeedsGeneric(*cache, P, c, l)) toGrad = true;
+                else toPlain = true;
+            }
+        }
+        AppendToList(next.large, &next.counts[0], i, toLarge);
+        AppendToList(next.smallGrad, &next.counts[1], i, toGrad);
+        AppendToList(next.smallPlain, &next.counts[2], i, toPlain);
+        A.rngState[i] = rng.state;
+    }
+    BlockReduceStats(st, A.counters, A.weightSum);
+}
+
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                     const NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
-    hipLaunchKernelGGL((k_step<false, true, false>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+                          const NextLists &next, int bvhDepth, int gridBlocks, hipStream_t s) {
+    const size_t ldsBytes = (size_t)256 * LDS_WORDS_PER_THREAD * sizeof(float);
+    if (bvhDepth <= BVH_LDS_STACK)
+        hipLaunchKernelGGL((k_step_small<true>), dim3(gridBlocks), dim3(256), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+    else
+        hipLaunchKernelGGL((k_step_small<false>), dim3(gridBlocks), dim3(256), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
 }

@@ -105,7 +105,7 @@ struct lmc_ctx {
     ChainArrays A;
     DevBuf<uint64_t> rngState;
     DevBuf<uint32_t> rngTab;
-    DevBuf<float> curPath, curContrib, scoreSum, gaussian, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
+    DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
         lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum;
     DevBuf<int> flags, curSplatCount, adjacentReject, sampleIdx, numSamples, pushDim;
     DevBuf<unsigned long long> counters;
@@ -120,6 +120,7 @@ struct lmc_ctx {
     DCache cacheHost;
     DevBuf<DCache> cacheDev;
     bool allCachesReady = false;
+    bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
     // init results
     float normalization = 0.f;
     long long numInitContribs = 0;
@@ -409,7 +410,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     }
     // ---- chain arrays
     c->rngState.Alloc(N), c->rngTab.Alloc(N * 64, false);
-    c->curPath.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS);
+    c->curPath.Alloc(N * DPATH_WORDS), c->pathBuf1.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS);
     c->curSplat.Alloc(N * MAXCONTRIB * SPLAT_WORDS), c->curSplatCount.Alloc(N);
     c->chV1.Alloc(N * MAXPSS), c->chV2.Alloc(N * MAXPSS), c->chCurrNewV2.Alloc(N * MAXPSS), c->chPropNewV1.Alloc(N * MAXPSS),
         c->chPropNewV2.Alloc(N * MAXPSS), c->chPss.Alloc(N * MAXPSS), c->chLastPss.Alloc(N * MAXPSS);
@@ -418,7 +419,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->counters.Alloc(8), c->weightSum.Alloc(1);
     ChainArrays &A = c->A;
     A.N = (int)N;
-    A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
+    A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.pathBuf1 = c->pathBuf1.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
     A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
     A.chV1 = c->chV1.p, A.chV2 = c->chV2.p, A.chCurrNewV2 = c->chCurrNewV2.p, A.chPropNewV1 = c->chPropNewV1.p, A.chPropNewV2 = c->chPropNewV2.p,
     A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
@@ -446,6 +447,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
     UploadCacheStruct(c);
     c->allCachesReady = false;
+    c->needGeneric = true;
     for (int b = 0; b < 2; b++) {
         for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
         c->listCounts[b].Alloc(4);
@@ -475,6 +477,9 @@ static void MaintainCache(lmc_ctx *c) {
     }
     if (!anyPending) {
         c->allCachesReady = true;
+        bool anyDeep = false;
+        for (int d = 2; d <= PSS_MAX_LENGTH; d++) anyDeep = anyDeep || (c->cacheDims[d].ready && c->cacheHost.d[d].deep);
+        c->needGeneric = anyDeep;
         return;
     }
     bool changed = false;
@@ -489,6 +494,7 @@ static void MaintainCache(lmc_ctx *c) {
             lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
             cd.nodes.Upload(t.nodes), cd.vind.Upload(t.vind);
             DCacheDim &D = c->cacheHost.d[d];
+            D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
             D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
             for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
             cd.ready = true;
@@ -505,7 +511,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
     hipStream_t s = c->stream;
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
     StepParams P;
-    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.useGradient = c->useGradient;
+    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient;
     for (int it = 0; it < nSteps; it++) {
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
@@ -516,9 +522,11 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
         const int *cnt = c->listCounts[cur].p;
         LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
-        if (c->useGradient && !c->allCachesReady)
+        // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
+        // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
+        if (c->needGeneric)
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
-        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->stepGrid, s);
         c->parity = nxt;
         HIP_CHECK(hipEventRecord(e1, s));
         c->events.emplace_back(e0, e1);
@@ -589,6 +597,8 @@ int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     const size_t N = which == 0 ? c->N : c->numChainsTotal;
     std::vector<float> path = (which == 0 ? c->curPath : c->initPath).Download();
+    std::vector<float> path1;
+    if (which == 0) path1 = c->pathBuf1.Download();
     std::vector<float> con = (which == 0 ? c->curContrib : c->initContrib).Download();
     std::vector<float> ss = (which == 0 ? c->scoreSum : c->initScoreSum).Download();
     std::vector<int> fl, sidx, nspl;
@@ -598,7 +608,8 @@ int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
         memset(o, 0, stride * sizeof(float));
         DPath p;
         float *w = reinterpret_cast<float *>(&p);
-        for (int k = 0; k < DPATH_WORDS; k++) w[k] = path[(size_t)k * N + i];
+        const std::vector<float> &src = (which == 0 && (fl[i] & F_SEL)) ? path1 : path;  // the chain's current buffer
+        for (int k = 0; k < DPATH_WORDS; k++) w[k] = src[(size_t)k * N + i];
         int cc, ll;
         memcpy(&cc, &con[0 * N + i], 4), memcpy(&ll, &con[1 * N + i], 4);
         o[0] = which == 0 ? float(fl[i] & F_VALID ? 1 : 0) : 0.f;
