@@ -15,6 +15,7 @@ constexpr int SPLAT_WORDS = 5;
 // flips the bit instead of copying the path)
 enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32 };
 enum : int { KIND_SMALL = 0, KIND_LARGE = 1 };
+enum : unsigned char { NEXT_DONE = 0, NEXT_LARGE = 1, NEXT_SMALL_GENERIC = 2, NEXT_SMALL_PLAIN = 3 };
 
 // global_cache.h:8-14, mala.h:9-13, mutation.h:5-8
 constexpr int PSS_MIN_LENGTH = 2, PSS_MAX_LENGTH = 12, PSS_MAX_SIZE = 3000;
@@ -61,6 +62,7 @@ struct ChainArrays {
     float *pathWeight, *lastScoreSum, *lastScore;
     int *adjacentReject, *sampleIdx, *numSamples;
     float *contribList;  // MAXCONTRIB*CONTRIB_WORDS x N (GeneratePathBidir scratch)
+    unsigned char *nextKind;  // N: which launch runs the chain's next step (NEXT_*), turned into id-ordered work lists by k_build_lists
     int *pushDim;        // N: dim of a pending global-cache push (0 = none)
     float *pushData;     // (3*MAXPSS+1) x N: pss, v1, v2, weight snapshot for the push
     // init states (outlier reset, mlt.cpp:147-169)

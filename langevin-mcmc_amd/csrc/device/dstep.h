@@ -149,18 +149,6 @@ LMC_D bool NeedsGeneric(const DCache &cache, const StepParams &P, int camDepth, 
     return deep || NeedsGradient(cache, P, camDepth, lgtDepth);
 }
 
-LMC_D void AppendToList(int *list, int *counter, int value, bool pred) {
-    // wave-aggregated append: one atomic per wave
-    const unsigned long long m = __ballot(pred);
-    if (!pred) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader);
-    list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
-}
-
 template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, class Stk>
 LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
                      GradWork &gw, StepStats &st, Stk &stk) {

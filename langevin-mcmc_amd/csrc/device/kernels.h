@@ -28,5 +28,7 @@ void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                           const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, int gridBlocks, hipStream_t s);
+// id-ordered work lists of the next step from A.nextKind (coalescing: a wave's 64 list entries are (nearly) consecutive chains)
+void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 void LaunchCachePush(const lmcd::ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s);

@@ -228,6 +228,51 @@ __global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal
     A.pushDim[i] = 0;
 }
 
+// Work lists of the next step.  Each block owns 1024 consecutive chains, reserves one contiguous range per list with a
+// single atomic and fills it in chain-id order: list entries that end up in one wave are (nearly) consecutive chains, so
+// the SoA chain state is read and written in whole cache lines.  (Appending straight from the step kernels scrambles
+// the order a little more every step until every lane touches its own cache line: profiles/r01_b_*.)
+__global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next) {
+    __shared__ unsigned long long sWave[4];
+    __shared__ int sBase[3];
+    const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned char k[4] = {0, 0, 0, 0};
+    if (first + 3 < A.N) {
+        const uchar4 v = *reinterpret_cast<const uchar4 *>(A.nextKind + first);
+        k[0] = v.x, k[1] = v.y, k[2] = v.z, k[3] = v.w;
+    } else {
+        for (int j = 0; j < 4; j++)
+            if (first + j < A.N) k[j] = A.nextKind[first + j];
+    }
+    // three 21-bit counters packed into one word: [large | generic << 21 | plain << 42]
+    unsigned long long mine = 0;
+    for (int j = 0; j < 4; j++)
+        if (k[j]) mine += 1ull << (21 * (k[j] - 1));
+    unsigned long long incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += sWave[w];
+        total += sWave[w];
+    }
+    if (threadIdx.x < 3) {
+        const int n = (int)((total >> (21 * threadIdx.x)) & 0x1fffff);
+        sBase[threadIdx.x] = n ? atomicAdd(&next.counts[threadIdx.x], n) : 0;
+    }
+    __syncthreads();
+    const unsigned long long excl = before + incl - mine;
+    int pos[3] = {sBase[0] + (int)(excl & 0x1fffff), sBase[1] + (int)((excl >> 21) & 0x1fffff), sBase[2] + (int)((excl >> 42) & 0x1fffff)};
+    int *lists[3] = {next.large, next.smallGrad, next.smallPlain};
+    for (int j = 0; j < 4; j++)
+        if (k[j]) lists[k[j] - 1][pos[k[j] - 1]++] = first + j;
+}
+
 // first step: every chain starts invalid -> large step (mlt.cpp:97)
 __global__ void k_init_lists(int n, int *large, int *counts) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) large[i] = i;
@@ -325,6 +370,9 @@ void LaunchCachePush(const ChainArrays &A, int dim, float *pss, float *v1, float
     hipLaunchKernelGGL(k_cache_push, dim3(1), dim3(1024), 0, s, A, dim, pss, v1, v2, weight, count);
 }
 
+void LaunchBuildLists(const ChainArrays &A, const NextLists &next, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_lists, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next);
+}
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lists, dim3(GridFor(n, 256)), dim3(256), 0, s, n, large, counts);
 }

@@ -39,9 +39,7 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
                 else toPlain = true;
             }
         }
-        AppendToList(next.large, &next.counts[0], i, toLarge);
-        AppendToList(next.smallGrad, &next.counts[1], i, toGrad);
-        AppendToList(next.smallPlain, &next.counts[2], i, toPlain);
+        A.nextKind[i] = toLarge ? NEXT_LARGE : toGrad ? NEXT_SMALL_GENERIC : toPlain ? NEXT_SMALL_PLAIN : NEXT_DONE;
         A.rngState[i] = rng.state;
     }
     BlockReduceStats(st, A.counters, A.weightSum);

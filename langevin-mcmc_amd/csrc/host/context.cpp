@@ -107,6 +107,7 @@ struct lmc_ctx {
     DevBuf<uint32_t> rngTab;
     DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
         lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum;
+    DevBuf<unsigned char> nextKind;
     DevBuf<int> flags, curSplatCount, adjacentReject, sampleIdx, numSamples, pushDim;
     DevBuf<unsigned long long> counters;
     DevBuf<double> weightSum;
@@ -415,7 +416,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->chV1.Alloc(N * MAXPSS), c->chV2.Alloc(N * MAXPSS), c->chCurrNewV2.Alloc(N * MAXPSS), c->chPropNewV1.Alloc(N * MAXPSS),
         c->chPropNewV2.Alloc(N * MAXPSS), c->chPss.Alloc(N * MAXPSS), c->chLastPss.Alloc(N * MAXPSS);
     c->pathWeight.Alloc(N), c->lastScoreSum.Alloc(N), c->lastScore.Alloc(N), c->contribList.Alloc(N * MAXCONTRIB * CONTRIB_WORDS, false);
-    c->pushData.Alloc(N * GAUSS_WORDS), c->flags.Alloc(N), c->adjacentReject.Alloc(N), c->sampleIdx.Alloc(N), c->numSamples.Alloc(N), c->pushDim.Alloc(N);
+    c->pushData.Alloc(N * GAUSS_WORDS), c->flags.Alloc(N), c->nextKind.Alloc(N + 4), c->adjacentReject.Alloc(N), c->sampleIdx.Alloc(N), c->numSamples.Alloc(N), c->pushDim.Alloc(N);
     c->counters.Alloc(8), c->weightSum.Alloc(1);
     ChainArrays &A = c->A;
     A.N = (int)N;
@@ -425,7 +426,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
     A.pathWeight = c->pathWeight.p, A.lastScoreSum = c->lastScoreSum.p, A.lastScore = c->lastScore.p;
     A.adjacentReject = c->adjacentReject.p, A.sampleIdx = c->sampleIdx.p, A.numSamples = c->numSamples.p;
-    A.contribList = c->contribList.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
+    A.contribList = c->contribList.p, A.nextKind = c->nextKind.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p;
     LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
@@ -527,6 +528,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         if (c->needGeneric)
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
         LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->stepGrid, s);
+        LaunchBuildLists(c->A, next, s);
         c->parity = nxt;
         HIP_CHECK(hipEventRecord(e1, s));
         c->events.emplace_back(e0, e1);
