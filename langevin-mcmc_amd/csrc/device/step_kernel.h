@@ -8,9 +8,12 @@
 
 namespace lmcd {
 
-__device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum) {
-    __shared__ int sInt[7];
-    __shared__ float sW;
+// `sh`: 8 words of LDS (7 counters + the weight sum); the lean kernel passes its dynamic LDS so that two of its 80 KB
+// blocks still fit the CU's 160 KB
+__device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum, int *sh) {
+    int *sInt = sh;
+    float &sW = *reinterpret_cast<float *>(sh + 7);
+    __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 0; k < 7; k++) sInt[k] = 0;
         sW = 0.f;
@@ -66,7 +69,8 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
         A.nextKind[i] = toLarge ? NEXT_LARGE : toGrad ? NEXT_SMALL_GENERIC : toPlain ? NEXT_SMALL_PLAIN : NEXT_DONE;
         A.rngState[i] = rng.state;
     }
-    BlockReduceStats(st, A.counters, A.weightSum);
+    __shared__ int sStats[8];
+    BlockReduceStats(st, A.counters, A.weightSum, sStats);
 }
 
 }  // namespace lmcd

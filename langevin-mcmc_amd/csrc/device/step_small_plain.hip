@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
         A.nextKind[i] = toLarge ? NEXT_LARGE : toGrad ? NEXT_SMALL_GENERIC : toPlain ? NEXT_SMALL_PLAIN : NEXT_DONE;
         A.rngState[i] = rng.state;
     }
-    BlockReduceStats(st, A.counters, A.weightSum);
+    BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
 }
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
