@@ -79,6 +79,10 @@ int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);
 int lmc_chain_summary(lmc_ctx *ctx, int which, float *out, int stride);
 /* kernel time (ms, HIP events on the launch stream) and launch count of the chain-step kernel since the last call */
 int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);
+/* split of the interval the last lmc_step_timing call covered: out3[0] = ms inside the lean small-step kernel
+ * (k_step_small, the dominant kernel), out3[1] = ms inside the large-step + generic small-step launches,
+ * out3[2] = chain-steps the lean kernel has run since lmc_chains_init (cumulative). */
+int lmc_kernel_timing(lmc_ctx *ctx, double *out3);
 
 /* Batched path program: n evaluations of technique (c,l); SoA, word-major: primary_soa[(2L+1)*n],
  * vert_soa[V*n], grad_soa[2L*n] (word w of item i at [w*n + i]); scene38 as lmc_scene_params.  Host pointers.
@@ -95,6 +99,10 @@ int lmc_rng_probe(int n_seeds, const unsigned long long *seeds, int mode, int n,
 int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, float radius_sq, int knn, int *out_n, int *out_idx, float *out_dist);
 /* ComputeGaussian (mala.cpp:7-52) + GaussianLogPdf (gaussian.cpp:24-36): out n x (3*dim+2) */
 int lmc_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out);
+/* HBM counter calibration: `reps` launches of a kernel that reads n_words floats and writes n_words floats with the
+ * chain state's access pattern (4 B per lane, SoA, unit stride).  Run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+ * to obtain the bytes-per-count factors profiles/pmc_step_kernel.json applies.  Returns 0 on success. */
+int lmc_stream_probe(long long n_words, int reps);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,8 @@ def lib():
         L.lmc_stats.argtypes = [vp, vp, vp]
         L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.lmc_step_timing.argtypes = [vp, vp, vp]
+        L.lmc_kernel_timing.argtypes = [vp, vp]
+        L.lmc_stream_probe.argtypes = [c_ll, ctypes.c_int]
         L.lmc_grad_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
         L.lmc_trace.argtypes = [vp, ctypes.c_int, vp, vp, vp]
         L.lmc_occluded.argtypes = [vp, ctypes.c_int, vp, vp]
@@ -151,6 +153,14 @@ class Renderer:
         if lib().lmc_step_timing(self.h, ctypes.byref(ms), ctypes.byref(n)) != 0:
             raise RuntimeError(_err())
         return ms.value, n.value
+
+    def kernel_timing(self):
+        """(ms in the lean small-step kernel, ms in the large/generic launches) over the interval of the last
+        step_timing() call, and the cumulative number of chain-steps the lean kernel has run."""
+        out = (ctypes.c_double * 3)()
+        if lib().lmc_kernel_timing(self.h, out) != 0:
+            raise RuntimeError(_err())
+        return out[0], out[1], int(out[2])
 
     def trace(self, rays):
         rays = np.ascontiguousarray(rays, np.float32)

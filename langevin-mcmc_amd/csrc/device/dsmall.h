@@ -260,6 +260,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     const int dim = PathDimension(c, l);
     const int camCount = max(c - 1, 0), lgtCount = max(l - 1, 0);
     st.steps++;
+    st.lean++;
 
     // ---- proposal offsets
     const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51

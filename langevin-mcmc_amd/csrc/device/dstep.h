@@ -9,7 +9,7 @@
 namespace lmcd {
 
 struct StepStats {  // per-thread increments, block-reduced by the kernel
-    int steps = 0, large = 0, accepted = 0, gradCalls = 0, cacheQueries = 0, cacheHits = 0, resets = 0;
+    int steps = 0, large = 0, accepted = 0, gradCalls = 0, cacheQueries = 0, cacheHits = 0, resets = 0, lean = 0;
     float wsum = 0.f;
 };
 

@@ -7,6 +7,7 @@
 
 void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s);
 void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out, hipStream_t s);
+void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s);
 void LaunchTrace(const lmcd::DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s);
 void LaunchKdProbe(const lmcd::DCacheDim &C, int dim, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist, hipStream_t s);
 void LaunchGaussProbe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out, hipStream_t s);

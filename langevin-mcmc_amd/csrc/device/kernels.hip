@@ -44,6 +44,11 @@ __global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mod
 }
 
 // ---------------------------------------------------------------------------------------------- probes
+// counter calibration: the chain state's access pattern (one dword per lane, unit stride) over a known byte count
+__global__ void k_stream_probe(long long n, const float *in, float *out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = in[i] + 1.0f;
+}
+
 __global__ void k_trace(DScene S, int n, const float *rays, int *prim, float *t, int anyHit) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *r = rays + (size_t)i * 8;
@@ -370,6 +375,9 @@ void LaunchCachePush(const ChainArrays &A, int dim, float *pss, float *v1, float
     hipLaunchKernelGGL(k_cache_push, dim3(1), dim3(1024), 0, s, A, dim, pss, v1, v2, weight, count);
 }
 
+void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
+}
 void LaunchBuildLists(const ChainArrays &A, const NextLists &next, hipStream_t s) {
     hipLaunchKernelGGL(k_build_lists, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next);
 }

@@ -8,31 +8,31 @@
 
 namespace lmcd {
 
-// `sh`: 8 words of LDS (7 counters + the weight sum); the lean kernel passes its dynamic LDS so that two of its 80 KB
+// `sh`: 9 words of LDS (8 counters + the weight sum); the lean kernel passes its dynamic LDS so that two of its 80 KB
 // blocks still fit the CU's 160 KB
 __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum, int *sh) {
     int *sInt = sh;
-    float &sW = *reinterpret_cast<float *>(sh + 7);
+    float &sW = *reinterpret_cast<float *>(sh + 8);
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 7; k++) sInt[k] = 0;
+        for (int k = 0; k < 8; k++) sInt[k] = 0;
         sW = 0.f;
     }
     __syncthreads();
-    int v[7] = {st.steps, st.large, st.accepted, st.gradCalls, st.cacheQueries, st.cacheHits, st.resets};
+    int v[8] = {st.steps, st.large, st.accepted, st.gradCalls, st.cacheQueries, st.cacheHits, st.resets, st.lean};
     float w = st.wsum;
     for (int off = 32; off > 0; off >>= 1) {  // wave reduction (64 lanes), then one LDS atomic per wave
-        for (int k = 0; k < 7; k++) v[k] += __shfl_down(v[k], off);
+        for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off);
         w += __shfl_down(w, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 7; k++)
+        for (int k = 0; k < 8; k++)
             if (v[k]) atomicAdd(&sInt[k], v[k]);
         atomicAdd(&sW, w);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 7; k++)
+        for (int k = 0; k < 8; k++)
             if (sInt[k]) atomicAdd(&counters[k], (unsigned long long)sInt[k]);
         if (sW != 0.f) atomicAdd(weightSum, (double)sW);
     }
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
         A.nextKind[i] = toLarge ? NEXT_LARGE : toGrad ? NEXT_SMALL_GENERIC : toPlain ? NEXT_SMALL_PLAIN : NEXT_DONE;
         A.rngState[i] = rng.state;
     }
-    __shared__ int sStats[8];
+    __shared__ int sStats[9];
     BlockReduceStats(st, A.counters, A.weightSum, sStats);
 }
 

@@ -126,14 +126,14 @@ struct lmc_ctx {
     float normalization = 0.f;
     long long numInitContribs = 0;
     // timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    double kernelMs = 0;
-    long long launches = 0;
+    struct StepEvents {
+        hipEvent_t e[4];  // step begin | large + generic launches done | lean small-step launch done | step end
+    };
+    std::vector<StepEvents> events;
+    double smallMs = 0, largeMs = 0;  // accumulated by lmc_step_timing for lmc_kernel_timing
     ~lmc_ctx() {
-        for (auto &e : events) {
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
-        }
+        for (auto &ev : events)
+            for (auto e : ev.e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -514,10 +514,9 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
     StepParams P;
     P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient;
     for (int it = 0; it < nSteps; it++) {
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, s));
+        lmc_ctx::StepEvents ev;
+        for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(ev.e[0], s));
         const int cur = c->parity, nxt = 1 - c->parity;
         NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
         HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
@@ -527,11 +526,13 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
         if (c->needGeneric)
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        HIP_CHECK(hipEventRecord(ev.e[1], s));
         LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->stepGrid, s);
+        HIP_CHECK(hipEventRecord(ev.e[2], s));
         LaunchBuildLists(c->A, next, s);
         c->parity = nxt;
-        HIP_CHECK(hipEventRecord(e1, s));
-        c->events.emplace_back(e0, e1);
+        HIP_CHECK(hipEventRecord(ev.e[3], s));
+        c->events.push_back(ev);
         if (!c->allCachesReady) MaintainCache(c);
     }
     HIP_CHECK(hipGetLastError());
@@ -551,16 +552,29 @@ int lmc_step_timing(lmc_ctx *c, double *kernelMs, long long *launches) {
     LMC_TRY
     HIP_CHECK(hipStreamSynchronize(c->stream));
     double ms = 0;
-    for (auto &e : c->events) {
+    c->smallMs = c->largeMs = 0;
+    for (auto &ev : c->events) {
         float t = 0;
-        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
+        HIP_CHECK(hipEventElapsedTime(&t, ev.e[0], ev.e[3]));
         ms += t;
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
+        HIP_CHECK(hipEventElapsedTime(&t, ev.e[1], ev.e[2]));
+        c->smallMs += t;
+        HIP_CHECK(hipEventElapsedTime(&t, ev.e[0], ev.e[1]));
+        c->largeMs += t;
+        for (auto e : ev.e) (void)hipEventDestroy(e);
     }
     if (kernelMs) *kernelMs = ms;
     if (launches) *launches = (long long)c->events.size();
     c->events.clear();
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_kernel_timing(lmc_ctx *c, double *out3) {
+    LMC_TRY
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    out3[0] = c->smallMs, out3[1] = c->largeMs;
+    out3[2] = (double)c->counters.Download()[7];
     return 0;
     LMC_CATCH(-1)
 }
@@ -692,6 +706,16 @@ int lmc_rng_probe(int nSeeds, const unsigned long long *seeds, int mode, int n, 
     LaunchRngProbe(nSeeds, dS.p, mode, n, mean, stddev, dTab.p, dOut.p, 0);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, dOut.p, dOut.n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_stream_probe(long long nWords, int reps) {
+    LMC_TRY
+    EnsureDevice(0);
+    DevBuf<float> a, b;
+    a.Alloc((size_t)nWords), b.Alloc((size_t)nWords, false);
+    for (int r = 0; r < reps; r++) LaunchStreamProbe(nWords, a.p, b.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
     return 0;
     LMC_CATCH(-1)
 }

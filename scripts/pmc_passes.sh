@@ -17,3 +17,13 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 done
 python "$REPO/scripts/pmc_summary.py" "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"
+# counter calibration on a known byte count (1 GiB read + 1 GiB written per launch, dword-per-lane pattern)
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/calib_$grp" -- python -c "
+import importlib,sys
+sys.path.insert(0,'$REPO')
+p=importlib.import_module('langevin-mcmc_amd')
+assert p.lib().lmc_stream_probe(1<<28, 4)==0" > "$OUT/calib_$grp.log" 2>&1
+done
+python "$REPO/scripts/pmc_summary.py" "$OUT" calib > "$OUT/calib.json"
+cat "$OUT/calib.json"

@@ -5,7 +5,8 @@ import csv, glob, json, os, sys, collections
 
 out = sys.argv[1]
 res = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
+prefix = "calib_*" if len(sys.argv) > 2 else "pass*"
+for f in glob.glob(os.path.join(out, prefix, "**", "*counter_collection.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
     # one row per (dispatch, counter)
     per = collections.defaultdict(dict)
