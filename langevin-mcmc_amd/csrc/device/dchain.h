@@ -40,6 +40,7 @@ struct DCacheDim {
     const KdNode *nodes;
     const int *vind;
     const float *pts, *v1, *v2;  // PSS_MAX_SIZE x dim, row-major
+    const float *ptsLeaf;        // the points again, in leaf order (row i = pts[vind[i]]): the lean kernel scans leaves from it
     float rootLow[MAXPSS], rootHigh[MAXPSS];
 };
 struct DCache {

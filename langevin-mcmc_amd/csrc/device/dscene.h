@@ -153,7 +153,11 @@ struct LdsStack {
     }
 };
 
-// closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer)
+// closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer).
+// "while-while" traversal: all lanes of a wave first descend through inner nodes until each has reached a leaf (or
+// finished), then all test their leaf's triangles together.  With the node test and the leaf test as two branches of
+// one loop a wave executed both bodies on almost every iteration (profiles/r01_d: 5270 vector-memory instructions per
+// wave-step for ~800 per lane); the visiting order, hence the result, is the same depth-first order.
 template <class Stk>
 LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stk &stk) {
     if (S.numNodes == 0) return -1;
@@ -162,36 +166,40 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     int best = -1;
     float bestT = tfar;
     int cur = 0;  // root is an inner node (or a single-leaf wrapper)
-    for (;;) {
-        if (cur >= 0) {
+    bool alive = true;
+    while (alive) {
+        while (cur >= 0) {
             const BvhNode nd = S.nodes[cur];
             float tl, tr;
-            bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, bestT, tl);
-            bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, bestT, tr);
+            const bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, bestT, tl);
+            const bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, bestT, tr);
             if (hl && hr) {
                 int nearC = nd.left, farC = nd.right;
                 if (tr < tl) nearC = nd.right, farC = nd.left;
                 stk.Push(farC);
                 cur = nearC;
-                continue;
             } else if (hl) {
                 cur = nd.left;
-                continue;
             } else if (hr) {
                 cur = nd.right;
-                continue;
+            } else {
+                if (stk.Empty()) {
+                    alive = false;
+                    break;
+                }
+                cur = stk.Pop();
             }
-        } else {
-            unsigned code = (unsigned)~cur;
-            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
-            for (int i = 0; i < cnt; i++) {
-                const LeafTri tr = S.leafTris[first + i];
-                float t;
-                if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, bestT, t)) {
-                    if (best < 0 || t < bestT || (t == bestT && tr.id < best)) {
-                        bestT = t;
-                        best = tr.id;
-                    }
+        }
+        if (!alive) break;
+        const unsigned code = (unsigned)~cur;
+        const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+        for (int i = 0; i < cnt; i++) {
+            const LeafTri tr = S.leafTris[first + i];
+            float t;
+            if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, bestT, t)) {
+                if (best < 0 || t < bestT || (t == bestT && tr.id < best)) {
+                    bestT = t;
+                    best = tr.id;
                 }
             }
         }
@@ -208,36 +216,40 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
     stk.Reset();
     int cur = 0;
-    for (;;) {
-        if (cur >= 0) {
+    bool alive = true, hit = false;
+    while (alive) {
+        while (cur >= 0) {
             const BvhNode nd = S.nodes[cur];
             float tl, tr;
-            bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, tfar, tl);
-            bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, tfar, tr);
+            const bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, tfar, tl);
+            const bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, tfar, tr);
             if (hl && hr) {
                 stk.Push(nd.right);
                 cur = nd.left;
-                continue;
             } else if (hl) {
                 cur = nd.left;
-                continue;
             } else if (hr) {
                 cur = nd.right;
-                continue;
-            }
-        } else {
-            unsigned code = (unsigned)~cur;
-            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
-            for (int i = 0; i < cnt; i++) {
-                const LeafTri tr = S.leafTris[first + i];
-                float t;
-                if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, tfar, t)) return true;
+            } else {
+                if (stk.Empty()) {
+                    alive = false;
+                    break;
+                }
+                cur = stk.Pop();
             }
         }
-        if (stk.Empty()) break;
+        if (!alive) break;
+        const unsigned code = (unsigned)~cur;
+        const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+        for (int i = 0; i < cnt; i++) {
+            const LeafTri tr = S.leafTris[first + i];
+            float t;
+            if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, tfar, t)) hit = true;
+        }
+        if (hit || stk.Empty()) break;
         cur = stk.Pop();
     }
-    return false;
+    return hit;
 }
 
 // scene.cpp:128-149

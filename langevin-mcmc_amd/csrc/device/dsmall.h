@@ -61,18 +61,29 @@ struct OffsetCursor {
     LMC_D float Pop() { return L.U(LDS_OFFSET_WORD + k++); }
 };
 
-// kd-tree radius search with all run-time indexed state in LDS (same traversal as KdRadiusSearch in dchain.h)
+// kd-tree radius search with all run-time indexed state in LDS: the traversal of KdRadiusSearch (dchain.h), i.e.
+// nanoflann's searchLevel with the reference's stop-after-knn result set, reorganised for a wave:
+//   * "while-while": every lane first walks its frame stack until its top frame is a leaf (or the search is over), then
+//     all lanes scan their leaf's points together.  As one loop with a leaf branch, a wave spent most of its
+//     vector-memory instructions scanning leaves with 2-3 active lanes (profiles/r01_e);
+//   * the points are read from a copy stored in leaf order (C.ptsLeaf), two coordinates per load, the query from
+//     registers.
+// Per lane the sequence of visited nodes, tested points and matches is unchanged.
 LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float radiusSq, int knn, int *idx, float *dist) {
     // union layout: [0,16) dists, then KD_LDS_DEPTH x (node | phase << 30, mindistsq until phase 2 / saved dists[id] afterwards)
+    float q[MAXPSS];
     float distsq = 0.f;
-    for (int i = 0; i < dim; i++) {
-        float d = 0.f;
-        const float qi = L.Q(i);
-        if (qi < C.rootLow[i]) d = (qi - C.rootLow[i]) * (qi - C.rootLow[i]);
-        if (qi > C.rootHigh[i]) d = (qi - C.rootHigh[i]) * (qi - C.rootHigh[i]);
-        // computeInitialDistances adds both tests' contributions; they are mutually exclusive
-        L.U(i) = d;
-        distsq += d;
+#pragma unroll
+    for (int i = 0; i < MAXPSS; i++) {
+        q[i] = 0.f;
+        if (i < dim) {
+            q[i] = L.Q(i);
+            float d = 0.f;
+            if (q[i] < C.rootLow[i]) d = (q[i] - C.rootLow[i]) * (q[i] - C.rootLow[i]);
+            if (q[i] > C.rootHigh[i]) d = (q[i] - C.rootHigh[i]) * (q[i] - C.rootHigh[i]);
+            L.U(i) = d;
+            distsq += d;
+        }
     }
     int sp = 0;
     int count = 0;
@@ -80,62 +91,76 @@ LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float
     auto FM = [&](int lvl) -> float & { return L.U(16 + 2 * lvl + 1); };
     FN(0) = __int_as_float(0), FM(0) = distsq;  // node 0, phase 0 (phase in the top 2 bits)
     sp = 1;
-    while (sp > 0) {
-        const int lvl = sp - 1;
-        const int packed = __float_as_int(FN(lvl));
-        const int node = packed & 0x3fffffff, phase = (unsigned)packed >> 30;
-        const KdNode nd = C.nodes[node];
-        if (nd.child1 < 0 && nd.child2 < 0) {
-            for (int i = nd.left; i < nd.right; ++i) {
-                const int index = C.vind[i];
-                float d = 0.f;
-                for (int k = 0; k < dim; ++k) {
-                    const float diff = L.Q(k) - C.pts[(size_t)index * dim + k];
-                    d += diff * diff;
-                }
-                if (d < radiusSq) {
-                    idx[count] = index;
-                    dist[count] = d;
-                    count++;
-                    if (count >= knn) return count;
-                }
+    for (;;) {
+        // ---- walk until the top frame is a leaf
+        int leafLeft = 0, leafRight = 0;
+        bool atLeaf = false;
+        while (sp > 0) {
+            const int lvl = sp - 1;
+            const int packed = __float_as_int(FN(lvl));
+            const int node = packed & 0x3fffffff, phase = (unsigned)packed >> 30;
+            const KdNode nd = C.nodes[node];
+            if (nd.child1 < 0 && nd.child2 < 0) {
+                leafLeft = nd.left, leafRight = nd.right;
+                atLeaf = true;
+                break;
             }
-            sp--;
-            continue;
-        }
-        const int id = nd.divfeat;
-        const float val = L.Q(id);
-        const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
-        int bestChild, otherChild;
-        float cut_dist;
-        if ((diff1 + diff2) < 0) {
-            bestChild = nd.child1, otherChild = nd.child2;
-            cut_dist = (val - nd.divhigh) * (val - nd.divhigh);
-        } else {
-            bestChild = nd.child2, otherChild = nd.child1;
-            cut_dist = (val - nd.divlow) * (val - nd.divlow);
-        }
-        if (phase == 0) {
-            FN(lvl) = __int_as_float(node | (1 << 30));
-            if (sp >= KD_LDS_DEPTH) return -1;  // host refuses trees deeper than KD_LDS_DEPTH for this kernel
-            FM(sp) = FM(lvl), FN(sp) = __int_as_float(bestChild);
-            sp++;
-            continue;
-        }
-        if (phase == 1) {
-            const float dst = L.U(id);
-            const float mindistsq = FM(lvl) + cut_dist - dst;
-            FM(lvl) = dst;  // the frame's mindistsq is dead from here on: the word now keeps dists[id] for the restore
-            L.U(id) = cut_dist;
-            FN(lvl) = __int_as_float(node | (2 << 30));
-            if (mindistsq * 1.0f <= radiusSq) {
-                if (sp >= KD_LDS_DEPTH) return -1;
-                FM(sp) = mindistsq, FN(sp) = __int_as_float(otherChild);
+            const int id = nd.divfeat;
+            const float val = L.Q(id);
+            const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+            int bestChild, otherChild;
+            float cut_dist;
+            if ((diff1 + diff2) < 0) {
+                bestChild = nd.child1, otherChild = nd.child2;
+                cut_dist = (val - nd.divhigh) * (val - nd.divhigh);
+            } else {
+                bestChild = nd.child2, otherChild = nd.child1;
+                cut_dist = (val - nd.divlow) * (val - nd.divlow);
+            }
+            if (phase == 0) {
+                FN(lvl) = __int_as_float(node | (1 << 30));
+                if (sp >= KD_LDS_DEPTH) return -1;  // the host routes deeper trees to the generic kernel
+                FM(sp) = FM(lvl), FN(sp) = __int_as_float(bestChild);
                 sp++;
                 continue;
             }
+            if (phase == 1) {
+                const float dst = L.U(id);
+                const float mindistsq = FM(lvl) + cut_dist - dst;
+                FM(lvl) = dst;  // the frame's mindistsq is dead from here on: the word now keeps dists[id] for the restore
+                L.U(id) = cut_dist;
+                FN(lvl) = __int_as_float(node | (2 << 30));
+                if (mindistsq * 1.0f <= radiusSq) {
+                    if (sp >= KD_LDS_DEPTH) return -1;
+                    FM(sp) = mindistsq, FN(sp) = __int_as_float(otherChild);
+                    sp++;
+                    continue;
+                }
+            }
+            L.U(id) = FM(lvl);
+            sp--;
         }
-        L.U(id) = FM(lvl);
+        if (!atLeaf) break;
+        // ---- scan the leaf
+        for (int i = leafLeft; i < leafRight; ++i) {
+            const float2 *row = reinterpret_cast<const float2 *>(C.ptsLeaf + (size_t)i * dim);
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXPSS / 2; ++k)
+                if (2 * k < dim) {
+                    const float2 p = row[k];
+                    const float diff0 = q[2 * k] - p.x;
+                    d += diff0 * diff0;
+                    const float diff1 = q[2 * k + 1] - p.y;
+                    d += diff1 * diff1;
+                }
+            if (d < radiusSq) {
+                idx[count] = C.vind[i];
+                dist[count] = d;
+                count++;
+                if (count >= knn) return count;
+            }
+        }
         sp--;
     }
     return count;

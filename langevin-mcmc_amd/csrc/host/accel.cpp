@@ -1,6 +1,8 @@
 // See accel.h.
 #include "accel.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -29,12 +31,13 @@ struct Builder {
     std::vector<Prim> prims;
     LbvhResult out;
     const std::vector<lmcd::TriData> *tris;
+    int maxLeaf = 4;  // triangles per leaf (<= 8 by the leaf encoding); LMC_BVH_LEAF overrides for experiments
 
     // returns encoded child (>= 0 inner node index, < 0 leaf) and its box
     int Build(int lo, int hi, float *bmin, float *bmax, int depth) {
         out.depth = std::max(out.depth, depth);
         const int n = hi - lo;
-        if (n <= 4) {
+        if (n <= maxLeaf) {
             int first = (int)out.leafTris.size();
             for (int k = 0; k < 3; k++) bmin[k] = INFINITY, bmax[k] = -INFINITY;
             for (int i = lo; i < hi; i++) {
@@ -85,6 +88,7 @@ struct Builder {
 LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris) {
     Builder B;
     B.tris = &tris;
+    if (const char *e = getenv("LMC_BVH_LEAF")) B.maxLeaf = std::max(1, std::min(8, atoi(e)));
     const int n = (int)tris.size();
     if (n == 0) return B.out;
     B.prims.resize(n);

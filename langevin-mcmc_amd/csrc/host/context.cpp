@@ -73,7 +73,7 @@ void EnsureDevice(int device) {
 }
 
 struct CacheDimHost {
-    DevBuf<float> pss, v1, v2, weight;
+    DevBuf<float> pss, v1, v2, weight, ptsLeaf;
     DevBuf<int> count;
     DevBuf<KdNode> nodes;
     DevBuf<int> vind;
@@ -494,9 +494,12 @@ static void MaintainCache(lmc_ctx *c) {
             std::vector<float> pts = cd.pss.Download();
             lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
             cd.nodes.Upload(t.nodes), cd.vind.Upload(t.vind);
+            std::vector<float> leafOrder((size_t)PSS_MAX_SIZE * d);
+            for (int i = 0; i < PSS_MAX_SIZE; i++) memcpy(&leafOrder[(size_t)i * d], &pts[(size_t)t.vind[i] * d], d * sizeof(float));
+            cd.ptsLeaf.Upload(leafOrder);
             DCacheDim &D = c->cacheHost.d[d];
             D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
-            D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
+            D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
             for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
             cd.ready = true;
             changed = true;
@@ -731,7 +734,7 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
     dOutN.Alloc(nq), dOutI.Alloc((size_t)nq * knn), dOutD.Alloc((size_t)nq * knn);
     DCacheDim C;
     memset(&C, 0, sizeof(C));
-    C.ready = 1, C.nodes = dN.p, C.vind = dV.p, C.pts = dP.p, C.v1 = dP.p, C.v2 = dP.p;
+    C.ready = 1, C.nodes = dN.p, C.vind = dV.p, C.pts = dP.p, C.ptsLeaf = nullptr, C.v1 = dP.p, C.v2 = dP.p;
     for (int k = 0; k < dim; k++) C.rootLow[k] = t.rootLow[k], C.rootHigh[k] = t.rootHigh[k];
     LaunchKdProbe(C, dim, nq, dQ.p, radiusSq, knn, dOutN.p, dOutI.p, dOutD.p, 0);
     HIP_CHECK(hipDeviceSynchronize());
