@@ -58,16 +58,17 @@ LMC_D void SerializeBSDF(const DScene &S, int tri, V2 st, StridedOut &o) {  // b
     if (m.type == BSDF_LAMBERTIAN) {
         V3 kd = EvalKd(S, m, st);
         o.Put(kd.x), o.Put(kd.y), o.Put(kd.z);
-    } else if (m.type == BSDF_PHONG) {
-        V3 kd = EvalKd(S, m, st);
+    } else if (m.type == BSDF_PHONG) {  // phong.cpp:14-20
+        V3 kd = EvalKd(S, m, st), ks = EvalTex(S, m.Ks, st);
         o.Put(kd.x), o.Put(kd.y), o.Put(kd.z);
-        o.Put(m.Ks[0]), o.Put(m.Ks[1]), o.Put(m.Ks[2]);
-        o.Put(m.expOrAlpha);
+        o.Put(ks.x), o.Put(ks.y), o.Put(ks.z);
+        o.Put(EvalTex(S, m.expOrAlpha, st).x);
         o.Put(m.KsWeight);
-    } else {
-        o.Put(m.Ks[0]), o.Put(m.Ks[1]), o.Put(m.Ks[2]);
-        o.Put(m.Kt[0]), o.Put(m.Kt[1]), o.Put(m.Kt[2]);
-        o.Put(m.eta), o.Put(m.invEta), o.Put(m.expOrAlpha);
+    } else {  // roughdielectric.cpp:13-20
+        V3 ks = EvalTex(S, m.Ks, st), kt = EvalTex(S, m.Kt, st);
+        o.Put(ks.x), o.Put(ks.y), o.Put(ks.z);
+        o.Put(kt.x), o.Put(kt.y), o.Put(kt.z);
+        o.Put(m.eta), o.Put(m.invEta), o.Put(EvalTex(S, m.expOrAlpha, st).x);
     }
     o.Skip(10 - (o.n - start));
 }

@@ -105,6 +105,40 @@ LMC_HD float fastlog(float x) {
     return 0.69314718f * (y - 124.22551499f - 1.498030302f * mx - 1.72587999f / (0.3520887068f + mx));
 }
 
+// fastpow = fastpow2(p * fastlog2(x)) (fastmath.h, Mineiro fastapprox), used by the bitmap texture gamma (bitmaptexture.h:94)
+LMC_HD float fastlog2(float x) {
+    uint32_t vi = __builtin_bit_cast(uint32_t, x);
+    float mx = __builtin_bit_cast(float, (vi & 0x007FFFFFu) | 0x3f000000u);
+    float y = (float)vi;
+    y *= 1.1920928955078125e-7f;
+    return y - 124.22551499f - 1.498030302f * mx - 1.72587999f / (0.3520887068f + mx);
+}
+LMC_HD float fastpow2(float p) {
+    float offset = (p < 0) ? 1.0f : 0.0f;
+    float clipp = (p < -126) ? -126.0f : p;
+    int w = (int)clipp;
+    float z = clipp - w + offset;
+    uint32_t v = (uint32_t)((1 << 23) * (clipp + 121.2740575f + 27.7280233f / (4.84252568f - z) - 1.49012907f * z));
+    return __builtin_bit_cast(float, v);
+}
+LMC_HD float fastpow(float x, float p) { return fastpow2(p * fastlog2(x)); }
+
+// pow / exp / log of the Phong and rough-dielectric code (phong.cpp:42,109, microfacet.h:17,173): evaluated in double and
+// rounded once to float, on the device, in the CPU oracle and in the host build of the path program alike.  The
+// reference calls libm's float versions, whose last bit differs between libm builds (and from the device libm); a
+// correctly rounded value is within that spread and makes the Russian-roulette / rejection decisions downstream of a
+// glossy vertex reproducible between CPU and GPU.
+LMC_HD float powd(float a, float e) { return (float)pow((double)a, (double)e); }
+LMC_HD float expd(float x) { return (float)exp((double)x); }
+LMC_HD float logd(float x) { return (float)log((double)x); }
+
+// utils.h:197-210
+LMC_HD V3 Reflect(V3 wi, V3 n) { return (2.0f * Dot(wi, n)) * n - wi; }
+LMC_HD V3 Refract(V3 wi, V3 n, float cosThetaT, float eta, float invEta) {
+    float eta_ = cosThetaT < 0.0f ? invEta : eta;
+    return n * (Dot(wi, n) * eta_ + cosThetaT) - wi * eta_;
+}
+
 // sampling.h
 LMC_HD V3 SampleSphere(V2 coord, float &jacobian) {
     const float scaledTheta = c_TWOPI * coord.x;

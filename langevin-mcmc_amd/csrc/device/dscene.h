@@ -40,11 +40,22 @@ struct DMesh {
     int areaOff, areaCdfOff;
     float areaFuncInt;
 };
+// constant or bitmap texture reference (texture.h, constanttexture.h, bitmaptexture.h)
+struct DTexRef {
+    int bitmap;  // index into DScene::bitmaps, -1 = constant
+    float value[3];
+    float sScale, tScale;
+};
+struct DBitmap {
+    const float *pix;  // W*H*3, row-major
+    int W, H;
+    float gamma;  // 2.2 for 8-bit files (bitmaptexture.h:135-144)
+};
 struct DMaterial {
     int type, twoSided;
-    float Kd[3], Ks[3], Kt[3];
-    float expOrAlpha, eta, invEta, KsWeight;
-    int KdTex;  // -1: constant (bitmap textures: SURVEY.md §8 config 3)
+    DTexRef Kd, Ks, Kt;  // Lambertian: Kd; Phong: Kd, Ks; RoughDielectric: Ks, Kt
+    DTexRef expOrAlpha;  // Phong exponent / dielectric alpha (channel 0)
+    float eta, invEta, KsWeight;
 };
 struct DLight {
     int type;
@@ -79,6 +90,7 @@ struct DScene {
     const TriData *tris;
     const DMesh *meshes;
     const DMaterial *materials;
+    const DBitmap *bitmaps;
     const DLight *lights;
     const float *areaFunc, *areaCdf;
     const float *lightFunc, *lightCdf;

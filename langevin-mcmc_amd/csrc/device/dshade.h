@@ -71,16 +71,80 @@ LMC_D float PickLightProb(const DScene &S, int light) { return S.lights[light].s
 // ---------------------------------------------------------------------------------------------- BSDF
 LMC_D const DMaterial &MaterialOfTri(const DScene &S, int tri) { return S.materials[S.meshes[S.tris[tri].mesh].material]; }
 
-LMC_D V3 EvalKd(const DScene &, const DMaterial &m, V2) { return V3{m.Kd[0], m.Kd[1], m.Kd[2]}; }
+// Texture::Eval.  Bitmaps: periodic bilinear lookup standing in for OIIO's TextureSystem::texture() with zero filter
+// width, then fastpow(max(v,0), gamma) (bitmaptexture.h:72-97); the same arithmetic as host/scene.cpp:EvalTexture.
+LMC_D V3 EvalTex(const DScene &S, const DTexRef &t, V2 st) {
+    if (t.bitmap < 0) return V3{t.value[0], t.value[1], t.value[2]};
+    const DBitmap bm = S.bitmaps[t.bitmap];
+    const int W = bm.W, H = bm.H;
+    const float fs = t.sScale * st.x * W - 0.5f, ft = t.tScale * st.y * H - 0.5f;
+    const float x0f = floorf(fs), y0f = floorf(ft);
+    const float dx = fs - x0f, dy = ft - y0f;
+    auto wrap = [](long long v, int n) {
+        long long r = v % n;
+        return (int)(r < 0 ? r + n : r);
+    };
+    const int x0 = wrap((long long)x0f, W), x1 = wrap((long long)x0f + 1, W), y0 = wrap((long long)y0f, H), y1 = wrap((long long)y0f + 1, H);
+    const float *p00 = bm.pix + ((size_t)y0 * W + x0) * 3, *p10 = bm.pix + ((size_t)y0 * W + x1) * 3;
+    const float *p01 = bm.pix + ((size_t)y1 * W + x0) * 3, *p11 = bm.pix + ((size_t)y1 * W + x1) * 3;
+    float o[3];
+    for (int k = 0; k < 3; k++) {
+        const float v = (1 - dx) * (1 - dy) * p00[k] + dx * (1 - dy) * p10[k] + (1 - dx) * dy * p01[k] + dx * dy * p11[k];
+        o[k] = fastpow(fmaxf(v, 0.f), bm.gamma);
+    }
+    return V3{o[0], o[1], o[2]};
+}
+LMC_D V3 EvalKd(const DScene &S, const DMaterial &m, V2 st) { return EvalTex(S, m.Kd, st); }
 
-LMC_D float BsdfRoughness(const DScene &, const DMaterial &m, V2, float) {
-    if (m.type == BSDF_ROUGHDIELECTRIC) return m.expOrAlpha;  // roughdielectric.h:61-63
-    return 1.0f;                                             // lambertian.h, phong.cpp:155-157
+LMC_D float BsdfRoughness(const DScene &S, const DMaterial &m, V2 st, float) {
+    if (m.type == BSDF_ROUGHDIELECTRIC) return EvalTex(S, m.expOrAlpha, st).x;  // roughdielectric.h:61-63
+    return 1.0f;                                                                // lambertian.h, phong.cpp:155-157
+}
+
+// ---- microfacet.h:6-70,165-185 (scalar versions)
+LMC_D float BeckmennDistributionTerm(V3 localH, float alphaU, float alphaV) {
+    const float cosTheta = localH.z, mu = localH.x, mv = localH.y;
+    const float cosTheta2 = square(cosTheta);
+    const float beckmannExponent = (square(mu) / square(alphaU) + square(mv) / square(alphaV)) / cosTheta2;
+    return expd(-beckmannExponent) / (c_PI * alphaU * alphaV * square(cosTheta2));
+}
+LMC_D float BeckmennGeometryTerm1(float alpha, float cosTheta) {
+    const float tanTheta = sqrtf(fabsf(1.0f - square(cosTheta))) / cosTheta;
+    if (tanTheta <= 0.0f) return 1.0f;
+    const float a = 1.0f / (alpha * tanTheta);
+    if (a >= 1.6f) return 1.0f;
+    const float aSqr = a * a;
+    return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+LMC_D float BeckmennGeometryTerm(float alpha, float cosWi, float cosWo) { return BeckmennGeometryTerm1(alpha, cosWi) * BeckmennGeometryTerm1(alpha, cosWo); }
+LMC_D float FresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta, float invEta) {
+    const float scale = (cosThetaI_ > 0) ? invEta : eta;
+    const float cosThetaTSqr = 1.0f - (1.0f - square(cosThetaI_)) * square(scale);
+    if (cosThetaTSqr <= 0.0f) {
+        cosThetaT_ = 0.0f;
+        return 1.0f;
+    }
+    const float cosThetaI = fabsf(cosThetaI_);
+    const float cosThetaT = sqrtf(cosThetaTSqr);
+    const float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    const float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (square(Rs) + square(Rp));
+}
+LMC_D V3 SampleMicronormal(V2 rndParam, float alpha, float &pdfW) {
+    const float phiM = c_TWOPI * rndParam.y;
+    const float sinPhiM = sinf(phiM), cosPhiM = cosf(phiM);
+    const float alphaSqr = square(alpha);
+    const float tanThetaMSqr = alphaSqr * (-logd(fmaxf(1.0f - rndParam.x, 1e-6f)));
+    const float cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+    const float cosThetaMSqr = square(cosThetaM);
+    pdfW = (1.0f - rndParam.x) / (c_PI * alphaSqr * cosThetaM * cosThetaMSqr);
+    const float sinThetaM = sqrtf(fmaxf(1.0f - cosThetaMSqr, 0.0f));  // ADEpsilon<Float>() == 0
+    return V3{sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM};
 }
 
 // lambertian.cpp:15-43 (pdf / revPdf are left untouched on the early-out, as in the reference)
-LMC_D void BsdfEvaluate(const DScene &S, const DMaterial &m, bool /*adjoint*/, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo,
-                        float &pdf, float &revPdf) {
+LMC_D void LambertianEvaluate(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo, float &pdf, float &revPdf) {
     float cosWi = Dot(normal, wi);
     V3 normal_ = normal;
     if (m.twoSided && cosWi < 0.0f) {
@@ -96,10 +160,8 @@ LMC_D void BsdfEvaluate(const DScene &S, const DMaterial &m, bool /*adjoint*/, V
     pdf = fwdScalar;
     revPdf = revScalar;
 }
-
 // lambertian.cpp:45-93
-LMC_D bool BsdfSample(const DScene &S, const DMaterial &m, bool /*adjoint*/, V3 wi, V3 normal, V2 st, V2 rnd, float /*uDiscrete*/, V3 &wo,
-                      V3 &contrib, float &cosWo, float &pdf, float &revPdf) {
+LMC_D bool LambertianSample(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V2 st, V2 rnd, V3 &wo, V3 &contrib, float &cosWo, float &pdf, float &revPdf) {
     float cosWi = Dot(wi, normal);
     V3 normal_ = normal;
     if (fabsf(cosWi) < c_CosEpsilon) return false;
@@ -120,6 +182,250 @@ LMC_D bool BsdfSample(const DScene &S, const DMaterial &m, bool /*adjoint*/, V3 
     revPdf = cosWi * c_INVPI;
     contrib = EvalKd(S, m, st);
     return true;
+}
+
+// phong.cpp:22-68
+LMC_D void PhongEvaluate(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo, float &pdf, float &revPdf) {
+    contrib = V3{0, 0, 0};
+    pdf = 0.0f;
+    revPdf = 0.0f;
+    float cosWi = Dot(normal, wi);
+    V3 normal_ = normal;
+    if (m.twoSided && cosWi < 0.0f) {
+        cosWi = -cosWi;
+        normal_ = -normal_;
+    }
+    cosWo = Dot(normal_, wo);
+    if (cosWi <= c_CosEpsilon || cosWo <= c_CosEpsilon) return;
+    const float KsWeight = m.KsWeight;
+    if (KsWeight > 0.0f) {
+        const float alpha = fmaxf(Dot(Reflect(wi, normal_), wo), 0.0f);
+        const float expo = EvalTex(S, m.expOrAlpha, st).x;
+        const float weight = powd(alpha, expo) * c_INVTWOPI;
+        const float expoConst1 = (expo + 1.0f);
+        const float expoConst2 = (expo + 2.0f);
+        if (weight > 1e-10f) {
+            contrib = EvalTex(S, m.Ks, st) * (expoConst2 * weight);
+            pdf = KsWeight * expoConst1 * weight;
+            revPdf = pdf;
+        }
+    }
+    if (KsWeight < 1.0f) {
+        pdf += (1.0f - KsWeight) * cosWo * c_INVPI;
+        revPdf += (1.0f - KsWeight) * cosWi * c_INVPI;
+        contrib = contrib + EvalTex(S, m.Kd, st) * c_INVPI;
+    }
+    contrib = contrib * cosWo;
+    if (MaxCoeff(contrib) < 1e-10f) contrib = V3{0, 0, 0};
+}
+// phong.cpp:70-153 (the lobe choice re-uses rndParam[0]; revPdf accumulates onto the caller's value when KsWeight == 0)
+LMC_D bool PhongSample(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V2 st, V2 rndParam, V3 &wo, V3 &contrib, float &cosWo, float &pdf, float &revPdf) {
+    float cosWi = Dot(wi, normal);
+    if (fabsf(cosWi) < c_CosEpsilon) return false;
+    V3 normal_ = normal;
+    if (cosWi < 0.0f) {
+        if (m.twoSided) {
+            cosWi = -cosWi;
+            normal_ = -normal_;
+        } else
+            return false;
+    }
+    const float KsWeight = m.KsWeight;
+    const float expo = EvalTex(S, m.expOrAlpha, st).x;
+    const V3 R = Reflect(wi, normal_);
+    float g;
+    V3 n;
+    const float uDiscrete = rndParam.x;
+    float rndParam0;
+    if (uDiscrete > KsWeight) {
+        g = 1.0f;
+        n = normal_;
+        rndParam0 = (uDiscrete - KsWeight) / (1.0f - KsWeight + 1e-10f);
+    } else {
+        g = expo;
+        n = R;
+        rndParam0 = uDiscrete / (KsWeight + 1e-10f);
+    }
+    const float power = 1.0f / (g + 1.0f);
+    const float cosAlpha = powd(rndParam.y, power);
+    const float sinAlpha = sqrtf(1.0f - square(cosAlpha));
+    const float phi = c_TWOPI * rndParam0;
+    const V3 localDir{sinAlpha * cosf(phi), sinAlpha * sinf(phi), cosAlpha};
+    V3 b0, b1;
+    CoordinateSystem(n, b0, b1);
+    wo = localDir.x * b0 + localDir.y * b1 + localDir.z * n;
+    cosWo = Dot(normal_, wo);
+    if (cosWo < c_CosEpsilon) return false;
+    contrib = V3{0, 0, 0};
+    pdf = 0.0f;
+    if (KsWeight > 0.0f) {
+        const float alpha = fmaxf(Dot(R, wo), 0.0f);
+        const float weight = powd(alpha, expo) * c_INVTWOPI;
+        const float expoConst1 = (expo + 1.0f);
+        const float expoConst2 = (expo + 2.0f);
+        if (weight > 1e-10f) {
+            contrib = EvalTex(S, m.Ks, st) * (expoConst2 * weight);
+            pdf = KsWeight * expoConst1 * weight;
+        }
+        revPdf = pdf;
+    }
+    if (KsWeight < 1.0f) {
+        contrib = contrib + EvalTex(S, m.Kd, st) * c_INVPI;
+        pdf += (1.0f - KsWeight) * cosWo * c_INVPI;
+        revPdf += (1.0f - KsWeight) * cosWi * c_INVPI;
+    }
+    contrib = contrib * cosWo;
+    if (pdf < 1e-10f) return false;
+    contrib = contrib * inverse(pdf);
+    return true;
+}
+
+// roughdielectric.cpp:22-121
+LMC_D void RoughDielectricEvaluate(const DScene &S, const DMaterial &m, bool adjoint, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo, float &pdf,
+                                   float &revPdf) {
+    const float eta = m.eta, invEta = m.invEta;
+    const float cosWi = Dot(wi, normal);
+    contrib = V3{0, 0, 0};
+    cosWo = 0.0f;
+    pdf = revPdf = 0.0f;
+    if (fabsf(cosWi) < c_CosEpsilon) return;
+    cosWo = Dot(wo, normal);
+    if (fabsf(cosWo) < c_CosEpsilon) return;
+    const bool reflect = cosWi * cosWo > 0.0f;
+    const float eta_ = cosWi > 0.0f ? eta : invEta;
+    const float revEta_ = cosWo > 0.0f ? eta : invEta;
+    V3 H;
+    if (reflect) H = Normalize(wi + wo);
+    else
+        H = Normalize(wi + wo * eta_);
+    if (Dot(H, normal) < 0.0f) H = -H;
+    const float cosHWi = Dot(wi, H);
+    const float cosHWo = Dot(wo, H);
+    if (fabsf(cosHWi) < c_CosEpsilon || fabsf(cosHWo) < c_CosEpsilon) return;
+    if (cosHWi * cosWi <= 0.0f) return;
+    if (cosHWo * cosWo <= 0.0f) return;
+    V3 b0, b1;
+    CoordinateSystem(normal, b0, b1);
+    const V3 localH{Dot(b0, H), Dot(b1, H), Dot(normal, H)};
+    const float alp = EvalTex(S, m.expOrAlpha, st).x;
+    const float D = BeckmennDistributionTerm(localH, alp, alp);
+    if (D <= 0.0f) return;
+    const float revCosHWi = cosHWo;
+    const float revCosHWo = cosHWi;
+    float unusedT;
+    const float F = FresnelDielectricExt(cosHWi, unusedT, eta, invEta);
+    const float aCosWi = fabsf(cosWi);
+    const float aCosWo = fabsf(cosWo);
+    const float G = BeckmennGeometryTerm(alp, aCosWi, aCosWo);
+    const float scaledAlpha = alp * (1.2f - 0.2f * sqrtf(aCosWi));
+    const float scaledD = BeckmennDistributionTerm(localH, scaledAlpha, scaledAlpha);
+    const float prob = localH.z * scaledD;
+    if (prob < 1e-20f) {
+        contrib = V3{0, 0, 0};
+        return;
+    }
+    const float revScaledAlpha = alp * (1.2f - 0.2f * sqrtf(aCosWo));
+    const float revScaledD = BeckmennDistributionTerm(localH, revScaledAlpha, revScaledAlpha);
+    const float revProb = localH.z * revScaledD;
+    if (reflect) {
+        const float scalar = fabsf(F * D * G / (4.0f * cosWi));
+        contrib = EvalTex(S, m.Ks, st) * scalar;
+        pdf = fabsf(prob * F / (4.0f * cosHWo));
+        revPdf = fabsf(revProb * F / (4.0f * revCosHWo));
+    } else {
+        const float sqrtDenom = cosHWi + eta_ * cosHWo;
+        const float revSqrtDenom = revCosHWi + revEta_ * revCosHWo;
+        const float factor = adjoint ? 1.0f : square(inverse(eta_));
+        const float scalar = fabsf(factor * ((1.0f - F) * D * G * square(eta_) * cosHWi * cosHWo) / (cosWi * square(sqrtDenom)));
+        contrib = EvalTex(S, m.Kt, st) * scalar;
+        pdf = fabsf(prob * (1.0f - F) * (square(eta_) * cosHWo) / (square(sqrtDenom)));
+        revPdf = fabsf(revProb * (1.0f - F) * (square(revEta_) * revCosHWo) / (square(revSqrtDenom)));
+    }
+}
+// roughdielectric.cpp:148-301
+LMC_D bool RoughDielectricSample(const DScene &S, const DMaterial &m, bool adjoint, V3 wi, V3 normal, V2 st, V2 rndParam, float uDiscrete, V3 &wo, V3 &contrib,
+                                 float &cosWo, float &pdf, float &revPdf) {
+    const float eta = m.eta, invEta = m.invEta;
+    const float cosWi = Dot(wi, normal);
+    if (fabsf(cosWi) < c_CosEpsilon) return false;
+    const float alp = EvalTex(S, m.expOrAlpha, st).x;
+    const float scaledAlp = alp * (1.2f - 0.2f * sqrtf(fabsf(cosWi)));
+    float mPdf;
+    const V3 localH = SampleMicronormal(rndParam, scaledAlp, mPdf);
+    pdf = mPdf;
+    V3 b0, b1;
+    CoordinateSystem(normal, b0, b1);
+    const V3 H = localH.x * b0 + localH.y * b1 + localH.z * normal;
+    const float cosHWi = Dot(wi, H);
+    if (fabsf(cosHWi) < c_CosEpsilon) return false;
+    float cosThetaT = 0.0f;
+    const float F = FresnelDielectricExt(cosHWi, cosThetaT, eta, invEta);
+    const bool reflect = uDiscrete <= F;
+    V3 refl;
+    float cosHWo;
+    if (reflect) {
+        wo = Reflect(wi, H);
+        if (F <= 0.0f || Dot(normal, wo) * Dot(normal, wi) <= 0.0f) return false;
+        refl = EvalTex(S, m.Ks, st);
+        cosHWo = Dot(wo, H);
+        pdf = fabsf(pdf * F / (4.0f * cosHWo));
+        const float revCosHWo = cosHWi;
+        const float rev_dwh_dwo = inverse(4.0f * revCosHWo);
+        cosWo = Dot(wo, normal);
+        if (fabsf(cosWo) < c_CosEpsilon) return false;
+        const float revScaledAlp = alp * (1.2f - 0.2f * sqrtf(fabsf(cosWo)));
+        const float revD = BeckmennDistributionTerm(localH, revScaledAlp, revScaledAlp);
+        revPdf = fabsf(F * revD * localH.z * rev_dwh_dwo);
+    } else {
+        wo = Refract(wi, H, cosThetaT, eta, invEta);
+        if (F >= 1.0f || cosThetaT == 0.0f || Dot(normal, wo) * Dot(normal, wi) >= 0.0f) return false;
+        const float eta_ = cosWi > 0.0f ? eta : invEta;
+        const float factor = adjoint ? 1.0f : square(inverse(eta_));
+        refl = EvalTex(S, m.Kt, st) * factor;
+        cosHWo = Dot(wo, H);
+        const float sqrtDenom = cosHWi + eta_ * cosHWo;
+        const float dwh_dwo = (square(eta_) * cosHWo) / square(sqrtDenom);
+        pdf = fabsf(pdf * (1.0f - F) * fabsf(dwh_dwo));
+        cosWo = Dot(wo, normal);
+        if (fabsf(cosWo) < c_CosEpsilon) return false;
+        const float revEta_ = cosWo > 0.0f ? eta : invEta;
+        const float revCosHWi = cosHWo;
+        const float revCosHWo = cosHWi;
+        const float revSqrtDenom = revCosHWi + revEta_ * revCosHWo;
+        const float rev_dwh_dwo = (square(revEta_) * revCosHWo) / square(revSqrtDenom);
+        const float revScaledAlp = alp * (1.2f - 0.2f * sqrtf(fabsf(cosWo)));
+        const float revD = BeckmennDistributionTerm(localH, revScaledAlp, revScaledAlp);
+        revPdf = fabsf((1.0f - F) * revD * localH.z * rev_dwh_dwo);
+    }
+    if (fabsf(cosHWo) < c_CosEpsilon) return false;
+    if (pdf < 1e-20f) return false;
+    if (cosHWi * cosWi <= 0.0f) return false;
+    if (cosHWo * cosWo <= 0.0f) return false;
+    const float aCosWi = fabsf(cosWi);
+    const float aCosWo = fabsf(cosWo);
+    const float D = BeckmennDistributionTerm(localH, alp, alp);
+    const float G = BeckmennGeometryTerm(alp, aCosWi, aCosWo);
+    const float numerator = D * G * cosHWi;
+    const float denominator = mPdf * aCosWi;
+    contrib = refl * fabsf(numerator / denominator);
+    return true;
+}
+
+// BSDF::Evaluate / EvaluateAdjoint (bsdf.h:16-38): only the rough dielectric distinguishes the adjoint
+LMC_D void BsdfEvaluate(const DScene &S, const DMaterial &m, bool adjoint, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo, float &pdf,
+                        float &revPdf) {
+    if (m.type == BSDF_LAMBERTIAN) LambertianEvaluate(S, m, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
+    else if (m.type == BSDF_PHONG)
+        PhongEvaluate(S, m, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
+    else
+        RoughDielectricEvaluate(S, m, adjoint, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
+}
+// BSDF::Sample / SampleAdjoint (bsdf.h:40-72)
+LMC_D bool BsdfSample(const DScene &S, const DMaterial &m, bool adjoint, V3 wi, V3 normal, V2 st, V2 rnd, float uDiscrete, V3 &wo, V3 &contrib,
+                      float &cosWo, float &pdf, float &revPdf) {
+    if (m.type == BSDF_LAMBERTIAN) return LambertianSample(S, m, wi, normal, st, rnd, wo, contrib, cosWo, pdf, revPdf);
+    if (m.type == BSDF_PHONG) return PhongSample(S, m, wi, normal, st, rnd, wo, contrib, cosWo, pdf, revPdf);
+    return RoughDielectricSample(S, m, adjoint, wi, normal, st, rnd, uDiscrete, wo, contrib, cosWo, pdf, revPdf);
 }
 
 // ---------------------------------------------------------------------------------------------- shapes

@@ -90,6 +90,16 @@ template <int N> LMC_HD bool operator>(const Dual<N> &a, float b) { return a.v >
 template <int N> LMC_HD bool operator<(const Dual<N> &a, const Dual<N> &b) { return a.v < b.v; }
 template <int N> LMC_HD bool operator>(const Dual<N> &a, const Dual<N> &b) { return a.v > b.v; }
 
+LMC_HD float Detach(float x) { return x; }
+template <int N> LMC_HD Dual<N> Detach(const Dual<N> &x) { return MakeDual<N>(x.v); }
+// chad's fabs / fmax are conditional expressions that pass their operand through (chad.h:1226-1244), and the code
+// chad generates for a passed-through node ASSIGNS its adjoint (`_accX = _accR`) instead of accumulating into it: every
+// contribution the reverse sweep had already gathered for X -- i.e. from the uses of X that come LATER in program order
+// -- is dropped.  The reference's derivative programs therefore are not the true gradient wherever a named value goes
+// through fabs()/fmax() and is used again afterwards (rough dielectric: cosWi, cos(H,wi), cosWo).  FabsW / FmaxW
+// reproduce this in forward mode: the operand's later uses see a constant.
+template <class T> LMC_HD T FabsW(T &x);
+template <class T> LMC_HD T FmaxW(T &x, float b);
 LMC_HD float Val(float x) { return x; }
 template <int N> LMC_HD float Val(const Dual<N> &x) { return x.v; }
 
@@ -102,6 +112,9 @@ LMC_HD float Fabs(float x) { return fabsf(x); }
 LMC_HD float Log(float x) { return logf(x); }
 LMC_HD float Exp(float x) { return expf(x); }
 LMC_HD float Fmax(float a, float b) { return fmaxf(a, b); }
+LMC_HD float Pow(float a, float e) { return powd(a, e); }
+LMC_HD float ExpD(float x) { return expd(x); }
+LMC_HD float LogD(float x) { return logd(x); }
 LMC_DUAL_T Sqrt(const Dual<N> &a) { float s = sqrtf(a.v); return Chain1(a, s, 0.5f / s); }
 LMC_DUAL_T Sin(const Dual<N> &a) { return Chain1(a, sinf(a.v), cosf(a.v)); }
 LMC_DUAL_T Cos(const Dual<N> &a) { return Chain1(a, cosf(a.v), -sinf(a.v)); }
@@ -116,7 +129,21 @@ LMC_DUAL_T Atan2(const Dual<N> &y, const Dual<N> &x) {
 LMC_DUAL_T Fabs(const Dual<N> &a) { return a.v >= 0.f ? a : -a; }  // chad.h:1226-1234: x >= 0 ? x : -x
 LMC_DUAL_T Log(const Dual<N> &a) { return Chain1(a, logf(a.v), 1.0f / a.v); }
 LMC_DUAL_T Exp(const Dual<N> &a) { float e = expf(a.v); return Chain1(a, e, e); }
+LMC_DUAL_T Pow(const Dual<N> &a, float e) { return Chain1(a, powd(a.v, e), e * powf(a.v, e - 1.0f)); }  // chad.h:727, exponent constant
+LMC_DUAL_T ExpD(const Dual<N> &a) { float e = expd(a.v); return Chain1(a, e, e); }
+LMC_DUAL_T LogD(const Dual<N> &a) { return Chain1(a, logd(a.v), 1.0f / a.v); }
 LMC_DUAL_T Fmax(const Dual<N> &a, float b) { return a.v >= b ? a : MakeDual<N>(b); }  // chad.h:1236-1244: a >= b ? a : b
+
+template <class T> LMC_HD T FabsW(T &x) {
+    T r = Fabs(x);
+    if (Val(x) >= 0.0f) x = Detach(x);
+    return r;
+}
+template <class T> LMC_HD T FmaxW(T &x, float b) {
+    T r = Fmax(x, b);
+    if (Val(x) >= b) x = Detach(x);
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------ small vectors
 template <class T>
@@ -288,9 +315,80 @@ LMC_HD T ShadingNormalCorrectionAdj(const V3T<T> &wi, const PState<T> &ps, const
 }
 
 // ------------------------------------------------------------------------------------------ BSDFs (10-float slot)
+template <class T> LMC_HD V3T<T> ReflectT(const V3T<T> &wi, const V3T<T> &n) { return n * (2.0f * DotT(wi, n)) - wi; }  // utils.h:197-200
+
+// ---- microfacet.h AD versions
+template <class T>
+LMC_HD T BeckmennDT(const V3T<T> &localH, const T &alphaU, const T &alphaV) {  // microfacet.h:6-19
+    T cosTheta2 = localH.z * localH.z;
+    T beckmannExponent = ((localH.x * localH.x) / (alphaU * alphaU) + (localH.y * localH.y) / (alphaV * alphaV)) / cosTheta2;
+    return ExpD(-beckmannExponent) / (c_PI * alphaU * alphaV * (cosTheta2 * cosTheta2));
+}
+template <class T>
+LMC_HD T BeckmennG1T(float alpha, const T &cosTheta) {  // microfacet.h:41-63 (note the 1 + 1e-6)
+    T tanTheta = Sqrt(Fabs((1.0f + 1e-6f) - cosTheta * cosTheta)) / cosTheta;
+    if (Val(tanTheta) <= 0.0f) return Lift<T>::Of(1.0f);
+    T a = 1.0f / (alpha * tanTheta);
+    if (Val(a) >= 1.6f) return Lift<T>::Of(1.0f);
+    T aSqr = a * a;
+    return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+template <class T>
+LMC_HD T FresnelDielectricExtT(T &cosThetaI_, T &cosThetaT_, float eta, float invEta) {  // microfacet.h:117-144 (its fabs wipes the operand)
+    const float scale = Val(cosThetaI_) > 0.0f ? invEta : eta;
+    T cosThetaTSqr = 1.0f - (1.0f - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (Val(cosThetaTSqr) <= 0.0f) {
+        cosThetaT_ = Lift<T>::Of(0.0f);
+        return Lift<T>::Of(1.0f);
+    }
+    const bool positive = Val(cosThetaI_) > 0.0f;
+    T cosThetaI = FabsW(cosThetaI_);
+    T cosThetaT = Sqrt(cosThetaTSqr);
+    T etaCosThetaT = eta * cosThetaT, etaCosThetaI = eta * cosThetaI;
+    T Rs = (cosThetaI - etaCosThetaT) / (cosThetaI + etaCosThetaT);
+    T Rp = (etaCosThetaI - cosThetaT) / (etaCosThetaI + cosThetaT);
+    cosThetaT_ = positive ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+template <class T>
+LMC_HD V3T<T> SampleMicronormalT(const T &r0, const T &r1, const T &alpha, T &pdfW) {  // microfacet.h:165-185, ADEpsilon = 1e-6
+    T phiM = c_TWOPI * r1;
+    T sinPhiM = Sin(phiM), cosPhiM = Cos(phiM);
+    T alphaSqr = alpha * alpha;
+    T tanThetaMSqr = alphaSqr * (-LogD(Fmax(1.0f - r0, 1e-6f)));
+    T cosThetaM = 1.0f / Sqrt(1.0f + tanThetaMSqr);
+    T cosThetaMSqr = cosThetaM * cosThetaM;
+    pdfW = (1.0f - r0) / (c_PI * alphaSqr * cosThetaM * cosThetaMSqr);
+    T sinThetaM = Sqrt(Fmax(1.0f - cosThetaMSqr, 1e-6f));
+    return V3T<T>{sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM};
+}
+
+// the specular + diffuse terms shared by EvaluatePhong and SamplePhong (phong.cpp:200-259 = :313-372)
+template <class T, class In>
+LMC_HD void PhongTermsT(const In &b, int off, const T &alpha, const T &cosWi, const T &cosWo, V3T<T> &contrib, T &pdf, T &revPdf) {
+    const float exponent = b[off + 7], KsWeight = b[off + 8];
+    contrib = C3<T>(0.f, 0.f, 0.f);
+    pdf = Lift<T>::Of(0.f);
+    if (KsWeight > 0.0f) {
+        T weight = Pow(alpha, exponent) * c_INVTWOPI;
+        if (Val(weight) > 1e-10f) {
+            contrib = C3<T>(b[off + 4], b[off + 5], b[off + 6]) * ((exponent + 2.0f) * weight);
+            pdf = (KsWeight * (exponent + 1.0f)) * weight;
+        }
+    }
+    revPdf = pdf;
+    if (KsWeight < 1.0f) {
+        const float tmp = (1.0f - KsWeight) * c_INVPI;
+        contrib = contrib + C3<T>(b[off + 1] * c_INVPI, b[off + 2] * c_INVPI, b[off + 3] * c_INVPI);
+        pdf = pdf + tmp * cosWo;
+        revPdf = revPdf + tmp * cosWi;
+    }
+    contrib = contrib * cosWo;
+}
+
 // EvaluateBSDF, bsdf.cpp:13-63.  Unknown types produce zeros like the generated else-branch.
 template <class T, class In>
-LMC_HD void EvaluateBSDFT(bool /*adjoint*/, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
+LMC_HD void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
                           T &pdf, T &revPdf) {
     const float type = b[off];
     if (type == (float)0 /*Lambertian*/) {  // lambertian.cpp:95-122
@@ -305,15 +403,62 @@ LMC_HD void EvaluateBSDFT(bool /*adjoint*/, const In &b, int off, const V3T<T> &
         contrib = C3<T>(b[off + 1], b[off + 2], b[off + 3]) * fwdScalar;
         pdf = fwdScalar;
         revPdf = cosWi * c_INVPI;
+    } else if (type == (float)1 /*Phong*/) {  // phong.cpp:171-259: no two-sided test, no rejection, no fmax on alpha
+        T cosWi = DotT(normal, wi);
+        V3T<T> n = normal;
+        if (!(Val(cosWi) > 0.0f)) {
+            n = -normal;
+            cosWi = -cosWi;
+        }
+        cosWo = DotT(n, wo);
+        T alpha = DotT(ReflectT(wi, n), wo);
+        PhongTermsT(b, off, alpha, cosWi, cosWo, contrib, pdf, revPdf);
+    } else if (type == (float)2 /*RoughDielectric*/) {  // roughdielectric.cpp:332-438, statement order kept (FabsW)
+        const V3T<T> Ks = C3<T>(b[off + 1], b[off + 2], b[off + 3]), Kt = C3<T>(b[off + 4], b[off + 5], b[off + 6]);
+        const float eta = b[off + 7], invEta = b[off + 8], alpha = b[off + 9];
+        T cosWi = DotT(wi, normal);
+        cosWo = DotT(wo, normal);
+        const bool reflect = Val(cosWi * cosWo) > 0.0f;
+        const float eta_ = Val(cosWi) > 0.0f ? eta : invEta;
+        const float revEta_ = Val(cosWo) > 0.0f ? eta : invEta;
+        V3T<T> H = reflect ? NormalizeT(wi + wo) : NormalizeT(wi + wo * Lift<T>::Of(eta_));
+        if (Val(DotT(H, normal)) < 0.0f) H = -H;
+        T cosHWi = DotT(wi, H), cosHWo = DotT(wo, H);
+        V3T<T> b0, b1;
+        CoordinateSystemT(normal, b0, b1);
+        V3T<T> localH{DotT(b0, H), DotT(b1, H), DotT(normal, H)};
+        const T alphaT = Lift<T>::Of(alpha);
+        T D = BeckmennDT(localH, alphaT, alphaT);
+        T unusedT;
+        T F = FresnelDielectricExtT(cosHWi, unusedT, eta, invEta);  // cosHWi (= revCosHWo) is constant from here on when >= 0
+        T aCosWi = FabsW(cosWi), aCosWo = FabsW(cosWo);
+        T G = BeckmennG1T(alpha, aCosWi) * BeckmennG1T(alpha, aCosWo);
+        T scaledAlpha = alpha * (1.2f - 0.2f * Sqrt(aCosWi));
+        T prob = localH.z * BeckmennDT(localH, scaledAlpha, scaledAlpha);
+        T revScaledAlpha = alpha * (1.2f - 0.2f * Sqrt(aCosWo));
+        T revProb = localH.z * BeckmennDT(localH, revScaledAlpha, revScaledAlpha);
+        if (reflect) {
+            T scalar = Fabs(F * D * G / (4.0f * cosWi));
+            contrib = Ks * scalar;
+            pdf = Fabs(prob * F / (4.0f * cosHWo));
+            revPdf = Fabs(revProb * F / (4.0f * cosHWi));
+        } else {
+            T sqrtDenom = cosHWi + eta_ * cosHWo;
+            T revSqrtDenom = cosHWo + revEta_ * cosHWi;
+            const float factor = adjoint ? 1.0f : (1.0f / eta_) * (1.0f / eta_);
+            T scalar = Fabs(factor * ((1.0f - F) * D * G * (eta_ * eta_) * cosHWi * cosHWo) / (cosWi * (sqrtDenom * sqrtDenom)));
+            contrib = Kt * scalar;
+            pdf = Fabs(prob * (1.0f - F) * ((eta_ * eta_) * cosHWo) / (sqrtDenom * sqrtDenom));
+            revPdf = Fabs(revProb * (1.0f - F) * ((revEta_ * revEta_) * cosHWi) / (revSqrtDenom * revSqrtDenom));
+        }
     } else {
-        // Phong / RoughDielectric twins (phong.cpp:171-393, roughdielectric.cpp:332-528): SURVEY.md §8 config 3, not built yet
-        contrib = C3<T>(NAN, NAN, NAN);
-        cosWo = pdf = revPdf = Lift<T>::Of(NAN);
+        contrib = C3<T>(0.f, 0.f, 0.f);
+        cosWo = pdf = revPdf = Lift<T>::Of(0.f);
     }
 }
 // SampleBSDF, bsdf.cpp:65-171 (fixDiscrete = false)
 template <class T, class In>
-LMC_HD void SampleBSDFT(bool /*adjoint*/, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const T &r0, const T &r1, float /*uDiscrete*/,
+LMC_HD void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const T &r0, const T &r1, float uDiscrete,
                         V3T<T> &wo, V3T<T> &contrib, T &cosWo, T &pdf, T &revPdf) {
     const float type = b[off];
     if (type == (float)0) {  // lambertian.cpp:124-151
@@ -331,9 +476,84 @@ LMC_HD void SampleBSDFT(bool /*adjoint*/, const In &b, int off, const V3T<T> &wi
         pdf = ret.z * c_INVPI;
         contrib = C3<T>(b[off + 1], b[off + 2], b[off + 3]);
         revPdf = cosWi * c_INVPI;
+    } else if (type == (float)1) {  // phong.cpp:261-393: lobe chosen by uDiscrete (the scalar sampler uses rndParam[0])
+        const float exponent = b[off + 7], KsWeight = b[off + 8];
+        T cosWi = DotT(normal, wi);
+        V3T<T> n = normal;
+        if (!(Val(cosWi) > 0.0f)) {
+            n = -normal;
+            cosWi = -cosWi;
+        }
+        V3T<T> R = ReflectT(wi, n);
+        V3T<T> b0, b1;
+        if (uDiscrete > KsWeight) {
+            V3T<T> localDir = SampleCosHemisphereT(r0, r1);
+            CoordinateSystemT(n, b0, b1);
+            wo = b0 * localDir.x + b1 * localDir.y + n * localDir.z;
+        } else {
+            const float power = 1.0f / (exponent + 1.0f);
+            T cosAlpha = Pow(r1, power);
+            T sinAlpha = Sqrt(Fmax(1.0f - cosAlpha * cosAlpha, 1e-6f));
+            T phi = c_TWOPI * r0;
+            CoordinateSystemT(R, b0, b1);
+            wo = b0 * (sinAlpha * Cos(phi)) + b1 * (sinAlpha * Sin(phi)) + R * cosAlpha;
+        }
+        cosWo = DotT(n, wo);
+        T alpha = DotT(R, wo);
+        PhongTermsT(b, off, alpha, cosWi, cosWo, contrib, pdf, revPdf);
+        contrib = contrib * (1.0f / pdf);
+    } else if (type == (float)2) {  // roughdielectric.cpp:440-528, statement order kept (FabsW)
+        const V3T<T> Ks = C3<T>(b[off + 1], b[off + 2], b[off + 3]), Kt = C3<T>(b[off + 4], b[off + 5], b[off + 6]);
+        const float eta = b[off + 7], invEta = b[off + 8], alpha = b[off + 9];
+        T cosWi = DotT(wi, normal);
+        T scaledAlpha = alpha * (1.2f - 0.2f * Sqrt(FabsW(cosWi)));
+        T mPdf;
+        V3T<T> localH = SampleMicronormalT(r0, r1, scaledAlpha, mPdf);
+        V3T<T> b0, b1;
+        CoordinateSystemT(normal, b0, b1);
+        V3T<T> H = b0 * localH.x + b1 * localH.y + normal * localH.z;
+        T cosHWi = DotT(wi, H);
+        T cosThetaT;
+        T F = FresnelDielectricExtT(cosHWi, cosThetaT, eta, invEta);
+        V3T<T> refl;
+        if (uDiscrete <= Val(F)) {
+            wo = ReflectT(wi, H);
+            refl = Ks;
+            T cosHWo = DotT(wo, H);
+            pdf = Fabs(mPdf * F / (4.0f * cosHWo));
+            T rev_dwh_dwo = 1.0f / (4.0f * cosHWi);
+            cosWo = DotT(wo, normal);
+            T revScaledAlp = alpha * (1.2f - 0.2f * Sqrt(FabsW(cosWo)));
+            T revD = BeckmennDT(localH, revScaledAlp, revScaledAlp);
+            revPdf = Fabs(F * revD * localH.z * rev_dwh_dwo);
+        } else {
+            const float etaR = Val(cosThetaT) < 0.0f ? invEta : eta;  // Refract, utils.h:202-210
+            wo = H * (DotT(wi, H) * etaR + cosThetaT) - wi * Lift<T>::Of(etaR);
+            const float eta_ = Val(cosWi) > 0.0f ? eta : invEta;
+            const float factor = adjoint ? 1.0f : (1.0f / eta_) * (1.0f / eta_);
+            refl = Kt * Lift<T>::Of(factor);
+            T cosHWo = DotT(wo, H);
+            T sqrtDenom = cosHWi + eta_ * cosHWo;
+            T dwh_dwo = ((eta_ * eta_) * cosHWo) / (sqrtDenom * sqrtDenom);
+            pdf = Fabs(mPdf * (1.0f - F) * Fabs(dwh_dwo));
+            cosWo = DotT(wo, normal);
+            const float revEta_ = Val(cosWo) > 0.0f ? eta : invEta;
+            T revSqrtDenom = cosHWo + revEta_ * cosHWi;
+            T rev_dwh_dwo = ((revEta_ * revEta_) * cosHWi) / (revSqrtDenom * revSqrtDenom);
+            T revScaledAlp = alpha * (1.2f - 0.2f * Sqrt(FabsW(cosWo)));
+            T revD = BeckmennDT(localH, revScaledAlp, revScaledAlp);
+            revPdf = Fabs((1.0f - F) * revD * localH.z * rev_dwh_dwo);
+        }
+        T aCosWi = FabsW(cosWi), aCosWo = FabsW(cosWo);
+        const T alphaT = Lift<T>::Of(alpha);
+        T D = BeckmennDT(localH, alphaT, alphaT);
+        T G = BeckmennG1T(alpha, aCosWi) * BeckmennG1T(alpha, aCosWo);
+        T numerator = D * G * cosHWi;
+        T denominator = mPdf * aCosWi;
+        contrib = refl * Fabs(numerator / denominator);
     } else {
-        wo = contrib = C3<T>(NAN, NAN, NAN);
-        cosWo = pdf = revPdf = Lift<T>::Of(NAN);
+        wo = contrib = C3<T>(0.f, 0.f, 0.f);
+        cosWo = pdf = revPdf = Lift<T>::Of(0.f);
     }
 }
 

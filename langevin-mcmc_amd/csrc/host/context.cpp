@@ -94,6 +94,8 @@ struct lmc_ctx {
     DevBuf<TriData> tris;
     DevBuf<DMesh> meshes;
     DevBuf<DMaterial> materials;
+    DevBuf<DBitmap> bitmaps;
+    std::vector<std::unique_ptr<DevBuf<float>>> bitmapPix;
     DevBuf<DLight> lights;
     DevBuf<float> areaFunc, areaCdf, lightFunc, lightCdf, envImage, envCdfRows, envCdfCols, envRowWeights;
     DScene S;
@@ -187,14 +189,27 @@ static void UploadScene(lmc_ctx *c) {
         DMaterial d;
         memset(&d, 0, sizeof(d));
         d.type = m.type, d.twoSided = m.twoSided ? 1 : 0;
-        memcpy(d.Kd, m.Kd.value, 12), memcpy(d.Ks, m.Ks.value, 12), memcpy(d.Kt, m.Kt.value, 12);
-        d.expOrAlpha = m.expOrAlpha.value[0], d.eta = m.eta, d.invEta = m.invEta, d.KsWeight = m.KsWeight;
-        d.KdTex = m.Kd.bitmap;
-        if (m.type != lmc::BSDF_LAMBERTIAN)
-            throw std::runtime_error("BSDF type not available on the MI355X back end yet (phong / roughdielectric: SURVEY.md §8 config 3); load with force_diffuse");
-        if (m.Kd.bitmap >= 0) throw std::runtime_error("bitmap textures are not available on the MI355X back end yet (SURVEY.md §8 config 3)");
+        auto tex = [](const lmc::TextureRef &t) {
+            DTexRef r;
+            r.bitmap = t.bitmap, r.sScale = t.sScale, r.tScale = t.tScale;
+            memcpy(r.value, t.value, 12);
+            return r;
+        };
+        d.Kd = tex(m.Kd), d.Ks = tex(m.Ks), d.Kt = tex(m.Kt), d.expOrAlpha = tex(m.expOrAlpha);
+        d.eta = m.eta, d.invEta = m.invEta, d.KsWeight = m.KsWeight;
+        if (m.type != lmc::BSDF_LAMBERTIAN && m.type != lmc::BSDF_PHONG && m.type != lmc::BSDF_ROUGHDIELECTRIC) throw std::runtime_error("unknown BSDF type");
         mats.push_back(d);
     }
+    std::vector<DBitmap> bitmaps;
+    c->bitmapPix.clear();
+    for (size_t i = 0; i < sc.bitmaps.size(); i++) {
+        const lmc::Bitmap &bm = sc.bitmaps[i];
+        c->bitmapPix.emplace_back(new DevBuf<float>());
+        c->bitmapPix.back()->Upload(bm.img.data);
+        bitmaps.push_back(DBitmap{c->bitmapPix.back()->p, bm.img.width, bm.img.height, bm.gamma});
+    }
+    if (bitmaps.empty()) bitmaps.push_back(DBitmap{nullptr, 0, 0, 1.f});
+    c->bitmaps.Upload(bitmaps);
     std::vector<DLight> lights;
     for (const lmc::Light &L : sc.lights) {
         DLight d;
@@ -208,7 +223,7 @@ static void UploadScene(lmc_ctx *c) {
     c->areaFunc.Upload(areaFunc), c->areaCdf.Upload(areaCdf), c->lightFunc.Upload(sc.lightFunc), c->lightCdf.Upload(sc.lightCdf);
     DScene &S = c->S;
     memset(&S, 0, sizeof(S));
-    S.nodes = c->nodes.p, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.lights = c->lights.p;
+    S.nodes = c->nodes.p, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
     S.areaFunc = c->areaFunc.p, S.areaCdf = c->areaCdf.p, S.lightFunc = c->lightFunc.p, S.lightCdf = c->lightCdf.p;
     S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
     S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size();

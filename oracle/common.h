@@ -55,6 +55,10 @@ struct Vector3 {
         v[0] *= s, v[1] *= s, v[2] *= s;
         return *this;
     }
+    Vector3 &operator+=(const Vector3 &o) {
+        v[0] += o.v[0], v[1] += o.v[1], v[2] += o.v[2];
+        return *this;
+    }
 };
 inline Vector3 operator+(const Vector3 &a, const Vector3 &b) { return Vector3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
 inline Vector3 operator-(const Vector3 &a, const Vector3 &b) { return Vector3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }

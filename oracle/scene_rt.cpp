@@ -332,6 +332,334 @@ struct Lambertian : BSDF {  // lambertian.cpp:15-93
     Float Roughness(const Vector2, const Float) const override { return Float(1.0); }
 };
 
+// pow / exp / log of the glossy BSDFs: double evaluation rounded once, the arithmetic contract shared with the device code
+// (device/dmath.h powd/expd/logd).  The reference calls the float libm functions here.
+static inline Float powd(Float a, Float e) { return (Float)std::pow((double)a, (double)e); }
+static inline Float expd(Float x) { return (Float)std::exp((double)x); }
+static inline Float logd(Float x) { return (Float)std::log((double)x); }
+
+// ---- microfacet helpers, microfacet.h:6-70,165-185 (scalar Float versions)
+static Float BeckmennDistributionTerm(const Vector3 &localH, Float alphaU, Float alphaV) {
+    const Float cosTheta = localH[2], mu = localH[0], mv = localH[1];
+    Float cosTheta2 = square(cosTheta);
+    Float beckmannExponent = (square(mu) / square(alphaU) + square(mv) / square(alphaV)) / cosTheta2;
+    return expd(-beckmannExponent) / (c_PI * alphaU * alphaV * square(cosTheta2));
+}
+static Float BeckmennGeometryTerm1(Float alpha, Float cosTheta) {
+    Float tanTheta = std::sqrt(std::fabs(Float(1.0) - square(cosTheta))) / cosTheta;
+    if (tanTheta <= 0.0) return Float(1.0);
+    Float a = Float(1.0) / (alpha * tanTheta);
+    if (a >= Float(1.6)) return Float(1.0);
+    Float aSqr = a * a;
+    return (Float(3.535) * a + Float(2.181) * aSqr) / (Float(1.0) + Float(2.276) * a + Float(2.577) * aSqr);
+}
+static Float BeckmennGeometryTerm(Float alpha, Float cosWi, Float cosWo) { return BeckmennGeometryTerm1(alpha, cosWi) * BeckmennGeometryTerm1(alpha, cosWo); }
+static Float FresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta, Float invEta) {
+    Float scale = (cosThetaI_ > 0) ? invEta : eta;
+    Float cosThetaTSqr = Float(1.0) - (Float(1.0) - square(cosThetaI_)) * square(scale);
+    if (cosThetaTSqr <= Float(0.0)) {
+        cosThetaT_ = Float(0.0);
+        return Float(1.0);
+    }
+    Float cosThetaI = std::fabs(cosThetaI_);
+    Float cosThetaT = std::sqrt(cosThetaTSqr);
+    Float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    Float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return Float(0.5) * (square(Rs) + square(Rp));
+}
+static Float FresnelDielectricExt(Float cosThetaI_, Float eta, Float invEta) {
+    Float unused;
+    return FresnelDielectricExt(cosThetaI_, unused, eta, invEta);
+}
+static Vector3 SampleMicronormal(const Vector2 rndParam, Float alpha, Float &pdfW) {
+    Float phiM = c_TWOPI * rndParam[1];
+    Float sinPhiM = std::sin(phiM), cosPhiM = std::cos(phiM);
+    Float alphaSqr = square(alpha);
+    Float tanThetaMSqr = alphaSqr * (-logd(std::fmax(Float(1.0) - rndParam[0], Float(1e-6))));
+    Float cosThetaM = Float(1.0) / std::sqrt(Float(1.0) + tanThetaMSqr);
+    Float cosThetaMSqr = square(cosThetaM);
+    pdfW = (Float(1.0) - rndParam[0]) / (c_PI * alphaSqr * cosThetaM * cosThetaMSqr);
+    Float sinThetaMSq = std::fmax(Float(1.0) - cosThetaMSqr, Float(0.0));  // ADEpsilon<Float>() == 0
+    Float sinThetaM = std::sqrt(sinThetaMSq);
+    return Vector3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+}
+
+struct TexturedBSDF : BSDF {
+    const lmc::Scene *S;
+    const lmc::Material *mat;
+    Vector3 Tex(const lmc::TextureRef &t, const Vector2 st) const {
+        float o[3];
+        lmc::EvalTexture(*S, t, st[0], st[1], o);
+        return Vector3(o[0], o[1], o[2]);
+    }
+};
+
+struct Phong : TexturedBSDF {  // phong.cpp:14-157
+    bool twoSided;
+    Float KsWeight;
+    int GetType() const override { return lmc::BSDF_PHONG; }
+    void Serialize(const Vector2 st, Float *buffer) const override {
+        buffer[0] = (Float)lmc::BSDF_PHONG;
+        Vector3 kd = Tex(mat->Kd, st), ks = Tex(mat->Ks, st);
+        buffer[1] = kd[0], buffer[2] = kd[1], buffer[3] = kd[2];
+        buffer[4] = ks[0], buffer[5] = ks[1], buffer[6] = ks[2];
+        buffer[7] = Tex(mat->expOrAlpha, st)[0];
+        buffer[8] = KsWeight;
+    }
+    void Evaluate(const Vector3 &wi, const Vector3 &normal, const Vector3 &wo, const Vector2 st, Vector3 &contrib, Float &cosWo, Float &pdf,
+                  Float &revPdf) const override {
+        contrib = Vector3::Zero();
+        pdf = Float(0.0);
+        revPdf = Float(0.0);
+        Float cosWi = Dot(normal, wi);
+        Vector3 normal_ = normal;
+        if (twoSided && cosWi < Float(0.0)) {
+            cosWi = -cosWi;
+            normal_ = -normal_;
+        }
+        cosWo = Dot(normal_, wo);
+        if (cosWi <= c_CosEpsilon || cosWo <= c_CosEpsilon) return;
+        if (KsWeight > Float(0.0)) {
+            const Float alpha = std::fmax(Dot(Reflect(wi, normal_), wo), Float(0.0));
+            const Float expo = Tex(mat->expOrAlpha, st)[0];
+            const Float weight = powd(alpha, expo) * c_INVTWOPI;
+            const Float expoConst1 = (expo + Float(1.0));
+            const Float expoConst2 = (expo + Float(2.0));
+            if (weight > Float(1e-10)) {
+                contrib = Tex(mat->Ks, st) * (expoConst2 * weight);
+                pdf = KsWeight * expoConst1 * weight;
+                revPdf = pdf;
+            }
+        }
+        if (KsWeight < Float(1.0)) {
+            pdf += (Float(1.0) - KsWeight) * cosWo * c_INVPI;
+            revPdf += (Float(1.0) - KsWeight) * cosWi * c_INVPI;
+            contrib += Tex(mat->Kd, st) * c_INVPI;
+        }
+        contrib *= cosWo;
+        if (contrib.maxCoeff() < Float(1e-10)) contrib = Vector3::Zero();
+    }
+    bool Sample(const Vector3 &wi, const Vector3 &normal, const Vector2 st, const Vector2 rndParam, const Float /*uDiscrete*/, Vector3 &wo,
+                Vector3 &contrib, Float &cosWo, Float &pdf, Float &revPdf) const override {
+        Float cosWi = Dot(wi, normal);
+        if (std::fabs(cosWi) < c_CosEpsilon) return false;
+        Vector3 normal_ = normal;
+        if (cosWi < Float(0.0)) {
+            if (twoSided) {
+                cosWi = -cosWi;
+                normal_ = -normal_;
+            } else
+                return false;
+        }
+        const Float expo = Tex(mat->expOrAlpha, st)[0];
+        const Vector3 R = Reflect(wi, normal_);
+        Float g;
+        Vector3 n;
+        const Float uDiscrete = rndParam[0];  // lobe selection re-uses rndParam[0] (phong.cpp:97-107)
+        Float rndParam0;
+        if (uDiscrete > KsWeight) {
+            g = Float(1.0);
+            n = normal_;
+            rndParam0 = (uDiscrete - KsWeight) / (Float(1.0) - KsWeight + Float(1e-10));
+        } else {
+            g = expo;
+            n = R;
+            rndParam0 = uDiscrete / (KsWeight + Float(1e-10));
+        }
+        const Float power = Float(1.0) / (g + Float(1.0));
+        const Float cosAlpha = powd(rndParam[1], power);
+        const Float sinAlpha = std::sqrt(Float(1.0) - square(cosAlpha));
+        const Float phi = c_TWOPI * rndParam0;
+        const Vector3 localDir = Vector3(sinAlpha * std::cos(phi), sinAlpha * std::sin(phi), cosAlpha);
+        Vector3 b0, b1;
+        CoordinateSystem(n, b0, b1);
+        wo = localDir[0] * b0 + localDir[1] * b1 + localDir[2] * n;
+        cosWo = Dot(normal_, wo);
+        if (cosWo < c_CosEpsilon) return false;
+        contrib = Vector3::Zero();
+        pdf = Float(0.0);
+        if (KsWeight > Float(0.0)) {
+            const Float alpha = std::fmax(Dot(R, wo), Float(0.0));
+            const Float weight = powd(alpha, expo) * c_INVTWOPI;
+            const Float expoConst1 = (expo + Float(1.0));
+            const Float expoConst2 = (expo + Float(2.0));
+            if (weight > Float(1e-10)) {
+                contrib = Tex(mat->Ks, st) * (expoConst2 * weight);
+                pdf = KsWeight * expoConst1 * weight;
+            }
+            revPdf = pdf;
+        }
+        if (KsWeight < Float(1.0)) {
+            contrib += Tex(mat->Kd, st) * c_INVPI;
+            pdf += (Float(1.0) - KsWeight) * cosWo * c_INVPI;
+            revPdf += (Float(1.0) - KsWeight) * cosWi * c_INVPI;  // NB: accumulates onto the caller's value when KsWeight == 0
+        }
+        contrib *= cosWo;
+        if (pdf < Float(1e-10)) return false;
+        contrib *= inverse(pdf);
+        return true;
+    }
+    Float Roughness(const Vector2, const Float) const override { return Float(1.0); }  // phong.cpp:155-157
+};
+
+struct RoughDielectric : TexturedBSDF {  // roughdielectric.cpp:13-330
+    Float eta, invEta;
+    int GetType() const override { return lmc::BSDF_ROUGHDIELECTRIC; }
+    void Serialize(const Vector2 st, Float *buffer) const override {
+        buffer[0] = (Float)lmc::BSDF_ROUGHDIELECTRIC;
+        Vector3 ks = Tex(mat->Ks, st), kt = Tex(mat->Kt, st);
+        buffer[1] = ks[0], buffer[2] = ks[1], buffer[3] = ks[2];
+        buffer[4] = kt[0], buffer[5] = kt[1], buffer[6] = kt[2];
+        buffer[7] = eta, buffer[8] = invEta;
+        buffer[9] = Tex(mat->expOrAlpha, st)[0];
+    }
+    template <bool adjoint>
+    void Eval(const Vector3 &wi, const Vector3 &normal, const Vector3 &wo, const Vector2 st, Vector3 &contrib, Float &cosWo, Float &pdf,
+              Float &revPdf) const {
+        Float cosWi = Dot(wi, normal);
+        contrib = Vector3::Zero();
+        cosWo = Float(0.0);
+        pdf = revPdf = Float(0.0);
+        if (std::fabs(cosWi) < c_CosEpsilon) return;
+        cosWo = Dot(wo, normal);
+        if (std::fabs(cosWo) < c_CosEpsilon) return;
+        bool reflect = cosWi * cosWo > Float(0.0);
+        Float eta_ = cosWi > Float(0.0) ? eta : invEta;
+        Float revEta_ = cosWo > Float(0.0) ? eta : invEta;
+        Vector3 H;
+        if (reflect) H = Normalize(Vector3(wi + wo));
+        else
+            H = Normalize(Vector3(wi + wo * eta_));
+        if (Dot(H, normal) < Float(0.0)) H = -H;
+        Float cosHWi = Dot(wi, H);
+        Float cosHWo = Dot(wo, H);
+        if (std::fabs(cosHWi) < c_CosEpsilon || std::fabs(cosHWo) < c_CosEpsilon) return;
+        if (cosHWi * cosWi <= Float(0.0)) return;
+        if (cosHWo * cosWo <= Float(0.0)) return;
+        Vector3 b0, b1;
+        CoordinateSystem(normal, b0, b1);
+        Vector3 localH = Vector3(Dot(b0, H), Dot(b1, H), Dot(normal, H));
+        Float alp = Tex(mat->expOrAlpha, st)[0];
+        Float D = BeckmennDistributionTerm(localH, alp, alp);
+        if (D <= Float(0.0)) return;
+        Float revCosHWi = cosHWo;
+        Float revCosHWo = cosHWi;
+        Float F = FresnelDielectricExt(cosHWi, eta, invEta);
+        Float aCosWi = std::fabs(cosWi);
+        Float aCosWo = std::fabs(cosWo);
+        Float G = BeckmennGeometryTerm(alp, aCosWi, aCosWo);
+        Float scaledAlpha = alp * (Float(1.2) - Float(0.2) * std::sqrt(aCosWi));
+        Float scaledD = BeckmennDistributionTerm(localH, scaledAlpha, scaledAlpha);
+        Float prob = localH[2] * scaledD;
+        if (prob < Float(1e-20)) {
+            contrib = Vector3::Zero();
+            return;
+        }
+        Float revScaledAlpha = alp * (Float(1.2) - Float(0.2) * std::sqrt(aCosWo));
+        Float revScaledD = BeckmennDistributionTerm(localH, revScaledAlpha, revScaledAlpha);
+        Float revProb = localH[2] * revScaledD;
+        if (reflect) {
+            Float scalar = std::fabs(F * D * G / (Float(4.0) * cosWi));
+            contrib = Tex(mat->Ks, st) * scalar;
+            pdf = std::fabs(prob * F / (Float(4.0) * cosHWo));
+            revPdf = std::fabs(revProb * F / (Float(4.0) * revCosHWo));
+        } else {
+            Float sqrtDenom = cosHWi + eta_ * cosHWo;
+            Float revSqrtDenom = revCosHWi + revEta_ * revCosHWo;
+            Float factor = adjoint ? Float(1.0) : square(inverse(eta_));
+            Float scalar = std::fabs(factor * ((Float(1.0) - F) * D * G * square(eta_) * cosHWi * cosHWo) / (cosWi * square(sqrtDenom)));
+            contrib = Tex(mat->Kt, st) * scalar;
+            pdf = std::fabs(prob * (Float(1.0) - F) * (square(eta_) * cosHWo) / (square(sqrtDenom)));
+            revPdf = std::fabs(revProb * (Float(1.0) - F) * (square(revEta_) * revCosHWo) / (square(revSqrtDenom)));
+        }
+    }
+    template <bool adjoint>
+    bool Samp(const Vector3 &wi, const Vector3 &normal, const Vector2 st, const Vector2 rndParam, const Float uDiscrete, Vector3 &wo,
+              Vector3 &contrib, Float &cosWo, Float &pdf, Float &revPdf) const {
+        Float cosWi = Dot(wi, normal);
+        if (std::fabs(cosWi) < c_CosEpsilon) return false;
+        Float alp = Tex(mat->expOrAlpha, st)[0];
+        Float scaledAlp = alp * (Float(1.2) - Float(0.2) * std::sqrt(std::fabs(cosWi)));
+        Float mPdf;
+        Vector3 localH = SampleMicronormal(rndParam, scaledAlp, mPdf);
+        pdf = mPdf;
+        Vector3 b0, b1;
+        CoordinateSystem(normal, b0, b1);
+        Vector3 H = localH[0] * b0 + localH[1] * b1 + localH[2] * normal;
+        Float cosHWi = Dot(wi, H);
+        if (std::fabs(cosHWi) < c_CosEpsilon) return false;
+        Float cosThetaT = 0.0;
+        Float F = FresnelDielectricExt(cosHWi, cosThetaT, eta, invEta);
+        bool reflect = uDiscrete <= F;
+        Vector3 refl;
+        Float cosHWo;
+        if (reflect) {
+            wo = Reflect(wi, H);
+            if (F <= Float(0.0) || Dot(normal, wo) * Dot(normal, wi) <= Float(0.0)) return false;
+            refl = Tex(mat->Ks, st);
+            cosHWo = Dot(wo, H);
+            pdf = std::fabs(pdf * F / (Float(4.0) * cosHWo));
+            Float revCosHWo = cosHWi;
+            Float rev_dwh_dwo = inverse(Float(4.0) * revCosHWo);
+            cosWo = Dot(wo, normal);
+            if (std::fabs(cosWo) < c_CosEpsilon) return false;
+            Float revScaledAlp = alp * (Float(1.2) - Float(0.2) * std::sqrt(std::fabs(cosWo)));
+            Float revD = BeckmennDistributionTerm(localH, revScaledAlp, revScaledAlp);
+            revPdf = std::fabs(F * revD * localH[2] * rev_dwh_dwo);
+        } else {
+            wo = Refract(wi, H, cosThetaT, eta, invEta);
+            if (F >= Float(1.0) || cosThetaT == Float(0.0) || Dot(normal, wo) * Dot(normal, wi) >= Float(0.0)) return false;
+            Float eta_ = cosWi > Float(0.0) ? eta : invEta;
+            Float factor = adjoint ? Float(1.0) : square(inverse(eta_));
+            refl = Tex(mat->Kt, st) * factor;
+            cosHWo = Dot(wo, H);
+            Float sqrtDenom = cosHWi + eta_ * cosHWo;
+            Float dwh_dwo = (square(eta_) * cosHWo) / square(sqrtDenom);
+            pdf = std::fabs(pdf * (Float(1.0) - F) * std::fabs(dwh_dwo));
+            cosWo = Dot(wo, normal);
+            if (std::fabs(cosWo) < c_CosEpsilon) return false;
+            Float revEta_ = cosWo > Float(0.0) ? eta : invEta;
+            Float revCosHWi = cosHWo;
+            Float revCosHWo = cosHWi;
+            Float revSqrtDenom = revCosHWi + revEta_ * revCosHWo;
+            Float rev_dwh_dwo = (square(revEta_) * revCosHWo) / square(revSqrtDenom);
+            Float revScaledAlp = alp * (Float(1.2) - Float(0.2) * std::sqrt(std::fabs(cosWo)));
+            Float revD = BeckmennDistributionTerm(localH, revScaledAlp, revScaledAlp);
+            revPdf = std::fabs((Float(1.0) - F) * revD * localH[2] * rev_dwh_dwo);
+        }
+        if (std::fabs(cosHWo) < c_CosEpsilon) return false;
+        if (pdf < Float(1e-20)) return false;
+        if (cosHWi * cosWi <= Float(0.0)) return false;
+        if (cosHWo * cosWo <= Float(0.0)) return false;
+        Float aCosWi = std::fabs(cosWi);
+        Float aCosWo = std::fabs(cosWo);
+        Float D = BeckmennDistributionTerm(localH, alp, alp);
+        Float G = BeckmennGeometryTerm(alp, aCosWi, aCosWo);
+        Float numerator = D * G * cosHWi;
+        Float denominator = mPdf * aCosWi;
+        contrib = refl * std::fabs(numerator / denominator);
+        return true;
+    }
+    void Evaluate(const Vector3 &wi, const Vector3 &normal, const Vector3 &wo, const Vector2 st, Vector3 &contrib, Float &cosWo, Float &pdf,
+                  Float &revPdf) const override {
+        Eval<false>(wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
+    }
+    void EvaluateAdjoint(const Vector3 &wi, const Vector3 &normal, const Vector3 &wo, const Vector2 st, Vector3 &contrib, Float &cosWo, Float &pdf,
+                         Float &revPdf) const override {
+        Eval<true>(wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
+    }
+    bool Sample(const Vector3 &wi, const Vector3 &normal, const Vector2 st, const Vector2 rndParam, const Float uDiscrete, Vector3 &wo,
+                Vector3 &contrib, Float &cosWo, Float &pdf, Float &revPdf) const override {
+        return Samp<false>(wi, normal, st, rndParam, uDiscrete, wo, contrib, cosWo, pdf, revPdf);
+    }
+    bool SampleAdjoint(const Vector3 &wi, const Vector3 &normal, const Vector2 st, const Vector2 rndParam, const Float uDiscrete, Vector3 &wo,
+                       Vector3 &contrib, Float &cosWo, Float &pdf, Float &revPdf) const override {
+        return Samp<true>(wi, normal, st, rndParam, uDiscrete, wo, contrib, cosWo, pdf, revPdf);
+    }
+    Float Roughness(const Vector2 st, const Float) const override { return Tex(mat->expOrAlpha, st)[0]; }  // roughdielectric.h:61-63
+};
+
 }  // namespace
 
 // ============================================================================================ lights
@@ -583,8 +911,16 @@ std::unique_ptr<RScene> BuildRScene(std::unique_ptr<lmc::Scene> desc) {
             auto *b = new Lambertian;
             b->S = &S, b->mat = &m, b->twoSided = m.twoSided;
             R->bsdfs.emplace_back(b);
+        } else if (m.type == lmc::BSDF_PHONG) {
+            auto *b = new Phong;
+            b->S = &S, b->mat = &m, b->twoSided = m.twoSided, b->KsWeight = m.KsWeight;
+            R->bsdfs.emplace_back(b);
+        } else if (m.type == lmc::BSDF_ROUGHDIELECTRIC) {
+            auto *b = new RoughDielectric;
+            b->S = &S, b->mat = &m, b->eta = m.eta, b->invEta = m.invEta;
+            R->bsdfs.emplace_back(b);
         } else
-            throw std::runtime_error("oracle: BSDF type not restated yet (phong / roughdielectric are SURVEY.md §8 config 3)");
+            throw std::runtime_error("oracle: unknown BSDF type");
     }
     int triBase = 0;
     for (size_t i = 0; i < S.meshes.size(); i++) {

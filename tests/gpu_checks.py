@@ -165,12 +165,29 @@ def lum(film):
     return film.astype(np.float64) @ np.array([0.212671, 0.715160, 0.072169])
 
 
-def run_pair(width, height, num_init, n_chains, init_threads, per_chain, steps, use_gradient, max_depth=6, scene=TORUS, mala=True, opts=None):
-    """Runs the same configuration on the oracle and on the GPU; returns a dict of comparison figures."""
+def host_pathfunc_lib():
+    """Test helper: the product's path program compiled for the host, exporting the plugin symbol names, so that the
+    oracle can draw its gradients from the same program the GPU runs (chain-loop parity independent of the AD)."""
+    import subprocess
+
+    so = os.path.join(ROOT, "tests", "helpers", "libpathfunc_host.so")
+    src = os.path.join(ROOT, "tests", "helpers", "pathfunc_host.cpp")
+    hdr = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "device", "pathfunc.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], cwd=ROOT)
+    return so
+
+
+def run_pair(width, height, num_init, n_chains, init_threads, per_chain, steps, use_gradient, max_depth=6, scene=TORUS, mala=True, opts=None,
+             force_diffuse=1, oracle_grad="reference"):
+    """Runs the same configuration on the oracle and on the GPU; returns a dict of comparison figures.
+    oracle_grad: "reference" = the reference's generated derivative programs (oracle/_ref), "product" = the product's
+    path program compiled for the host (tests/helpers)."""
     p = pkg()
     L = oracle_lib()
-    orc = _orc.Oracle(L, scene, 1, max_depth, width, height, 0, pathref() if use_gradient else "")
-    ren = p.Renderer(scene, force_diffuse=1, max_depth=max_depth, width=width, height=height, seed_offset=0, use_gradient=use_gradient)
+    glib = (pathref() if oracle_grad == "reference" else host_pathfunc_lib()) if use_gradient else ""
+    orc = _orc.Oracle(L, scene, force_diffuse, max_depth, width, height, 0, glib)
+    ren = p.Renderer(scene, force_diffuse=force_diffuse, max_depth=max_depth, width=width, height=height, seed_offset=0, use_gradient=use_gradient)
     for k, v in (opts or {}).items():
         L.orc_set_option(orc.h, k.encode(), float(v))
         ren.set_option(k, v)

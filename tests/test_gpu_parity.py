@@ -28,6 +28,19 @@ def pair(L):
     ren.close()
 
 
+@pytest.fixture(scope="module")
+def pair_full(L):
+    """oracle + GPU on the shipped torus scene with its own materials (Phong, rough dielectric, bitmap texture), maxdepth 8"""
+    if not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    orc = _orc.Oracle(L, gc.TORUS, 0, 8, 160, 120, 0, gc.pathref())
+    ren = gc.pkg().Renderer(gc.TORUS, force_diffuse=0, max_depth=8, width=160, height=120, seed_offset=0)
+    orc.init(60000, 1024, 8)
+    yield orc, ren
+    orc.close()
+    ren.close()
+
+
 def test_native_library_is_loaded():
     p = gc.pkg()
     assert os.path.exists(p.LIB_PATH)
@@ -162,6 +175,52 @@ def test_chain_loop_parity(use_gradient):
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
+@pytest.mark.parametrize("use_gradient", [0, 1])
+def test_full_material_scene_chain_parity(use_gradient):
+    """The shipped torus scene as is (Phong floor with a bitmap texture, Phong metal, rough-dielectric glass, diffuse
+    donut; BASELINE.json configs[2] materials) at maxdepth 8: same checks as test_chain_loop_parity.  With gradients the
+    oracle evaluates them through the product's path program compiled for the host, so that this test isolates the
+    chain loop + BSDF code (the AD itself is checked against the reference's programs separately)."""
+    # one init stream per sample (init_threads == num_init): a Russian-roulette decision that flips on a last-bit difference
+    # of a glossy BSDF value (exp(-tan^2/alpha^2) with alpha = 0.04 amplifies rounding ~600x) then stays local to its sample
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=use_gradient, max_depth=8, force_diffuse=0, oracle_grad="product")
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
+    assert r["init_cl_match"] > 0.97
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == 256 * 40
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 3
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
+    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * max(so["gradCalls"], 100)
+    assert r["film_rel_l2"] < 0.15  # 256 chains x 40 steps: one diverged chain moves a few percent of the film energy
+    assert r["final_state_match"] > 0.95
+    assert r["nonfinite_gpu"] == 0
+    assert abs(r["energy_gpu"] - 1.0) < 1e-4
+
+
+def test_full_material_gradient_kernel_vs_reference_programs(pair_full):
+    """GPU path program with Phong / rough-dielectric slots against the reference's generated programs.  logLum must
+    agree everywhere (5e-3: 6-decimal constants in the generated code compound over up to 8 vertices).  The reference's
+    derivative programs are not the true gradient on glass paths (chad assigns instead of accumulating adjoints at
+    pass-through conditionals, see pathfunc.h FabsW); the product reproduces the dominant sites: >= 90 % of the states
+    must agree within 1e-2 relative L2."""
+    orc, ren = pair_full
+    inputs = gc.collect_grad_inputs(orc, 1024)
+    ok = tot = 0
+    p = gc.pkg()
+    sp = ren.scene_params()
+    for (c, l), (prim, vert) in sorted(inputs.items()):
+        ll, g = p.grad_batch(c, l, prim.T.copy(), sp, vert.T.copy())
+        for i in range(len(prim)):
+            r = orc.ref_eval(c, l, prim[i], vert[i])
+            if r is None or not np.isfinite(r[0]) or not np.isfinite(r[1]).all():
+                continue
+            assert abs(r[0] - ll[i]) < 5e-3
+            tot += 1
+            ok += np.linalg.norm(r[1] - g[:, i]) <= 1e-2 * max(np.linalg.norm(r[1]), 1e-2)
+    assert tot > 500 and ok >= 0.9 * tot, (ok, tot)
+
+
 def test_isotropic_small_step_only():
     """mala = false: plain Kelemen small steps (mutation_small.h) + large steps."""
     r = gc.run_pair(96, 72, 20000, 128, 4, 300, 30, use_gradient=0, mala=False)
@@ -225,8 +284,8 @@ def test_bad_inputs_fail_cleanly():
     p = gc.pkg()
     with pytest.raises(RuntimeError):
         p.Renderer(os.path.join(gc.ROOT, "scenes", "torus", "missing.xml"))
-    with pytest.raises(RuntimeError, match="force_diffuse|BSDF"):
-        p.Renderer(gc.TORUS, force_diffuse=0)  # shipped phong / roughdielectric materials: config 3, refused not mis-rendered
+    with pytest.raises(RuntimeError, match="maxdepth"):
+        p.Renderer(gc.TORUS, force_diffuse=1, max_depth=12)  # path storage is sized for maxdepth <= 8: refused, not truncated
     ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=32, height=24)
     with pytest.raises(RuntimeError, match="initialization failed"):
         ren.init_chains(100, 4096, 4, 10)  # fewer contributions than chains (mlt.h:101-105)

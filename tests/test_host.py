@@ -69,9 +69,11 @@ def test_scene_front_end(oracle):
     o.close()
     with pytest.raises(RuntimeError):
         _orc.Oracle(oracle, os.path.join(ROOT, "scenes", "torus", "nope.xml"))
-    # shipped materials (phong / roughdielectric) are config 3: the oracle says so instead of mis-rendering
-    with pytest.raises(RuntimeError, match="not restated"):
-        _orc.Oracle(oracle, gc.TORUS, 0, 6, 0, 0, 0, "")
+    # shipped materials (phong + bitmap texture, rough dielectric): loads and runs
+    f = _orc.Oracle(oracle, gc.TORUS, 0, 6, 64, 48, 0, "")
+    norm, nc = f.init(4000, 32, 4)
+    assert norm > 0 and nc > 32
+    f.close()
 
 
 def test_oracle_energy_and_determinism(oracle):
@@ -116,11 +118,7 @@ def test_oracle_scalar_path_matches_reference_forward_program(oracle, pathref_pa
 
 
 def _host_pathfunc():
-    so = os.path.join(ROOT, "tests", "helpers", "libpathfunc_host.so")
-    src = os.path.join(ROOT, "tests", "helpers", "pathfunc_host.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], cwd=ROOT)
-    return ctypes.CDLL(so)
+    return ctypes.CDLL(gc.host_pathfunc_lib())
 
 
 def test_product_path_program_matches_reference_programs(oracle, pathref_path):
@@ -146,6 +144,41 @@ def test_product_path_program_matches_reference_programs(oracle, pathref_path):
         assert np.linalg.norm(g - g2[:dim]) <= 1e-2 * max(np.linalg.norm(g), 1e-2)
         seen.add((c, l))
     assert {(3, 1), (4, 0), (4, 1), (5, 0)} <= seen
+    o.close()
+
+
+def test_full_material_identity_and_path_program(oracle, pathref_path):
+    """Shipped torus materials (Phong incl. the checker bitmap, rough dielectric), maxdepth 8:
+    (1) log(ssScore) of the oracle's scalar sampler == the reference's forward programs on the oracle's Serialize output
+        (3e-3: fastpow texture gamma, 6-decimal constants, up to 8 vertices);
+    (2) the product's path program == the reference's forward programs (2e-3) and >= 90 % of the gradients agree with the
+        reference's derivative programs within 1e-2 (the remainder: chad's adjoint-overwrite defect, pathfunc.h FabsW)."""
+    H = _host_pathfunc()
+    o = _orc.Oracle(oracle, gc.TORUS, 0, 8, 160, 120, 0, pathref_path)
+    o.init(60000, 768, 8)
+    s = o.summary(1)
+    sp = o.scene_params()
+    n = ok = 0
+    kinds = set()
+    for i in range(768):
+        c, l, prim, vert = o.serialize_init_state(i)
+        ll, g = o.ref_eval(c, l, prim, vert)
+        if not np.isfinite(ll) or not np.isfinite(g).all():
+            continue
+        if l == 0 and vert[3 + 59 * (c - 2) + 46 + 35] >= 256:  # wrapped env texel, see the identity test above
+            continue
+        assert abs(ll - np.log(s[i, 4])) < 3e-3, (i, c, l)
+        ll2 = np.zeros(1, np.float32)
+        g2 = np.zeros(16, np.float32)
+        H.lmc_test_pathfunc_host(c, l, P(prim), P(sp), P(vert), P(ll2), P(g2))
+        assert abs(ll - ll2[0]) < 2e-3
+        dim = 2 * (c + l - 1)
+        n += 1
+        ok += np.linalg.norm(g - g2[:dim]) <= 1e-2 * max(np.linalg.norm(g), 1e-2)
+        for k in range(c - 2):
+            kinds.add(int(vert[3 + 59 * k + 48]))
+    assert n > 400 and ok >= 0.9 * n, (ok, n)
+    assert kinds == {0, 1, 2}
     o.close()
 
 
