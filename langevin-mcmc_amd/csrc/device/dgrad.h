@@ -169,7 +169,7 @@ LMC_D void ComputeGradient(const DScene &S, const DPath &path, const Contrib &sp
     SerializePath(S, path, primary, o);
     StridedIn vin{gw.buf + gw.slot, gw.stride};
     float logLum;
-    PathFuncGrad(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, grad);
+    PathFuncGradUpTo12(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, grad);
     (void)sp;
 }
 

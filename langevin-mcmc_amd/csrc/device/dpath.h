@@ -158,7 +158,7 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
     V2 st{lgtVertex.st0, lgtVertex.st1};
     V3 bsdfContrib;
     float cosToCamera, bsdfPdf, bsdfRevPdf;
-    BsdfEvaluate(S, m, true, ps.wi, ps.isect.shadingNormal, dirToCamera, st, bsdfContrib, cosToCamera, bsdfPdf, bsdfRevPdf);
+    BsdfEvaluate<Stk::kGlossy>(S, m, true, ps.wi, ps.isect.shadingNormal, dirToCamera, st, bsdfContrib, cosToCamera, bsdfPdf, bsdfRevPdf);
     if (IsZero(bsdfContrib)) return false;
     const float factor = ShadingNormalCorrection<true>(ps.wi, ps.isect, dirToCamera);
     if (factor <= 0.0f) return false;
@@ -183,17 +183,17 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
 
 // path.cpp:747-900.  `in` and `out` may alias (the reference passes the same object in the camera loop);
 // every field of `in` is read before the aliased field of `out` is written.
-template <bool adjoint, bool perturb>
+template <bool adjoint, bool perturb, bool GLOSSY>
 LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib) {
     const DMaterial &m = MaterialOfTri(S, v.tri);
     V2 st{v.st0, v.st1};
     float cosWo, bsdfPdf, bsdfRevPdf;
-    v.useAbs = (BsdfRoughness(S, m, st, v.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : 0.0f;
+    v.useAbs = (BsdfRoughness<GLOSSY>(S, m, st, v.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : 0.0f;
     const V3 wi = in.wi;
     const float inSsJac = in.ssJacobian, inAccThis = in.accMISWThis, inAccPrev = in.accMISWPrev;
     const V3 inThr = in.throughput;
     if (!perturb || v.useAbs == 0.0f) {
-        if (!BsdfSample(S, m, adjoint, wi, in.isect.shadingNormal, st, V2{v.rnd0, v.rnd1}, v.bsdfDiscrete, dir, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf))
+        if (!BsdfSample<GLOSSY>(S, m, adjoint, wi, in.isect.shadingNormal, st, V2{v.rnd0, v.rnd1}, v.bsdfDiscrete, dir, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf))
             return false;
         if (v.useAbs == 1.0f) {
             float jacobian;
@@ -205,7 +205,7 @@ LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3
     } else {
         float jacobian;
         dir = SampleSphere(V2{v.rnd0, v.rnd1}, jacobian);
-        BsdfEvaluate(S, m, adjoint, wi, in.isect.shadingNormal, dir, st, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+        BsdfEvaluate<GLOSSY>(S, m, adjoint, wi, in.isect.shadingNormal, dir, st, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
         if (IsZero(bsdfContrib) || bsdfPdf <= 0.0f) return false;
         bsdfContrib = bsdfContrib * inverse(bsdfPdf);
         jacobian *= bsdfPdf;
@@ -260,7 +260,7 @@ LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 scree
     if (Occluded(S, ps.isect.position, dirToLight, dist, stk)) return false;
     V3 bsdfContrib;
     float cosToLight, bsdfPdf, bsdfRevPdf;
-    BsdfEvaluate(S, m, false, ps.wi, ps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, bsdfContrib, cosToLight, bsdfPdf, bsdfRevPdf);
+    BsdfEvaluate<Stk::kGlossy>(S, m, false, ps.wi, ps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, bsdfContrib, cosToLight, bsdfPdf, bsdfRevPdf);
     if (IsZero(bsdfContrib)) return false;
     const float factor = ShadingNormalCorrection<false>(ps.wi, ps.isect, dirToLight);
     if (factor <= 0.0f) return false;
@@ -290,7 +290,7 @@ LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS 
     if (Occluded(S, cps.isect.position, dirToLight, dist, stk)) return false;
     V3 camBsdfFactor;
     float cosCamera, camBsdfPdf, camBsdfRevPdf;
-    BsdfEvaluate(S, MaterialOfTri(S, camVertex.tri), false, cps.wi, cps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, camBsdfFactor,
+    BsdfEvaluate<Stk::kGlossy>(S, MaterialOfTri(S, camVertex.tri), false, cps.wi, cps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, camBsdfFactor,
                  cosCamera, camBsdfPdf, camBsdfRevPdf);
     if (IsZero(camBsdfFactor)) return false;
     float camFactor = ShadingNormalCorrection<false>(cps.wi, cps.isect, dirToLight);
@@ -298,7 +298,7 @@ LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS 
     camBsdfFactor = camBsdfFactor * camFactor;
     V3 lgtBsdfFactor;
     float cosLight, lgtBsdfPdf, lgtBsdfRevPdf;
-    BsdfEvaluate(S, MaterialOfTri(S, lgtVertex.tri), true, lps.wi, lps.isect.shadingNormal, -dirToLight, V2{lgtVertex.st0, lgtVertex.st1}, lgtBsdfFactor,
+    BsdfEvaluate<Stk::kGlossy>(S, MaterialOfTri(S, lgtVertex.tri), true, lps.wi, lps.isect.shadingNormal, -dirToLight, V2{lgtVertex.st0, lgtVertex.st1}, lgtBsdfFactor,
                  cosLight, lgtBsdfPdf, lgtBsdfRevPdf);
     if (IsZero(lgtBsdfFactor)) return false;
     float lgtFactor = ShadingNormalCorrection<true>(lps.wi, lps.isect, -dirToLight);
@@ -377,7 +377,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         V2 r = RndVec2(rng);
         sv.rnd0 = r.x, sv.rnd1 = r.y;
         V3 bsdfContrib;
-        if (!BSDFSampling<true, false>(S, lightStates[lgtDepth], sv, lightStates[lgtDepth + 1], dir, bsdfContrib)) {
+        if (!BSDFSampling<true, false, Stk::kGlossy>(S, lightStates[lgtDepth], sv, lightStates[lgtDepth + 1], dir, bsdfContrib)) {
             numLightStates--;
             break;
         }
@@ -438,7 +438,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         V2 r = RndVec2(rng);
         sv.rnd0 = r.x, sv.rnd1 = r.y;
         V3 bsdfContrib;
-        if (!BSDFSampling<false, false>(S, cps, sv, cps, dir, bsdfContrib)) break;
+        if (!BSDFSampling<false, false, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
         if (!RussianRoulette(camDepth, bsdfContrib, sv.rrWeight, cps.throughput, rng)) break;
         org = cps.isect.position;
         tnear = c_IsectEpsilon;
@@ -506,7 +506,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
             sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
             sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);
             V3 bsdfContrib;
-            if (!BSDFSampling<true, true>(S, lps, sv, lps, dir, bsdfContrib)) return false;
+            if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) return false;
             lps.throughput = lps.throughput * sv.rrWeight;
             org = lps.isect.position;
         }
@@ -545,7 +545,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
         sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);
         V3 bsdfContrib;
-        if (!BSDFSampling<false, true>(S, cps, sv, cps, dir, bsdfContrib)) return false;
+        if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) return false;
         cps.throughput = cps.throughput * sv.rrWeight;
         org = cps.isect.position;
         tnear = c_IsectEpsilon;

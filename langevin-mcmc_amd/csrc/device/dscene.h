@@ -96,6 +96,7 @@ struct DScene {
     const float *lightFunc, *lightCdf;
     float lightFuncInt, lightWeightSum;
     int numTris, numNodes, numMeshes, numLights, envLight;
+    int glossy;  // any non-Lambertian BSDF: selects the kernel instantiations that carry the Phong / rough-dielectric code
     DEnv env;
     DCamera cam;
     DOptions opt;
@@ -140,7 +141,12 @@ constexpr int BVH_LDS_STACK = 32;  // entries of the per-thread LDS stack (the h
 // Traversal stack policies.  Private arrays indexed at run time live in scratch memory, which on gfx950 is HBM-backed
 // and was the bottleneck of the first version of the step kernel (profiles/r01_a_*): the hot kernels keep the stack
 // in LDS instead, laid out [entry][thread] so that a wave's accesses are conflict-free.
-struct LocalStack {
+// Both policies also carry kGlossy: whether the scene has non-Lambertian BSDFs.  Every kernel is instantiated for both
+// values so that Lambertian-only scenes (BASELINE.json configs[1]) do not pay registers / code for Phong and the rough
+// dielectric.
+template <bool GLOSSY>
+struct LocalStackT {
+    static constexpr bool kGlossy = GLOSSY;
     int s[BVH_STACK];
     int sp = 0;
     LMC_D void Reset() { sp = 0; }
@@ -150,7 +156,9 @@ struct LocalStack {
     }
     LMC_D int Pop() { return s[--sp]; }
 };
-struct LdsStack {
+template <bool GLOSSY>
+struct LdsStackT {
+    static constexpr bool kGlossy = GLOSSY;
     int *base;   // &lds[threadIdx.x]
     int stride;  // blockDim.x
     int sp;

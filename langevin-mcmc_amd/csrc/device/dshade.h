@@ -96,8 +96,9 @@ LMC_D V3 EvalTex(const DScene &S, const DTexRef &t, V2 st) {
 }
 LMC_D V3 EvalKd(const DScene &S, const DMaterial &m, V2 st) { return EvalTex(S, m.Kd, st); }
 
+template <bool GLOSSY>
 LMC_D float BsdfRoughness(const DScene &S, const DMaterial &m, V2 st, float) {
-    if (m.type == BSDF_ROUGHDIELECTRIC) return EvalTex(S, m.expOrAlpha, st).x;  // roughdielectric.h:61-63
+    if (GLOSSY && m.type == BSDF_ROUGHDIELECTRIC) return EvalTex(S, m.expOrAlpha, st).x;  // roughdielectric.h:61-63
     return 1.0f;                                                                // lambertian.h, phong.cpp:155-157
 }
 
@@ -412,18 +413,20 @@ LMC_D bool RoughDielectricSample(const DScene &S, const DMaterial &m, bool adjoi
 }
 
 // BSDF::Evaluate / EvaluateAdjoint (bsdf.h:16-38): only the rough dielectric distinguishes the adjoint
+template <bool GLOSSY>
 LMC_D void BsdfEvaluate(const DScene &S, const DMaterial &m, bool adjoint, V3 wi, V3 normal, V3 wo, V2 st, V3 &contrib, float &cosWo, float &pdf,
                         float &revPdf) {
-    if (m.type == BSDF_LAMBERTIAN) LambertianEvaluate(S, m, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
+    if (!GLOSSY || m.type == BSDF_LAMBERTIAN) LambertianEvaluate(S, m, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
     else if (m.type == BSDF_PHONG)
         PhongEvaluate(S, m, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
     else
         RoughDielectricEvaluate(S, m, adjoint, wi, normal, wo, st, contrib, cosWo, pdf, revPdf);
 }
 // BSDF::Sample / SampleAdjoint (bsdf.h:40-72)
+template <bool GLOSSY>
 LMC_D bool BsdfSample(const DScene &S, const DMaterial &m, bool adjoint, V3 wi, V3 normal, V2 st, V2 rnd, float uDiscrete, V3 &wo, V3 &contrib,
                       float &cosWo, float &pdf, float &revPdf) {
-    if (m.type == BSDF_LAMBERTIAN) return LambertianSample(S, m, wi, normal, st, rnd, wo, contrib, cosWo, pdf, revPdf);
+    if (!GLOSSY || m.type == BSDF_LAMBERTIAN) return LambertianSample(S, m, wi, normal, st, rnd, wo, contrib, cosWo, pdf, revPdf);
     if (m.type == BSDF_PHONG) return PhongSample(S, m, wi, normal, st, rnd, wo, contrib, cosWo, pdf, revPdf);
     return RoughDielectricSample(S, m, adjoint, wi, normal, st, rnd, uDiscrete, wo, contrib, cosWo, pdf, revPdf);
 }

@@ -400,7 +400,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
                 ConvertMIS(S, lgtDepth, lgtLight, org, dir, lps);
                 if (lgtDepth == lgtCount - 1 && c == 1) {
-                    sv.useAbs = (BsdfRoughness(S, MaterialOfTri(S, sv.tri), V2{sv.st0, sv.st1}, sv.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : sv.useAbs;
+                    sv.useAbs = (BsdfRoughness<Stk::kGlossy>(S, MaterialOfTri(S, sv.tri), V2{sv.st0, sv.st1}, sv.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : sv.useAbs;
                     ok = ConnectToCamera(S, lgtDepth, lps, sv, pc, stk);
                     StoreVertex(prop, N, i, true, lgtDepth, sv);
                     done = true;
@@ -415,7 +415,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
                 L.Q(qn++) = sv.rnd0, L.Q(qn++) = sv.rnd1;
                 V3 bsdfContrib;
-                if (!BSDFSampling<true, true>(S, lps, sv, lps, dir, bsdfContrib)) {
+                if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) {
                     done = true;
                     break;
                 }
@@ -468,7 +468,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
                 L.Q(qn++) = sv.rnd0, L.Q(qn++) = sv.rnd1;
                 V3 bsdfContrib;
-                if (!BSDFSampling<false, true>(S, cps, sv, cps, dir, bsdfContrib)) break;
+                if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
                 StoreVertex(prop, N, i, false, camDepth, sv);
                 cps.throughput = cps.throughput * sv.rrWeight;
                 org = cps.isect.position;

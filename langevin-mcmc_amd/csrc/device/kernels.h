@@ -24,11 +24,11 @@ void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChains
 // one of the three step launches (device/step_*.hip): chains of `list` (count read on the device) run one mutation and
 // append themselves to the lists of the next step
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                         const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+                         const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                          const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, int gridBlocks, hipStream_t s);
+                          const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, hipStream_t s);
 // id-ordered work lists of the next step from A.nextKind (coalescing: a wave's 64 list entries are (nearly) consecutive chains)
 void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);

@@ -53,7 +53,7 @@ __global__ void k_trace(DScene S, int n, const float *rays, int *prim, float *t,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *r = rays + (size_t)i * 8;
         V3 org{r[0], r[1], r[2]}, dir{r[3], r[4], r[5]};
-        LocalStack stk;
+        LocalStackT<false> stk;
         if (anyHit) {
             prim[i] = BvhOccluded(S, org, dir, r[6], r[7], stk) ? 1 : 0;
         } else {
@@ -120,6 +120,7 @@ __global__ void k_grad_batch(int c, int l, int n, const float *primarySoA, const
 // ---------------------------------------------------------------------------------------------- MLT init
 // pass 1: one thread per virtual init thread (mlt.h:66-98 with NumSystemCores() := V): RNG(threadId + seedOffset),
 // samples drawn back to back; records the per-sample RNG checkpoint and the number of contributions.
+template <bool GLOSSY>
 __global__ void k_init_pass1(DScene S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
                              uint32_t *ckTicks, unsigned char *count) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,7 +133,7 @@ __global__ void k_init_pass1(DScene S, int V, long long perThread, long long ext
     long long base = (long long)t * perThread + (t < extra ? t : extra);
     const int minPathLength = max(S.opt.minDepth, 3);
     DPath path;
-    LocalStack stk;
+    LocalStackT<GLOSSY> stk;
     for (long long s = 0; s < n; s++) {
         ckState[base + s] = rng.state;
         ckTicks[base + s] = rng.ticks;
@@ -156,13 +157,14 @@ LMC_D void RngFromCheckpoint(Rng &rng, uint64_t seed, uint64_t state, uint32_t t
 }
 
 // pass 2: one grid-stride thread per sample; re-runs the sample from its checkpoint and writes (c,l,lsScore) compactly
+template <bool GLOSSY>
 __global__ void k_init_pass2(DScene S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
                              const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs) {
     int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nSlots) return;
     const int minPathLength = max(S.opt.minDepth, 3);
     DPath path;
-    LocalStack stk;
+    LocalStackT<GLOSSY> stk;
     for (long long g = slot; g < numSamples; g += nSlots) {
         Rng rng;
         rng.tab = tabScratch + (size_t)slot * 64;
@@ -180,6 +182,7 @@ __global__ void k_init_pass2(DScene S, long long numSamples, long long perThread
 }
 
 // regenerate the selected seed paths (mlt.h:121-148) into the init-state arrays (size = total number of chains)
+template <bool GLOSSY>
 __global__ void k_init_regen(DScene S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
                              uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath,
                              float *initContrib, float *initScoreSum) {
@@ -192,7 +195,7 @@ __global__ void k_init_regen(DScene S, int numChains, long long perThread, long 
     RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
     DPath path;
     ContribSink sink{contribScratch, (size_t)numChains, (size_t)i, 0};
-    LocalStack stk;
+    LocalStackT<GLOSSY> stk;
     GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, path, sink, rng, stk);
     float scoreSum = 0.f;
     Contrib sel;
@@ -355,17 +358,25 @@ void LaunchGradBatch(int c, int l, int n, const float *primarySoA, const float *
 }
 void LaunchInitPass1(const DScene &S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
                      uint32_t *ckTicks, unsigned char *count, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_pass1, dim3((V + 127) / 128), dim3(128), 0, s, S, V, perThread, extra, tabScratch, contribScratch, ckState, ckTicks, count);
+    if (S.glossy) hipLaunchKernelGGL(k_init_pass1<true>, dim3((V + 127) / 128), dim3(128), 0, s, S, V, perThread, extra, tabScratch, contribScratch, ckState, ckTicks, count);
+    else
+        hipLaunchKernelGGL(k_init_pass1<false>, dim3((V + 127) / 128), dim3(128), 0, s, S, V, perThread, extra, tabScratch, contribScratch, ckState, ckTicks, count);
 }
 void LaunchInitPass2(const DScene &S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
                      const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_pass2, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, numSamples, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
+    if (S.glossy) hipLaunchKernelGGL(k_init_pass2<true>, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, numSamples, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
+                       ckTicks, offset, outCL, outLs);
+    else
+        hipLaunchKernelGGL(k_init_pass2<false>, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, numSamples, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
                        ckTicks, offset, outCL, outLs);
 }
 void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
                      uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
                      float *initScoreSum, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_regen, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
+    if (S.glossy) hipLaunchKernelGGL(k_init_regen<true>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
+                       contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
+    else
+        hipLaunchKernelGGL(k_init_regen<false>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
                        contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
 }
 void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s) {

@@ -963,4 +963,16 @@ LMC_HD void PathFuncGrad(int c, int l, const float *primary, const float *scene,
     else PathFuncGradN<16>(c, l, primary, scene, vp, logLum, grad);
 }
 
+// The chain loop only differentiates states with dim <= PSS_MAX_LENGTH = 12 (mutation_mala.h:94-96): no Dual<16> copy of
+// the program in the step kernel, and one non-inlined copy per kernel instead of one per call site (compile time).
+#ifdef __HIPCC__
+template <class In>
+__device__ __noinline__ void PathFuncGradUpTo12(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    if (dim <= 8) PathFuncGradN<8>(c, l, primary, scene, vp, logLum, grad);
+    else
+        PathFuncGradN<12>(c, l, primary, scene, vp, logLum, grad);
+}
+#endif
+
 }  // namespace lmcd

@@ -38,7 +38,7 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
     }
 }
 
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD>
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY>
 __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
     StepStats st;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
         rng.ticks = 0;
         GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
         const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
-        LocalStack stk;
+        LocalStackT<GLOSSY> stk;
         StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
         // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
         bool toLarge = false, toGrad = false, toPlain = false;

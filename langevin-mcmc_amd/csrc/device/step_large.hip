@@ -4,6 +4,8 @@
 using namespace lmcd;
 
 void LaunchStepLarge(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                     const NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
-    hipLaunchKernelGGL((k_step<true, false, false>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+                     const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s) {
+    if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+    else
+        hipLaunchKernelGGL((k_step<true, false, false, false>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
 }

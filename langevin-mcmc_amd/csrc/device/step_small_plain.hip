@@ -6,7 +6,7 @@
 
 using namespace lmcd;
 
-template <bool USE_LDS_STACK>
+template <bool USE_LDS_STACK, bool GLOSSY>
 __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                     const int *listCount, NextLists next) {
     extern __shared__ float lds[];
@@ -21,10 +21,10 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
         rng.tab = A.rngTab + (size_t)i * 64;
         rng.ticks = 0;
         if (USE_LDS_STACK) {
-            LdsStack stk{reinterpret_cast<int *>(L.base), L.stride, 0};
+            LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
             SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
         } else {
-            LocalStack stk;
+            LocalStackT<GLOSSY> stk;
             SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
         }
         // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
@@ -46,10 +46,16 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
 }
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                          const NextLists &next, int bvhDepth, int gridBlocks, hipStream_t s) {
+                          const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, hipStream_t s) {
     const size_t ldsBytes = (size_t)256 * LDS_WORDS_PER_THREAD * sizeof(float);
-    if (bvhDepth <= BVH_LDS_STACK)
-        hipLaunchKernelGGL((k_step_small<true>), dim3(gridBlocks), dim3(256), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+    const bool lds = bvhDepth <= BVH_LDS_STACK;
+#define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(256), ldsBytes, s, S, cache, A, film, P, list, listCount, next)
+    if (lds && !glossy) LMC_LAUNCH_SMALL(true, false);
+    else if (lds && glossy)
+        LMC_LAUNCH_SMALL(true, true);
+    else if (!glossy)
+        LMC_LAUNCH_SMALL(false, false);
     else
-        hipLaunchKernelGGL((k_step_small<false>), dim3(gridBlocks), dim3(256), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+        LMC_LAUNCH_SMALL(false, true);
+#undef LMC_LAUNCH_SMALL
 }

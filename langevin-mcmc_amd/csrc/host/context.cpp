@@ -185,6 +185,7 @@ static void UploadScene(lmc_ctx *c) {
     lmc::LbvhResult bvh = lmc::BuildLbvh(tris);
     c->bvhDepth = bvh.depth;
     std::vector<DMaterial> mats;
+    int glossy = 0;
     for (const lmc::Material &m : sc.materials) {
         DMaterial d;
         memset(&d, 0, sizeof(d));
@@ -198,6 +199,7 @@ static void UploadScene(lmc_ctx *c) {
         d.Kd = tex(m.Kd), d.Ks = tex(m.Ks), d.Kt = tex(m.Kt), d.expOrAlpha = tex(m.expOrAlpha);
         d.eta = m.eta, d.invEta = m.invEta, d.KsWeight = m.KsWeight;
         if (m.type != lmc::BSDF_LAMBERTIAN && m.type != lmc::BSDF_PHONG && m.type != lmc::BSDF_ROUGHDIELECTRIC) throw std::runtime_error("unknown BSDF type");
+        if (m.type != lmc::BSDF_LAMBERTIAN) glossy = 1;
         mats.push_back(d);
     }
     std::vector<DBitmap> bitmaps;
@@ -228,6 +230,7 @@ static void UploadScene(lmc_ctx *c) {
     S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
     S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size();
     S.envLight = sc.envLight;
+    S.glossy = glossy;
     if (sc.envLight >= 0) {
         const lmc::Light &L = sc.lights[sc.envLight];
         c->envImage.Upload(L.image.data), c->envCdfRows.Upload(L.sampleInfo.cdfRows), c->envCdfCols.Upload(L.sampleInfo.cdfCols),
@@ -539,13 +542,13 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
         HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
         const int *cnt = c->listCounts[cur].p;
-        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, s);
         // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
         // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
         if (c->needGeneric)
-            LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, s);
+            LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, s);
         HIP_CHECK(hipEventRecord(ev.e[1], s));
-        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->stepGrid, s);
+        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->stepGrid, s);
         HIP_CHECK(hipEventRecord(ev.e[2], s));
         LaunchBuildLists(c->A, next, s);
         c->parity = nxt;
