@@ -70,6 +70,11 @@ int lmc_sync(lmc_ctx *ctx);
 /* indirect film buffer, W*H*3 floats, un-normalised like indirectBuffer (mlt.cpp:54) */
 int lmc_film_read(lmc_ctx *ctx, float *rgb);
 int lmc_film_clear(lmc_ctx *ctx);
+/* DirectLighting(scene, directBuffer) (direct.cpp:4-54): direct_spp samples per pixel of paths of length <= 2, tile RNG
+ * streams seeded tileIndex + seedOffset; un-normalised W*H*3 buffer like directBuffer (mlt.cpp:33-34).  The image the
+ * reference writes is direct / directSpp + indirect / spp (mlt.cpp:203-207). */
+int lmc_direct_lighting(lmc_ctx *ctx, int direct_spp);
+int lmc_direct_read(lmc_ctx *ctx, float *rgb);
 /* out[0..7] = steps, largeSteps, accepted, gradCalls, cacheQueries, cacheHits, resets, cacheReadyMask; *weight_sum =
  * sum over steps of the splatted weight (film luminance == normalization * weight_sum) */
 int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);

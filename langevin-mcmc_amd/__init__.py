@@ -58,6 +58,8 @@ def lib():
         L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.lmc_step_timing.argtypes = [vp, vp, vp]
         L.lmc_kernel_timing.argtypes = [vp, vp]
+        L.lmc_direct_lighting.argtypes = [vp, ctypes.c_int]
+        L.lmc_direct_read.argtypes = [vp, vp]
         L.lmc_stream_probe.argtypes = [c_ll, ctypes.c_int]
         L.lmc_grad_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
         L.lmc_trace.argtypes = [vp, ctypes.c_int, vp, vp, vp]
@@ -129,6 +131,15 @@ class Renderer:
         if lib().lmc_film_read(self.h, P(f)) != 0:
             raise RuntimeError(_err())
         return f
+
+    def direct_lighting(self, direct_spp):
+        """DirectLighting pre-pass (direct.cpp); returns the un-normalised direct buffer [H, W, 3]."""
+        if lib().lmc_direct_lighting(self.h, int(direct_spp)) != 0:
+            raise RuntimeError(_err())
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        if lib().lmc_direct_read(self.h, P(out)) != 0:
+            raise RuntimeError(_err())
+        return out
 
     def stats(self):
         s = (c_ll * 8)()

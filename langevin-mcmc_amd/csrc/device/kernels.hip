@@ -3,6 +3,7 @@
 // steps run in separate, divergence-free launches.  Launch glue is in host/context.cpp.
 #include "kernels.h"
 
+#include "ddirect.h"
 #include "dstep.h"
 
 namespace lmcd {
@@ -215,6 +216,25 @@ __global__ void k_init_regen(DScene S, int numChains, long long perThread, long 
     initScoreSum[i] = scoreSum;
 }
 
+// direct-lighting pre-pass (direct.cpp:4-54): one thread per 16x16 tile, RNG(tileIndex + seedOffset), pixels and samples
+// in the reference's order so that the stream is consumed identically
+template <bool GLOSSY>
+__global__ void k_direct(DScene S, Film film, int directSpp, int nXTiles, int nYTiles, uint32_t *tabScratch) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= nXTiles * nYTiles) return;
+    const int tx = tile % nXTiles, ty = tile / nXTiles;
+    Rng rng;
+    rng.tab = tabScratch + (size_t)tile * 64;
+    rng.state = PcgSeed((uint64_t)(tile + S.opt.seedOffset), rng.tab);
+    rng.ticks = 0;
+    const int x0 = tx * 16, x1 = min(x0 + 16, S.cam.width), y0 = ty * 16, y1 = min(y0 + 16, S.cam.height);
+    const int minDepth = min(S.opt.minDepth, 2), maxDepth = min(S.opt.maxDepth, 2);
+    LocalStackT<GLOSSY> stk;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++)
+            for (int s = 0; s < directSpp; s++) DirectSample(S, film, x, y, minDepth, maxDepth, rng, stk);
+}
+
 // chain set-up (mlt.cpp:60-90): current state = init state of the chain's GLOBAL id, everything else cleared
 __global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,6 +398,12 @@ void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long l
     else
         hipLaunchKernelGGL(k_init_regen<false>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
                        contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
+}
+void LaunchDirect(const DScene &S, const Film &film, int directSpp, uint32_t *tabScratch, hipStream_t s) {
+    const int nX = (S.cam.width + 15) / 16, nY = (S.cam.height + 15) / 16;
+    if (S.glossy) hipLaunchKernelGGL(k_direct<true>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, nX, nY, tabScratch);
+    else
+        hipLaunchKernelGGL(k_direct<false>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, nX, nY, tabScratch);
 }
 void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s) {
     hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, numChainsTotal, perChain, chainsNeedExtra);

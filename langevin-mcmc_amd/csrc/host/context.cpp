@@ -101,7 +101,7 @@ struct lmc_ctx {
     DScene S;
     int bvhDepth = 0;
     // film
-    DevBuf<float> film;
+    DevBuf<float> film, directFilm;
     // chains
     int N = 0, numChainsTotal = 0, chainBegin = 0;
     ChainArrays A;
@@ -604,6 +604,33 @@ int lmc_film_read(lmc_ctx *c, float *rgb) {
     LMC_TRY
     HIP_CHECK(hipStreamSynchronize(c->stream));
     HIP_CHECK(hipMemcpy(rgb, c->film.p, c->film.n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// DirectLighting(scene, directBuffer), direct.cpp:4-54 (skipped when mindepth > 2 or maxdepth < 1, :6-8)
+int lmc_direct_lighting(lmc_ctx *c, int directSpp) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    const int W = c->S.cam.width, H = c->S.cam.height;
+    c->directFilm.Alloc((size_t)W * H * 3);
+    if (c->S.opt.minDepth > 2 || c->S.opt.maxDepth < 1 || directSpp <= 0) return 0;
+    const int nTiles = ((W + 15) / 16) * ((H + 15) / 16);
+    DevBuf<uint32_t> tab;
+    tab.Alloc((size_t)nTiles * 64, false);
+    Film film{c->directFilm.p, W, H};
+    LaunchDirect(c->S, film, directSpp, tab.p, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipGetLastError());
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_direct_read(lmc_ctx *c, float *rgb) {
+    LMC_TRY
+    if (c->directFilm.n == 0) throw std::runtime_error("lmc_direct_read before lmc_direct_lighting");
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpy(rgb, c->directFilm.p, c->directFilm.n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
     LMC_CATCH(-1)
 }

@@ -100,6 +100,34 @@ int orc_step(void *h, int nsteps) {
     ORC_CATCH(-1)
 }
 
+// DirectLighting(scene, buffer), direct.cpp:4-54: 16x16 tiles, RNG(tileIndex + seedOffset), pixels row by row, directSpp
+// samples each; out = un-normalised W*H*3 buffer
+int orc_direct(void *h, int directSpp, float *out) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    const RScene *scene = m->scene.get();
+    const int W = scene->camera.pixelWidth, H = scene->camera.pixelHeight;
+    std::vector<Float> buf((size_t)W * H * 3, 0.f);
+    if (!(scene->options->minDepth > 2 || scene->options->maxDepth < 1)) {
+        const int tileSize = 16, nX = (W + tileSize - 1) / tileSize, nY = (H + tileSize - 1) / tileSize;
+        for (int ty = 0; ty < nY; ty++)
+            for (int tx = 0; tx < nX; tx++) {
+                RNG rng(ty * nX + tx + scene->options->seedOffset);
+                const int x0 = tx * tileSize, x1 = std::min(x0 + tileSize, W), y0 = ty * tileSize, y1 = std::min(y0 + tileSize, H);
+                for (int y = y0; y < y1; y++)
+                    for (int x = x0; x < x1; x++)
+                        for (int s = 0; s < directSpp; s++) {
+                            std::vector<SubpathContrib> sp;
+                            GeneratePathUni(scene, x, y, std::min(scene->options->minDepth, 2), std::min(scene->options->maxDepth, 2), sp, rng);
+                            for (const auto &c : sp) m->Splat(buf, c.screenPos, c.contrib);
+                        }
+            }
+    }
+    memcpy(out, buf.data(), buf.size() * sizeof(float));
+    return 0;
+    ORC_CATCH(-1)
+}
+
 void orc_film(void *h, float *out) {
     MLT *m = (MLT *)h;
     memcpy(out, m->film.data(), m->film.size() * sizeof(float));

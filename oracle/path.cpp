@@ -553,6 +553,106 @@ void GeneratePathBidir(const RScene *scene, const int sx, const int sy, const in
     }
 }
 
+// ---- unidirectional generator of the direct-lighting pre-pass: GeneratePath, path.cpp:406-527, with its own helpers
+// HandleHitLight :121-183, DirectLighting :195-294 (no shading-normal correction, power-heuristic MISWeight :23-27),
+// BSDFSampling :296-386 (perturb = false); the lens* / jacobian bookkeeping feeds nothing in this pass and is left out.
+static inline Float MISWeight(const Float pdfA, const Float pdfB) {
+    Float ratioSq = square(pdfB / pdfA);
+    return Float(1.0) / (Float(1.0) + ratioSq);
+}
+void GeneratePathUni(const RScene *scene, const int sx, const int sy, const int minDepth, const int maxDepth, std::vector<SubpathContrib> &contribs,
+                     RNG &rng) {
+    std::uniform_real_distribution<Float> uniDist(Float(0.0), Float(1.0));
+    Float time = uniDist(rng);
+    const RCamera *camera = &scene->camera;
+    // Vector2(f(u), g(u)): see RndVec2 for the evaluation order
+    Float first = uniDist(rng), second = uniDist(rng);
+#if ORC_ARGS_LEFT_TO_RIGHT
+    Vector2 screenPos((sx + first) / Float(camera->pixelWidth), (sy + second) / Float(camera->pixelHeight));
+#else
+    Vector2 screenPos((sx + second) / Float(camera->pixelWidth), (sy + first) / Float(camera->pixelHeight));
+#endif
+    RaySegment raySeg;
+    SamplePrimary(camera, screenPos, time, raySeg);
+    Vector3 throughput(Float(1.0), Float(1.0), Float(1.0));
+    Float lastBsdfPdf = Float(1.0);
+    Intersection isect;
+    for (int camDepth = 0;; camDepth++) {
+        SurfaceVertex surfVertex;
+        bool hitSurface = Intersect(scene, time, raySeg, surfVertex.shapeInst, isect);
+        const Light *light = GetHitLight(scene, hitSurface, surfVertex.shapeInst.obj);
+        if (light != nullptr && camDepth + 1 >= minDepth) {
+            LightPrimID lPrimID = 0;
+            Vector3 emission;
+            Float directPdf, emissionPdf;
+            light->Emission(scene->bSphere, raySeg.ray.dir, isect.shadingNormal, time, lPrimID, emission, directPdf, emissionPdf);
+            if (emission.sum() > Float(0.0)) {
+                if (hitSurface) {
+                    Float distSq = DistanceSquared(raySeg.ray.org, isect.position);
+                    Float cosTheta = -Dot(raySeg.ray.dir, isect.shadingNormal);
+                    directPdf *= (distSq / cosTheta);
+                }
+                Vector3 contrib = throughput.cwiseProduct(emission);
+                Float misWeight = Float(1.0);
+                if (camDepth > 0) {
+                    Float lightPickProb = PickLightProb(scene, light);
+                    misWeight = MISWeight(lastBsdfPdf, directPdf * lightPickProb);
+                    contrib *= misWeight;
+                }
+                const Float score = Luminance(contrib);
+                if (score > Float(0.0)) contribs.emplace_back(SubpathContrib{2 + camDepth, 0, screenPos, contrib, score, score, Float(0.0), misWeight});
+            }
+            return;
+        }
+        if (!hitSurface || (maxDepth != -1 && camDepth + 1 >= maxDepth)) break;
+        surfVertex.bsdfDiscrete = uniDist(rng);
+        const Vector3 wi = -raySeg.ray.dir;
+        const BSDF *bsdf = surfVertex.shapeInst.obj->bsdf;
+        if (camDepth + 2 >= minDepth) {
+            Float lightPickProb = Float(1.0);
+            {  // DirectLightingInit, path.cpp:184-193
+                const Light *dirLight = PickLight(scene, uniDist(rng), lightPickProb);
+                surfVertex.directLightRndParam = RndVec2(uniDist, rng);
+                surfVertex.directLightInst.light = dirLight;
+                surfVertex.directLightInst.lPrimID = dirLight->SampleDiscrete(uniDist(rng));
+            }
+            const Light *dl = surfVertex.directLightInst.light;
+            LightPrimID &lPrimID = surfVertex.directLightInst.lPrimID;
+            Vector3 dirToLight, lightContrib;
+            Float distToLight, cosAtLight, directPdf, emissionPdf;
+            if (dl->SampleDirect(scene->bSphere, isect.position, isect.shadingNormal, surfVertex.directLightRndParam, time, lPrimID, dirToLight,
+                                 distToLight, lightContrib, cosAtLight, directPdf, emissionPdf) &&
+                !Occluded(scene, time, Ray{isect.position, dirToLight}, distToLight)) {
+                Vector3 bsdfContrib;
+                Float cosWo, bsdfPdf, bsdfRevPdf;
+                bsdf->Evaluate(wi, isect.shadingNormal, dirToLight, surfVertex.shapeInst.st, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+                if (!bsdfContrib.isZero()) {
+                    Vector3 contrib = throughput.cwiseProduct(bsdfContrib);
+                    contrib = contrib.cwiseProduct(lightContrib) * inverse(lightPickProb);
+                    Float misWeight = Float(1.0);
+                    if (!dl->IsDelta()) {
+                        misWeight = MISWeight(directPdf * lightPickProb, bsdfPdf);
+                        contrib *= misWeight;
+                    }
+                    const Float score = Luminance(contrib);
+                    if (score > Float(0.0)) contribs.emplace_back(SubpathContrib{2 + camDepth, 1, screenPos, contrib, score, score, Float(0.0), misWeight});
+                }
+            }
+        }
+        surfVertex.bsdfRndParam = RndVec2(uniDist, rng);
+        Vector3 bsdfContrib;
+        Float cosWo, bsdfPdfRev;
+        if (!bsdf->Sample(wi, isect.shadingNormal, surfVertex.shapeInst.st, surfVertex.bsdfRndParam, surfVertex.bsdfDiscrete, raySeg.ray.dir, bsdfContrib,
+                          cosWo, lastBsdfPdf, bsdfPdfRev))
+            break;
+        throughput = throughput.cwiseProduct(bsdfContrib);
+        raySeg.ray.org = isect.position;
+        if (!RussianRoulette(camDepth, bsdfContrib, surfVertex.rrWeight, throughput, rng)) break;
+        raySeg.minT = c_IsectEpsilon;
+        raySeg.maxT = std::numeric_limits<Float>::infinity();
+    }
+}
+
 void ToSubpath(const int camDepth, const int lgtDepth, Path &path) {  // path.cpp:1660-1669
     path.camSurfaceVertex.resize(std::max(camDepth - 1, 0));
     path.lgtSurfaceVertex.resize(std::max(lgtDepth - 1, 0));

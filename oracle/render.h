@@ -196,6 +196,8 @@ struct SerializedSubpath {
 void Clear(Path &path);
 void GeneratePathBidir(const RScene *scene, const int screenPosiX, const int screenPosiY, const int minDepth, const int maxDepth,
                        Path &path, std::vector<SubpathContrib> &contribs, RNG &rng);
+void GeneratePathUni(const RScene *scene, const int screenPosiX, const int screenPosiY, const int minDepth, const int maxDepth,
+                     std::vector<SubpathContrib> &contribs, RNG &rng);
 void ToSubpath(const int camDepth, const int lightDepth, Path &path);
 void PerturbPathBidir(const RScene *scene, const std::vector<Float> &offset, Path &path, std::vector<SubpathContrib> &contribs,
                       RNG &rng);

@@ -22,6 +22,7 @@ def load(so):
     L.orc_setup_chains.argtypes = [vp, c_ll, c_ll]
     L.orc_step.argtypes = [vp, ctypes.c_int]
     L.orc_film.argtypes = [vp, vp]
+    L.orc_direct.argtypes = [vp, ctypes.c_int, vp]
     L.orc_stats.argtypes = [vp, vp]
     L.orc_info.argtypes = [vp, vp]
     L.orc_scene_params.argtypes = [vp, vp]
@@ -83,6 +84,12 @@ class Oracle:
     def film(self):
         f = np.zeros((self.height, self.width, 3), np.float32)
         self.L.orc_film(self.h, P(f))
+        return f
+
+    def direct(self, direct_spp):
+        f = np.zeros((self.height, self.width, 3), np.float32)
+        if self.L.orc_direct(self.h, int(direct_spp), P(f)) != 0:
+            raise RuntimeError("orc_direct failed")
         return f
 
     def stats(self):

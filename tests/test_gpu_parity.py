@@ -221,6 +221,21 @@ def test_full_material_gradient_kernel_vs_reference_programs(pair_full):
     assert tot > 500 and ok >= 0.9 * tot, (ok, tot)
 
 
+@pytest.mark.parametrize("force_diffuse", [1, 0])
+def test_direct_lighting_prepass_parity(L, force_diffuse):
+    """DirectLighting pre-pass (direct.cpp): identical tile RNG streams on both sides.  Per-pixel sums of up to 8 x 256
+    float splats in the same order: 1e-4 relative L2 (libm rounding), energy within 1e-5."""
+    orc = _orc.Oracle(L, gc.TORUS, force_diffuse, 8, 96, 64, 0, "")
+    ren = gc.pkg().Renderer(gc.TORUS, force_diffuse=force_diffuse, max_depth=8, width=96, height=64, seed_offset=0)
+    a, b = orc.direct(8), ren.direct_lighting(8)
+    orc.close()
+    ren.close()
+    la, lb = gc.lum(a.reshape(-1, 3)), gc.lum(b.reshape(-1, 3))
+    assert la.sum() > 0 and np.isfinite(b).all()
+    assert abs(la.sum() - lb.sum()) <= 1e-4 * la.sum()
+    assert np.linalg.norm(la - lb) <= (1e-4 if force_diffuse else 2e-2) * np.linalg.norm(la)
+
+
 def test_isotropic_small_step_only():
     """mala = false: plain Kelemen small steps (mutation_small.h) + large steps."""
     r = gc.run_pair(96, 72, 20000, 128, 4, 300, 30, use_gradient=0, mala=False)
