@@ -52,8 +52,18 @@ int lmc_info(lmc_ctx *ctx, int *out8);
 /* the 38-float scene block of the plugin ABI (scene.cpp:160-169) */
 int lmc_scene_params(lmc_ctx *ctx, float *out38);
 /* <dpt> float options by XML name: largestepprob, largestepscale, mala, uniformmixprob, mala-stepsize, mala-gn,
- * perturbstddev, mindepth (parsescene.cpp:538-585) */
+ * perturbstddev, mindepth (parsescene.cpp:538-585); plus one key the reference does not have: seedchains = 1 starts every
+ * chain in the state MLTInit resampled for it (the reference discards those, mlt.h:121, and begins with a forced large
+ * step): removes the start-up bias of the short chains a GPU runs */
 int lmc_set_option(lmc_ctx *ctx, const char *name, double value);
+/* <dpt> options as parsed: spp, numinitsamples, numchains, directspp, mindepth, maxdepth, largestepprob, largestepscale,
+ * mala, h2mc, seedoffset (dptoptions.h:7-34) */
+int lmc_get_option(lmc_ctx *ctx, const char *name, double *value);
+/* film "filename" of the scene (outputName); the reference appends "_timeuse_<seconds>s.exr" (mlt.cpp:208) */
+const char *lmc_output_name(lmc_ctx *ctx);
+/* image files through the library's own codecs: EXR / PNG in (rgb == NULL: size only), RGB half ZIP EXR out (image.cpp:44-62) */
+int lmc_image_read(const char *path, int *w, int *h, float *rgb);
+int lmc_image_write_exr(const char *path, const float *rgb, int w, int h);
 
 /* MLTInit (mlt.h:41-154) + chain set-up (mlt.cpp:60-90).  `init_threads` plays NumSystemCores(): init stream t is
  * seeded RNG(t + seedOffset) (mlt.h:67).  The chains [chain_begin, chain_end) of the n_chains_total chains live on
@@ -75,6 +85,12 @@ int lmc_film_clear(lmc_ctx *ctx);
  * reference writes is direct / directSpp + indirect / spp (mlt.cpp:203-207). */
 int lmc_direct_lighting(lmc_ctx *ctx, int direct_spp);
 int lmc_direct_read(lmc_ctx *ctx, float *rgb);
+/* same generator over the scene's full depth range (the reference's "mc" integrator sampler, pathtrace.cpp): an independent
+ * estimator used to cross-check the MLT image; result through lmc_direct_read */
+int lmc_path_trace(lmc_ctx *ctx, int spp);
+/* plain Monte Carlo over GeneratePathBidir samples (path length >= 3), radiance image through lmc_direct_read: a second
+ * cross-check estimator that isolates the bidirectional generator from the Markov chain */
+int lmc_bidir_mc(lmc_ctx *ctx, int spp);
 /* out[0..7] = steps, largeSteps, accepted, gradCalls, cacheQueries, cacheHits, resets, cacheReadyMask; *weight_sum =
  * sum over steps of the splatted weight (film luminance == normalization * weight_sum) */
 int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);

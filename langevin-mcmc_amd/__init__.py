@@ -58,8 +58,15 @@ def lib():
         L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.lmc_step_timing.argtypes = [vp, vp, vp]
         L.lmc_kernel_timing.argtypes = [vp, vp]
+        L.lmc_get_option.argtypes = [vp, ctypes.c_char_p, vp]
+        L.lmc_output_name.argtypes = [vp]
+        L.lmc_output_name.restype = ctypes.c_char_p
+        L.lmc_image_read.argtypes = [ctypes.c_char_p, vp, vp, vp]
+        L.lmc_image_write_exr.argtypes = [ctypes.c_char_p, vp, ctypes.c_int, ctypes.c_int]
         L.lmc_direct_lighting.argtypes = [vp, ctypes.c_int]
         L.lmc_direct_read.argtypes = [vp, vp]
+        L.lmc_path_trace.argtypes = [vp, ctypes.c_int]
+        L.lmc_bidir_mc.argtypes = [vp, ctypes.c_int]
         L.lmc_stream_probe.argtypes = [c_ll, ctypes.c_int]
         L.lmc_grad_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
         L.lmc_trace.argtypes = [vp, ctypes.c_int, vp, vp, vp]
@@ -100,6 +107,12 @@ class Renderer:
         if lib().lmc_set_option(self.h, name.encode(), float(value)) != 0:
             raise RuntimeError(_err())
 
+    def get_option(self, name):
+        v = ctypes.c_double()
+        if lib().lmc_get_option(self.h, name.encode(), ctypes.byref(v)) != 0:
+            raise RuntimeError(_err())
+        return v.value
+
     def scene_params(self):
         s = np.zeros(38, np.float32)
         lib().lmc_scene_params(self.h, P(s))
@@ -135,6 +148,24 @@ class Renderer:
     def direct_lighting(self, direct_spp):
         """DirectLighting pre-pass (direct.cpp); returns the un-normalised direct buffer [H, W, 3]."""
         if lib().lmc_direct_lighting(self.h, int(direct_spp)) != 0:
+            raise RuntimeError(_err())
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        if lib().lmc_direct_read(self.h, P(out)) != 0:
+            raise RuntimeError(_err())
+        return out
+
+    def path_trace(self, spp):
+        """Unidirectional path tracing with next-event estimation over the scene's full depth range (cross-check estimator)."""
+        if lib().lmc_path_trace(self.h, int(spp)) != 0:
+            raise RuntimeError(_err())
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        if lib().lmc_direct_read(self.h, P(out)) != 0:
+            raise RuntimeError(_err())
+        return out
+
+    def bidir_mc(self, spp):
+        """Plain Monte Carlo over bidirectional samples (path length >= 3): radiance image [H, W, 3]."""
+        if lib().lmc_bidir_mc(self.h, int(spp)) != 0:
             raise RuntimeError(_err())
         out = np.zeros((self.height, self.width, 3), np.float32)
         if lib().lmc_direct_read(self.h, P(out)) != 0:
@@ -188,6 +219,23 @@ class Renderer:
         if lib().lmc_occluded(self.h, len(rays), P(rays), P(occ)) != 0:
             raise RuntimeError(_err())
         return occ
+
+
+def read_image(path):
+    """EXR / PNG -> float32 [H, W, 3] through the library's own readers."""
+    w, h = ctypes.c_int(), ctypes.c_int()
+    if lib().lmc_image_read(path.encode(), ctypes.byref(w), ctypes.byref(h), None) != 0:
+        raise RuntimeError(_err())
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    if lib().lmc_image_read(path.encode(), None, None, P(out)) != 0:
+        raise RuntimeError(_err())
+    return out
+
+
+def write_exr(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    if lib().lmc_image_write_exr(path.encode(), P(rgb), rgb.shape[1], rgb.shape[0]) != 0:
+        raise RuntimeError(_err())
 
 
 def grad_batch(c, l, primary_soa, scene38, vert_soa, want_grad=True):

@@ -21,8 +21,11 @@ void LaunchInitRegen(const lmcd::DScene &S, int numChains, long long perThread, 
                      uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
                      float *initScoreSum, hipStream_t s);
 // direct.cpp:4-54; tabScratch: 64 words per 16x16 tile
-void LaunchDirect(const lmcd::DScene &S, const lmcd::Film &film, int directSpp, uint32_t *tabScratch, hipStream_t s);
-void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s);
+void LaunchDirect(const lmcd::DScene &S, const lmcd::Film &film, int directSpp, int minDepth, int maxDepth, uint32_t *tabScratch, hipStream_t s);
+void LaunchBidirMC(const lmcd::DScene &S, const lmcd::Film &film, int nThreads, int samplesPerThread, uint32_t *tabScratch, float *contribScratch, hipStream_t s);
+void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
+                       float normalization, hipStream_t s);
+void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::StepParams &P, hipStream_t s);
 // one of the three step launches (device/step_*.hip): chains of `list` (count read on the device) run one mutation and
 // append themselves to the lists of the next step
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,

@@ -219,7 +219,7 @@ __global__ void k_init_regen(DScene S, int numChains, long long perThread, long 
 // direct-lighting pre-pass (direct.cpp:4-54): one thread per 16x16 tile, RNG(tileIndex + seedOffset), pixels and samples
 // in the reference's order so that the stream is consumed identically
 template <bool GLOSSY>
-__global__ void k_direct(DScene S, Film film, int directSpp, int nXTiles, int nYTiles, uint32_t *tabScratch) {
+__global__ void k_direct(DScene S, Film film, int directSpp, int minDepth, int maxDepth, int nXTiles, int nYTiles, uint32_t *tabScratch) {
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= nXTiles * nYTiles) return;
     const int tx = tile % nXTiles, ty = tile / nXTiles;
@@ -228,15 +228,40 @@ __global__ void k_direct(DScene S, Film film, int directSpp, int nXTiles, int nY
     rng.state = PcgSeed((uint64_t)(tile + S.opt.seedOffset), rng.tab);
     rng.ticks = 0;
     const int x0 = tx * 16, x1 = min(x0 + 16, S.cam.width), y0 = ty * 16, y1 = min(y0 + 16, S.cam.height);
-    const int minDepth = min(S.opt.minDepth, 2), maxDepth = min(S.opt.maxDepth, 2);
     LocalStackT<GLOSSY> stk;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++)
             for (int s = 0; s < directSpp; s++) DirectSample(S, film, x, y, minDepth, maxDepth, rng, stk);
 }
 
+// cross-check estimator: plain Monte Carlo over GeneratePathBidir samples (uniform screen positions), every contribution
+// splatted unweighted; image = film * W * H / numSamples.  Isolates the bidirectional generator from the Markov chain.
+template <bool GLOSSY>
+__global__ void k_bidir_mc(DScene S, Film film, int nThreads, int samplesPerThread, uint32_t *tabScratch, float *contribScratch) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nThreads) return;
+    Rng rng;
+    rng.tab = tabScratch + (size_t)t * 64;
+    rng.state = PcgSeed((uint64_t)(t + S.opt.seedOffset), rng.tab);
+    rng.ticks = 0;
+    LocalStackT<GLOSSY> stk;
+    DPath path;
+    for (int s = 0; s < samplesPerThread; s++) {
+        ContribSink sink{contribScratch, (size_t)nThreads, (size_t)t, 0};
+        GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, path, sink, rng, stk);
+        for (int k = 0; k < sink.count; k++) {
+            Contrib c = sink.Get(k);
+            Splat(film, c.screenPos, c.contrib);
+        }
+    }
+}
+
 // chain set-up (mlt.cpp:60-90): current state = init state of the chain's GLOBAL id, everything else cleared
-__global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra) {
+// seedValid (not in the reference, which marks every init state invalid, mlt.h:121, so that each chain begins with an
+// unconditionally accepted large step): the chain starts in the state MLTInit resampled for it -- Veach's equal-spaced
+// seeding put to use -- with that state's own pending splat.  Removes the start-up bias of short chains.
+__global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
+                               float normalization) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.N) return;
     const int gid = chainBegin + i;
@@ -250,10 +275,43 @@ __global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal
     A.pathWeight[i] = 0.f;
     A.lastScoreSum[i] = 1.0f;
     A.lastScore[i] = 1.0f;
+    if (seedValid) {
+        const Contrib c = LoadContrib(A.initContrib, numChainsTotal, gid);
+        if (c.lsScore > 0.f) {
+            const V3 v = c.contrib * (normalization / c.lsScore);
+            float *sp = A.curSplat + i;
+            const size_t N = A.N;
+            sp[0] = c.screenPos.x, sp[N] = c.screenPos.y, sp[2 * N] = v.x, sp[3 * N] = v.y, sp[4 * N] = v.z;
+            A.curSplatCount[i] = 1;
+            A.lastScore[i] = c.lsScore;
+            A.lastScoreSum[i] = A.initScoreSum[gid];
+            A.flags[i] = F_VALID;
+        }
+    }
     A.adjacentReject[i] = 0;
     A.sampleIdx[i] = 0;
     A.numSamples[i] = (int)(perChain + (gid < chainsNeedExtra ? 1 : 0));
     A.pushDim[i] = 0;
+}
+
+// kind of the very first step (only needed when chains start valid: an invalid state always takes a large step)
+__global__ void k_first_kind(DScene S, const DCache *cache, ChainArrays A, StepParams P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.N) return;
+    Rng rng;
+    rng.state = A.rngState[i];
+    rng.tab = A.rngTab + (size_t)i * 64;
+    rng.ticks = 0;
+    unsigned char k = NEXT_DONE;
+    if (A.sampleIdx[i] < A.numSamples[i]) {
+        if (DecideKind(S, A, i, rng) == KIND_LARGE) k = NEXT_LARGE;
+        else {
+            const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
+            k = (S.opt.mala && NeedsGeneric(*cache, P, c, l)) ? NEXT_SMALL_GENERIC : NEXT_SMALL_PLAIN;
+        }
+    }
+    A.nextKind[i] = k;
+    A.rngState[i] = rng.state;
 }
 
 // Work lists of the next step.  Each block owns 1024 consecutive chains, reserves one contiguous range per list with a
@@ -399,14 +457,24 @@ void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long l
         hipLaunchKernelGGL(k_init_regen<false>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
                        contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
 }
-void LaunchDirect(const DScene &S, const Film &film, int directSpp, uint32_t *tabScratch, hipStream_t s) {
+void LaunchDirect(const DScene &S, const Film &film, int directSpp, int minDepth, int maxDepth, uint32_t *tabScratch, hipStream_t s) {
     const int nX = (S.cam.width + 15) / 16, nY = (S.cam.height + 15) / 16;
-    if (S.glossy) hipLaunchKernelGGL(k_direct<true>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, nX, nY, tabScratch);
+    if (S.glossy) hipLaunchKernelGGL(k_direct<true>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, minDepth, maxDepth, nX, nY, tabScratch);
     else
-        hipLaunchKernelGGL(k_direct<false>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, nX, nY, tabScratch);
+        hipLaunchKernelGGL(k_direct<false>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, minDepth, maxDepth, nX, nY, tabScratch);
 }
-void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, hipStream_t s) {
-    hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, numChainsTotal, perChain, chainsNeedExtra);
+void LaunchBidirMC(const DScene &S, const Film &film, int nThreads, int samplesPerThread, uint32_t *tabScratch, float *contribScratch, hipStream_t s) {
+    if (S.glossy) hipLaunchKernelGGL(k_bidir_mc<true>, dim3((nThreads + 127) / 128), dim3(128), 0, s, S, film, nThreads, samplesPerThread, tabScratch, contribScratch);
+    else
+        hipLaunchKernelGGL(k_bidir_mc<false>, dim3((nThreads + 127) / 128), dim3(128), 0, s, S, film, nThreads, samplesPerThread, tabScratch, contribScratch);
+}
+void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
+                       float normalization, hipStream_t s) {
+    hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, seedValid,
+                       normalization);
+}
+void LaunchFirstKind(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_first_kind, dim3((A.N + 255) / 256), dim3(256), 0, s, S, cache, A, P);
 }
 void LaunchCachePush(const ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s) {
     hipLaunchKernelGGL(k_cache_push, dim3(1), dim3(1024), 0, s, A, dim, pss, v1, v2, weight, count);

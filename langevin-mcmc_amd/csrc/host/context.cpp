@@ -123,6 +123,7 @@ struct lmc_ctx {
     DCache cacheHost;
     DevBuf<DCache> cacheDev;
     bool allCachesReady = false;
+    bool seedChains = false;  // lmc_set_option("seedchains", 1): start chains in their resampled init state (not in the reference)
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
     // init results
     float normalization = 0.f;
@@ -335,8 +336,51 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "mala-gn") o.malaGN = (float)v;
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
+    else if (n == "seedchains") c->seedChains = v != 0;
     else throw std::runtime_error("Unknown dpt option:" + n);
     SyncOptions(c);
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// <dpt> options as parsed (parsescene.cpp:535-590), by XML name
+int lmc_get_option(lmc_ctx *c, const char *name, double *v) {
+    LMC_TRY
+    const lmc::DptOptions &o = c->scene->options;
+    std::string n(name);
+    if (n == "spp") *v = o.spp;
+    else if (n == "numinitsamples") *v = o.numInitSamples;
+    else if (n == "numchains") *v = o.numChains;
+    else if (n == "directspp") *v = o.directSpp;
+    else if (n == "mindepth") *v = o.minDepth;
+    else if (n == "maxdepth") *v = o.maxDepth;
+    else if (n == "largestepprob") *v = o.largeStepProbability;
+    else if (n == "largestepscale") *v = o.largeStepProbScale;
+    else if (n == "mala") *v = o.mala ? 1 : 0;
+    else if (n == "h2mc") *v = o.h2mc ? 1 : 0;
+    else if (n == "seedoffset") *v = o.seedOffset;
+    else throw std::runtime_error("Unknown dpt option:" + n);
+    return 0;
+    LMC_CATCH(-1)
+}
+// film "filename" of the scene (parsescene.cpp: outputName), without extension handling: the caller appends
+// "_timeuse_<seconds>s.exr" like mlt.cpp:208
+const char *lmc_output_name(lmc_ctx *c) { return c->scene->outputName.c_str(); }
+
+// image files through the library's own readers / writer (host/imageio.cpp): EXR (NONE/ZIPS/ZIP, half or float) and PNG in,
+// RGB half ZIP EXR out like the reference's WriteImage.  rgb == NULL: only the size is returned.
+int lmc_image_read(const char *path, int *w, int *h, float *rgb) {
+    LMC_TRY
+    lmc::Image3f img = lmc::ReadImage(path);
+    if (w) *w = img.width;
+    if (h) *h = img.height;
+    if (rgb) memcpy(rgb, img.data.data(), img.data.size() * sizeof(float));
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_image_write_exr(const char *path, const float *rgb, int w, int h) {
+    LMC_TRY
+    lmc::WriteEXRHalf(path, rgb, w, h);
     return 0;
     LMC_CATCH(-1)
 }
@@ -448,7 +492,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p;
     LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
-    LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, s);
+    LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, c->seedChains ? 1 : 0, c->normalization, s);
     // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
     c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
     c->gradStride = c->stepGrid * 256;
@@ -472,7 +516,14 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
         c->listCounts[b].Alloc(4);
     }
     c->parity = 0;
-    LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
+    if (c->seedChains) {  // chains start valid: the first step's kind is drawn like any other (mlt.cpp:96-97)
+        StepParams P;
+        P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient;
+        LaunchFirstKind(c->S, c->cacheDev.p, c->A, P, s);
+        NextLists first{c->lists[0][0].p, c->lists[0][1].p, c->lists[0][2].p, c->listCounts[0].p};
+        LaunchBuildLists(c->A, first, s);
+    } else
+        LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
     HIP_CHECK(hipStreamSynchronize(s));
     return 0;
@@ -609,17 +660,48 @@ int lmc_film_read(lmc_ctx *c, float *rgb) {
 }
 
 // DirectLighting(scene, directBuffer), direct.cpp:4-54 (skipped when mindepth > 2 or maxdepth < 1, :6-8)
+static int PathTracePass(lmc_ctx *c, int spp, int minDepth, int maxDepth);
 int lmc_direct_lighting(lmc_ctx *c, int directSpp) {
+    if (c->S.opt.minDepth > 2 || c->S.opt.maxDepth < 1) directSpp = 0;
+    return PathTracePass(c, directSpp, std::min(c->S.opt.minDepth, 2), std::min(c->S.opt.maxDepth, 2));
+}
+// GeneratePath with the scene's own depth range: the reference's "mc" integrator kernel (pathtrace.cpp uses the same
+// generator); here a cross-check of the MLT result, not a product path
+int lmc_path_trace(lmc_ctx *c, int spp) { return PathTracePass(c, spp, c->S.opt.minDepth, c->S.opt.maxDepth); }
+// plain Monte Carlo over GeneratePathBidir samples (paths of length >= 3), `spp` samples per pixel on average; result
+// (already scaled to radiance) through lmc_direct_read.  Cross-check estimator for tests / DESIGN.md, not a product path.
+int lmc_bidir_mc(lmc_ctx *c, int spp) {
     LMC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     const int W = c->S.cam.width, H = c->S.cam.height;
     c->directFilm.Alloc((size_t)W * H * 3);
-    if (c->S.opt.minDepth > 2 || c->S.opt.maxDepth < 1 || directSpp <= 0) return 0;
+    const int nThreads = 65536;
+    const long long total = (long long)spp * W * H;
+    const int per = (int)((total + nThreads - 1) / nThreads);
+    DevBuf<uint32_t> tab;
+    DevBuf<float> contrib;
+    tab.Alloc((size_t)nThreads * 64, false), contrib.Alloc((size_t)nThreads * MAXCONTRIB * CONTRIB_WORDS, false);
+    Film film{c->directFilm.p, W, H};
+    LaunchBidirMC(c->S, film, nThreads, per, tab.p, contrib.p, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<float> h = c->directFilm.Download();
+    const float scale = (float)((double)W * H / ((double)per * nThreads));
+    for (auto &v : h) v *= scale;
+    HIP_CHECK(hipMemcpy(c->directFilm.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+    LMC_CATCH(-1)
+}
+static int PathTracePass(lmc_ctx *c, int directSpp, int minDepth, int maxDepth) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    const int W = c->S.cam.width, H = c->S.cam.height;
+    c->directFilm.Alloc((size_t)W * H * 3);
+    if (directSpp <= 0) return 0;
     const int nTiles = ((W + 15) / 16) * ((H + 15) / 16);
     DevBuf<uint32_t> tab;
     tab.Alloc((size_t)nTiles * 64, false);
     Film film{c->directFilm.p, W, H};
-    LaunchDirect(c->S, film, directSpp, tab.p, c->stream);
+    LaunchDirect(c->S, film, directSpp, minDepth, maxDepth, tab.p, c->stream);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     HIP_CHECK(hipGetLastError());
     return 0;

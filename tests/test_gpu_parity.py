@@ -236,6 +236,48 @@ def test_direct_lighting_prepass_parity(L, force_diffuse):
     assert np.linalg.norm(la - lb) <= (1e-4 if force_diffuse else 2e-2) * np.linalg.norm(la)
 
 
+def test_full_render_matches_reference_image():
+    """End to end against the reference authors' own render of the shipped scene file (tests/golden/torus_ref_images_256x192.npz =
+    scenes/torus/lmc_timeuse_44.689152s.exr, 245 spp, box-downsampled 4x): direct pre-pass / directSpp + chain loop / spp at
+    512x384, the scene's own materials, maxdepth 8, 2^16 chains x 480 steps, chains seeded from MLTInit (seedchains = 1).
+
+    How the bars were set (scripts/region_spread.py, 4 independent seed offsets spaced 2^20 apart -- offsets closer than the
+    number of streams reuse the same PCG streams and are NOT independent -- gpurun_out/region_spread.json):
+      * a first guess of "every probe region within 10 % in one run" FAILED (top face 1.148) and was not supportable: single
+        seeded runs scatter by up to +-24 % per glass region (left face 0.97 .. 1.24 over the 4 seeds);
+      * what the 4 runs do support, asserted here with margin: mean luminance 1.011 .. 1.013 (bar 3 %), floor region
+        1.002 .. 1.007 (bar 2 %), trimmed relative MSE 0.011 .. 0.014 (bar 0.02; the two reference renders differ by 0.005),
+        and the 4-seed AVERAGE of each glass region 1.02 .. 1.08 (bar 15 %).
+    With the reference's own start-up semantics (seedchains = 0) the same configuration is reproducibly 21-24 % too bright on
+    the left cube face (4/4 seeds, spread 1 %): chains this short have not reached stationarity.  That is documented in
+    DESIGN.md, not asserted."""
+    p = gc.pkg()
+    ref = np.load(os.path.join(gc.ROOT, "tests", "golden", "torus_ref_images_256x192.npz"))["lmc"]
+    lum = lambda x: x @ np.array([0.212671, 0.715160, 0.072169])
+    lr = lum(ref)
+    regions = {"left face": (100, 120, 60, 100), "front face": (175, 225, 62, 112), "torus": (140, 170, 65, 100), "top face": (110, 190, 22, 37)}
+    acc = {k: [] for k in regions}
+    for so in (0, 1 << 20, 2 << 20, 3 << 20):
+        ren = p.Renderer(gc.TORUS, width=512, height=384, seed_offset=so)
+        ren.set_option("seedchains", 1)
+        dspp, spp, chains = 64, 160, 1 << 16
+        direct = ren.direct_lighting(dspp)
+        per = spp * 512 * 384 // chains
+        ren.init_chains(32 * chains, chains, 65536, per, per % chains)
+        ren.step(per + 1)
+        img = direct / dspp + ren.film() / spp
+        ren.close()
+        lg = lum(img.reshape(192, 2, 256, 2, 3).mean(axis=(1, 3)))
+        assert abs(lg.mean() / lr.mean() - 1) < 0.03, so
+        assert abs(lg[75:125, 5:50].mean() / lr[75:125, 5:50].mean() - 1) < 0.02, so
+        err = np.sort(((lg - lr) ** 2 / (lr ** 2 + 1e-2)).ravel())
+        assert err[: int(0.995 * err.size)].mean() < 0.02, so
+        for k, (x0, x1, y0, y1) in regions.items():
+            acc[k].append(lg[y0:y1, x0:x1].mean() / lr[y0:y1, x0:x1].mean())
+    for k, v in acc.items():
+        assert abs(np.mean(v) - 1) < 0.15, (k, v)
+
+
 def test_isotropic_small_step_only():
     """mala = false: plain Kelemen small steps (mutation_small.h) + large steps."""
     r = gc.run_pair(96, 72, 20000, 128, 4, 300, 30, use_gradient=0, mala=False)
