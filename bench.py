@@ -112,6 +112,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    ren.set_option("timing", 1)  # per-step HIP events on the launch stream (lmc_step_timing / lmc_kernel_timing)
     ren.step(args.warmup)
     ren.step_timing()  # discard warm-up launches
     lean_before = ren.kernel_timing()[2]

@@ -46,6 +46,12 @@ struct DCacheDim {
 struct DCache {
     DCacheDim d[PSS_MAX_LENGTH + 1];
 };
+// Fill side of the cache: dims 6, 8, 10, 12 (MLT states have path length >= 3, mlt.h:76) <-> slot (dim - 6) / 2
+constexpr int CACHE_SLOTS = 4;
+struct CachePushTargets {
+    float *pss[CACHE_SLOTS], *v1[CACHE_SLOTS], *v2[CACHE_SLOTS], *weight[CACHE_SLOTS];  // PSS_MAX_SIZE rows each (nullptr: dim not in use)
+    int *count;                                                                           // [CACHE_SLOTS] rows filled
+};
 
 struct ChainArrays {
     int N;
@@ -280,7 +286,7 @@ LMC_D bool CacheQuery(const DCacheDim &C, int dim, const float *pss, float *v1, 
     int idx[5];
     float dist[5];
     const int nMatches = KdRadiusSearch(C, dim, pss, radius, 5, idx, dist);
-    if (!nMatches) return false;
+    if (nMatches <= 0) return false;  // 0 matches, or -1: tree deeper than the stack (refused on the host)
     double sum_w = 0;
     for (int i = 0; i < dim; i++) v1[i] = 0.f, v2[i] = 0.f;
     for (int k = 0; k < nMatches; k++) {

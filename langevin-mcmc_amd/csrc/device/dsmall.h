@@ -400,7 +400,6 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
                 ConvertMIS(S, lgtDepth, lgtLight, org, dir, lps);
                 if (lgtDepth == lgtCount - 1 && c == 1) {
-                    sv.useAbs = (BsdfRoughness<Stk::kGlossy>(S, MaterialOfTri(S, sv.tri), V2{sv.st0, sv.st1}, sv.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : sv.useAbs;
                     ok = ConnectToCamera(S, lgtDepth, lps, sv, pc, stk);
                     StoreVertex(prop, N, i, true, lgtDepth, sv);
                     done = true;

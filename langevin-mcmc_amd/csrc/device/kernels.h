@@ -37,4 +37,5 @@ void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, cons
 // id-ordered work lists of the next step from A.nextKind (coalescing: a wave's 64 list entries are (nearly) consecutive chains)
 void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
-void LaunchCachePush(const lmcd::ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s);
+// pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
+void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);

@@ -365,42 +365,104 @@ __global__ void k_init_lists(int n, int *large, int *counts) {
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n, counts[1] = 0, counts[2] = 0;
 }
 
-// applies the pending global-cache pushes of the step in chain order (one block per dim; deterministic)
-__global__ void k_cache_push(ChainArrays A, int dim, float *pss, float *v1, float *v2, float *weight, int *count) {
-    __shared__ int sBase;
-    __shared__ int sWave[16];
-    if (threadIdx.x == 0) sBase = *count;
+// Global-cache pushes of one step (mlt.cpp:120-127, global_cache.h:66-92), applied after the step in chain-id order
+// (the lock-step contract of DESIGN.md).  Three small launches replace the per-dim single-block scan of round 1:
+//   k_push_count   per 1024-chain tile, how many chains push to each dim (slot = (dim - 6) / 2; MLT states have L >= 3)
+//   k_push_scatter every tile ranks its pushes behind those of all lower tiles and copies them into the cache rows
+//   k_push_finish  adds the totals to the per-dim fill counts
+// Counts of the four slots travel packed 4 x 16 bit (a tile holds 1024 chains, so a field never overflows).
+LMC_D unsigned long long PushKey(int dim) { return (dim >= 6 && dim <= PSS_MAX_LENGTH && !(dim & 1)) ? 1ull << (16 * ((dim - 6) >> 1)) : 0ull; }
+
+__global__ void __launch_bounds__(256) k_push_count(ChainArrays A, unsigned long long *tileCounts) {
+    __shared__ unsigned long long sTotal;
+    if (threadIdx.x == 0) sTotal = 0;
     __syncthreads();
-    const int N = A.N;
-    for (int start = 0; start < N; start += blockDim.x) {
-        if (sBase >= PSS_MAX_SIZE) break;
-        const int i = start + threadIdx.x;
-        const int want = (i < N && A.pushDim[i] == dim) ? 1 : 0;
-        // block-wide exclusive scan of `want`
-        unsigned long long ballot = __ballot(want);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int inWave = __popcll(ballot & ((1ull << lane) - 1ull));
-        if (lane == 0) sWave[wave] = __popcll(ballot);
-        __syncthreads();
-        int before = 0, totalWant = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
-            if (w < wave) before += sWave[w];
-            totalWant += sWave[w];
-        }
-        const int slot = sBase + before + inWave;
-        if (want && slot < PSS_MAX_SIZE) {
-            for (int k = 0; k < dim; k++) {
-                pss[(size_t)slot * dim + k] = A.pushData[(size_t)k * N + i];
-                v1[(size_t)slot * dim + k] = A.pushData[(size_t)(MAXPSS + k) * N + i];
-                v2[(size_t)slot * dim + k] = A.pushData[(size_t)(2 * MAXPSS + k) * N + i];
-            }
-            weight[slot] = A.pushData[(size_t)(3 * MAXPSS) * N + i];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) sBase = min(sBase + totalWant, PSS_MAX_SIZE);
-        __syncthreads();
+    const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned long long mine = 0;
+    for (int j = 0; j < 4; j++)
+        if (first + j < A.N) mine += PushKey(A.pushDim[first + j]);
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sTotal, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tileCounts[blockIdx.x] = sTotal;
+}
+
+__global__ void __launch_bounds__(256) k_push_scatter(ChainArrays A, const unsigned long long *tileCounts, CachePushTargets T) {
+    __shared__ unsigned long long sWave[4];
+    if (tileCounts[blockIdx.x] == 0) return;  // nothing to push in this tile (the common case once the caches fill up)
+    // pushes of all lower tiles; a lower tile's field can exceed 16 bits only in the sum, so widen while adding
+    unsigned long long lo = 0, hi = 0;  // slots 0,1 (32 bit each) | slots 2,3
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) {
+        const unsigned long long v = tileCounts[b];
+        lo += (v & 0xffffull) | (((v >> 16) & 0xffffull) << 32);
+        hi += ((v >> 32) & 0xffffull) | (((v >> 48) & 0xffffull) << 32);
     }
-    if (threadIdx.x == 0) *count = sBase;
+    for (int off = 32; off > 0; off >>= 1) lo += __shfl_down(lo, off), hi += __shfl_down(hi, off);
+    __shared__ unsigned long long sLo, sHi;
+    if (threadIdx.x == 0) sLo = 0, sHi = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sLo, lo), atomicAdd(&sHi, hi);
+    const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
+    int dims[4] = {0, 0, 0, 0};
+    unsigned long long mine = 0;
+    for (int j = 0; j < 4; j++)
+        if (first + j < A.N) {
+            dims[j] = A.pushDim[first + j];
+            if (!PushKey(dims[j])) dims[j] = 0;
+            mine += PushKey(dims[j]);
+        }
+    unsigned long long incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int w = 0; w < wave; w++) before += sWave[w];
+    const unsigned long long excl = before + incl - mine;
+    const size_t N = A.N;
+    for (int j = 0; j < 4; j++) {
+        const int dim = dims[j];
+        if (!dim) continue;
+        const int slot = (dim - 6) >> 1;
+        const long long lower = slot == 0 ? (long long)(sLo & 0xffffffffull) : slot == 1 ? (long long)(sLo >> 32) : slot == 2 ? (long long)(sHi & 0xffffffffull) : (long long)(sHi >> 32);
+        int rank = (int)((excl >> (16 * slot)) & 0xffffull);
+        for (int jj = 0; jj < j; jj++) rank += dims[jj] == dim ? 1 : 0;
+        const long long row = (long long)T.count[slot] + lower + rank;
+        const int i = first + j;
+        if (row < PSS_MAX_SIZE) {
+            for (int k = 0; k < dim; k++) {
+                T.pss[slot][(size_t)row * dim + k] = A.pushData[(size_t)k * N + i];
+                T.v1[slot][(size_t)row * dim + k] = A.pushData[(size_t)(MAXPSS + k) * N + i];
+                T.v2[slot][(size_t)row * dim + k] = A.pushData[(size_t)(2 * MAXPSS + k) * N + i];
+            }
+            T.weight[slot][row] = A.pushData[(size_t)(3 * MAXPSS) * N + i];
+        }
+        A.pushDim[i] = 0;  // consumed: a chain that has run its last step must not be pushed again by the following steps
+    }
+}
+
+__global__ void __launch_bounds__(256) k_push_finish(const unsigned long long *tileCounts, int nTiles, CachePushTargets T) {
+    __shared__ unsigned long long sLo, sHi;
+    if (threadIdx.x == 0) sLo = 0, sHi = 0;
+    __syncthreads();
+    unsigned long long lo = 0, hi = 0;
+    for (int b = threadIdx.x; b < nTiles; b += 256) {
+        const unsigned long long v = tileCounts[b];
+        lo += (v & 0xffffull) | (((v >> 16) & 0xffffull) << 32);
+        hi += ((v >> 32) & 0xffffull) | (((v >> 48) & 0xffffull) << 32);
+    }
+    for (int off = 32; off > 0; off >>= 1) lo += __shfl_down(lo, off), hi += __shfl_down(hi, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sLo, lo), atomicAdd(&sHi, hi);
+    __syncthreads();
+    if (threadIdx.x < CACHE_SLOTS) {
+        const int slot = threadIdx.x;
+        const long long add = slot == 0 ? (long long)(sLo & 0xffffffffull) : slot == 1 ? (long long)(sLo >> 32) : slot == 2 ? (long long)(sHi & 0xffffffffull) : (long long)(sHi >> 32);
+        const long long n = (long long)T.count[slot] + add;
+        T.count[slot] = (int)(n < PSS_MAX_SIZE ? n : PSS_MAX_SIZE);
+    }
 }
 
 }  // namespace lmcd
@@ -476,8 +538,11 @@ void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal,
 void LaunchFirstKind(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, hipStream_t s) {
     hipLaunchKernelGGL(k_first_kind, dim3((A.N + 255) / 256), dim3(256), 0, s, S, cache, A, P);
 }
-void LaunchCachePush(const ChainArrays &A, int dim, float *pss, float *v1, float *v2, float *weight, int *count, hipStream_t s) {
-    hipLaunchKernelGGL(k_cache_push, dim3(1), dim3(1024), 0, s, A, dim, pss, v1, v2, weight, count);
+void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s) {
+    const int nTiles = (A.N + 1023) / 1024;
+    hipLaunchKernelGGL(k_push_count, dim3(nTiles), dim3(256), 0, s, A, tileCounts);
+    hipLaunchKernelGGL(k_push_scatter, dim3(nTiles), dim3(256), 0, s, A, tileCounts, T);
+    hipLaunchKernelGGL(k_push_finish, dim3(1), dim3(256), 0, s, tileCounts, nTiles, T);
 }
 
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {

@@ -74,7 +74,6 @@ void EnsureDevice(int device) {
 
 struct CacheDimHost {
     DevBuf<float> pss, v1, v2, weight, ptsLeaf;
-    DevBuf<int> count;
     DevBuf<KdNode> nodes;
     DevBuf<int> vind;
     bool ready = false;
@@ -122,6 +121,10 @@ struct lmc_ctx {
     CacheDimHost cacheDims[PSS_MAX_LENGTH + 1];
     DCache cacheHost;
     DevBuf<DCache> cacheDev;
+    DevBuf<int> cacheCounts;                 // rows filled per slot (dims 6, 8, 10, 12)
+    DevBuf<unsigned long long> pushTiles;    // scratch of the push launches: one word per 1024 chains
+    CachePushTargets pushT;
+    int *hostCounts = nullptr;               // pinned mirror of cacheCounts
     bool allCachesReady = false;
     bool seedChains = false;  // lmc_set_option("seedchains", 1): start chains in their resampled init state (not in the reference)
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
@@ -132,11 +135,16 @@ struct lmc_ctx {
     struct StepEvents {
         hipEvent_t e[4];  // step begin | large + generic launches done | lean small-step launch done | step end
     };
-    std::vector<StepEvents> events;
+    // Events are recorded only between lmc_set_option("timing", 1) and the lmc_step_timing call that reads them, and come
+    // from a pool that is reused: a render that never asks for timings (dpt_amd) creates none.
+    bool timing = false;
+    std::vector<StepEvents> events, eventPool;
     double smallMs = 0, largeMs = 0;  // accumulated by lmc_step_timing for lmc_kernel_timing
     ~lmc_ctx() {
-        for (auto &ev : events)
-            for (auto e : ev.e) (void)hipEventDestroy(e);
+        for (auto *v : {&events, &eventPool})
+            for (auto &ev : *v)
+                for (auto e : ev.e) (void)hipEventDestroy(e);
+        if (hostCounts) (void)hipHostFree(hostCounts);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -275,7 +283,8 @@ static void SyncOptions(lmc_ctx *c) {
 }
 
 static void UploadCacheStruct(lmc_ctx *c) {
-    c->cacheDev.Upload(&c->cacheHost, 1);
+    if (c->cacheDev.n != 1) c->cacheDev.Alloc(1);
+    HIP_CHECK(hipMemcpy(c->cacheDev.p, &c->cacheHost, sizeof(DCache), hipMemcpyHostToDevice));  // in place: the kernels keep the pointer
 }
 
 // ------------------------------------------------------------------------------------------------ ABI
@@ -337,6 +346,7 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
     else if (n == "seedchains") c->seedChains = v != 0;
+    else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else throw std::runtime_error("Unknown dpt option:" + n);
     SyncOptions(c);
     return 0;
@@ -504,8 +514,16 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
         cd.relevant = (d % 2 == 0) && d >= 2 * std::max(c->S.opt.minDepth, 3) && d <= 2 * c->S.opt.maxDepth;
         if (cd.relevant) {
             cd.pss.Alloc((size_t)PSS_MAX_SIZE * d), cd.v1.Alloc((size_t)PSS_MAX_SIZE * d), cd.v2.Alloc((size_t)PSS_MAX_SIZE * d);
-            cd.weight.Alloc(PSS_MAX_SIZE), cd.count.Alloc(1);
+            cd.weight.Alloc(PSS_MAX_SIZE);
         }
+    }
+    c->cacheCounts.Alloc(CACHE_SLOTS), c->pushTiles.Alloc((N + 1023) / 1024);
+    if (!c->hostCounts) HIP_CHECK(hipHostMalloc((void **)&c->hostCounts, CACHE_SLOTS * sizeof(int)));
+    memset(&c->pushT, 0, sizeof(c->pushT));
+    c->pushT.count = c->cacheCounts.p;
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) {
+        CacheDimHost &cd = c->cacheDims[6 + 2 * sl];
+        if (cd.relevant) c->pushT.pss[sl] = cd.pss.p, c->pushT.v1[sl] = cd.v1.p, c->pushT.v2[sl] = cd.v2.p, c->pushT.weight[sl] = cd.weight.p;
     }
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
     UploadCacheStruct(c);
@@ -536,15 +554,13 @@ int lmc_init_result(lmc_ctx *c, float *normalization, long long *numContribs) {
     return 0;
 }
 
+// After every step, until all caches in use are full: apply the step's pushes (three small launches for all dims), read the
+// four fill counts back and build the kd-tree of a dim that has just reached PSS_MAX_SIZE (global_cache.h:85-92), so
+// that the next step already queries it -- the lock-step contract the oracle implements too.
 static void MaintainCache(lmc_ctx *c) {
     hipStream_t s = c->stream;
     bool anyPending = false;
-    for (int d = 2; d <= PSS_MAX_LENGTH; d++) {
-        CacheDimHost &cd = c->cacheDims[d];
-        if (!cd.relevant || cd.ready) continue;
-        anyPending = true;
-        LaunchCachePush(c->A, d, cd.pss.p, cd.v1.p, cd.v2.p, cd.weight.p, cd.count.p, s);
-    }
+    for (int d = 6; d <= PSS_MAX_LENGTH; d += 2) anyPending = anyPending || (c->cacheDims[d].relevant && !c->cacheDims[d].ready);
     if (!anyPending) {
         c->allCachesReady = true;
         bool anyDeep = false;
@@ -552,27 +568,26 @@ static void MaintainCache(lmc_ctx *c) {
         c->needGeneric = anyDeep;
         return;
     }
+    LaunchCachePush(c->A, c->pushT, c->pushTiles.p, s);
+    HIP_CHECK(hipMemcpyAsync(c->hostCounts, c->cacheCounts.p, CACHE_SLOTS * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     bool changed = false;
-    for (int d = 2; d <= PSS_MAX_LENGTH; d++) {
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) {
+        const int d = 6 + 2 * sl;
         CacheDimHost &cd = c->cacheDims[d];
-        if (!cd.relevant || cd.ready) continue;
-        int cnt = 0;
-        HIP_CHECK(hipMemcpyAsync(&cnt, cd.count.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        if (cnt >= PSS_MAX_SIZE) {  // global_cache.h:85-92: build the kd-tree once full
-            std::vector<float> pts = cd.pss.Download();
-            lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
-            cd.nodes.Upload(t.nodes), cd.vind.Upload(t.vind);
-            std::vector<float> leafOrder((size_t)PSS_MAX_SIZE * d);
-            for (int i = 0; i < PSS_MAX_SIZE; i++) memcpy(&leafOrder[(size_t)i * d], &pts[(size_t)t.vind[i] * d], d * sizeof(float));
-            cd.ptsLeaf.Upload(leafOrder);
-            DCacheDim &D = c->cacheHost.d[d];
-            D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
-            D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
-            for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
-            cd.ready = true;
-            changed = true;
-        }
+        if (!cd.relevant || cd.ready || c->hostCounts[sl] < PSS_MAX_SIZE) continue;
+        std::vector<float> pts = cd.pss.Download();
+        lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
+        cd.nodes.Upload(t.nodes), cd.vind.Upload(t.vind);
+        std::vector<float> leafOrder((size_t)PSS_MAX_SIZE * d);
+        for (int i = 0; i < PSS_MAX_SIZE; i++) memcpy(&leafOrder[(size_t)i * d], &pts[(size_t)t.vind[i] * d], d * sizeof(float));
+        cd.ptsLeaf.Upload(leafOrder);
+        DCacheDim &D = c->cacheHost.d[d];
+        D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
+        D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
+        for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
+        cd.ready = true;
+        changed = true;
     }
     if (changed) UploadCacheStruct(c);
 }
@@ -587,8 +602,15 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
     P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient;
     for (int it = 0; it < nSteps; it++) {
         lmc_ctx::StepEvents ev;
-        for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
-        HIP_CHECK(hipEventRecord(ev.e[0], s));
+        if (c->timing) {
+            if (c->eventPool.empty()) {
+                for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
+            } else {
+                ev = c->eventPool.back();
+                c->eventPool.pop_back();
+            }
+            HIP_CHECK(hipEventRecord(ev.e[0], s));
+        }
         const int cur = c->parity, nxt = 1 - c->parity;
         NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
         HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
@@ -598,13 +620,15 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
         if (c->needGeneric)
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, s);
-        HIP_CHECK(hipEventRecord(ev.e[1], s));
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
         LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->stepGrid, s);
-        HIP_CHECK(hipEventRecord(ev.e[2], s));
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));
         LaunchBuildLists(c->A, next, s);
         c->parity = nxt;
-        HIP_CHECK(hipEventRecord(ev.e[3], s));
-        c->events.push_back(ev);
+        if (c->timing) {
+            HIP_CHECK(hipEventRecord(ev.e[3], s));
+            c->events.push_back(ev);
+        }
         if (!c->allCachesReady) MaintainCache(c);
     }
     HIP_CHECK(hipGetLastError());
@@ -633,7 +657,7 @@ int lmc_step_timing(lmc_ctx *c, double *kernelMs, long long *launches) {
         c->smallMs += t;
         HIP_CHECK(hipEventElapsedTime(&t, ev.e[0], ev.e[1]));
         c->largeMs += t;
-        for (auto e : ev.e) (void)hipEventDestroy(e);
+        c->eventPool.push_back(ev);
     }
     if (kernelMs) *kernelMs = ms;
     if (launches) *launches = (long long)c->events.size();

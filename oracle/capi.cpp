@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 
 #include "mlt.h"
@@ -360,6 +361,65 @@ double orc_bench_steps(void *h, int nsteps, int threads, long long *stepsDone) {
     }
     double sec = std::chrono::duration<double>(t1 - t0).count();
     long long done = m->stats.steps - before;
+    if (stepsDone) *stepsDone = done;
+    return done / sec;
+}
+
+// ---- The reference's own scheduling (mlt.cpp:60-196 over parallel.cpp:82-142): one chain per work item, each worker runs
+// its chain from the first to the last mutation; accepted large steps push to the global cache at once under the dim's
+// mutex (mlt.cpp:120-127), readers see is_ready without a lock (global_cache.h:66-68).  Not lock step, hence not
+// reproducible run to run -- exactly like the reference.  Used for (a) the CPU baseline of bench.py, (b) the CPU leg of
+// the equal-time RMSE, (c) the CPU run of the reference's shipped chain configuration (128 chains).
+// maxSeconds > 0: workers stop at the deadline (throughput measurement on a bounded sample).  Returns chain-steps/s.
+double orc_run_async(void *h, int threads, double maxSeconds, long long *stepsDone) {
+    MLT *m = (MLT *)h;
+    const int n = (int)m->chains.size();
+    threads = std::max(1, std::min(threads, std::max(1, n)));
+    const long long before = m->stats.steps;
+    std::vector<std::vector<Float>> films(threads);
+    std::vector<StepStats> st(threads);
+    std::mutex dimMutex[17];
+    std::atomic<int> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&, t]() {
+            films[t].assign(m->film.size(), 0.f);
+            std::vector<PendingPush> pushes;
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n) break;
+                ChainCtx &c = m->chains[i];
+                c.film = &films[t], c.st = &st[t];
+                while (c.sampleIdx < c.numSamplesThisChain) {
+                    m->StepChain(c, pushes);
+                    if (!pushes.empty()) {
+                        for (auto &p : pushes) {
+                            std::lock_guard<std::mutex> lock(dimMutex[p.dim]);
+                            m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
+                        }
+                        pushes.clear();
+                    }
+                    if (maxSeconds > 0 && (c.sampleIdx & 1023) == 0 &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > maxSeconds)
+                        break;
+                }
+                if (maxSeconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > maxSeconds) break;
+            }
+        });
+    for (auto &th : pool) th.join();
+    auto t1 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) {
+        if (films[t].size() == m->film.size())
+            for (size_t i = 0; i < m->film.size(); i++) m->film[i] += films[t][i];
+        m->stats.steps += st[t].steps, m->stats.largeSteps += st[t].largeSteps, m->stats.accepted += st[t].accepted;
+        m->stats.gradCalls += st[t].gradCalls, m->stats.cacheQueries += st[t].cacheQueries, m->stats.cacheHits += st[t].cacheHits;
+        m->stats.resets += st[t].resets;
+        m->stats.weightSum += st[t].weightSum;
+    }
+    for (auto &c : m->chains) c.film = &m->film, c.st = &m->stats;
+    const double sec = std::chrono::duration<double>(t1 - t0).count();
+    const long long done = m->stats.steps - before;
     if (stepsDone) *stepsDone = done;
     return done / sec;
 }

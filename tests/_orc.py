@@ -17,6 +17,8 @@ def load(so):
     L.orc_last_error.restype = ctypes.c_char_p
     L.orc_bench_steps.restype = ctypes.c_double
     L.orc_bench_steps.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    L.orc_run_async.restype = ctypes.c_double
+    L.orc_run_async.argtypes = [vp, ctypes.c_int, ctypes.c_double, vp]
     L.orc_destroy.argtypes = [vp]
     L.orc_init.argtypes = [vp, c_ll, ctypes.c_int, ctypes.c_int, vp, vp]
     L.orc_setup_chains.argtypes = [vp, c_ll, c_ll]
@@ -80,6 +82,12 @@ class Oracle:
     def step(self, n):
         if self.L.orc_step(self.h, n) != 0:
             raise RuntimeError(self.L.orc_last_error().decode())
+
+    def run_async(self, threads, max_seconds=0.0):
+        """the reference's scheduling: one chain per work item, immediate cache pushes; returns (chain-steps/s, steps done)"""
+        done = c_ll()
+        rate = self.L.orc_run_async(self.h, int(threads), float(max_seconds), ctypes.byref(done))
+        return rate, done.value
 
     def film(self):
         f = np.zeros((self.height, self.width, 3), np.float32)
