@@ -13,7 +13,8 @@ constexpr int SPLAT_WORDS = 5;
 
 // F_SEL: which of the two path buffers holds the chain's current path (the other receives the proposal; acceptance
 // flips the bit instead of copying the path)
-enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32 };
+// F_GSEL: the same for the two Gaussian buffers (the lean kernel streams the proposal's Gaussian into the other buffer)
+enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64 };
 enum : int { KIND_SMALL = 0, KIND_LARGE = 1 };
 enum : unsigned char { NEXT_DONE = 0, NEXT_LARGE = 1, NEXT_SMALL_GENERIC = 2, NEXT_SMALL_PLAIN = 3 };
 
@@ -24,7 +25,7 @@ constexpr float PCD_MIN = 0.01f, PCD_MAX = 100.f, MTM_MIN = -5.0f, MTM_MAX = 5.0
 constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
 constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
 
-constexpr int KD_LDS_DEPTH = 24;  // deepest tree the lean small-step kernel searches with its frames in LDS (dsmall.h)
+constexpr int KD_LDS_DEPTH = 22;  // deepest tree the lean small-step kernel searches with its frames in LDS (dsmall.h)
 constexpr int KD_STACK = 160;  // deepest kd-tree the in-kernel search accepts (the host refuses deeper ones)
 
 struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly like nanoflann's divideTree)
@@ -62,7 +63,8 @@ struct ChainArrays {
     float *curContrib; // CONTRIB_WORDS x N
     float *scoreSum;   // N
     int *flags;        // N
-    float *gaussian;   // GAUSS_WORDS x N
+    float *gaussian;   // GAUSS_WORDS x N: Gaussian buffer 0
+    float *gaussian1;  // GAUSS_WORDS x N: Gaussian buffer 1 (see F_GSEL)
     float *curSplat;   // MAXCONTRIB*SPLAT_WORDS x N
     int *curSplatCount;
     float *chV1, *chV2, *chCurrNewV2, *chPropNewV1, *chPropNewV2, *chPss, *chLastPss;  // MAXPSS x N each
@@ -116,6 +118,8 @@ LMC_D void StorePath(float *base, int N, int i, const DPath &p) {
 }
 LMC_D float *CurPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.pathBuf1 : A.curPath; }
 LMC_D float *PropPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.curPath : A.pathBuf1; }
+LMC_D float *CurGaussBuf(const ChainArrays &A, int flags) { return (flags & F_GSEL) ? A.gaussian1 : A.gaussian; }
+LMC_D float *PropGaussBuf(const ChainArrays &A, int flags) { return (flags & F_GSEL) ? A.gaussian : A.gaussian1; }
 LMC_D Contrib LoadContrib(const float *base, int N, int i) {
     Contrib c;
     c.camDepth = __float_as_int(base[0 * (size_t)N + i]);

@@ -139,25 +139,38 @@ LMC_HD V3 Refract(V3 wi, V3 n, float cosThetaT, float eta, float invEta) {
     return n * (Dot(wi, n) * eta_ + cosThetaT) - wi * eta_;
 }
 
+// Trigonometry out of line: the device libm's sinf / cosf carry a large-argument (Payne-Hanek) reduction path of ~150
+// instructions each; inlined at every sampling site they made up a fifth of the lean step kernel's code.  One copy per
+// kernel image, reached by a call, returns the same bits.
+#if defined(__HIPCC__)
+#define LMC_OUTLINE __host__ __device__ inline __attribute__((noinline))
+#else
+#define LMC_OUTLINE inline
+#endif
+LMC_OUTLINE float lsinf(float x) { return sinf(x); }
+LMC_OUTLINE float lcosf(float x) { return cosf(x); }
+LMC_OUTLINE float lacosf(float x) { return acosf(x); }
+LMC_OUTLINE float latan2f(float y, float x) { return atan2f(y, x); }
+
 // sampling.h
 LMC_HD V3 SampleSphere(V2 coord, float &jacobian) {
     const float scaledTheta = c_TWOPI * coord.x;
     const float scaledPhi = c_PI * coord.y;
-    const float sinPhi = sinf(scaledPhi), cosPhi = cosf(scaledPhi);
-    V3 dir{sinPhi * cosf(scaledTheta), sinPhi * sinf(scaledTheta), cosPhi};
+    const float sinPhi = lsinf(scaledPhi), cosPhi = lcosf(scaledPhi);
+    V3 dir{sinPhi * lcosf(scaledTheta), sinPhi * lsinf(scaledTheta), cosPhi};
     jacobian = fabsf(sinPhi) * c_TWOPI * c_PI;
     return dir;
 }
 LMC_HD float patan2(float y, float x) {
     if (y == 0.0f && x == 0.0f) return 0.0f;
-    float r = atan2f(y, x);
+    float r = latan2f(y, x);
     if (r < 0.0f) r += c_TWOPI;
     return r;
 }
 LMC_HD V2 ToSphericalCoord(V3 dir, float &jacobian) {
     float theta = patan2(dir.y, dir.x) * c_INVTWOPI;
-    float phi = acosf(dir.z);
-    jacobian = fabsf(sinf(phi)) * c_TWOPI * c_PI;
+    float phi = lacosf(dir.z);
+    jacobian = fabsf(lsinf(phi)) * c_TWOPI * c_PI;
     phi *= c_INVPI;
     return V2{theta, phi};
 }
@@ -173,12 +186,12 @@ LMC_HD V2 SampleConcentricDisc(V2 rnd) {
         r = r2;
         phi = c_PIOVERTWO - (r1 / r2) * c_PIOVERFOUR;
     }
-    return V2{r * cosf(phi), r * sinf(phi)};
+    return V2{r * lcosf(phi), r * lsinf(phi)};
 }
 LMC_HD V3 SampleCosHemisphere(V2 rnd) {
     float phi = c_TWOPI * rnd.x;
     float tmp = sqrtf(fmaxf(1.0f - rnd.y, 0.0f));
-    return V3{cosf(phi) * tmp, sinf(phi) * tmp, sqrtf(fmaxf(rnd.y, 0.0f))};
+    return V3{lcosf(phi) * tmp, lsinf(phi) * tmp, sqrtf(fmaxf(rnd.y, 0.0f))};
 }
 
 // 4x4 row-major helpers (transform.h:48-79)

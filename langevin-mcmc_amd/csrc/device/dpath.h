@@ -8,10 +8,15 @@
 
 namespace lmcd {
 
-constexpr int MAXD = 8;        // largest supported <dpt maxdepth> (shipped scenes use 8; PSS dims <= 16)
+constexpr int MAXD = 12;       // largest supported <dpt maxdepth> (shipped scenes use 8, BASELINE configs[2] 12; PSS dims <= 24)
 constexpr int MAXPSS = 2 * MAXD;
-// contributions one GeneratePathBidir call can emit: one per (c,l) with 3 <= c+l-1 <= maxDepth
-constexpr int MAXCONTRIB = 39;
+// contributions one GeneratePathBidir call can emit: one per (c,l) with 3 <= c+l-1 <= maxDepth, i.e. sum of (L + 1)
+constexpr int MAXCONTRIB = 85;
+LMC_HD int MaxContribs(int maxDepth) {
+    int n = 0;
+    for (int L = 3; L <= maxDepth; L++) n += L + 1;
+    return n > 0 ? n : 1;
+}
 
 struct DVertex {  // SurfaceVertex, path.h:24-32
     int tri;
@@ -141,9 +146,31 @@ LMC_D void ConvertMIS(const DScene &S, int depth, int light, V3 rayOrg, V3 rayDi
     ps.accMISWThis *= invCosTheta;
 }
 
+// How the three connection strategies below test visibility.  TraceOcclusion casts the shadow ray on the spot (the
+// reference's order).  DeferOcclusion only records it and answers "visible": the caller (the lean small-step kernel,
+// dsmall.h) then casts it from ONE place after the strategy has been evaluated and drops the contribution if the ray is
+// blocked -- the strategies draw no random numbers and have no other side effects, so the result is the same, and the
+// kernel carries one copy of the any-hit traversal instead of three.
+struct TraceOcclusion {
+    template <class Stk>
+    LMC_D bool Test(const DScene &S, V3 org, V3 dir, float dist, Stk &stk) {
+        return Occluded(S, org, dir, dist, stk);
+    }
+};
+struct DeferOcclusion {
+    V3 org, dir;
+    float dist;
+    bool pending = false;
+    template <class Stk>
+    LMC_D bool Test(const DScene &, V3 o, V3 d, float t, Stk &) {
+        org = o, dir = d, dist = t, pending = true;
+        return false;
+    }
+};
+
 // path.cpp:633-745; returns true and fills `out` when a contribution is produced
-template <class Stk>
-LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const DVertex &lgtVertex, Contrib &out, Stk &stk) {
+template <class Stk, class Occ>
+LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const DVertex &lgtVertex, Contrib &out, Stk &stk, Occ &occ) {
     V3 camOrg, camDir;
     SamplePrimary(S, V2{0.5f, 0.5f}, camOrg, camDir);
     V3 dirToCamera = camOrg - ps.isect.position;
@@ -153,7 +180,7 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
     const float distSq = LengthSquared(dirToCamera);
     const float dist = sqrtf(distSq);
     dirToCamera = dirToCamera * inverse(dist);
-    if (Occluded(S, ps.isect.position, dirToCamera, dist, stk)) return false;
+    if (occ.Test(S, ps.isect.position, dirToCamera, dist, stk)) return false;
     const DMaterial &m = MaterialOfTri(S, lgtVertex.tri);
     V2 st{lgtVertex.st0, lgtVertex.st1};
     V3 bsdfContrib;
@@ -248,8 +275,8 @@ LMC_D bool HandleHitLight(const DScene &S, int camDepth, int light, bool hitSurf
 }
 
 // path.cpp:969-1089 (doOcclusion = true, bidirMIS = true)
-template <class Stk>
-LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk) {
+template <class Stk, class Occ>
+LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk, Occ &occ) {
     const DMaterial &m = MaterialOfTri(S, camVertex.tri);
     const int light = camVertex.dirLight;
     V3 dirToLight, lightContrib;
@@ -257,7 +284,7 @@ LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 scree
     if (!LightSampleDirect(S, light, ps.isect.position, V2{camVertex.dirRnd0, camVertex.dirRnd1}, camVertex.dirPrim, dirToLight, dist, lightContrib,
                            cosAtLight, directPdf, emissionPdf))
         return false;
-    if (Occluded(S, ps.isect.position, dirToLight, dist, stk)) return false;
+    if (occ.Test(S, ps.isect.position, dirToLight, dist, stk)) return false;
     V3 bsdfContrib;
     float cosToLight, bsdfPdf, bsdfRevPdf;
     BsdfEvaluate<Stk::kGlossy>(S, m, false, ps.wi, ps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, bsdfContrib, cosToLight, bsdfPdf, bsdfRevPdf);
@@ -280,14 +307,14 @@ LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 scree
 }
 
 // path.cpp:1091-1235 (doOcclusion = true)
-template <class Stk>
+template <class Stk, class Occ>
 LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS &lps, const DVertex &lgtVertex, const BPS &cps,
-                         const DVertex &camVertex, V2 screenPos, Contrib &out, Stk &stk) {
+                         const DVertex &camVertex, V2 screenPos, Contrib &out, Stk &stk, Occ &occ) {
     V3 dirToLight = lps.isect.position - cps.isect.position;
     const float distSq = LengthSquared(dirToLight);
     const float dist = sqrtf(distSq);
     dirToLight = dirToLight * inverse(dist);
-    if (Occluded(S, cps.isect.position, dirToLight, dist, stk)) return false;
+    if (occ.Test(S, cps.isect.position, dirToLight, dist, stk)) return false;
     V3 camBsdfFactor;
     float cosCamera, camBsdfPdf, camBsdfRevPdf;
     BsdfEvaluate<Stk::kGlossy>(S, MaterialOfTri(S, camVertex.tri), false, cps.wi, cps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, camBsdfFactor,
@@ -340,6 +367,7 @@ LMC_D int HitLightOf(const DScene &S, bool hitSurface, int tri) {  // GetHitLigh
 // GeneratePathBidir, path.cpp:1237-1449 with screenPosi = (-1,-1)
 template <class Stk>
 LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath &path, ContribSink &sink, Rng &rng, Stk &stk) {
+    TraceOcclusion trace;
     path.camCount = path.lgtCount = 0;
     path.envPrim = -1;
     path.time = rng.Uniform();
@@ -369,7 +397,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         ConvertMIS(S, lgtDepth, path.lgtLight, org, dir, lightStates[lgtDepth]);
         if (lgtDepth + 2 >= minDepth) {
             Contrib c;
-            if (ConnectToCamera(S, lgtDepth, lightStates[lgtDepth], sv, c, stk)) sink.Push(c);
+            if (ConnectToCamera(S, lgtDepth, lightStates[lgtDepth], sv, c, stk, trace)) sink.Push(c);
         }
         if (maxDepth != -1 && lgtDepth + 2 >= maxDepth) break;
         if (lgtDepth + 1 >= MAXD) break;  // storage bound (never reached for maxDepth <= MAXD)
@@ -426,13 +454,13 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
             sv.dirRnd0 = r.x, sv.dirRnd1 = r.y;
             sv.dirPrim = LightSampleDiscrete(S, sv.dirLight, rng.Uniform());
             Contrib c;
-            if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk)) sink.Push(c);
+            if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk, trace)) sink.Push(c);
         }
         int maxLgtDepth = maxDepth == -1 ? (numLightStates - 1) : min(maxDepth - camDepth - 3, numLightStates - 1);
         for (int lgtDepth = 0; lgtDepth <= maxLgtDepth; lgtDepth++) {
             if (camDepth + lgtDepth + 3 >= minDepth) {
                 Contrib c;
-                if (ConnectVertex(S, camDepth, lgtDepth, lightStates[lgtDepth], path.lgt[lgtDepth], cps, sv, screenPos, c, stk)) sink.Push(c);
+                if (ConnectVertex(S, camDepth, lgtDepth, lightStates[lgtDepth], path.lgt[lgtDepth], cps, sv, screenPos, c, stk, trace)) sink.Push(c);
             }
         }
         V2 r = RndVec2(rng);
@@ -482,6 +510,7 @@ LMC_D int GetPathPss(const DPath &path, float *pss) {
 template <class Stk>
 LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, Contrib &out, Rng &rng, Stk &stk) {
     NormalDist normDist(0.0f, S.opt.discreteStdDev);
+    TraceOcclusion trace;
     int offsetId = 0;
     path.time = Modulo1(path.time + normDist(rng));
     BPS lps;
@@ -501,7 +530,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
             lps.wi = -dir;
             sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
             ConvertMIS(S, lgtDepth, path.lgtLight, org, dir, lps);
-            if (lgtDepth == path.lgtCount - 1 && path.camDepth == 1) return ConnectToCamera(S, lgtDepth, lps, sv, out, stk);
+            if (lgtDepth == path.lgtCount - 1 && path.camDepth == 1) return ConnectToCamera(S, lgtDepth, lps, sv, out, stk, trace);
             if (lgtDepth == path.lgtCount - 1) break;
             sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
             sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);
@@ -538,9 +567,9 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
                 const float directLightPickProb = PickLightProb(S, sv.dirLight);
                 sv.dirRnd0 = Modulo1(sv.dirRnd0 + offset[offsetId++]);
                 sv.dirRnd1 = Modulo1(sv.dirRnd1 + offset[offsetId++]);
-                return DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, out, stk);
+                return DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, out, stk, trace);
             }
-            return ConnectVertex(S, camDepth, path.lgtCount - 1, lps, path.lgt[path.lgtCount - 1], cps, sv, screenPos, out, stk);
+            return ConnectVertex(S, camDepth, path.lgtCount - 1, lps, path.lgt[path.lgtCount - 1], cps, sv, screenPos, out, stk, trace);
         }
         sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
         sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);

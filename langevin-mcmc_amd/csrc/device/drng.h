@@ -44,7 +44,14 @@ LMC_HD bool PcgExternalStep(uint32_t &randval, uint32_t i) {  // inside_out::ext
     randval = result;
     return result == 0u;
 }
-LMC_HD void PcgAdvanceTable(uint32_t *tab) {  // pcg_random.hpp:1439-1448
+// cold: runs once per 2^32 draws of a stream; kept out of line so that the ~40 inlined RNG call sites of a step kernel
+// do not each carry the 64-entry table walk
+#if defined(__HIPCC__)
+__host__ __device__ inline __attribute__((noinline))
+#else
+inline
+#endif
+void PcgAdvanceTable(uint32_t *tab) {  // pcg_random.hpp:1439-1448
     bool carry = false;
     for (uint32_t i = 0; i < 64; ++i) {
         uint32_t v = tab[i];

@@ -134,7 +134,7 @@ LMC_D float FresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta,
 }
 LMC_D V3 SampleMicronormal(V2 rndParam, float alpha, float &pdfW) {
     const float phiM = c_TWOPI * rndParam.y;
-    const float sinPhiM = sinf(phiM), cosPhiM = cosf(phiM);
+    const float sinPhiM = lsinf(phiM), cosPhiM = lcosf(phiM);
     const float alphaSqr = square(alpha);
     const float tanThetaMSqr = alphaSqr * (-logd(fmaxf(1.0f - rndParam.x, 1e-6f)));
     const float cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
@@ -251,7 +251,7 @@ LMC_D bool PhongSample(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V2
     const float cosAlpha = powd(rndParam.y, power);
     const float sinAlpha = sqrtf(1.0f - square(cosAlpha));
     const float phi = c_TWOPI * rndParam0;
-    const V3 localDir{sinAlpha * cosf(phi), sinAlpha * sinf(phi), cosAlpha};
+    const V3 localDir{sinAlpha * lcosf(phi), sinAlpha * lsinf(phi), cosAlpha};
     V3 b0, b1;
     CoordinateSystem(n, b0, b1);
     wo = localDir.x * b0 + localDir.y * b1 + localDir.z * n;
@@ -483,7 +483,7 @@ LMC_D void EnvSampleDirection(const DScene &S, V2 rnd, int &lPrimID, V3 &dirToLi
     V2 tent{Tent(u0), Tent(u1)};
     float phi = (((float)col + tent.x) + 0.5f) * E.pixelSize[0];
     float theta = (((float)row + tent.y) + 0.5f) * E.pixelSize[1];
-    float sinPhi = sinf(phi), cosPhi = cosf(phi), sinTheta = sinf(theta), cosTheta = cosf(theta);
+    float sinPhi = lsinf(phi), cosPhi = lcosf(phi), sinTheta = lsinf(theta), cosTheta = lcosf(theta);
     dirToLight = XformVector(E.toWorld, V3{sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta});
     float dx1 = tent.x, dx2 = 1.0f - tent.x, dy1 = tent.y, dy2 = 1.0f - tent.y;
     V3 value1 = EnvAtLinear(E, col, row) * dx2 * dy2 + EnvAtLinear(E, col + 1, row) * dx1 * dy2;
@@ -546,8 +546,8 @@ LMC_D void LightEmission(const DScene &S, int light, V3 dirToLight, V3 normalOnL
     if (L.type == LIGHT_ENV) {
         const DEnv &E = S.env;
         V3 d = XformVector(E.toLight, dirToLight);
-        float uvx = atan2f(d.x, -d.z) * c_INVTWOPI * (float)E.W - 0.5f;
-        float uvy = acosf(d.y) * c_INVPI * (float)E.H - 0.5f;
+        float uvx = latan2f(d.x, -d.z) * c_INVTWOPI * (float)E.W - 0.5f;
+        float uvy = lacosf(d.y) * c_INVPI * (float)E.H - 0.5f;
         int col = (int)floorf(uvx), row = (int)floorf(uvy);
         lPrimID = Moduloi(row, E.H) * E.W + Moduloi(col, E.W);
         float dx1 = uvx - col, dx2 = 1.0f - dx1, dy1 = uvy - row, dy2 = 1.0f - dy1;

@@ -1,12 +1,16 @@
 // The hot kernel body: one plain small step (isotropic SmallStep or MALASmallStep with the global cache ready or
-// not applicable) of one chain, written so that NOTHING lives in scratch memory:
+// not applicable) of one chain, written so that NOTHING lives in scratch memory and as little as possible in registers:
 //   * the path is streamed vertex by vertex from the chain's current SoA buffer in HBM into registers and the
 //     perturbed vertex is streamed out to the chain's other buffer (double buffering, one select bit per chain;
 //     acceptance flips the bit instead of copying) -- coalesced reads/writes of exactly the words the
 //     reference's PerturbPathBidir touches (path.cpp:1953-2160);
-//   * the proposal offsets sit in 16 registers consumed through a shifting queue (static indexing only);
-//   * everything indexed at run time (BVH stack, kd-tree search frames / per-dimension distances, the new
-//     primary-sample vector) lives in LDS, laid out [word][thread].
+//   * the Gaussians are streamed too: one dimension at a time from / to the chain's two Gaussian buffers (same select-bit
+//     scheme), so that neither the current nor the proposal Gaussian ever exists as a register array;
+//   * ONE closest-hit traversal site (light and camera sub-path share a loop) and ONE any-hit site (the connection
+//     strategies record their shadow ray, DeferOcclusion in dpath.h): the kernel's code is a fraction of the fully inlined
+//     form, which matters on a 64 KB instruction cache shared by two CUs;
+//   * everything indexed at run time (BVH stack, kd-tree search frames / per-dimension distances, the proposal offsets,
+//     the new primary-sample vector) lives in LDS, laid out [word][thread].
 // Same arithmetic, same RNG order as the generic StepChain (dstep.h), which remains the implementation for
 // large steps and for gradient-evaluating small steps and which the parity tests cross-check against this one.
 #pragma once
@@ -14,18 +18,28 @@
 
 namespace lmcd {
 
-// LDS words per thread: a union of the BVH stack (32) and the kd search state (16 per-dimension distances + KD_LDS_DEPTH
-// two-word frames), followed by the new pss vector (16): 80 words = 320 B per thread, 80 KB per 256-thread block, two
-// blocks (8 waves) per CU.
-constexpr int LDS_UNION_WORDS = 16 + 2 * KD_LDS_DEPTH;  // 64 >= BVH_LDS_STACK
-static_assert(LDS_UNION_WORDS >= BVH_LDS_STACK, "BVH stack must fit the union region");
-constexpr int LDS_WORDS_PER_THREAD = LDS_UNION_WORDS + MAXPSS;
+// Dimensions that can carry a non-isotropic Gaussian / a cache query (mutation_mala.h:94-96): states of dimension above
+// PSS_MAX_LENGTH always get IsotropicGaussian(malaStdDev), which needs no per-dimension storage at all.
+constexpr int MD = PSS_MAX_LENGTH;
+
+// LDS words per thread (80 = 320 B; 20 KB per wave, 8 waves per CU):
+//   [0, 56)   union of the BVH stack (32 entries) and the kd search state (MD per-dimension distances + KD_LDS_DEPTH
+//             two-word frames)
+//   [56, 68)  the proposal offsets of a state with dim <= MD; they must survive the kd search of the proposal state.
+//             A state with dim > MD (up to 2 * MAXD offsets) is never searched for: its offsets use [32, 56)
+//   [68, 80)  the new primary-sample vector (first MD entries; longer ones are never looked up)
+constexpr int LDS_KD_FRAMES = MD;
+constexpr int LDS_UNION_WORDS = LDS_KD_FRAMES + 2 * KD_LDS_DEPTH;  // 56
+static_assert(LDS_UNION_WORDS >= BVH_LDS_STACK + MAXPSS, "long offset vectors sit above the BVH stack inside the union region");
+constexpr int LDS_OFF_SHORT = LDS_UNION_WORDS, LDS_OFF_LONG = BVH_LDS_STACK;
+constexpr int LDS_Q_WORD = LDS_OFF_SHORT + MD;
+constexpr int LDS_WORDS_PER_THREAD = LDS_Q_WORD + MD;  // 80
 
 struct LdsView {
     float *base;  // &lds[threadIdx.x]
     int stride;   // blockDim.x
-    LMC_D float &U(int w) const { return base[w * stride]; }                          // union region
-    LMC_D float &Q(int k) const { return base[(LDS_UNION_WORDS + k) * stride]; }      // new pss
+    LMC_D float &U(int w) const { return base[w * stride]; }                // any word
+    LMC_D float &Q(int k) const { return base[(LDS_Q_WORD + k) * stride]; }  // new pss
 };
 
 // word offsets inside the SoA path record (DPath layout)
@@ -52,13 +66,20 @@ LMC_D void StoreVertex(float *buf, size_t N, int i, bool lgt, int d, const DVert
     p[10 * N] = v.dirRnd0, p[11 * N] = v.dirRnd1;
 }
 
-// The proposal offsets are consumed in PerturbPathBidir's order through a cursor over U[32,48): above the BVH stack,
-// inside the region the kd search later reuses for frames (the offsets are pulled into registers before that search).
-constexpr int LDS_OFFSET_WORD = BVH_LDS_STACK;
+// The proposal offsets are consumed in PerturbPathBidir's order through a cursor
 struct OffsetCursor {
     const LdsView &L;
-    int k = 0;
-    LMC_D float Pop() { return L.U(LDS_OFFSET_WORD + k++); }
+    int w;  // next word
+    LMC_D float Pop() { return L.U(w++); }
+};
+// the new primary-sample vector: only its first MD entries are ever looked up (cache query / reuse test)
+struct PssSink {
+    const LdsView &L;
+    int n = 0;
+    LMC_D void Push(float v) {
+        if (n < MD) L.Q(n) = v;
+        n++;
+    }
 };
 
 // kd-tree radius search with all run-time indexed state in LDS: the traversal of KdRadiusSearch (dchain.h), i.e.
@@ -70,11 +91,11 @@ struct OffsetCursor {
 //     registers.
 // Per lane the sequence of visited nodes, tested points and matches is unchanged.
 LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float radiusSq, int knn, int *idx, float *dist) {
-    // union layout: [0,16) dists, then KD_LDS_DEPTH x (node | phase << 30, mindistsq until phase 2 / saved dists[id] afterwards)
-    float q[MAXPSS];
+    // union layout: [0,MD) dists, then KD_LDS_DEPTH x (node | phase << 30, mindistsq until phase 2 / saved dists[id] afterwards)
+    float q[MD];
     float distsq = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPSS; i++) {
+    for (int i = 0; i < MD; i++) {
         q[i] = 0.f;
         if (i < dim) {
             q[i] = L.Q(i);
@@ -87,8 +108,8 @@ LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float
     }
     int sp = 0;
     int count = 0;
-    auto FN = [&](int lvl) -> float & { return L.U(16 + 2 * lvl); };
-    auto FM = [&](int lvl) -> float & { return L.U(16 + 2 * lvl + 1); };
+    auto FN = [&](int lvl) -> float & { return L.U(LDS_KD_FRAMES + 2 * lvl); };
+    auto FM = [&](int lvl) -> float & { return L.U(LDS_KD_FRAMES + 2 * lvl + 1); };
     FN(0) = __int_as_float(0), FM(0) = distsq;  // node 0, phase 0 (phase in the top 2 bits)
     sp = 1;
     for (;;) {
@@ -146,7 +167,7 @@ LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float
             const float2 *row = reinterpret_cast<const float2 *>(C.ptsLeaf + (size_t)i * dim);
             float d = 0.f;
 #pragma unroll
-            for (int k = 0; k < MAXPSS / 2; ++k)
+            for (int k = 0; k < MD / 2; ++k)
                 if (2 * k < dim) {
                     const float2 p = row[k];
                     const float diff0 = q[2 * k] - p.x;
@@ -166,108 +187,107 @@ LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float
     return count;
 }
 
-struct GaussR {  // Gaussian in registers: statically indexed arrays
-    float mean[MAXPSS], covL[MAXPSS], invCov[MAXPSS];
-    float logDet;
+// Where the moment vectors (v1, v2) behind a state's Gaussian come from (mutation_mala.h:131-164 and :224-257, cache /
+// isotropic branches; chains that would evaluate a gradient run the generic kernel instead).
+struct VSource {
+    int mode;  // 0: IsotropicGaussian(malaStdDev); 1: chain->v1 / v2 re-used; 2: inverse-distance blend of nMatches cache entries
+    int nMatches;
+    int idx[5];
+    float w[5];
+    double sum_w;
 };
+enum : int { VS_ISOTROPIC = 0, VS_REUSE = 1, VS_BLEND = 2 };
 
-// cache / isotropic branch of InitGaussianFor (mutation_mala.h:131-164 and :224-257) for a state whose pss is in L.Q;
-// never evaluates a gradient (chains that need one are dispatched to the gradient-capable launch).
-LMC_D void InitGaussianLean(const DScene &S, const DCache &cache, const ChainArrays &A, int i, int dim, float lsScore, float ssScore, int &flags,
-                            const LdsView &L, GaussR &g, StepStats &st) {
+// First half of InitGaussianFor for a state whose pss is in L.Q: bookkeeping writes, re-use test, cache query.
+LMC_D void PrepareGaussianLean(const DCache &cache, const ChainArrays &A, int i, int dim, float lsScore, int flags, const LdsView &L, VSource &vs,
+                               StepStats &st) {
     const size_t N = A.N;
-#pragma unroll
-    for (int k = 0; k < MAXPSS; k++)
-        if (k < dim) A.chPss[(size_t)k * N + i] = L.Q(k);
+    vs.mode = VS_ISOTROPIC;
+    vs.nMatches = 0;
+    vs.sum_w = 0;
     A.pathWeight[i] = lsScore;
-    const bool inRange = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH;
-    const bool ready = inRange && cache.d[dim].ready;
-    const float ss = S.opt.malaStepsize, shk = S.opt.malaStdDev;
-    bool fromV = false;
-    float v1[MAXPSS], v2[MAXPSS];
-    if (ready) {
-        bool reuse = false;
-        if (flags & F_QUERIED) {
-            float dist_sqr = 0.f;
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++)
-                if (k < dim) {
-                    float diff = L.Q(k) - A.chLastPss[(size_t)k * N + i];
-                    dist_sqr += diff * diff;
-                }
-            if (dist_sqr < dim * (PSS_REUSE_DIST * PSS_REUSE_DIST)) reuse = true;
+    if (dim > MD) return;  // PSS_MAX_LENGTH: no cache, chain->pss is never read for such a state
+#pragma unroll 1
+    for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = L.Q(k);  // GetPathPss(path, chain->pss)
+    if (dim < PSS_MIN_LENGTH || !cache.d[dim].ready) return;
+    if (flags & F_QUERIED) {
+        float dist_sqr = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < dim; k++) {
+            const float diff = L.Q(k) - A.chLastPss[(size_t)k * N + i];
+            dist_sqr += diff * diff;
         }
-        if (reuse) {
+        if (dist_sqr < dim * (PSS_REUSE_DIST * PSS_REUSE_DIST)) {
+            vs.mode = VS_REUSE;
+            return;
+        }
+    }
+    st.cacheQueries++;
+    float dist[5];
+    const int n = KdRadiusSearchLds(cache.d[dim], dim, L, dim * (PSS_QUERY_DIST * PSS_QUERY_DIST), 5, vs.idx, dist);
+    if (n > 0) {  // global_cache.h:106-123
+        st.cacheHits++;
+        vs.mode = VS_BLEND;
+        vs.nMatches = n;
 #pragma unroll
-            for (int k = 0; k < MAXPSS; k++)
-                if (k < dim) v1[k] = A.chV1[(size_t)k * N + i], v2[k] = A.chV2[(size_t)k * N + i];
-            fromV = true;
-        } else {
-            st.cacheQueries++;
-            const DCacheDim &C = cache.d[dim];
-            int idx[5];
-            float dist[5];
-            const int nMatches = KdRadiusSearchLds(C, dim, L, dim * (PSS_QUERY_DIST * PSS_QUERY_DIST), 5, idx, dist);
-            if (nMatches > 0) {  // global_cache.h:106-123
-                st.cacheHits++;
-                double sum_w = 0;
-#pragma unroll
-                for (int k = 0; k < MAXPSS; k++) v1[k] = 0.f, v2[k] = 0.f;
-#pragma unroll
-                for (int m = 0; m < 5; m++)
-                    if (m < nMatches) {
-                        const int index = idx[m];
-                        const float d = dist[m];
-                        const float w = inverse(d * d + 1e-6f);
-#pragma unroll
-                        for (int k = 0; k < MAXPSS; k++)
-                            if (k < dim) {
-                                v1[k] += C.v1[(size_t)index * dim + k] * w;
-                                v2[k] += C.v2[(size_t)index * dim + k] * w;
-                            }
-                        sum_w += w;
-                    }
-#pragma unroll
-                for (int k = 0; k < MAXPSS; k++) {
-                    if (k < dim) {
-                        v1[k] = (float)((double)v1[k] / sum_w);
-                        v2[k] = (float)((double)v2[k] / sum_w);
-                    }
-                    A.chV1[(size_t)k * N + i] = k < dim ? v1[k] : 0.f;
-                    A.chV2[(size_t)k * N + i] = k < dim ? v2[k] : 0.f;
-                    A.chLastPss[(size_t)k * N + i] = A.chPss[(size_t)k * N + i];  // last_pss = pss (whole vector)
-                }
-                flags |= F_QUERIED;
-                fromV = true;
+        for (int m = 0; m < 5; m++)
+            if (m < n) {
+                vs.w[m] = inverse(dist[m] * dist[m] + 1e-6f);
+                vs.sum_w += vs.w[m];
             }
-        }
     }
-    if (fromV) {  // M + ComputeGaussian, mala.cpp:7-52
-        g.logDet = 0.0f;
-        const float shrk = inverse(shk * shk);
-        if (ssScore <= 1e-10f) {
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++) g.mean[k] = 0.0f, g.invCov[k] = shrk, g.covL[k] = shk;
-            g.logDet = dim * fastlog(inverse(shk * shk));
-        } else {
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++)
-                if (k < dim) {
-                    const float M = Clampf(1.0f / (1e-3f + sqrtf(v2[k])), PCD_MIN, PCD_MAX);
-                    float cov_t = ss * ss * (M + 1.0f);
-                    float invcov = inverse(cov_t) + shrk;
-                    float cov = inverse(invcov);
-                    g.invCov[k] = invcov;
-                    g.covL[k] = sqrtf(cov);
-                    g.mean[k] = Clampf(v1[k], MTM_MIN, MTM_MAX) * cov / 2;
-                    g.logDet += fastlog(invcov);
-                }
-        }
-    } else {  // IsotropicGaussian, gaussian.cpp:4-22
-#pragma unroll
-        for (int k = 0; k < MAXPSS; k++) g.mean[k] = 0.0f, g.covL[k] = shk, g.invCov[k] = 1.0f / (shk * shk);
-        g.logDet = dim * fastlog(1.0f / (shk * shk));
+}
+
+// Second half, one dimension at a time: (v1[k], v2[k]) -> M -> ComputeGaussian (mala.cpp:7-52) or the isotropic values.
+// A blend also performs query()'s writes of chain->v1 / v2 and last_pss (global_cache.h:107-123, mutation_mala.h:147-151).
+struct GaussK {
+    float mean, covL, invCov;
+};
+LMC_D GaussK GaussianDim(const DScene &S, const DCacheDim &C, const ChainArrays &A, int i, int dim, int k, const VSource &vs, float ssScore, const LdsView &L,
+                         float &logDet) {
+    const size_t N = A.N;
+    const float ss = S.opt.malaStepsize, shk = S.opt.malaStdDev;
+    GaussK g;
+    if (vs.mode == VS_ISOTROPIC) {  // gaussian.cpp:4-22
+        g.mean = 0.0f, g.covL = shk, g.invCov = 1.0f / (shk * shk);
+        return g;
     }
+    float v1, v2;
+    if (vs.mode == VS_REUSE) {
+        v1 = A.chV1[(size_t)k * N + i], v2 = A.chV2[(size_t)k * N + i];
+    } else {
+        v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 5; m++)
+            if (m < vs.nMatches) {
+                v1 += C.v1[(size_t)vs.idx[m] * dim + k] * vs.w[m];
+                v2 += C.v2[(size_t)vs.idx[m] * dim + k] * vs.w[m];
+            }
+        v1 = (float)((double)v1 / vs.sum_w);
+        v2 = (float)((double)v2 / vs.sum_w);
+        A.chV1[(size_t)k * N + i] = v1, A.chV2[(size_t)k * N + i] = v2;
+        A.chLastPss[(size_t)k * N + i] = L.Q(k);  // last_pss = pss
+    }
+    const float shrk = inverse(shk * shk);
+    if (ssScore <= 1e-10f) {
+        g.mean = 0.0f, g.invCov = shrk, g.covL = shk;
+        return g;
+    }
+    const float M = Clampf(1.0f / (1e-3f + sqrtf(v2)), PCD_MIN, PCD_MAX);
+    const float cov_t = ss * ss * (M + 1.0f);
+    const float invcov = inverse(cov_t) + shrk;
+    const float cov = inverse(invcov);
+    g.invCov = invcov;
+    g.covL = sqrtf(cov);
+    g.mean = Clampf(v1, MTM_MIN, MTM_MAX) * cov / 2;
+    logDet += fastlog(invcov);
+    return g;
+}
+// logDet of the branches that do not accumulate it dimension by dimension
+LMC_D bool LogDetIsClosedForm(const VSource &vs, float ssScore) { return vs.mode == VS_ISOTROPIC || ssScore <= 1e-10f; }
+LMC_D float ClosedFormLogDet(const DScene &S, const VSource &vs, int dim) {
+    const float shk = S.opt.malaStdDev;
+    return vs.mode == VS_ISOTROPIC ? dim * fastlog(1.0f / (shk * shk)) : dim * fastlog(inverse(shk * shk));
 }
 
 // One plain small step of chain i.  Returns nothing; all state changes go to HBM.
@@ -284,18 +304,22 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     const float curLs = A.curContrib[7 * N + i], curSs = A.curContrib[8 * N + i];
     const int dim = PathDimension(c, l);
     const int camCount = max(c - 1, 0), lgtCount = max(l - 1, 0);
+    const bool shortState = dim <= MD;  // may carry a stored Gaussian / be looked up in the cache
+    const int offBase = shortState ? LDS_OFF_SHORT : LDS_OFF_LONG;
+    const DCacheDim &C = cache.d[shortState ? dim : 0];
     st.steps++;
     st.lean++;
 
     // ---- proposal offsets
     const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51
-    OffsetCursor off{L};
     float py = 0.f;
     if (!mala) {  // SmallStep::Mutate, mutation_small.h:29-37
         NormalDist nd(0.0f, S.opt.perturbStdDev);
-        for (int k = 0; k < dim; k++) L.U(LDS_OFFSET_WORD + k) = nd(rng);
+#pragma unroll 1
+        for (int k = 0; k < dim; k++) L.U(offBase + k) = nd(rng);
     } else {
         if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81
+#pragma unroll 1
             for (int k = 0; k < MAXPSS; k++) {
                 size_t o = (size_t)k * N + i;
                 A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
@@ -303,77 +327,96 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             flags |= F_BUFFERED;
             flags &= ~F_QUERIED;
         }
-        GaussR cg;
+        // currentState.gaussian: stored (F_GAUSS) or initialised now from the cache / isotropic (mutation_mala.h:83-166);
+        // GenerateSample (gaussian.cpp:38-55) and GaussianLogPdf(offset, currentState.gaussian) (gaussian.cpp:24-36) are
+        // fused into the same pass over the dimensions (the affine map draws nothing)
+        float *G = CurGaussBuf(A, flags);
+        const bool stored = (flags & F_GAUSS) && shortState;
+        VSource vs;
+        vs.mode = VS_ISOTROPIC;
+        float logDet = 0.f;
         if (!(flags & F_GAUSS)) {
             // GetPathPss(currentState.path) into LDS, path.cpp:2588-2632
-            int k = 0;
+            PssSink qs{L};
             if (l > 1) {
-                L.Q(k++) = cur[(size_t)PW_LGTPOS0 * N + i], L.Q(k++) = cur[(size_t)PW_LGTPOS1 * N + i];
-                L.Q(k++) = cur[(size_t)PW_LGTDIR0 * N + i], L.Q(k++) = cur[(size_t)PW_LGTDIR1 * N + i];
-                for (int d = 0; d < lgtCount - 1; d++)
-                    L.Q(k++) = cur[(size_t)VertWord(true, d, 3) * N + i], L.Q(k++) = cur[(size_t)VertWord(true, d, 4) * N + i];
+                qs.Push(cur[(size_t)PW_LGTPOS0 * N + i]), qs.Push(cur[(size_t)PW_LGTPOS1 * N + i]);
+                qs.Push(cur[(size_t)PW_LGTDIR0 * N + i]), qs.Push(cur[(size_t)PW_LGTDIR1 * N + i]);
+                for (int d = 0; d < lgtCount - 1; d++) qs.Push(cur[(size_t)VertWord(true, d, 3) * N + i]), qs.Push(cur[(size_t)VertWord(true, d, 4) * N + i]);
             }
             if (c > 1) {
-                L.Q(k++) = cur[(size_t)PW_SCREEN0 * N + i], L.Q(k++) = cur[(size_t)PW_SCREEN1 * N + i];
-                for (int d = 0; d < camCount - 1; d++)
-                    L.Q(k++) = cur[(size_t)VertWord(false, d, 3) * N + i], L.Q(k++) = cur[(size_t)VertWord(false, d, 4) * N + i];
-                if (l == 1) L.Q(k++) = cur[(size_t)VertWord(false, camCount - 1, 10) * N + i], L.Q(k++) = cur[(size_t)VertWord(false, camCount - 1, 11) * N + i];
+                qs.Push(cur[(size_t)PW_SCREEN0 * N + i]), qs.Push(cur[(size_t)PW_SCREEN1 * N + i]);
+                for (int d = 0; d < camCount - 1; d++) qs.Push(cur[(size_t)VertWord(false, d, 3) * N + i]), qs.Push(cur[(size_t)VertWord(false, d, 4) * N + i]);
+                if (l == 1) qs.Push(cur[(size_t)VertWord(false, camCount - 1, 10) * N + i]), qs.Push(cur[(size_t)VertWord(false, camCount - 1, 11) * N + i]);
             }
-            InitGaussianLean(S, cache, A, i, dim, curLs, curSs, flags, L, cg, st);
-#pragma unroll
-            for (int k2 = 0; k2 < MAXPSS; k2++)
-                if (k2 < dim) {
-                    A.gaussian[(size_t)k2 * N + i] = cg.mean[k2];
-                    A.gaussian[(size_t)(MAXPSS + k2) * N + i] = cg.covL[k2];
-                    A.gaussian[(size_t)(2 * MAXPSS + k2) * N + i] = cg.invCov[k2];
-                }
-            A.gaussian[(size_t)(3 * MAXPSS) * N + i] = cg.logDet;
+            PrepareGaussianLean(cache, A, i, dim, curLs, flags, L, vs, st);
+            if (vs.mode == VS_BLEND) flags |= F_QUERIED;
             flags |= F_GAUSS;
-        } else {
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++)
-                if (k < dim) {
-                    cg.mean[k] = A.gaussian[(size_t)k * N + i];
-                    cg.covL[k] = A.gaussian[(size_t)(MAXPSS + k) * N + i];
-                    cg.invCov[k] = A.gaussian[(size_t)(2 * MAXPSS + k) * N + i];
-                }
-            cg.logDet = A.gaussian[(size_t)(3 * MAXPSS) * N + i];
         }
-        NormalDist nd(0.0f, 1.0f);  // GenerateSample, gaussian.cpp:38-55 (the affine map draws nothing, so it is fused)
-        float q = 0.f;              // GaussianLogPdf(offset, currentState.gaussian), gaussian.cpp:24-36
-#pragma unroll
-        for (int k = 0; k < MAXPSS; k++)
-            if (k < dim) {
-                const float o = cg.covL[k] * nd(rng) + cg.mean[k];
-                L.U(LDS_OFFSET_WORD + k) = o;
-                const float d = o - cg.mean[k];
-                q += d * (cg.invCov[k] * d);
+        NormalDist nd(0.0f, 1.0f);
+        float q = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < dim; k++) {
+            GaussK g;
+            if (stored) {
+                g.mean = G[(size_t)k * N + i], g.covL = G[(size_t)(MAXPSS + k) * N + i], g.invCov = G[(size_t)(2 * MAXPSS + k) * N + i];
+            } else {
+                g = GaussianDim(S, C, A, i, dim, k, vs, curSs, L, logDet);
+                if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
             }
+            const float o = g.covL * nd(rng) + g.mean;
+            L.U(offBase + k) = o;
+            const float d = o - g.mean;
+            q += d * (g.invCov * d);
+        }
+        if (stored) {
+            logDet = G[(size_t)(3 * MAXPSS) * N + i];
+        } else {
+            if (LogDetIsClosedForm(vs, curSs)) logDet = ClosedFormLogDet(S, vs, dim);
+            if (shortState) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
+        }
         py = dim * (-0.9189385332046727f);
-        py += 0.5f * cg.logDet;
+        py += 0.5f * logDet;
         py -= 0.5f * q;
     }
 
-    // ---- PerturbPathBidir, path.cpp:1953-2160, streamed
+    // ---- PerturbPathBidir, path.cpp:1953-2160, streamed.  Light and camera sub-path share one loop so that the closest-hit
+    // traversal (and the hit reconstruction behind it) is instantiated once; the connection strategies defer their shadow ray
     Contrib pc;
     pc.camDepth = pc.lightDepth = 0;
     pc.lsScore = pc.ssScore = 0.f;
+    pc.screenPos = V2{0.f, 0.f};
+    pc.contrib = V3{0.f, 0.f, 0.f};
     bool ok = false;
-    int qn = 0;  // number of new pss values written to L.Q
+    DeferOcclusion occ;
     {
+        OffsetCursor off{L, offBase};
+        PssSink qs{L};
         NormalDist normDist(0.0f, S.opt.discreteStdDev);
         const float time = Modulo1(cur[(size_t)PW_TIME * N + i] + normDist(rng));
         prop[(size_t)PW_TIME * N + i] = time;
         prop[(size_t)PW_CAMDEPTH * N + i] = __int_as_float(c), prop[(size_t)PW_LGTDEPTH * N + i] = __int_as_float(l);
         prop[(size_t)PW_CAMCOUNT * N + i] = __int_as_float(camCount), prop[(size_t)PW_LGTCOUNT * N + i] = __int_as_float(lgtCount);
         int envPrim = (l == 0) ? __float_as_int(cur[(size_t)PW_ENVPRIM * N + i]) : -1;  // ToSubpath: -1 unless lgtDepth == 0
-        BPS lps;
+        BPS lps, cps;
         DVertex lastLgt;
         lastLgt.tri = -1;
         V3 org, dir;
-        bool done = false;  // a terminal strategy has been evaluated (or the path died)
+        float tnear = c_IsectEpsilon, tfar = INFINITY;
+        V2 screenPos{0.f, 0.f};
         int lgtLight = -1;
+        bool lightPhase = false;
+        auto BeginCamera = [&]() {  // EmitFromCamera with the perturbed screen position, path.cpp:2032-2038
+            const float screen0 = Modulo1(cur[(size_t)PW_SCREEN0 * N + i] + off.Pop());
+            const float screen1 = Modulo1(cur[(size_t)PW_SCREEN1 * N + i] + off.Pop());
+            prop[(size_t)PW_SCREEN0 * N + i] = screen0, prop[(size_t)PW_SCREEN1 * N + i] = screen1;
+            qs.Push(screen0), qs.Push(screen1);
+            screenPos = V2{screen0, screen1};
+            EmitFromCamera(S, screenPos, org, dir, cps);
+            tnear = PrimaryMinT(S, screenPos, tfar);
+            lightPhase = false;
+        };
         if (l > 1) {
+            lightPhase = true;
             lgtLight = __float_as_int(cur[(size_t)PW_LGTLIGHT * N + i]);
             const float lightPickProb = PickLightProb(S, lgtLight);
             DPath hd;  // only the emitter fields are used by EmitFromLight
@@ -383,119 +426,116 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             hd.lgtDir1 = Modulo1(cur[(size_t)PW_LGTDIR1 * N + i] + off.Pop());
             hd.lgtLight = lgtLight;
             hd.lgtPrim = __float_as_int(cur[(size_t)PW_LGTPRIM * N + i]);
-            L.Q(qn++) = hd.lgtPos0, L.Q(qn++) = hd.lgtPos1, L.Q(qn++) = hd.lgtDir0, L.Q(qn++) = hd.lgtDir1;
+            qs.Push(hd.lgtPos0), qs.Push(hd.lgtPos1), qs.Push(hd.lgtDir0), qs.Push(hd.lgtDir1);
             EmitFromLight(S, lightPickProb, hd, org, dir, lps);
             prop[(size_t)PW_LGTPOS0 * N + i] = hd.lgtPos0, prop[(size_t)PW_LGTPOS1 * N + i] = hd.lgtPos1;
             prop[(size_t)PW_LGTDIR0 * N + i] = hd.lgtDir0, prop[(size_t)PW_LGTDIR1 * N + i] = hd.lgtDir1;
             prop[(size_t)PW_LGTLIGHT * N + i] = __int_as_float(lgtLight), prop[(size_t)PW_LGTPRIM * N + i] = __int_as_float(hd.lgtPrim);
-            for (int lgtDepth = 0; lgtDepth < lgtCount && !done; lgtDepth++) {
-                DVertex sv = LoadVertex(cur, N, i, true, lgtDepth);
-                SurfHit hit;
-                if (!IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lps.isect, stk)) {
-                    done = true;
-                    break;
-                }
+        } else {
+            BeginCamera();
+        }
+        int depth = 0;  // vertex index inside the current sub-path
+        // every iteration = one path segment; `break` = the step's contribution is decided (ok) or the path died
+        while (lightPhase || depth < camCount) {
+            DVertex sv = LoadVertex(cur, N, i, lightPhase, depth);
+            SurfHit hit;
+            hit.tri = -1;
+            hit.st = V2{0.f, 0.f};
+            Isect isect;
+            isect.position = isect.shadingNormal = isect.geomNormal = V3{0.f, 0.f, 0.f};
+            const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk);
+            if (lightPhase) {
+                if (!hitSurface) break;
+                lps.isect = isect;
                 sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
                 lps.wi = -dir;
                 sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
-                ConvertMIS(S, lgtDepth, lgtLight, org, dir, lps);
-                if (lgtDepth == lgtCount - 1 && c == 1) {
-                    ok = ConnectToCamera(S, lgtDepth, lps, sv, pc, stk);
-                    StoreVertex(prop, N, i, true, lgtDepth, sv);
-                    done = true;
+                ConvertMIS(S, depth, lgtLight, org, dir, lps);
+                if (depth == lgtCount - 1 && c == 1) {
+                    ok = ConnectToCamera(S, depth, lps, sv, pc, stk, occ);
+                    StoreVertex(prop, N, i, true, depth, sv);
                     break;
                 }
-                if (lgtDepth == lgtCount - 1) {
-                    StoreVertex(prop, N, i, true, lgtDepth, sv);
+                if (depth == lgtCount - 1) {
+                    StoreVertex(prop, N, i, true, depth, sv);
                     lastLgt = sv;
-                    break;
+                    BeginCamera();
+                    depth = 0;
+                    continue;
                 }
                 sv.rnd0 = Modulo1(sv.rnd0 + off.Pop());
                 sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
-                L.Q(qn++) = sv.rnd0, L.Q(qn++) = sv.rnd1;
+                qs.Push(sv.rnd0), qs.Push(sv.rnd1);
                 V3 bsdfContrib;
-                if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) {
-                    done = true;
-                    break;
-                }
-                StoreVertex(prop, N, i, true, lgtDepth, sv);
+                if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) break;
+                StoreVertex(prop, N, i, true, depth, sv);
                 lps.throughput = lps.throughput * sv.rrWeight;
                 org = lps.isect.position;
+                depth++;
+                continue;
             }
-        }
-        if (!done) {
-            const float screen0 = Modulo1(cur[(size_t)PW_SCREEN0 * N + i] + off.Pop());
-            const float screen1 = Modulo1(cur[(size_t)PW_SCREEN1 * N + i] + off.Pop());
-            prop[(size_t)PW_SCREEN0 * N + i] = screen0, prop[(size_t)PW_SCREEN1 * N + i] = screen1;
-            L.Q(qn++) = screen0, L.Q(qn++) = screen1;
-            const V2 screenPos{screen0, screen1};
-            BPS cps;
-            EmitFromCamera(S, screenPos, org, dir, cps);
-            float tnear, tfar;
-            tnear = PrimaryMinT(S, screenPos, tfar);
-            for (int camDepth = 0; camDepth < camCount; camDepth++) {
-                DVertex sv = LoadVertex(cur, N, i, false, camDepth);
-                SurfHit hit;
-                hit.tri = -1;
-                hit.st = V2{0.f, 0.f};
-                const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect, stk);
-                sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
-                cps.wi = -dir;
-                if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
-                if (camDepth == camCount - 1 && l == 0) {
-                    const int light = HitLightOf(S, hitSurface, hit.tri);
-                    if (light >= 0) ok = HandleHitLight(S, camDepth, light, hitSurface, dir, screenPos, cps, envPrim, pc);
-                    StoreVertex(prop, N, i, false, camDepth, sv);
-                    break;
-                }
-                if (!hitSurface) break;
-                sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
-                if (camDepth == camCount - 1) {
-                    if (l == 1) {
-                        const float directLightPickProb = PickLightProb(S, sv.dirLight);
-                        sv.dirRnd0 = Modulo1(sv.dirRnd0 + off.Pop());
-                        sv.dirRnd1 = Modulo1(sv.dirRnd1 + off.Pop());
-                        L.Q(qn++) = sv.dirRnd0, L.Q(qn++) = sv.dirRnd1;
-                        ok = DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, pc, stk);
-                    } else {
-                        ok = ConnectVertex(S, camDepth, lgtCount - 1, lps, lastLgt, cps, sv, screenPos, pc, stk);
-                    }
-                    StoreVertex(prop, N, i, false, camDepth, sv);
-                    break;
-                }
-                sv.rnd0 = Modulo1(sv.rnd0 + off.Pop());
-                sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
-                L.Q(qn++) = sv.rnd0, L.Q(qn++) = sv.rnd1;
-                V3 bsdfContrib;
-                if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
-                StoreVertex(prop, N, i, false, camDepth, sv);
-                cps.throughput = cps.throughput * sv.rrWeight;
-                org = cps.isect.position;
-                tnear = c_IsectEpsilon;
-                tfar = INFINITY;
+            if (hitSurface) cps.isect = isect;
+            sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
+            cps.wi = -dir;
+            if (hitSurface) ConvertMIS(S, depth, -1, org, dir, cps);
+            if (depth == camCount - 1 && l == 0) {
+                const int light = HitLightOf(S, hitSurface, hit.tri);
+                if (light >= 0) ok = HandleHitLight(S, depth, light, hitSurface, dir, screenPos, cps, envPrim, pc);
+                StoreVertex(prop, N, i, false, depth, sv);
+                break;
             }
+            if (!hitSurface) break;
+            sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
+            if (depth == camCount - 1) {
+                if (l == 1) {
+                    const float directLightPickProb = PickLightProb(S, sv.dirLight);
+                    sv.dirRnd0 = Modulo1(sv.dirRnd0 + off.Pop());
+                    sv.dirRnd1 = Modulo1(sv.dirRnd1 + off.Pop());
+                    qs.Push(sv.dirRnd0), qs.Push(sv.dirRnd1);
+                    ok = DirectLighting(S, depth, cps, screenPos, directLightPickProb, sv, pc, stk, occ);
+                } else {
+                    ok = ConnectVertex(S, depth, lgtCount - 1, lps, lastLgt, cps, sv, screenPos, pc, stk, occ);
+                }
+                StoreVertex(prop, N, i, false, depth, sv);
+                break;
+            }
+            sv.rnd0 = Modulo1(sv.rnd0 + off.Pop());
+            sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
+            qs.Push(sv.rnd0), qs.Push(sv.rnd1);
+            V3 bsdfContrib;
+            if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
+            StoreVertex(prop, N, i, false, depth, sv);
+            cps.throughput = cps.throughput * sv.rrWeight;
+            org = cps.isect.position;
+            tnear = c_IsectEpsilon;
+            tfar = INFINITY;
+            depth++;
         }
         prop[(size_t)PW_ENVPRIM * N + i] = __int_as_float(envPrim);
     }
+    // the one shadow ray of the step (scene.cpp:128-149), cast after its strategy has been evaluated
+    if (ok && occ.pending) ok = !Occluded(S, occ.org, occ.dir, occ.dist, stk);
 
-    // ---- proposal Gaussian + acceptance probability
+    // ---- proposal Gaussian + acceptance probability (mutation_mala.h:174-267)
     float a = 0.0f;
-    GaussR pg;
     if (ok) {
         if (mala) {
-            float offKeep[MAXPSS];  // the kd search reuses their LDS words
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++) offKeep[k] = (k < dim) ? L.U(LDS_OFFSET_WORD + k) : 0.f;
-            InitGaussianLean(S, cache, A, i, dim, pc.lsScore, pc.ssScore, flags, L, pg, st);
-            float q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++)
-                if (k < dim) {
-                    const float d = -offKeep[k] - pg.mean[k];
-                    q += d * (pg.invCov[k] * d);
-                }
+            float *G = PropGaussBuf(A, flags);
+            VSource vs;
+            PrepareGaussianLean(cache, A, i, dim, pc.lsScore, flags, L, vs, st);
+            if (vs.mode == VS_BLEND) flags |= F_QUERIED;
+            float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
+#pragma unroll 1
+            for (int k = 0; k < dim; k++) {
+                const GaussK g = GaussianDim(S, C, A, i, dim, k, vs, pc.ssScore, L, logDet);
+                if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
+                const float d = -L.U(offBase + k) - g.mean;
+                q += d * (g.invCov * d);
+            }
+            if (LogDetIsClosedForm(vs, pc.ssScore)) logDet = ClosedFormLogDet(S, vs, dim);
+            if (shortState) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
             float px = dim * (-0.9189385332046727f);
-            px += 0.5f * pg.logDet;
+            px += 0.5f * logDet;
             px -= 0.5f * q;
             a = Clampf(expf(px - py) * pc.ssScore / curSs, 0.0f, 1.0f);
         } else {
@@ -527,19 +567,13 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         p[0] = pc.screenPos.x, p[N] = pc.screenPos.y, p[2 * N] = smallSplat.x, p[3 * N] = smallSplat.y, p[4 * N] = smallSplat.z;
         A.curSplatCount[i] = 1;
         if (mala) {  // mlt.cpp:133-142
+#pragma unroll 1
             for (int k = 0; k < MAXPSS; k++) {
                 A.chV1[(size_t)k * N + i] = A.chPropNewV1[(size_t)k * N + i];
                 A.chV2[(size_t)k * N + i] = A.chPropNewV2[(size_t)k * N + i];
             }
             flags |= F_BUFFERED | F_GAUSS;
-#pragma unroll
-            for (int k = 0; k < MAXPSS; k++)
-                if (k < dim) {
-                    A.gaussian[(size_t)k * N + i] = pg.mean[k];
-                    A.gaussian[(size_t)(MAXPSS + k) * N + i] = pg.covL[k];
-                    A.gaussian[(size_t)(2 * MAXPSS + k) * N + i] = pg.invCov[k];
-                }
-            A.gaussian[(size_t)(3 * MAXPSS) * N + i] = pg.logDet;
+            flags ^= F_GSEL;  // the proposal's Gaussian (streamed into the other buffer above) becomes the current one
         } else {
             flags &= ~F_GAUSS;
         }
@@ -556,7 +590,9 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 chainId = (int)(((long long)chainId + sampleIdx + cnt++) % P.numChains);
             }
             float *curW = sel ? A.pathBuf1 : A.curPath;
+#pragma unroll 1
             for (int w = 0; w < DPATH_WORDS; w++) curW[(size_t)w * N + i] = A.initPath[(size_t)w * P.numChains + chainId];
+#pragma unroll 1
             for (int w = 0; w < CONTRIB_WORDS; w++) A.curContrib[(size_t)w * N + i] = A.initContrib[(size_t)w * P.numChains + chainId];
             A.scoreSum[i] = A.initScoreSum[chainId];
             A.curSplatCount[i] = 0;

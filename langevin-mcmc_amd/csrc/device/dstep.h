@@ -13,23 +13,26 @@ struct StepStats {  // per-thread increments, block-reduced by the kernel
     float wsum = 0.f;
 };
 
-LMC_D void LoadGauss(const ChainArrays &A, int i, int dim, Gauss &g) {
+// the chain's current Gaussian lives in the buffer F_GSEL selects (dchain.h)
+LMC_D void LoadGauss(const ChainArrays &A, int i, int dim, int flags, Gauss &g) {
     const size_t N = A.N;
+    const float *G = CurGaussBuf(A, flags);
     for (int k = 0; k < dim; k++) {
-        g.mean[k] = A.gaussian[(size_t)k * N + i];
-        g.covL[k] = A.gaussian[(size_t)(MAXPSS + k) * N + i];
-        g.invCov[k] = A.gaussian[(size_t)(2 * MAXPSS + k) * N + i];
+        g.mean[k] = G[(size_t)k * N + i];
+        g.covL[k] = G[(size_t)(MAXPSS + k) * N + i];
+        g.invCov[k] = G[(size_t)(2 * MAXPSS + k) * N + i];
     }
-    g.logDet = A.gaussian[(size_t)(3 * MAXPSS) * N + i];
+    g.logDet = G[(size_t)(3 * MAXPSS) * N + i];
 }
-LMC_D void StoreGauss(const ChainArrays &A, int i, int dim, const Gauss &g) {
+LMC_D void StoreGauss(const ChainArrays &A, int i, int dim, int flags, const Gauss &g) {
     const size_t N = A.N;
+    float *G = CurGaussBuf(A, flags);
     for (int k = 0; k < dim; k++) {
-        A.gaussian[(size_t)k * N + i] = g.mean[k];
-        A.gaussian[(size_t)(MAXPSS + k) * N + i] = g.covL[k];
-        A.gaussian[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov[k];
+        G[(size_t)k * N + i] = g.mean[k];
+        G[(size_t)(MAXPSS + k) * N + i] = g.covL[k];
+        G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov[k];
     }
-    A.gaussian[(size_t)(3 * MAXPSS) * N + i] = g.logDet;
+    G[(size_t)(3 * MAXPSS) * N + i] = g.logDet;
 }
 
 // The twin blocks of MALASmallStep::Mutate (mutation_mala.h:83-166 current, :174-260 proposal).
@@ -47,7 +50,7 @@ LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArra
     A.pathWeight[i] = sp.lsScore;
     const bool inRange = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH;
     const bool ready = inRange && cache.d[dim].ready;
-    const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth);
+    const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth) && path.camDepth + path.lgtDepth - 1 <= P.maxDervDepth;
     const float ss = S.opt.malaStepsize, shk = S.opt.malaStdDev;
     float M[MAXPSS];
     if (inRange && !ready && haveDerv) {
@@ -139,7 +142,8 @@ LMC_D int DecideKind(const DScene &S, const ChainArrays &A, int i, Rng &rng) {
 // Will the next small step of a chain whose state has dimension `dim` evaluate a gradient?  (mutation_mala.h:94-96)
 LMC_D bool NeedsGradient(const DCache &cache, const StepParams &P, int camDepth, int lgtDepth) {
     const int dim = PathDimension(camDepth, lgtDepth);
-    return P.useGradient && dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH && !cache.d[dim].ready && GradAvailable(camDepth, lgtDepth);
+    return P.useGradient && dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH && !cache.d[dim].ready && GradAvailable(camDepth, lgtDepth) &&
+           camDepth + lgtDepth - 1 <= P.maxDervDepth;
 }
 
 // ... or query a cache tree too deep for the lean kernel's LDS search (dsmall.h)?  Such chains run the generic kernel.
@@ -147,6 +151,31 @@ LMC_D bool NeedsGeneric(const DCache &cache, const StepParams &P, int camDepth, 
     const int dim = PathDimension(camDepth, lgtDepth);
     const bool deep = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH && cache.d[dim].ready && cache.d[dim].deep;
     return deep || NeedsGradient(cache, P, camDepth, lgtDepth);
+}
+
+// A.nextKind byte: bits 0-1 = which launch runs the chain's next step (NEXT_*), bits 2-7 = sort key of plain small steps.
+// k_build_lists groups the plain entries of every 1024-chain tile by this key so that the 64 chains of a wave retrace the
+// same technique (c,l): same number of rays, same terminal strategy, same code path.  Path length first, then the
+// light-subpath length.
+LMC_D unsigned char TechniqueKey(int c, int l) {
+    const int L = max(c + l - 1, 3);
+    const int k = (L - 3) * 6 + min(l, 5);
+    return (unsigned char)min(k, 63);
+}
+// End of a step: decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between, so the RNG order is the
+// reference's) and publish it for k_build_lists.
+LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, Rng &rng) {
+    unsigned char nk = NEXT_DONE;
+    if (A.sampleIdx[i] < A.numSamples[i]) {
+        if (DecideKind(S, A, i, rng) == KIND_LARGE) {
+            nk = NEXT_LARGE;
+        } else {
+            const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
+            if (S.opt.mala && NeedsGeneric(cache, P, c, l)) nk = NEXT_SMALL_GENERIC;
+            else nk = (unsigned char)(NEXT_SMALL_PLAIN | (TechniqueKey(c, l) << 2));
+        }
+    }
+    A.nextKind[i] = nk;
 }
 
 template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, class Stk>
@@ -215,10 +244,10 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             }
             if (!(flags & F_GAUSS)) {
                 InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, cur, false, flags, cg, gw, st);
-                StoreGauss(A, i, dim, cg);
+                StoreGauss(A, i, dim, flags, cg);
                 flags |= F_GAUSS;
             } else {
-                LoadGauss(A, i, dim, cg);
+                LoadGauss(A, i, dim, flags, cg);
             }
             NormalDist nd(0.0f, 1.0f);  // GenerateSample, gaussian.cpp:38-55
             for (int k = 0; k < dim; k++) offset[k] = nd(rng);
@@ -310,7 +339,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
                     A.chV2[(size_t)k * N + i] = A.chPropNewV2[(size_t)k * N + i];
                 }
                 flags |= F_BUFFERED | F_GAUSS;
-                StoreGauss(A, i, PathDimension(pc.camDepth, pc.lightDepth), pg);
+                StoreGauss(A, i, PathDimension(pc.camDepth, pc.lightDepth), flags, pg);
             } else {
                 flags &= ~F_GAUSS;  // proposalState.gaussianInitialized = false, mutation_small.h:39
             }

@@ -33,9 +33,11 @@ void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                          const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, hipStream_t s);
+                          const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads,
+                          hipStream_t s);
 // id-ordered work lists of the next step from A.nextKind (coalescing: a wave's 64 list entries are (nearly) consecutive chains)
-void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, hipStream_t s);
+// sortPlain: group the plain small steps of every 1024-chain tile by technique (QueueNext's key)
+void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, int sortPlain, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 // pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
 void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);

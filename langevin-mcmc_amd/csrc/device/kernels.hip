@@ -302,25 +302,25 @@ __global__ void k_first_kind(DScene S, const DCache *cache, ChainArrays A, StepP
     rng.state = A.rngState[i];
     rng.tab = A.rngTab + (size_t)i * 64;
     rng.ticks = 0;
-    unsigned char k = NEXT_DONE;
-    if (A.sampleIdx[i] < A.numSamples[i]) {
-        if (DecideKind(S, A, i, rng) == KIND_LARGE) k = NEXT_LARGE;
-        else {
-            const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
-            k = (S.opt.mala && NeedsGeneric(*cache, P, c, l)) ? NEXT_SMALL_GENERIC : NEXT_SMALL_PLAIN;
-        }
-    }
-    A.nextKind[i] = k;
+    QueueNext(S, *cache, A, P, i, rng);
     A.rngState[i] = rng.state;
 }
 
-// Work lists of the next step.  Each block owns 1024 consecutive chains, reserves one contiguous range per list with a
-// single atomic and fills it in chain-id order: list entries that end up in one wave are (nearly) consecutive chains, so
-// the SoA chain state is read and written in whole cache lines.  (Appending straight from the step kernels scrambles
-// the order a little more every step until every lane touches its own cache line: profiles/r01_b_*.)
-__global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next) {
+// Work lists of the next step.  Each block owns a tile of 1024 consecutive chains and reserves one contiguous range per
+// list with a single atomic.
+//   * large / generic lists: filled in chain-id order (ordered scan), so that the SoA chain state is read and written in
+//     whole cache lines.  (Appending straight from the step kernels scrambles the order a little more every step until
+//     every lane touches its own cache line: profiles/r01_b_*.)
+//   * plain small steps: counting sort of the tile's entries by technique key (QueueNext), so that a wave of the lean
+//     kernel retraces ONE technique -- same ray count, same terminal strategy -- instead of the 5 different ones a wave of
+//     64 consecutive chains holds on average (profiles/r02_*).  A wave's chains still come from one 1024-chain tile: its
+//     state accesses stay within a few cache lines per word.
+__global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next, int sortPlain) {
     __shared__ unsigned long long sWave[4];
     __shared__ int sBase[3];
+    __shared__ int sHist[64], sStart[64];
+    if (threadIdx.x < 64) sHist[threadIdx.x] = 0;
+    __syncthreads();
     const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
     unsigned char k[4] = {0, 0, 0, 0};
     if (first + 3 < A.N) {
@@ -332,8 +332,11 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
     }
     // three 21-bit counters packed into one word: [large | generic << 21 | plain << 42]
     unsigned long long mine = 0;
-    for (int j = 0; j < 4; j++)
-        if (k[j]) mine += 1ull << (21 * (k[j] - 1));
+    for (int j = 0; j < 4; j++) {
+        const int kind = k[j] & 3;
+        if (kind) mine += 1ull << (21 * (kind - 1));
+        if (kind == NEXT_SMALL_PLAIN && sortPlain) atomicAdd(&sHist[k[j] >> 2], 1);
+    }
     unsigned long long incl = mine;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int off = 1; off < 64; off <<= 1) {
@@ -351,12 +354,25 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
         const int n = (int)((total >> (21 * threadIdx.x)) & 0x1fffff);
         sBase[threadIdx.x] = n ? atomicAdd(&next.counts[threadIdx.x], n) : 0;
     }
+    if (wave == 1) {  // exclusive prefix of the key histogram; the bins then serve as cursors
+        int h = sHist[lane], inc = h;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        sStart[lane] = inc - h;
+    }
     __syncthreads();
     const unsigned long long excl = before + incl - mine;
     int pos[3] = {sBase[0] + (int)(excl & 0x1fffff), sBase[1] + (int)((excl >> 21) & 0x1fffff), sBase[2] + (int)((excl >> 42) & 0x1fffff)};
     int *lists[3] = {next.large, next.smallGrad, next.smallPlain};
-    for (int j = 0; j < 4; j++)
-        if (k[j]) lists[k[j] - 1][pos[k[j] - 1]++] = first + j;
+    for (int j = 0; j < 4; j++) {
+        const int kind = k[j] & 3;
+        if (!kind) continue;
+        if (kind == NEXT_SMALL_PLAIN && sortPlain) next.smallPlain[sBase[2] + atomicAdd(&sStart[k[j] >> 2], 1)] = first + j;
+        else
+            lists[kind - 1][pos[kind - 1]++] = first + j;
+    }
 }
 
 // first step: every chain starts invalid -> large step (mlt.cpp:97)
@@ -548,8 +564,8 @@ void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned l
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }
-void LaunchBuildLists(const ChainArrays &A, const NextLists &next, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_lists, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next);
+void LaunchBuildLists(const ChainArrays &A, const NextLists &next, int sortPlain, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_lists, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next, sortPlain);
 }
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lists, dim3(GridFor(n, 256)), dim3(256), 0, s, n, large, counts);

@@ -54,19 +54,7 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
         const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
         LocalStackT<GLOSSY> stk;
         StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
-        // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
-        bool toLarge = false, toGrad = false, toPlain = false;
-        if (A.sampleIdx[i] < A.numSamples[i]) {
-            const int nk = DecideKind(S, A, i, rng);
-            if (nk == KIND_LARGE) {
-                toLarge = true;
-            } else {
-                const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
-                if (S.opt.mala && NeedsGeneric(*cache, P, c, l)) toGrad = true;
-                else toPlain = true;
-            }
-        }
-        A.nextKind[i] = toLarge ? NEXT_LARGE : toGrad ? NEXT_SMALL_GENERIC : toPlain ? NEXT_SMALL_PLAIN : NEXT_DONE;
+        QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;
     }
     __shared__ int sStats[9];

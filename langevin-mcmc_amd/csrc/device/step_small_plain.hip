@@ -27,29 +27,17 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
             LocalStackT<GLOSSY> stk;
             SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
         }
-        // ---- decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between) and queue the chain
-        bool toLarge = false, toGrad = false, toPlain = false;
-        if (A.sampleIdx[i] < A.numSamples[i]) {
-            const int nk = DecideKind(S, A, i, rng);
-            if (nk == KIND_LARGE) {
-                toLarge = true;
-            } else {
-                const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
-                if (S.opt.mala && NeedsGeneric(*cache, P, c, l)) toGrad = true;
-                else toPlain = true;
-            }
-        }
-        A.nextKind[i] = toLarge ? NEXT_LARGE : toGrad ? NEXT_SMALL_GENERIC : toPlain ? NEXT_SMALL_PLAIN : NEXT_DONE;
+        QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;
     }
     BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
 }
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                          const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, hipStream_t s) {
-    const size_t ldsBytes = (size_t)256 * LDS_WORDS_PER_THREAD * sizeof(float);
+                          const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, hipStream_t s) {
+    const size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float);
     const bool lds = bvhDepth <= BVH_LDS_STACK;
-#define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(256), ldsBytes, s, S, cache, A, film, P, list, listCount, next)
+#define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next)
     if (lds && !glossy) LMC_LAUNCH_SMALL(true, false);
     else if (lds && glossy)
         LMC_LAUNCH_SMALL(true, true);

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 
 namespace lmc {
 
@@ -84,6 +85,165 @@ struct Builder {
     }
 };
 }  // namespace
+
+// Top-down binned-SAH build over the same leaf / node format (the scene is static and built once on the host, so build
+// quality is free): 16 centroid bins per axis, leaf when <= maxLeaf triangles and splitting does not pay, median split of
+// the widest axis when every centroid falls into one bin.  Closest hits are tree independent (ties -> lowest triangle
+// id), so the two builders are interchangeable; tests/test_host.py checks that on random rays.
+namespace {
+struct SahBuilder {
+    std::vector<Prim> prims;
+    std::vector<float> cen;  // 3 per prim (by position in prims)
+    LbvhResult out;
+    const std::vector<lmcd::TriData> *tris;
+    int maxLeaf = 4;
+
+    static float Area(const float *mn, const float *mx) {
+        float d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.f;
+        return 2.f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+    int MakeLeaf(int lo, int hi, float *bmin, float *bmax) {
+        int first = (int)out.leafTris.size();
+        for (int k = 0; k < 3; k++) bmin[k] = INFINITY, bmax[k] = -INFINITY;
+        std::sort(prims.begin() + lo, prims.begin() + hi, [](const Prim &a, const Prim &b) { return a.id < b.id; });
+        for (int i = lo; i < hi; i++) {
+            const lmcd::TriData &T = (*tris)[prims[i].id];
+            lmcd::LeafTri lt;
+            memset(&lt, 0, sizeof(lt));
+            memcpy(lt.p0, T.p0, 12), memcpy(lt.e1, T.e1, 12), memcpy(lt.e2, T.e2, 12);
+            lt.id = prims[i].id;
+            out.leafTris.push_back(lt);
+            for (int k = 0; k < 3; k++) bmin[k] = std::min(bmin[k], prims[i].bmin[k]), bmax[k] = std::max(bmax[k], prims[i].bmax[k]);
+        }
+        return ~((first << 3) | (hi - lo - 1));
+    }
+    static float Centroid(const Prim &p, int k) { return 0.5f * (p.bmin[k] + p.bmax[k]); }
+    int Build(int lo, int hi, float *bmin, float *bmax, int depth) {
+        out.depth = std::max(out.depth, depth);
+        const int n = hi - lo;
+        if (n <= 1) return MakeLeaf(lo, hi, bmin, bmax);
+        float bb[2][3] = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}, cb[2][3] = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+        for (int i = lo; i < hi; i++)
+            for (int k = 0; k < 3; k++) {
+                bb[0][k] = std::min(bb[0][k], prims[i].bmin[k]), bb[1][k] = std::max(bb[1][k], prims[i].bmax[k]);
+                const float c = Centroid(prims[i], k);
+                cb[0][k] = std::min(cb[0][k], c), cb[1][k] = std::max(cb[1][k], c);
+            }
+        constexpr int NB = 16;
+        float bestCost = INFINITY;
+        int bestAxis = -1, bestBin = -1;
+        for (int ax = 0; ax < 3; ax++) {
+            const float ext = cb[1][ax] - cb[0][ax];
+            if (!(ext > 0)) continue;
+            int cnt[NB] = {0};
+            float bmn[NB][3], bmx[NB][3];
+            for (int b = 0; b < NB; b++)
+                for (int k = 0; k < 3; k++) bmn[b][k] = INFINITY, bmx[b][k] = -INFINITY;
+            for (int i = lo; i < hi; i++) {
+                int b = std::min(NB - 1, (int)((Centroid(prims[i], ax) - cb[0][ax]) / ext * NB));
+                cnt[b]++;
+                for (int k = 0; k < 3; k++) bmn[b][k] = std::min(bmn[b][k], prims[i].bmin[k]), bmx[b][k] = std::max(bmx[b][k], prims[i].bmax[k]);
+            }
+            float rArea[NB];
+            int rCnt[NB];
+            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int c = 0;
+            for (int b = NB - 1; b > 0; b--) {
+                for (int k = 0; k < 3; k++) mn[k] = std::min(mn[k], bmn[b][k]), mx[k] = std::max(mx[k], bmx[b][k]);
+                c += cnt[b];
+                rArea[b] = Area(mn, mx), rCnt[b] = c;
+            }
+            for (int k = 0; k < 3; k++) mn[k] = INFINITY, mx[k] = -INFINITY;
+            c = 0;
+            for (int b = 0; b < NB - 1; b++) {
+                for (int k = 0; k < 3; k++) mn[k] = std::min(mn[k], bmn[b][k]), mx[k] = std::max(mx[k], bmx[b][k]);
+                c += cnt[b];
+                if (c == 0 || rCnt[b + 1] == 0) continue;
+                // cost in units of one triangle test; leaves hold up to maxLeaf triangles fetched together
+                const float cost = Area(mn, mx) * c + rArea[b + 1] * rCnt[b + 1];
+                if (cost < bestCost) bestCost = cost, bestAxis = ax, bestBin = b;
+            }
+        }
+        const float parentArea = Area(bb[0], bb[1]);
+        if (n <= maxLeaf) {
+            // a node visit costs about as much as two triangle tests (one 64 B fetch + two slab tests)
+            const float leafCost = (float)n, splitCost = bestAxis >= 0 && parentArea > 0 ? 2.0f + bestCost / parentArea : INFINITY;
+            if (!(splitCost < leafCost)) return MakeLeaf(lo, hi, bmin, bmax);
+        }
+        int mid;
+        if (bestAxis < 0) {
+            mid = (lo + hi) / 2;  // all centroids coincide
+        } else {
+            const float ext = cb[1][bestAxis] - cb[0][bestAxis];
+            auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const Prim &p) {
+                int b = std::min(NB - 1, (int)((Centroid(p, bestAxis) - cb[0][bestAxis]) / ext * NB));
+                return b <= bestBin;
+            });
+            mid = (int)(it - prims.begin());
+            if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+        }
+        int ni = (int)out.nodes.size();
+        out.nodes.push_back(lmcd::BvhNode());
+        float lmin[3], lmax[3], rmin[3], rmax[3];
+        int left = Build(lo, mid, lmin, lmax, depth + 1);
+        int right = Build(mid, hi, rmin, rmax, depth + 1);
+        lmcd::BvhNode &nd = out.nodes[ni];
+        memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 3; k++) {
+            nd.lmin[k] = lmin[k], nd.lmax[k] = lmax[k], nd.rmin[k] = rmin[k], nd.rmax[k] = rmax[k];
+            bmin[k] = std::min(lmin[k], rmin[k]), bmax[k] = std::max(lmax[k], rmax[k]);
+        }
+        nd.left = left, nd.right = right;
+        return ni;
+    }
+};
+}  // namespace
+
+static void PrimBounds(const std::vector<lmcd::TriData> &tris, std::vector<Prim> &prims) {
+    prims.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {
+        const lmcd::TriData &T = tris[i];
+        for (int k = 0; k < 3; k++) {
+            float p0 = T.p0[k], p1 = T.p0[k] + T.e1[k], p2 = T.p0[k] + T.e2[k];
+            prims[i].bmin[k] = std::min(p0, std::min(p1, p2));
+            prims[i].bmax[k] = std::max(p0, std::max(p1, p2));
+        }
+        prims[i].id = (int)i;
+        prims[i].code = 0;
+    }
+}
+
+static void WrapSingleLeaf(LbvhResult &out, int root, const float *bmin, const float *bmax) {
+    if (root >= 0) return;  // the whole scene is one leaf: wrap it so that node 0 is an inner node
+    lmcd::BvhNode nd;
+    memset(&nd, 0, sizeof(nd));
+    for (int k = 0; k < 3; k++) nd.lmin[k] = bmin[k], nd.lmax[k] = bmax[k], nd.rmin[k] = INFINITY, nd.rmax[k] = -INFINITY;
+    nd.left = root;
+    nd.right = root;
+    out.nodes.push_back(nd);
+}
+
+LbvhResult BuildSahBvh(const std::vector<lmcd::TriData> &tris, int maxLeaf) {
+    SahBuilder B;
+    B.tris = &tris;
+    B.maxLeaf = std::max(1, std::min(8, maxLeaf));
+    if (tris.empty()) return B.out;
+    PrimBounds(tris, B.prims);
+    float bmin[3], bmax[3];
+    int root = B.Build(0, (int)tris.size(), bmin, bmax, 1);
+    WrapSingleLeaf(B.out, root, bmin, bmax);
+    if (B.out.depth > lmcd::BVH_STACK) throw std::runtime_error("BVH deeper than the traversal stack");
+    return B.out;
+}
+
+LbvhResult BuildSceneBvh(const std::vector<lmcd::TriData> &tris) {
+    const char *mode = getenv("LMC_BVH");
+    int leaf = 4;
+    if (const char *e = getenv("LMC_BVH_LEAF")) leaf = std::max(1, std::min(8, atoi(e)));
+    if (mode && std::string(mode) == "lbvh") return BuildLbvh(tris);
+    return BuildSahBvh(tris, leaf);
+}
 
 LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris) {
     Builder B;

@@ -18,6 +18,10 @@ struct LbvhResult {
     int depth = 0;
 };
 LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris);
+// same node / leaf format from a top-down binned-SAH build (fewer node visits per ray than the Morton tree)
+LbvhResult BuildSahBvh(const std::vector<lmcd::TriData> &tris, int maxLeaf = 4);
+// the tree the renderer uploads: SAH unless LMC_BVH=lbvh (A/B switch; hits do not depend on the tree)
+LbvhResult BuildSceneBvh(const std::vector<lmcd::TriData> &tris);
 
 struct KdTreeResult {
     std::vector<lmcd::KdNode> nodes;

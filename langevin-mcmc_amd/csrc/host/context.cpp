@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -86,7 +87,14 @@ struct lmc_ctx {
     std::unique_ptr<lmc::Scene> scene;
     int device = 0;
     int useGradient = 1;
+    int maxDervDepth = 8;  // --max-derivatives-depth default, main.cpp:46
     hipStream_t stream = nullptr;
+    // The three step launches of one iteration touch disjoint chains, so they run concurrently: large steps and the generic
+    // (gradient) small steps on two side streams, the lean small steps on the main stream, joined before k_build_lists.
+    // LMC_OVERLAP=0 serialises them on the main stream (A/B).
+    hipStream_t sideStream[2] = {nullptr, nullptr};
+    hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
+    bool overlap = true;
     // scene buffers
     DevBuf<BvhNode> nodes;
     DevBuf<LeafTri> leafTris;
@@ -114,6 +122,9 @@ struct lmc_ctx {
     DevBuf<double> weightSum;
     DevBuf<float> gradBuf;
     int gradStride = 0, stepGrid = 0;
+    // launch shape of the lean small-step kernel and the technique sort of its work list; LMC_LEAN_BLOCK / LMC_SORT_PLAIN
+    // override them for A/B runs (profiles/)
+    int leanBlock = 64, leanGrid = 0, sortPlain = 0;
     // work lists (double buffered): [parity][large | smallGrad | smallPlain]
     DevBuf<int> lists[2][3], listCounts[2];
     int parity = 0;
@@ -133,7 +144,7 @@ struct lmc_ctx {
     long long numInitContribs = 0;
     // timing
     struct StepEvents {
-        hipEvent_t e[4];  // step begin | large + generic launches done | lean small-step launch done | step end
+        hipEvent_t e[8];  // main stream: step begin | lean launch begin | lean launch end | step end;  side streams: large begin / end, generic begin / end
     };
     // Events are recorded only between lmc_set_option("timing", 1) and the lmc_step_timing call that reads them, and come
     // from a pool that is reused: a render that never asks for timings (dpt_amd) creates none.
@@ -145,6 +156,10 @@ struct lmc_ctx {
             for (auto &ev : *v)
                 for (auto e : ev.e) (void)hipEventDestroy(e);
         if (hostCounts) (void)hipHostFree(hostCounts);
+        for (auto e : {forkEvent, joinEvent[0], joinEvent[1]})
+            if (e) (void)hipEventDestroy(e);
+        for (auto st : sideStream)
+            if (st) (void)hipStreamDestroy(st);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -191,7 +206,7 @@ static void UploadScene(lmc_ctx *c) {
         triBase += dm.numTris;
         meshes.push_back(dm);
     }
-    lmc::LbvhResult bvh = lmc::BuildLbvh(tris);
+    lmc::LbvhResult bvh = lmc::BuildSceneBvh(tris);
     c->bvhDepth = bvh.depth;
     std::vector<DMaterial> mats;
     int glossy = 0;
@@ -277,7 +292,7 @@ static void SyncOptions(lmc_ctx *c) {
     d.roughnessThreshold = o.roughnessThreshold, d.largeStepProbability = o.largeStepProbability, d.largeStepProbScale = o.largeStepProbScale;
     d.malaGN = o.malaGN, d.malaStepsize = o.malaStepsize, d.malaStdDev = o.malaStdDev, d.perturbStdDev = o.perturbStdDev;
     d.discreteStdDev = o.discreteStdDev, d.uniformMixingProbability = o.uniformMixingProbability, d.seedOffset = o.seedOffset;
-    if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 8] on the MI355X back end");
+    if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 12] on the MI355X back end");
     if (o.largeStepMultiplexed || o.sampleFromGlobalCache || o.useLightCoordinateSampling || o.h2mc)
         throw std::runtime_error("largestepmultiplexed / samplecache / uselightcoordinatesampling / h2mc are out of scope (SURVEY.md §8f)");
 }
@@ -312,6 +327,10 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     ov.maxDepth = desc->max_depth, ov.width = desc->width, ov.height = desc->height, ov.seedOffset = desc->seed_offset;
     c->scene = lmc::ParseScene(desc->scene_xml, ov);
     HIP_CHECK(hipStreamCreate(&c->stream));
+    for (auto &st : c->sideStream) HIP_CHECK(hipStreamCreate(&st));
+    HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
+    for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -346,6 +365,7 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
     else if (n == "seedchains") c->seedChains = v != 0;
+    else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else throw std::runtime_error("Unknown dpt option:" + n);
     SyncOptions(c);
@@ -506,6 +526,9 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
     c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
     c->gradStride = c->stepGrid * 256;
+    if (const char *e = getenv("LMC_LEAN_BLOCK")) c->leanBlock = std::max(64, std::min(256, atoi(e) / 64 * 64));
+    if (const char *e = getenv("LMC_SORT_PLAIN")) c->sortPlain = atoi(e) != 0;
+    c->leanGrid = (int)std::min<size_t>((N + c->leanBlock - 1) / c->leanBlock, (size_t)4096 * 256 / c->leanBlock);
     c->gradBuf.Alloc(c->useGradient ? (size_t)c->gradStride * 640 : 1, false);  // V <= 238 + 59*6 = 592 words for c+l <= 9
     // global cache: dims 2L for L in [3, maxDepth], capped by PSS_MAX_LENGTH
     for (int d = 0; d <= PSS_MAX_LENGTH; d++) {
@@ -536,10 +559,10 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->parity = 0;
     if (c->seedChains) {  // chains start valid: the first step's kind is drawn like any other (mlt.cpp:96-97)
         StepParams P;
-        P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient;
+        P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth;
         LaunchFirstKind(c->S, c->cacheDev.p, c->A, P, s);
         NextLists first{c->lists[0][0].p, c->lists[0][1].p, c->lists[0][2].p, c->listCounts[0].p};
-        LaunchBuildLists(c->A, first, s);
+        LaunchBuildLists(c->A, first, c->sortPlain, s);
     } else
         LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
@@ -599,7 +622,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
     hipStream_t s = c->stream;
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
     StepParams P;
-    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient;
+    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth;
     for (int it = 0; it < nSteps; it++) {
         lmc_ctx::StepEvents ev;
         if (c->timing) {
@@ -615,15 +638,33 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
         HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
         const int *cnt = c->listCounts[cur].p;
-        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, s);
+        hipStream_t sL = c->overlap ? c->sideStream[0] : s, sG = c->overlap ? c->sideStream[1] : s;
+        if (c->overlap) {
+            HIP_CHECK(hipEventRecord(c->forkEvent, s));
+            HIP_CHECK(hipStreamWaitEvent(sL, c->forkEvent, 0));
+            if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
+        }
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
+        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sL);
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
         // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
         // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
         if (c->needGeneric)
-            LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, s);
+            LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
-        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->stepGrid, s);
+        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, s);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));
-        LaunchBuildLists(c->A, next, s);
+        if (c->overlap) {
+            HIP_CHECK(hipEventRecord(c->joinEvent[0], sL));
+            HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[0], 0));
+            if (c->needGeneric) {
+                HIP_CHECK(hipEventRecord(c->joinEvent[1], sG));
+                HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[1], 0));
+            }
+        }
+        LaunchBuildLists(c->A, next, c->sortPlain, s);
         c->parity = nxt;
         if (c->timing) {
             HIP_CHECK(hipEventRecord(ev.e[3], s));
@@ -655,7 +696,9 @@ int lmc_step_timing(lmc_ctx *c, double *kernelMs, long long *launches) {
         ms += t;
         HIP_CHECK(hipEventElapsedTime(&t, ev.e[1], ev.e[2]));
         c->smallMs += t;
-        HIP_CHECK(hipEventElapsedTime(&t, ev.e[0], ev.e[1]));
+        HIP_CHECK(hipEventElapsedTime(&t, ev.e[4], ev.e[5]));
+        c->largeMs += t;
+        HIP_CHECK(hipEventElapsedTime(&t, ev.e[6], ev.e[7]));
         c->largeMs += t;
         c->eventPool.push_back(ev);
     }

@@ -1,0 +1,64 @@
+"""`-m gpu` tier: the process surface.  langevin-mcmc_amd/dpt_amd is the reference's command line (`dpt [--seedoffset N] scene.xml`,
+/root/reference/src/main.cpp:35-120) over the C ABI: same scene XML and <dpt> keys, same stdout lines, same output naming
+(mlt.cpp:44-47,200-213)."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import gpu_checks as gc
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(gc.ROOT, "langevin-mcmc_amd", "dpt_amd")
+
+
+def _small_scene(tmp_path, width=96, height=72, spp=64):
+    """the shipped scene file with a smaller film and budget (the reference reads these from the XML: parsescene.cpp:160-209,535-590)"""
+    xml = open(gc.TORUS).read()
+    xml = xml.replace('<integer name="height" value="768"/>', '<integer name="height" value="%d"/>' % height)
+    xml = xml.replace('<integer name="width" value="1024"/>', '<integer name="width" value="%d"/>' % width)
+    xml = re.sub(r'<integer name="spp"\s+value="245"/>', '<integer name="spp" value="%d"/>' % spp, xml)
+    assert 'value="%d"' % spp in xml and 'value="%d"' % width in xml
+    os.symlink(os.path.join(gc.ROOT, "scenes", "torus", "data"), tmp_path / "data")
+    p = tmp_path / "lmc.xml"
+    p.write_text(xml)
+    return str(p)
+
+
+def test_dpt_amd_runs_the_shipped_scene_file(tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("dpt_amd not built")
+    scene = _small_scene(tmp_path)
+    r = subprocess.run([CLI, "--seedoffset", "3", "--max-derivatives-depth", "8", scene], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    out = r.stdout
+    assert r.returncode == 0, out
+    # stdout lines of the reference: mlt.cpp:46 ("Average brightness:"), :201 ("Elapsed time:"), :213 ("Done!")
+    m = re.search(r"Average brightness:([0-9.eE+-]+)", out)
+    assert m and 0.01 < float(m.group(1)) < 1.0, out
+    m = re.search(r"Elapsed time:([0-9.eE+-]+)", out)
+    assert m, out
+    assert out.rstrip().endswith("Done!"), out
+    # output naming: <film filename>_timeuse_<std::to_string(elapsed)>s.exr next to the scene (mlt.cpp:208-210)
+    exrs = [f for f in os.listdir(tmp_path) if re.fullmatch(r"lmc_timeuse_[0-9]+\.[0-9]{6}s\.exr", f)]
+    assert len(exrs) == 1, os.listdir(tmp_path)
+    img = gc.pkg().read_image(str(tmp_path / exrs[0]))
+    assert img.shape == (72, 96, 3) and np.isfinite(img).all() and img.mean() > 0.01
+    # the image is the scene: brighter sky half than floor shadow, same mean as the shipped render within Monte Carlo noise of 64 spp
+    ref = np.load(os.path.join(gc.ROOT, "tests", "golden", "torus_ref_images_256x192.npz"))["lmc"]
+    assert abs(img.mean() / ref.mean() - 1) < 0.15
+
+
+def test_dpt_amd_refuses_what_it_does_not_serve(tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("dpt_amd not built")
+    xml = open(gc.TORUS).read().replace('<boolean name="mala"           value="true"/>', '<boolean name="mala" value="false"/>')
+    if 'name="mala" value="false"' not in xml:
+        pytest.skip("scene file layout changed")
+    os.symlink(os.path.join(gc.ROOT, "scenes", "torus", "data"), tmp_path / "data")
+    p = tmp_path / "nomala.xml"
+    p.write_text(xml)
+    r = subprocess.run([CLI, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and "LMC path only" in r.stdout

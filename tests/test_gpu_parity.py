@@ -238,44 +238,102 @@ def test_direct_lighting_prepass_parity(L, force_diffuse):
 
 def test_full_render_matches_reference_image():
     """End to end against the reference authors' own render of the shipped scene file (tests/golden/torus_ref_images_256x192.npz =
-    scenes/torus/lmc_timeuse_44.689152s.exr, 245 spp, box-downsampled 4x): direct pre-pass / directSpp + chain loop / spp at
-    512x384, the scene's own materials, maxdepth 8, 2^16 chains x 480 steps, chains seeded from MLTInit (seedchains = 1).
+    scenes/torus/lmc_timeuse_44.689152s.exr, 245 spp, box-downsampled 4x) with the reference's own semantics -- no option the
+    reference does not have: every chain starts with a forced large step (mlt.h:121), the scene's own materials, maxdepth 8,
+    largestepprob 0.05 x 4, direct pre-pass / directSpp + chain loop / spp.
 
-    How the bars were set (scripts/region_spread.py, 4 independent seed offsets spaced 2^20 apart -- offsets closer than the
-    number of streams reuse the same PCG streams and are NOT independent -- gpurun_out/region_spread.json):
-      * a first guess of "every probe region within 10 % in one run" FAILED (top face 1.148) and was not supportable: single
-        seeded runs scatter by up to +-24 % per glass region (left face 0.97 .. 1.24 over the 4 seeds);
-      * what the 4 runs do support, asserted here with margin: mean luminance 1.011 .. 1.013 (bar 3 %), floor region
-        1.002 .. 1.007 (bar 2 %), trimmed relative MSE 0.011 .. 0.014 (bar 0.02; the two reference renders differ by 0.005),
-        and the 4-seed AVERAGE of each glass region 1.02 .. 1.08 (bar 15 %).
-    With the reference's own start-up semantics (seedchains = 0) the same configuration is reproducibly 21-24 % too bright on
-    the left cube face (4/4 seeds, spread 1 %): chains this short have not reached stationarity.  That is documented in
-    DESIGN.md, not asserted."""
+    The reference runs 128 chains x 1.5 M mutations.  What matters for the image is the chain LENGTH: the start-up transient of
+    an MLT chain (bright, rarely proposed states are under-represented at first, everything else over-represented) decays
+    with the number of mutations per chain, on the GPU and on the CPU oracle alike (profiles/r02_a_chain_length_sweep_256x192.json:
+    left cube face 1.15-1.28 at 735 steps/chain, 1.06-1.14 at 5.9 k, 1.00-1.11 at 47 k, 1.04 at 376 k; the oracle with the
+    reference's exact 128 x 1.5 M configuration at 1024x768: 0.985, relMSE 0.0035, profiles/r02_b_oracle_reference_config_fullres.json;
+    the GPU at 1024x768 with 2048 x 94 k: relMSE 0.0035, profiles/r02_b_gpu_fullres_seedchains0.json).  This test runs 1024 chains x
+    47 k mutations at 256x192 (980 spp = a quarter of the reference's samples per low-resolution pixel).
+
+    Bars.  SURVEY.md 8(d): relMSE <= 2 x the relMSE between the two renders the reference ships (LMC vs H2MC: 0.005) = 0.01 holds
+    at the reference's sample count (0.0035 measured, above); at this test's quarter budget the noise term is 4 x larger, so
+    the bar here is 0.02 on the 0.5 %-trimmed relMSE, 3 % on the mean and the floor, 12 % on each glass region (residual transient
+    at 47 k steps: <= 11 % over the seeds of the sweep)."""
     p = gc.pkg()
     ref = np.load(os.path.join(gc.ROOT, "tests", "golden", "torus_ref_images_256x192.npz"))["lmc"]
     lum = lambda x: x @ np.array([0.212671, 0.715160, 0.072169])
     lr = lum(ref)
     regions = {"left face": (100, 120, 60, 100), "front face": (175, 225, 62, 112), "torus": (140, 170, 65, 100), "top face": (110, 190, 22, 37)}
-    acc = {k: [] for k in regions}
-    for so in (0, 1 << 20, 2 << 20, 3 << 20):
-        ren = p.Renderer(gc.TORUS, width=512, height=384, seed_offset=so)
-        ren.set_option("seedchains", 1)
-        dspp, spp, chains = 64, 160, 1 << 16
-        direct = ren.direct_lighting(dspp)
-        per = spp * 512 * 384 // chains
-        ren.init_chains(32 * chains, chains, 65536, per, per % chains)
-        ren.step(per + 1)
-        img = direct / dspp + ren.film() / spp
-        ren.close()
-        lg = lum(img.reshape(192, 2, 256, 2, 3).mean(axis=(1, 3)))
-        assert abs(lg.mean() / lr.mean() - 1) < 0.03, so
-        assert abs(lg[75:125, 5:50].mean() / lr[75:125, 5:50].mean() - 1) < 0.02, so
-        err = np.sort(((lg - lr) ** 2 / (lr ** 2 + 1e-2)).ravel())
-        assert err[: int(0.995 * err.size)].mean() < 0.02, so
-        for k, (x0, x1, y0, y1) in regions.items():
-            acc[k].append(lg[y0:y1, x0:x1].mean() / lr[y0:y1, x0:x1].mean())
-    for k, v in acc.items():
-        assert abs(np.mean(v) - 1) < 0.15, (k, v)
+    W, H, dspp, spp, chains = 256, 192, 64, 980, 1024
+    ren = p.Renderer(gc.TORUS, width=W, height=H, seed_offset=0)
+    direct = ren.direct_lighting(dspp)
+    per = spp * W * H // chains
+    ren.init_chains(300000, chains, 8192, per, per % chains)  # numinitsamples as shipped (dptoptions.h:10)
+    done = 0
+    while done < per + 1:
+        ren.step(min(4096, per + 1 - done))
+        done += 4096
+    img = direct / dspp + ren.film() / spp
+    st = ren.stats()
+    ren.close()
+    assert st["steps"] == per * chains + per % chains
+    lg = lum(img)
+    assert abs(lg.mean() / lr.mean() - 1) < 0.03
+    assert abs(lg[75:125, 5:50].mean() / lr[75:125, 5:50].mean() - 1) < 0.03
+    err = np.sort(((lg - lr) ** 2 / (lr ** 2 + 1e-2)).ravel())
+    assert err[: int(0.995 * err.size)].mean() < 0.02
+    for k, (x0, x1, y0, y1) in regions.items():
+        assert abs(lg[y0:y1, x0:x1].mean() / lr[y0:y1, x0:x1].mean() - 1) < 0.12, k
+
+
+def test_short_chains_show_the_startup_transient():
+    """The other side of the same measurement, kept as a tracked fact rather than prose: at GPU-sized chain counts with the
+    reference's budget (2^16 chains x 183 mutations at 256x192) the glass regions are too bright -- chains that short have not
+    forgotten their uniform start.  Not a defect of the kernels (the CPU oracle shows the same); it bounds how many chains a
+    drop-in may use for a given budget.  If this ever stops holding, the test above can use more chains."""
+    p = gc.pkg()
+    ref = np.load(os.path.join(gc.ROOT, "tests", "golden", "torus_ref_images_256x192.npz"))["lmc"]
+    lum = lambda x: x @ np.array([0.212671, 0.715160, 0.072169])
+    lr = lum(ref)
+    W, H, dspp, spp, chains = 256, 192, 64, 245, 1 << 16
+    ren = p.Renderer(gc.TORUS, width=W, height=H, seed_offset=0)
+    direct = ren.direct_lighting(dspp)
+    per = spp * W * H // chains
+    ren.init_chains(32 * chains, chains, 65536, per, per % chains)
+    ren.step(per + 1)
+    lg = lum(direct / dspp + ren.film() / spp)
+    ren.close()
+    left = lg[60:100, 100:120].mean() / lr[60:100, 100:120].mean()
+    floor = lg[75:125, 5:50].mean() / lr[75:125, 5:50].mean()
+    assert abs(floor - 1) < 0.03
+    assert 1.08 < left < 1.6, left
+
+
+def test_maxdepth_12_chain_parity():
+    """BASELINE.json configs[2]: the scene's own materials at max path length 12 (the reference has no depth cap in its path
+    storage, path.h:38-56).  Same checks as the maxdepth-8 test; gradients exist for dim <= 12 only (mutation_mala.h:94-96), longer
+    states take isotropic proposals on both sides."""
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=1, max_depth=12, force_diffuse=0, oracle_grad="product")
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 4
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
+    assert r["init_cl_match"] > 0.97
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == 256 * 40
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 3
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
+    assert r["film_rel_l2"] < 0.15
+    assert r["final_state_match"] > 0.95
+    assert r["nonfinite_gpu"] == 0
+    assert abs(r["energy_gpu"] - 1.0) < 1e-4
+
+
+def test_maxdepth_12_diffuse_long_paths_exact():
+    """Lambertian-only at maxdepth 12 (no glossy rounding amplification): the discrete history must agree exactly, including the
+    chains whose state has more than 12 primary-sample dimensions (lean kernel: scalar isotropic Gaussian, offsets above the
+    BVH stack in LDS)."""
+    r = gc.run_pair(160, 120, 40000, 512, 8, 400, 40, use_gradient=0, max_depth=12, opts={"largestepprob": 0.3})
+    assert r["contribs_gpu"] == r["contribs_oracle"]
+    assert r["init_cl_match"] == 1.0
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["largeSteps"] == so["largeSteps"]
+    assert abs(sg["accepted"] - so["accepted"]) <= 3
+    assert r["film_rel_l2"] < 2e-3
+    assert r["final_state_match"] > 0.98
 
 
 def test_isotropic_small_step_only():
@@ -342,7 +400,7 @@ def test_bad_inputs_fail_cleanly():
     with pytest.raises(RuntimeError):
         p.Renderer(os.path.join(gc.ROOT, "scenes", "torus", "missing.xml"))
     with pytest.raises(RuntimeError, match="maxdepth"):
-        p.Renderer(gc.TORUS, force_diffuse=1, max_depth=12)  # path storage is sized for maxdepth <= 8: refused, not truncated
+        p.Renderer(gc.TORUS, force_diffuse=1, max_depth=13)  # path storage is sized for maxdepth <= 12: refused, not truncated
     ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=32, height=24)
     with pytest.raises(RuntimeError, match="initialization failed"):
         ren.init_chains(100, 4096, 4, 10)  # fewer contributions than chains (mlt.h:101-105)

@@ -25,13 +25,13 @@ static double Opt(lmc_ctx *ctx, const char *name) {
 int main(int argc, char *argv[]) {
     if (argc <= 1) return 0;
     printf("Langevin MCMC dpt (MI355X back end)\n");
-    int seedoffset = 0, device = 0, forceDiffuse = 0, maxDepth = 0, initThreads = 65536;
+    int seedoffset = 0, device = 0, forceDiffuse = 0, maxDepth = 0, initThreads = 65536, maxDervDepth = 8;
     long long chains = 0;
     std::vector<std::string> filenames;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--seedoffset") seedoffset = std::stoi(argv[++i]);
-        else if (a == "--max-derivatives-depth") ++i;  // accepted for compatibility: the gradient kernels cover every technique with dim <= 12
+        else if (a == "--max-derivatives-depth") maxDervDepth = std::stoi(argv[++i]);  // main.cpp:59-60: techniques longer than this get isotropic proposals
         else if (a == "--compile-pathlib" || a == "--compile-bidirpathlib" || a == "--compile-bidirpathlib2") {
             printf("%s: nothing to compile, the path programs are part of liblmc_hip.so\n", a.c_str());
         } else if (a == "--chains") chains = std::stoll(argv[++i]);
@@ -51,6 +51,7 @@ int main(int argc, char *argv[]) {
             fprintf(stderr, "%s\n", lmc_last_error());
             return 1;
         }
+        lmc_set_option(ctx, "max-derivatives-depth", maxDervDepth);
         if (Opt(ctx, "mala") == 0 || Opt(ctx, "h2mc") != 0) {
             fprintf(stderr, "dpt_amd serves the LMC path only (<dpt> integrator=mcmc, mala=true)\n");
             return 1;
