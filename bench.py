@@ -31,30 +31,28 @@ def parse():
     ap.add_argument("--init-threads", type=int, default=65536)
     ap.add_argument("--samples-per-chain", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chains", type=int, default=32768)
-    ap.add_argument("--cpu-steps", type=int, default=48)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time bound of the CPU baseline sample")
+    ap.add_argument("--no-rmse", action="store_true")
+    ap.add_argument("--rmse-seconds", type=float, default=2.0, help="GPU wall time of the equal-time RMSE leg")
+    ap.add_argument("--rmse-gt-spp", type=int, default=8192)
     return ap.parse_args()
 
 
 def cpu_baseline(args):
     """The CPU oracle (port of the reference's chain loop; gradients from the reference's own generated programs when
-    oracle/_ref is present) on a bounded sample of the same workload, all host cores."""
+    oracle/_ref is present) with the reference's own scheduling -- one chain per work item on a pool of host threads
+    (parallel.cpp:82-142), chains never wait for each other, cache pushes under a mutex (mlt.cpp:120-127) -- on a bounded
+    sample of the same workload (torus, Lambertian-only, maxdepth 6, full-size film)."""
     from tests import _orc, gpu_checks as gc
 
     L = gc.oracle_lib()
     cores = os.cpu_count() or 1
-    cores = max(1, min(cores, args.cpu_chains // 64))  # at least 64 chains per worker thread between barriers
     orc = _orc.Oracle(L, gc.TORUS, 1, 6, 0, 0, 0, gc.pathref())
-    n = args.cpu_chains
-    orc.init(max(8 * n, 20000), n, 64)
-    orc.setup_chains(args.samples_per_chain, 0)
-    import ctypes
-
-    done = ctypes.c_longlong()
-    # untimed warm-up so that the timed part sits in the same regime as the GPU measurement
-    L.orc_bench_steps(orc.h, min(args.warmup, 16), cores, ctypes.byref(done))
+    n = 4 * cores  # a few chains per worker, like the reference's 128 chains on 32 cores
+    orc.init(300000, n, min(cores, 64))
+    orc.setup_chains(1 << 30, 0)  # far more mutations than the time limit allows: every worker runs until the deadline
     t0 = time.time()
-    rate = L.orc_bench_steps(orc.h, args.cpu_steps, cores, ctypes.byref(done))
+    rate, done = orc.run_async(cores, args.cpu_seconds)
     dt = time.time() - t0
     orc.close()
     return {
@@ -62,8 +60,62 @@ def cpu_baseline(args):
         "unit": "chain-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d chains x %d steps (%.1f s), torus diffuse maxdepth 6, full-size film, gradients via %s"
-        % (n, args.cpu_steps, dt, "reference derivative programs (oracle/_ref)" if gc.pathref() else "none (isotropic)"),
+        "sample": "%d chains on %d threads for %.1f s = %d mutations; torus diffuse maxdepth 6, 1024x768 film, one chain per work item (the reference's "
+        "scheduling), gradients via %s" % (n, cores, dt, done, "the reference's derivative programs (oracle/_ref)" if gc.pathref() else "none (isotropic)"),
+        "reference_authors": {"value": 4.31e6, "cores": 32, "note": "derived from the shipped render's file name: 245 spp x 1024x768 in 44.69 s, full-material torus (BASELINE.md)"},
+    }
+
+
+def lum(img):
+    import numpy as np
+
+    return img.astype(np.float64) @ np.array([0.212671, 0.715160, 0.072169])
+
+
+def equal_time_rmse(args, p, gc, gpu_rate, cpu_rate, cores):
+    """BASELINE.json's second metric.  Same workload as the throughput figure at a 256x192 film: the GPU renders for about
+    args.rmse_seconds, the CPU oracle (reference scheduling, all host cores) gets the same wall time, both are compared with a
+    plain Monte Carlo estimate of the same quantity (lmc_bidir_mc: bidirectional samples of path length >= 3, no Markov chain).
+    The Markov chains only carry paths of length >= 3 (mlt.h:76); the direct pre-pass is the same estimator on both sides and
+    is left out, like it is left out of the reference's timer (mlt.cpp:56-57,200)."""
+    import numpy as np
+    from tests import _orc
+
+    W, H = 256, 192
+    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=W, height=H, seed_offset=0, use_gradient=1)
+    t0 = time.time()
+    gt = lum(ren.bidir_mc(args.rmse_gt_spp))
+    t_gt = time.time() - t0
+    chains = 1 << 16
+    spp = max(64, int(gpu_rate * 0.25 * args.rmse_seconds / (W * H)))  # 2^16 chains run at about a quarter of the 2^20-chain rate
+    per = spp * W * H // chains
+    ren.init_chains(8 * chains, chains, 65536, per, per % chains)
+    ren.sync()
+    t0 = time.time()
+    ren.step(per + 1)
+    ren.sync()
+    t_gpu = time.time() - t0
+    img_gpu = lum(ren.film()) / spp
+    ren.close()
+    L = gc.oracle_lib()
+    orc = _orc.Oracle(L, gc.TORUS, 1, 6, W, H, 0, gc.pathref())
+    n = 4 * cores
+    spp_cpu = max(1, int(cpu_rate * t_gpu / (W * H)))
+    per_c = spp_cpu * W * H // n
+    orc.init(300000, n, min(cores, 64))
+    orc.setup_chains(per_c, per_c % n)
+    t0 = time.time()
+    orc.run_async(cores, 0.0)
+    t_cpu = time.time() - t0
+    img_cpu = lum(orc.film()) / spp_cpu
+    orc.close()
+    rel = lambda a: float(np.sqrt(np.mean((a - gt) ** 2)) / gt.mean())
+    return {
+        "film": [W, H],
+        "metric": "relative RMSE of the luminance of the indirect (path length >= 3) image vs a plain-MC bidirectional estimate",
+        "ground_truth": {"estimator": "lmc_bidir_mc", "spp": args.rmse_gt_spp, "seconds": t_gt},
+        "gpu": {"seconds": t_gpu, "spp": spp, "chains": chains, "mutations_per_chain": per, "rel_rmse": rel(img_gpu), "mean_ratio": float(img_gpu.mean() / gt.mean())},
+        "cpu": {"seconds": t_cpu, "spp": spp_cpu, "chains": n, "cores": cores, "mutations_per_chain": per_c, "rel_rmse": rel(img_cpu), "mean_ratio": float(img_cpu.mean() / gt.mean())},
     }
 
 
@@ -112,6 +164,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if dist is not None:
+        import torch
+
+        # bootstrap of the in-library RCCL communicator: rank 0's 128-byte id over torch.distributed (the only use of torch here)
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt = torch.tensor(list(p.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(idt, 0)
+        ren.comm_init(world, rank, bytes(idt.cpu().tolist()))
     ren.set_option("timing", 1)  # per-step HIP events on the launch stream (lmc_step_timing / lmc_kernel_timing)
     ren.step(args.warmup)
     ren.step_timing()  # discard warm-up launches
@@ -123,12 +184,9 @@ def main():
     if dist is not None:
         import torch
 
-        # the single data-path collective: film buffer + normalisation scalar over RCCL/xGMI
-        film_t = torch.from_numpy(ren.film()).cuda()
-        norm_t = torch.tensor([norm], device="cuda")
-        dist.all_reduce(film_t)
-        dist.all_reduce(norm_t)
-        film = film_t
+        # the single data-path collective: the device films are summed in place by the library (RCCL over xGMI, on the step
+        # stream, no host staging); `normalization` is identical on all ranks (every rank runs the same MLTInit)
+        ren.film_allreduce()
     barrier()
     dt = time.time() - t0
     if dist is not None:
@@ -191,6 +249,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"value": None, "unit": "chain-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %s" % e}
+            if not args.no_rmse and out["cpu_baseline"].get("value"):
+                try:
+                    ren.close()
+                    out["equal_time_rmse"] = equal_time_rmse(args, p, gc, value, out["cpu_baseline"]["value"], out["cpu_baseline"]["cores"])
+                except Exception as e:
+                    out["equal_time_rmse"] = {"failed": str(e)}
         print(json.dumps(out))
     ren.close()
     if dist is not None:

@@ -105,10 +105,25 @@ int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);
  * out3[2] = chain-steps the lean kernel has run since lmc_chains_init (cumulative). */
 int lmc_kernel_timing(lmc_ctx *ctx, double *out3);
 
+/* ---- multi-GPU (one process per GPU; chains sharded by contiguous global id range through lmc_chains_init).
+ * The only data-path collective is the sum of the per-GPU films: rank 0 calls lmc_comm_unique_id and the host program
+ * ships the 128 bytes to the other ranks (any side channel), every rank calls lmc_comm_init, and after its last step
+ * lmc_film_allreduce sums the device films in place with RCCL on the step stream (no host staging) together with the
+ * splat-weight sum.  lmc_film_device_ptr exposes the device buffer for hosts that bring their own collective library. */
+int lmc_comm_unique_id(unsigned char *out128);
+int lmc_comm_init(lmc_ctx *ctx, int n_ranks, int rank, const unsigned char *id128);
+int lmc_film_allreduce(lmc_ctx *ctx);
+void *lmc_film_device_ptr(lmc_ctx *ctx, long long *n_floats);
+
 /* Batched path program: n evaluations of technique (c,l); SoA, word-major: primary_soa[(2L+1)*n],
  * vert_soa[V*n], grad_soa[2L*n] (word w of item i at [w*n + i]); scene38 as lmc_scene_params.  Host pointers.
  * loglum and grad_soa may each be NULL. */
 int lmc_grad_batch(int c, int l, int n, const float *primary_soa, const float *scene38, const float *vert_soa, float *loglum, float *grad_soa);
+
+/* H2MC library (the reference's pathlibbidir.so): symbols evaluate_path_bidir_<c>_<l>_static{,_derv}, the derivative with
+ * a 6th `hess` argument ((2L)^2 floats, row i at hess[i*2L]; path.h:122-123, mutation_h2mc.h:74-79), are exported next to
+ * the MALA ones.  Batched form: hess_soa[(2L)^2 * n], entry (i,k) of item j at [(i*2L + k)*n + j]. */
+int lmc_hess_batch(int c, int l, int n, const float *primary_soa, const float *scene38, const float *vert_soa, float *loglum, float *grad_soa, float *hess_soa);
 
 /* ---- probes used by the parity tests (tests/) ---- */
 /* rays: n x [ox,oy,oz,dx,dy,dz,tnear,tfar]; closest hit -> global triangle id (or -1) and t */

@@ -74,6 +74,11 @@ def lib():
         L.lmc_rng_probe.argtypes = [ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
         L.lmc_kd_probe.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp]
         L.lmc_gauss_probe.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        L.lmc_comm_unique_id.argtypes = [vp]
+        L.lmc_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+        L.lmc_film_allreduce.argtypes = [vp]
+        L.lmc_film_device_ptr.argtypes = [vp, vp]
+        L.lmc_film_device_ptr.restype = vp
         _lib = L
     return _lib
 
@@ -144,6 +149,16 @@ class Renderer:
         if lib().lmc_film_read(self.h, P(f)) != 0:
             raise RuntimeError(_err())
         return f
+
+    # ---- multi-GPU (include/lmc_abi.h): in-library RCCL sum of the device films
+    def comm_init(self, n_ranks, rank, id128):
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        if lib().lmc_comm_init(self.h, n_ranks, rank, buf) != 0:
+            raise RuntimeError("lmc_comm_init failed: " + _err())
+
+    def film_allreduce(self):
+        if lib().lmc_film_allreduce(self.h) != 0:
+            raise RuntimeError("lmc_film_allreduce failed: " + _err())
 
     def direct_lighting(self, direct_spp):
         """DirectLighting pre-pass (direct.cpp); returns the un-normalised direct buffer [H, W, 3]."""
@@ -219,6 +234,14 @@ class Renderer:
         if lib().lmc_occluded(self.h, len(rays), P(rays), P(occ)) != 0:
             raise RuntimeError(_err())
         return occ
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it, the host program broadcasts it)"""
+    buf = (ctypes.c_ubyte * 128)()
+    if lib().lmc_comm_unique_id(buf) != 0:
+        raise RuntimeError("lmc_comm_unique_id failed: " + _err())
+    return bytes(buf)
 
 
 def read_image(path):

@@ -1,0 +1,166 @@
+// H2MC proposal Gaussian from gradient + Hessian of log f in primary sample space:
+// /root/reference/src/h2mc.h:9-29 (H2MCParam) and h2mc.cpp:3-142 (ComputeGaussian): symmetric eigen-decomposition of the
+// Hessian, per-eigenvalue variance / offset remap (cosh-sinh for positive, sin-cos for negative curvature, L = pi/2),
+// isotropic prior 1/sigma^2, dense mean / covL / invCov / logDet.
+// The reference calls Eigen::SelfAdjointEigenSolver (third party, not vendored: parity unpinned); here a cyclic
+// Jacobi solver, shared by the device kernels and the CPU oracle so that both produce the same eigenvectors (their sign and
+// order are a convention: mean, invCov, covL covL^T and logDet do not depend on it; tests/test_h2mc.py checks those
+// against numpy.linalg.eigh).  Host- and device-compilable.
+#pragma once
+#include "dmath.h"
+
+namespace lmcd {
+
+constexpr int H2_MAXDIM = 16;  // derivative programs exist up to path length 8 (--max-derivatives-depth 8)
+
+struct H2MCParam {
+    float sigma, posScaleFactor, posOffsetFactor, negScaleFactor, negOffsetFactor, L;
+};
+LMC_HD H2MCParam MakeH2MCParam(float sigma) {  // h2mc.h:10-16, L = pi/2
+    H2MCParam p;
+    p.sigma = sigma;
+    p.L = float(3.14159265358979323846 / 2.0);
+    // exp / sin / cos / log of this file are evaluated in double and rounded once (dmath.h: expd, logd), so that the CPU oracle and
+    // the device agree to the bit; the reference's float libm calls are within one ulp of these
+    const float eL = expd(p.L), emL = expd(-p.L);
+    p.posScaleFactor = 0.5f * (eL - emL) * 0.5f * (eL - emL);
+    p.posOffsetFactor = 0.5f * (eL + emL - 1.0f);
+    const float sL = (float)sin((double)p.L), cL = (float)cos((double)p.L);
+    p.negScaleFactor = sL * sL;
+    p.negOffsetFactor = -(cL - 1.0f);
+    return p;
+}
+
+// Symmetric eigen-decomposition by cyclic Jacobi rotations.  A (n x n, row-major, stride n) is destroyed; on return w holds
+// the eigenvalues in ascending order (Eigen's convention) and column j of V (row-major, stride n) the unit eigenvector of w[j].
+LMC_HD void JacobiEigenSym(int n, float *A, float *V, float *w) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0f : 0.0f;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        float off = 0.f, diag = 0.f;
+        for (int i = 0; i < n; i++) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        }
+        if (!(off > 1e-14f * (diag + off))) break;  // also leaves on NaN
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const float apq = A[p * n + q];
+                if (apq == 0.0f) continue;
+                const float app = A[p * n + p], aqq = A[q * n + q];
+                const float theta = (aqq - app) / (2.0f * apq);
+                const float t = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                const float c = 1.0f / sqrtf(t * t + 1.0f), s = t * c;
+                for (int k = 0; k < n; k++) {  // A <- A J  (columns p, q)
+                    const float akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {  // A <- J^T A (rows p, q)
+                    const float apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {  // V <- V J
+                    const float vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; i++) {  // ascending order (selection sort; ties keep their order)
+        int m = i;
+        for (int j = i + 1; j < n; j++)
+            if (w[j] < w[m]) m = j;
+        if (m != i) {
+            const float tw = w[i];
+            w[i] = w[m], w[m] = tw;
+            for (int k = 0; k < n; k++) {
+                const float tv = V[k * n + i];
+                V[k * n + i] = V[k * n + m], V[k * n + m] = tv;
+            }
+        }
+    }
+}
+
+// Dense Gaussian of one state: mean[n], covL[n*n], invCov[n*n] (row-major, stride n), logDet.
+// `hess` is the n x n matrix as the derivative program delivers it (row i at hess[i*n]); `work` needs 2*n*n + 4*n floats.
+LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const float *grad, const float *hess, float *mean, float *covL, float *invCov,
+                                float &logDet, float *work) {
+    const float sigma = param.sigma, invSigmaSq = 1.0f / (sigma * sigma);
+    float hnorm = 0.f;
+    for (int i = 0; i < n * n; i++) hnorm += hess[i] * hess[i];
+    hnorm = sqrtf(hnorm);
+    if (sc <= 1e-15f || hnorm < 0.5f / (sigma * sigma) || !(hnorm == hnorm)) {  // h2mc.cpp:84-92 (NaN cannot occur: the caller zeroes non-finite input)
+        for (int i = 0; i < n; i++) {
+            mean[i] = 0.f;
+            for (int j = 0; j < n; j++) covL[i * n + j] = (i == j) ? sigma : 0.f, invCov[i * n + j] = (i == j) ? invSigmaSq : 0.f;
+        }
+        logDet = 0.f;
+        for (int i = 0; i < n; i++) logDet += logd(invSigmaSq);
+        return;
+    }
+    float *A = work, *V = work + n * n, *w = work + 2 * n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) A[i * n + j] = 0.5f * (hess[i * n + j] + hess[j * n + i]);  // the solver reads one triangle; symmetrise
+    JacobiEigenSym(n, A, V, w);
+    for (int i = 0; i < n; i++) eigenBuff[i] = fabsf(w[i]) > 1e-10f ? 1.0f / fabsf(w[i]) : 0.0f;
+    for (int i = 0; i < n; i++) {  // offsetBuff = diag(eigenBuff) (V^T grad)
+        float dot = 0.f;
+        for (int k = 0; k < n; k++) dot += V[k * n + i] * grad[k];
+        offsetBuff[i] = eigenBuff[i] * dot;
+    }
+    for (int i = 0; i < n; i++) {
+        float s2 = 1.0f, o = 0.0f;
+        if (fabsf(w[i]) > 1e-10f) {
+            o = offsetBuff[i];
+            if (w[i] > 0.0f) s2 = param.posScaleFactor, o *= param.posOffsetFactor;
+            else
+                s2 = param.negScaleFactor, o *= param.negOffsetFactor;
+        } else {
+            s2 = param.L * param.L;
+            o = 0.5f * offsetBuff[i] * param.L * param.L;
+        }
+        eigenBuff[i] *= s2;
+        eigenBuff[i] = eigenBuff[i] > 1e-10f ? 1.0f / eigenBuff[i] : 0.0f;
+        offsetBuff[i] = o;
+    }
+    for (int i = 0; i < n; i++) post[i] = eigenBuff[i] + invSigmaSq;
+    for (int i = 0; i < n; i++) {
+        float m = 0.f;
+        for (int k = 0; k < n; k++) m += V[i * n + k] * ((eigenBuff[k] / post[k]) * offsetBuff[k]);
+        mean[i] = m;
+        for (int j = 0; j < n; j++) {
+            float ic = 0.f;
+            for (int k = 0; k < n; k++) ic += V[i * n + k] * post[k] * V[j * n + k];
+            invCov[i * n + j] = ic;
+            covL[i * n + j] = V[i * n + j] * sqrtf(1.0f / post[j]);
+        }
+    }
+    logDet = 0.f;
+    for (int i = 0; i < n; i++) logDet += logd(post[i]);
+}
+
+// gaussian.cpp:24-36 / :38-55, dense branch
+LMC_HD float DenseGaussianLogPdf(int n, const float *offset, bool negate, const float *mean, const float *invCov, float logDet) {
+    float logPdf = n * (-0.9189385332046727f);
+    logPdf += 0.5f * logDet;
+    float q = 0.f;
+    for (int i = 0; i < n; i++) {
+        float r = 0.f;
+        for (int j = 0; j < n; j++) r += invCov[i * n + j] * ((negate ? -offset[j] : offset[j]) - mean[j]);
+        q += ((negate ? -offset[i] : offset[i]) - mean[i]) * r;
+    }
+    logPdf -= 0.5f * q;
+    return logPdf;
+}
+LMC_HD void DenseGaussianMap(int n, const float *z, const float *mean, const float *covL, float *x) {  // x = covL z + mean
+    for (int i = 0; i < n; i++) {
+        float r = 0.f;
+        for (int j = 0; j < n; j++) r += covL[i * n + j] * z[j];
+        x[i] = r + mean[i];
+    }
+}
+
+}  // namespace lmcd

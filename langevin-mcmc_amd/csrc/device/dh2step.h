@@ -1,0 +1,208 @@
+// H2MC small step on the device: H2MCSmallStep::Mutate (/root/reference/src/mutation_h2mc.h:38-128) inside the chain loop
+// body of mlt.cpp:91-170.  One thread = one chain; all small steps of an H2MC render run here (large steps are the same as
+// for LMC and keep their own launch; the global cache and the Adam-style moments do not exist on this path).
+// Per state: gradient and Hessian of log f through the path program (pathfunc.h: PathFuncHess, one nested-dual pass per
+// Hessian row), symmetric eigen-solve + Gaussian (dh2mc.h), dense sample x = covL z + mean, dense log pdf.
+// The chain's current Gaussian (mean, covL, invCov, logDet: up to 16 + 2 * 256 + 1 words) lives in HBM (A.h2Gauss, SoA).
+#pragma once
+#include "dh2mc.h"
+#include "dstep.h"
+
+namespace lmcd {
+
+constexpr int H2_GAUSS_WORDS = H2_MAXDIM + 2 * H2_MAXDIM * H2_MAXDIM + 1;
+
+struct DenseGauss {
+    float mean[H2_MAXDIM], covL[H2_MAXDIM * H2_MAXDIM], invCov[H2_MAXDIM * H2_MAXDIM];
+    float logDet;
+    bool dense;  // false: IsotropicGaussian(sigma) (no derivative program for this technique), diagonal stored in covL / invCov all the same
+};
+
+#ifdef __HIPCC__
+template <class In>
+__device__ __noinline__ void PathFuncHessDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
+    PathFuncHess(c, l, primary, scene, vp, logLum, grad, hess);
+}
+#endif
+
+// initGaussian lambda of H2MCSmallStep::Mutate (mutation_h2mc.h:60-93)
+LMC_D void InitGaussianH2MC(const DScene &S, const StepParams &P, const H2MCParam &param, const DPath &path, const Contrib &sp, DenseGauss &g, GradWork &gw,
+                            StepStats &st) {
+    const int dim = PathDimension(path.camDepth, path.lgtDepth);
+    const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth) && path.camDepth + path.lgtDepth - 1 <= P.maxDervDepth && dim <= H2_MAXDIM;
+    if (!haveDerv) {  // IsotropicGaussian(dim, sigma), gaussian.cpp:4-22
+        const float sigma = param.sigma;
+        for (int i = 0; i < dim; i++) {
+            g.mean[i] = 0.f;
+            for (int j = 0; j < dim; j++) g.covL[i * dim + j] = (i == j) ? sigma : 0.f, g.invCov[i * dim + j] = (i == j) ? 1.0f / (sigma * sigma) : 0.f;
+        }
+        g.logDet = dim * fastlog(1.0f / (sigma * sigma));
+        g.dense = false;
+        return;
+    }
+    float vGrad[H2_MAXDIM], vHess[H2_MAXDIM * H2_MAXDIM];
+    for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
+    for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
+    if (sp.ssScore > 1e-15f) {
+        float primary[2 * MAXD + 1];
+        StridedOut o{gw.buf + gw.slot, gw.stride, 0};
+        SerializePath(S, path, primary, o);
+        StridedIn vin{gw.buf + gw.slot, gw.stride};
+        float logLum;
+        PathFuncHessDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
+        st.gradCalls++;
+        bool finite = true;
+        for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);
+        for (int k = 0; k < dim * dim; k++) finite = finite && isfinite(vHess[k]);
+        if (!finite) {
+            for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
+            for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
+        }
+    }
+    float work[2 * H2_MAXDIM * H2_MAXDIM + 4 * H2_MAXDIM];
+    ComputeGaussianH2MC(param, dim, sp.ssScore, vGrad, vHess, g.mean, g.covL, g.invCov, g.logDet, work);
+    g.dense = true;
+}
+
+LMC_D void LoadDense(const ChainArrays &A, int i, int dim, DenseGauss &g) {
+    const size_t N = A.N;
+    const float *G = A.h2Gauss;
+    for (int k = 0; k < dim; k++) g.mean[k] = G[(size_t)k * N + i];
+    for (int k = 0; k < dim * dim; k++) {
+        g.covL[k] = G[(size_t)(H2_MAXDIM + k) * N + i];
+        g.invCov[k] = G[(size_t)(H2_MAXDIM + H2_MAXDIM * H2_MAXDIM + k) * N + i];
+    }
+    g.logDet = G[(size_t)(H2_GAUSS_WORDS - 1) * N + i];
+}
+LMC_D void StoreDense(const ChainArrays &A, int i, int dim, const DenseGauss &g) {
+    const size_t N = A.N;
+    float *G = A.h2Gauss;
+    for (int k = 0; k < dim; k++) G[(size_t)k * N + i] = g.mean[k];
+    for (int k = 0; k < dim * dim; k++) {
+        G[(size_t)(H2_MAXDIM + k) * N + i] = g.covL[k];
+        G[(size_t)(H2_MAXDIM + H2_MAXDIM * H2_MAXDIM + k) * N + i] = g.invCov[k];
+    }
+    G[(size_t)(H2_GAUSS_WORDS - 1) * N + i] = g.logDet;
+}
+
+template <class Stk>
+LMC_D void StepChainH2MC(const DScene &S, const ChainArrays &A, const Film &film, const StepParams &P, int i, Rng &rng, GradWork &gw, StepStats &st, Stk &stk) {
+    const size_t N = A.N;
+    int flags = A.flags[i];
+    const bool curValid = flags & F_VALID;
+    const Contrib cur = LoadContrib(A.curContrib, A.N, i);
+    DPath prop;
+    Contrib pc;
+    pc.camDepth = pc.lightDepth = 0;
+    pc.lsScore = pc.ssScore = 0.f;
+    pc.screenPos = V2{0.f, 0.f};
+    pc.contrib = V3{0.f, 0.f, 0.f};
+    float a = 1.0f;
+    st.steps++;
+    LoadPath(CurPathBuf(A, flags), A.N, i, prop);  // proposalState.path = currentState.path
+    const int dim = PathDimension(prop.camDepth, prop.lgtDepth);
+    float offset[MAXPSS];
+    const bool h2 = !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_h2mc.h:49-55
+    const H2MCParam param = MakeH2MCParam(S.opt.perturbStdDev);
+    DenseGauss cg, pg;
+    const bool useDense = dim <= H2_MAXDIM;  // longer states have no derivative program: isotropic, nothing stored
+    if (!h2) {  // SmallStep::Mutate, mutation_small.h:16-56
+        NormalDist nd(0.0f, S.opt.perturbStdDev);
+        for (int k = 0; k < dim; k++) offset[k] = nd(rng);
+    } else {
+        if (useDense) {
+            if (!(flags & F_GAUSS)) {
+                InitGaussianH2MC(S, P, param, prop, cur, cg, gw, st);
+                StoreDense(A, i, dim, cg);
+                flags |= F_GAUSS;
+            } else {
+                LoadDense(A, i, dim, cg);
+            }
+        }
+        NormalDist nd(0.0f, 1.0f);  // GenerateSample, gaussian.cpp:38-55
+        float z[MAXPSS];
+        for (int k = 0; k < dim; k++) z[k] = nd(rng);
+        if (useDense) DenseGaussianMap(dim, z, cg.mean, cg.covL, offset);
+        else
+            for (int k = 0; k < dim; k++) offset[k] = param.sigma * z[k] + 0.0f;
+    }
+    if (PerturbPathBidir(S, offset, prop, pc, rng, stk)) {
+        if (h2) {
+            float py, px;
+            if (useDense) {
+                InitGaussianH2MC(S, P, param, prop, pc, pg, gw, st);
+                py = DenseGaussianLogPdf(dim, offset, false, cg.mean, cg.invCov, cg.logDet);
+                px = DenseGaussianLogPdf(dim, offset, true, pg.mean, pg.invCov, pg.logDet);
+            } else {  // both isotropic with the same sigma: the dense form with a diagonal matrix, written out
+                const float inv = 1.0f / (param.sigma * param.sigma), logDet = dim * fastlog(inv);
+                float q = 0.f;
+                for (int k = 0; k < dim; k++) q += offset[k] * (inv * offset[k]);
+                py = dim * (-0.9189385332046727f);
+                py += 0.5f * logDet;
+                py -= 0.5f * q;
+                px = py;
+            }
+            a = Clampf(expf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+        } else {
+            a = Clampf(pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+        }
+    } else {
+        a = 0.0f;
+    }
+    // ---- splats, mlt.cpp:103-112 (both small-step flavours: contrib * (normalization / lsScore), mutation_h2mc.h:119-121)
+    if (curValid && a < 1.0f) {
+        const int n = A.curSplatCount[i];
+        for (int k = 0; k < n; k++) {
+            const float *p = A.curSplat + ((size_t)k * SPLAT_WORDS) * N + i;
+            Splat(film, V2{p[0], p[N]}, (1.0f - a) * V3{p[2 * N], p[3 * N], p[4 * N]});
+        }
+    }
+    const V3 smallSplat = pc.contrib * (P.normalization / pc.lsScore);
+    if (a > 0.0f) Splat(film, pc.screenPos, a * smallSplat);
+    st.wsum += curValid ? 1.0f : (a > 0.0f ? a : 0.0f);
+    // ---- accept / reject, mlt.cpp:113-170
+    const int sampleIdx = A.sampleIdx[i];
+    A.pushDim[i] = 0;
+    if (a > 0.0f && rng.Uniform() <= a) {
+        st.accepted++;
+        ToSubpath(pc.camDepth, pc.lightDepth, prop);
+        StorePath(PropPathBuf(A, flags), A.N, i, prop);
+        flags ^= F_SEL;
+        StoreContrib(A.curContrib, A.N, i, pc);
+        A.adjacentReject[i] = 0;
+        float *p = A.curSplat + i;
+        p[0] = pc.screenPos.x, p[N] = pc.screenPos.y, p[2 * N] = smallSplat.x, p[3 * N] = smallSplat.y, p[4 * N] = smallSplat.z;
+        A.curSplatCount[i] = 1;
+        if (h2) {  // std::swap(currentState, proposalState): the proposal's Gaussian is the current one now
+            if (useDense) StoreDense(A, i, dim, pg);
+            flags |= F_GAUSS;
+        } else {
+            flags &= ~F_GAUSS;  // mutation_small.h:39
+        }
+        flags |= F_VALID;
+    } else {
+        int rej = A.adjacentReject[i] + 1;  // REMOVE_OUTLIERS, mlt.cpp:147-169
+        A.adjacentReject[i] = rej;
+        const bool strongReject = cur.lsScore > OUTLIER_RATIO_THRESHOLD * P.normalization;
+        if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
+            int chainId = P.chainBegin + i, cnt = 0;
+            for (;;) {
+                const float ls = A.initContrib[7 * (size_t)P.numChains + chainId];
+                if (ls < OUTLIER_RATIO_THRESHOLD * P.normalization) break;
+                chainId = (int)(((long long)chainId + sampleIdx + cnt++) % P.numChains);
+            }
+            DPath ip;
+            LoadPath(A.initPath, P.numChains, chainId, ip);
+            StorePath(CurPathBuf(A, flags), A.N, i, ip);
+            StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, P.numChains, chainId));
+            A.scoreSum[i] = A.initScoreSum[chainId];
+            A.curSplatCount[i] = 0;
+            flags &= ~(F_VALID | F_GAUSS | F_BUFFERED);
+            st.resets++;
+        }
+    }
+    A.flags[i] = flags;
+    A.sampleIdx[i] = sampleIdx + 1;
+}
+
+}  // namespace lmcd

@@ -78,7 +78,7 @@ struct DCamera {
     float nearClip, farClip, dist;
 };
 struct DOptions {
-    int minDepth, maxDepth, mala;
+    int minDepth, maxDepth, mala, h2mc;
     float roughnessThreshold, largeStepProbability, largeStepProbScale;
     float malaGN, malaStepsize, malaStdDev, perturbStdDev, discreteStdDev, uniformMixingProbability;
     int seedOffset;

@@ -35,6 +35,12 @@ void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                           const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads,
                           hipStream_t s);
+// all small steps of an H2MC render (device/step_small_h2mc.hip)
+void LaunchStepSmallH2MC(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
+                         const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+// n gradient + Hessian evaluations of the (c,l) path program (the throughput form of the H2MC plugin symbols)
+void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, float *hessSoA,
+                     hipStream_t s);
 // id-ordered work lists of the next step from A.nextKind (coalescing: a wave's 64 list entries are (nearly) consecutive chains)
 // sortPlain: group the plain small steps of every 1024-chain tile by technique (QueueNext's key)
 void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, int sortPlain, hipStream_t s);

@@ -13,6 +13,15 @@
 #pragma once
 #include "dmath.h"
 
+// The per-vertex building blocks of the path program.  Inlined into the program for the value / gradient types; a translation
+// unit that instantiates the second-order (nested dual) type defines LMC_PF_OUTLINE first: one out-of-line copy per block keeps
+// the compile time of that instantiation to minutes (inlined at every call site it took 8 min per Hessian width).
+#if defined(LMC_PF_OUTLINE) && defined(__HIPCC__)
+#define LMC_PF __host__ __device__ inline __attribute__((noinline))
+#else
+#define LMC_PF LMC_HD
+#endif
+
 namespace lmcd {
 
 struct ContigIn {
@@ -26,72 +35,93 @@ struct StridedIn {
 };
 
 // ------------------------------------------------------------------------------------------ dual numbers
+// Forward-mode AD value: v + sum_i d[i] eps_i.  The scalar type S is float for gradients (Dual<N>) and itself a dual
+// number for second derivatives: DualS<1, Dual<N>> carries, next to value and gradient, the derivative of both along one
+// more direction, i.e. one row of the Hessian per evaluation (the reference's Hessian programs are built the same way:
+// one directional pass per row over the reverse sweep, chad.cpp:333-544).
+template <int N, class S = float>
+struct DualS {
+    S v;
+    S d[N];
+};
 template <int N>
-struct Dual {
-    float v;
-    float d[N];
+using Dual = DualS<N, float>;
+
+template <class T> struct Lift;  // constant -> T
+template <> struct Lift<float> { static LMC_HD float Of(float v) { return v; } };
+template <int N, class S> struct Lift<DualS<N, S>> {
+    static LMC_HD DualS<N, S> Of(float v) {
+        DualS<N, S> r;
+        r.v = Lift<S>::Of(v);
+        for (int i = 0; i < N; i++) r.d[i] = Lift<S>::Of(0.f);
+        return r;
+    }
 };
 template <int N>
 LMC_HD Dual<N> MakeDual(float v) {
-    Dual<N> r;
-    r.v = v;
-    for (int i = 0; i < N; i++) r.d[i] = 0.f;
-    return r;
+    return Lift<Dual<N>>::Of(v);
 }
-template <int N>
-LMC_HD Dual<N> Chain1(const Dual<N> &a, float v, float dv) {  // f(a) with f' = dv
-    Dual<N> r;
+LMC_HD float Val(float x) { return x; }
+template <int N, class S> LMC_HD float Val(const DualS<N, S> &x) { return Val(x.v); }
+
+#define LMC_DUAL_T template <int N, class S> LMC_HD DualS<N, S>
+LMC_DUAL_T Chain1(const DualS<N, S> &a, const S &v, const S &dv) {  // f(a) with f' = dv
+    DualS<N, S> r;
     r.v = v;
     for (int i = 0; i < N; i++) r.d[i] = dv * a.d[i];
     return r;
 }
-#define LMC_DUAL_T template <int N> LMC_HD Dual<N>
-LMC_DUAL_T operator+(const Dual<N> &a, const Dual<N> &b) {
-    Dual<N> r;
+LMC_DUAL_T operator+(const DualS<N, S> &a, const DualS<N, S> &b) {
+    DualS<N, S> r;
     r.v = a.v + b.v;
     for (int i = 0; i < N; i++) r.d[i] = a.d[i] + b.d[i];
     return r;
 }
-LMC_DUAL_T operator-(const Dual<N> &a, const Dual<N> &b) {
-    Dual<N> r;
+LMC_DUAL_T operator-(const DualS<N, S> &a, const DualS<N, S> &b) {
+    DualS<N, S> r;
     r.v = a.v - b.v;
     for (int i = 0; i < N; i++) r.d[i] = a.d[i] - b.d[i];
     return r;
 }
-LMC_DUAL_T operator*(const Dual<N> &a, const Dual<N> &b) {
-    Dual<N> r;
+LMC_DUAL_T operator*(const DualS<N, S> &a, const DualS<N, S> &b) {
+    DualS<N, S> r;
     r.v = a.v * b.v;
     for (int i = 0; i < N; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
     return r;
 }
-LMC_DUAL_T operator/(const Dual<N> &a, const Dual<N> &b) {
-    Dual<N> r;
-    float inv = 1.0f / b.v;
+LMC_DUAL_T operator/(const DualS<N, S> &a, const DualS<N, S> &b) {
+    DualS<N, S> r;
+    S inv = 1.0f / b.v;
     r.v = a.v * inv;
     for (int i = 0; i < N; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
     return r;
 }
-LMC_DUAL_T operator-(const Dual<N> &a) {
-    Dual<N> r;
+LMC_DUAL_T operator-(const DualS<N, S> &a) {
+    DualS<N, S> r;
     r.v = -a.v;
     for (int i = 0; i < N; i++) r.d[i] = -a.d[i];
     return r;
 }
-LMC_DUAL_T operator+(const Dual<N> &a, float b) { Dual<N> r = a; r.v += b; return r; }
-LMC_DUAL_T operator+(float b, const Dual<N> &a) { Dual<N> r = a; r.v += b; return r; }
-LMC_DUAL_T operator-(const Dual<N> &a, float b) { Dual<N> r = a; r.v -= b; return r; }
-LMC_DUAL_T operator-(float b, const Dual<N> &a) { Dual<N> r = -a; r.v += b; return r; }
-LMC_DUAL_T operator*(const Dual<N> &a, float b) { return Chain1(a, a.v * b, b); }
-LMC_DUAL_T operator*(float b, const Dual<N> &a) { return Chain1(a, a.v * b, b); }
-LMC_DUAL_T operator/(const Dual<N> &a, float b) { float inv = 1.0f / b; return Chain1(a, a.v * inv, inv); }
-LMC_DUAL_T operator/(float b, const Dual<N> &a) { float inv = 1.0f / a.v; return Chain1(a, b * inv, -b * inv * inv); }
-template <int N> LMC_HD bool operator<(const Dual<N> &a, float b) { return a.v < b; }
-template <int N> LMC_HD bool operator>(const Dual<N> &a, float b) { return a.v > b; }
-template <int N> LMC_HD bool operator<(const Dual<N> &a, const Dual<N> &b) { return a.v < b.v; }
-template <int N> LMC_HD bool operator>(const Dual<N> &a, const Dual<N> &b) { return a.v > b.v; }
+LMC_DUAL_T operator+(const DualS<N, S> &a, float b) { DualS<N, S> r = a; r.v = r.v + b; return r; }
+LMC_DUAL_T operator+(float b, const DualS<N, S> &a) { DualS<N, S> r = a; r.v = r.v + b; return r; }
+LMC_DUAL_T operator-(const DualS<N, S> &a, float b) { DualS<N, S> r = a; r.v = r.v - b; return r; }
+LMC_DUAL_T operator-(float b, const DualS<N, S> &a) { DualS<N, S> r = -a; r.v = r.v + b; return r; }
+LMC_DUAL_T operator*(const DualS<N, S> &a, float b) {
+    DualS<N, S> r;
+    r.v = a.v * b;
+    for (int i = 0; i < N; i++) r.d[i] = b * a.d[i];
+    return r;
+}
+LMC_DUAL_T operator*(float b, const DualS<N, S> &a) { return a * b; }
+LMC_DUAL_T operator/(const DualS<N, S> &a, float b) { float inv = 1.0f / b; return a * inv; }
+LMC_DUAL_T operator/(float b, const DualS<N, S> &a) { S inv = 1.0f / a.v; return Chain1(a, S(b * inv), S(-b * inv * inv)); }
+template <int N, class S> LMC_HD bool operator<(const DualS<N, S> &a, float b) { return Val(a) < b; }
+template <int N, class S> LMC_HD bool operator>(const DualS<N, S> &a, float b) { return Val(a) > b; }
+template <int N, class S> LMC_HD bool operator<(const DualS<N, S> &a, const DualS<N, S> &b) { return Val(a) < Val(b); }
+template <int N, class S> LMC_HD bool operator>(const DualS<N, S> &a, const DualS<N, S> &b) { return Val(a) > Val(b); }
 
 LMC_HD float Detach(float x) { return x; }
-template <int N> LMC_HD Dual<N> Detach(const Dual<N> &x) { return MakeDual<N>(x.v); }
+template <int N, class S> LMC_HD DualS<N, S> Detach(const DualS<N, S> &x) { return Lift<DualS<N, S>>::Of(Val(x)); }
 // chad's fabs / fmax are conditional expressions that pass their operand through (chad.h:1226-1244), and the code
 // chad generates for a passed-through node ASSIGNS its adjoint (`_accX = _accR`) instead of accumulating into it: every
 // contribution the reverse sweep had already gathered for X -- i.e. from the uses of X that come LATER in program order
@@ -100,8 +130,6 @@ template <int N> LMC_HD Dual<N> Detach(const Dual<N> &x) { return MakeDual<N>(x.
 // reproduce this in forward mode: the operand's later uses see a constant.
 template <class T> LMC_HD T FabsW(T &x);
 template <class T> LMC_HD T FmaxW(T &x, float b);
-LMC_HD float Val(float x) { return x; }
-template <int N> LMC_HD float Val(const Dual<N> &x) { return x.v; }
 
 LMC_HD float Sqrt(float x) { return sqrtf(x); }
 LMC_HD float Sin(float x) { return sinf(x); }
@@ -113,35 +141,50 @@ LMC_HD float Log(float x) { return logf(x); }
 LMC_HD float Exp(float x) { return expf(x); }
 LMC_HD float Fmax(float a, float b) { return fmaxf(a, b); }
 LMC_HD float Pow(float a, float e) { return powd(a, e); }
+LMC_HD float PowRaw(float a, float e) { return powf(a, e); }  // the derivative factor of Pow (chad.h:727 emits pow(x, e - 1))
 LMC_HD float ExpD(float x) { return expd(x); }
 LMC_HD float LogD(float x) { return logd(x); }
-LMC_DUAL_T Sqrt(const Dual<N> &a) { float s = sqrtf(a.v); return Chain1(a, s, 0.5f / s); }
-LMC_DUAL_T Sin(const Dual<N> &a) { return Chain1(a, sinf(a.v), cosf(a.v)); }
-LMC_DUAL_T Cos(const Dual<N> &a) { return Chain1(a, cosf(a.v), -sinf(a.v)); }
-LMC_DUAL_T Acos(const Dual<N> &a) { return Chain1(a, acosf(a.v), -1.0f / sqrtf(1.0f - a.v * a.v)); }
-LMC_DUAL_T Atan2(const Dual<N> &y, const Dual<N> &x) {
-    Dual<N> r;
-    r.v = atan2f(y.v, x.v);
-    float inv = 1.0f / (x.v * x.v + y.v * y.v);
+LMC_DUAL_T Sqrt(const DualS<N, S> &a) { S s = Sqrt(a.v); return Chain1(a, s, S(0.5f / s)); }
+LMC_DUAL_T Sin(const DualS<N, S> &a) { return Chain1(a, S(Sin(a.v)), S(Cos(a.v))); }
+LMC_DUAL_T Cos(const DualS<N, S> &a) { return Chain1(a, S(Cos(a.v)), S(-Sin(a.v))); }
+LMC_DUAL_T Acos(const DualS<N, S> &a) { return Chain1(a, S(Acos(a.v)), S(-1.0f / Sqrt(1.0f - a.v * a.v))); }
+LMC_DUAL_T Atan2(const DualS<N, S> &y, const DualS<N, S> &x) {
+    DualS<N, S> r;
+    r.v = Atan2(y.v, x.v);
+    S inv = 1.0f / (x.v * x.v + y.v * y.v);
     for (int i = 0; i < N; i++) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * inv;
     return r;
 }
-LMC_DUAL_T Fabs(const Dual<N> &a) { return a.v >= 0.f ? a : -a; }  // chad.h:1226-1234: x >= 0 ? x : -x
-LMC_DUAL_T Log(const Dual<N> &a) { return Chain1(a, logf(a.v), 1.0f / a.v); }
-LMC_DUAL_T Exp(const Dual<N> &a) { float e = expf(a.v); return Chain1(a, e, e); }
-LMC_DUAL_T Pow(const Dual<N> &a, float e) { return Chain1(a, powd(a.v, e), e * powf(a.v, e - 1.0f)); }  // chad.h:727, exponent constant
-LMC_DUAL_T ExpD(const Dual<N> &a) { float e = expd(a.v); return Chain1(a, e, e); }
-LMC_DUAL_T LogD(const Dual<N> &a) { return Chain1(a, logd(a.v), 1.0f / a.v); }
-LMC_DUAL_T Fmax(const Dual<N> &a, float b) { return a.v >= b ? a : MakeDual<N>(b); }  // chad.h:1236-1244: a >= b ? a : b
+LMC_DUAL_T Fabs(const DualS<N, S> &a) { return Val(a) >= 0.f ? a : -a; }  // chad.h:1226-1234: x >= 0 ? x : -x
+LMC_DUAL_T Log(const DualS<N, S> &a) { return Chain1(a, S(Log(a.v)), S(1.0f / a.v)); }
+LMC_DUAL_T Exp(const DualS<N, S> &a) { S e = Exp(a.v); return Chain1(a, e, e); }
+LMC_DUAL_T PowRaw(const DualS<N, S> &a, float e) { return Chain1(a, S(PowRaw(a.v, e)), S(e * PowRaw(a.v, e - 1.0f))); }
+LMC_DUAL_T Pow(const DualS<N, S> &a, float e) { return Chain1(a, S(Pow(a.v, e)), S(e * PowRaw(a.v, e - 1.0f))); }  // chad.h:727, exponent constant
+LMC_DUAL_T ExpD(const DualS<N, S> &a) { S e = ExpD(a.v); return Chain1(a, e, e); }
+LMC_DUAL_T LogD(const DualS<N, S> &a) { return Chain1(a, S(LogD(a.v)), S(1.0f / a.v)); }
+LMC_DUAL_T Fmax(const DualS<N, S> &a, float b) { return Val(a) >= b ? a : Lift<DualS<N, S>>::Of(b); }  // chad.h:1236-1244: a >= b ? a : b
 
+// Second order: the reference's Hessian programs are reverse over forward (chad.cpp:333-544: the kernel takes a direction d,
+// returns g = d . grad f by a forward sweep -- exact -- and h = the reverse-mode gradient of g, emitted by the same reverse
+// emitter with the same overwrite).  In the nested type DualS<1, Dual<N>> the outer level is that forward direction and the
+// inner Dual<N> plays the reverse sweep: the operand's later uses lose their INNER derivatives (at both outer levels) and
+// keep the outer one.  Gradient = outer derivative of the value, Hessian row = its inner gradient (PathFuncHessN).
+LMC_HD float DetachW(float x) { return x; }
+template <int N> LMC_HD Dual<N> DetachW(const Dual<N> &x) { return Lift<Dual<N>>::Of(x.v); }
+template <int N, int M> LMC_HD DualS<N, Dual<M>> DetachW(const DualS<N, Dual<M>> &x) {
+    DualS<N, Dual<M>> r;
+    r.v = Lift<Dual<M>>::Of(x.v.v);
+    for (int i = 0; i < N; i++) r.d[i] = Lift<Dual<M>>::Of(x.d[i].v);
+    return r;
+}
 template <class T> LMC_HD T FabsW(T &x) {
     T r = Fabs(x);
-    if (Val(x) >= 0.0f) x = Detach(x);
+    if (Val(x) >= 0.0f) x = DetachW(x);
     return r;
 }
 template <class T> LMC_HD T FmaxW(T &x, float b) {
     T r = Fmax(x, b);
-    if (Val(x) >= b) x = Detach(x);
+    if (Val(x) >= b) x = DetachW(x);
     return r;
 }
 
@@ -168,9 +211,6 @@ template <class T> LMC_HD V3T<T> CrossT(const V3T<T> &a, const V3T<T> &b) {
 }
 template <class T> LMC_HD T LumT(const V3T<T> &v) { return v.x * 0.212671f + v.y * 0.715160f + v.z * 0.072169f; }
 
-template <class T> struct Lift;  // constant -> T
-template <> struct Lift<float> { static LMC_HD float Of(float v) { return v; } };
-template <int N> struct Lift<Dual<N>> { static LMC_HD Dual<N> Of(float v) { return MakeDual<N>(v); } };
 template <class T> LMC_HD V3T<T> C3(float a, float b, float c) { return V3T<T>{Lift<T>::Of(a), Lift<T>::Of(b), Lift<T>::Of(c)}; }
 template <class T> LMC_HD T MISq(const T &p) { return p * p; }
 
@@ -236,7 +276,7 @@ LMC_HD void SamplePrimaryT(const SceneBlk &sc, const T &sx, const T &sy, V3T<T> 
 
 // trianglemesh.cpp:55-77 + IntersectTriangleMesh :367-473 (isStatic); consumes the 46-float shape slot
 template <class T, class In>
-LMC_HD void IntersectT(const In &b, int off, const V3T<T> &org, const V3T<T> &dir, PState<T> &ps, T &st0, T &st1) {
+LMC_PF void IntersectT(const In &b, int off, const V3T<T> &org, const V3T<T> &dir, PState<T> &ps, T &st0, T &st1) {
     // [type, isMoving, p0, e1, e2, n0, n1, n2, (same at t=1), noST, st0, st1, st2, invTotalArea]
     V3T<T> p0 = C3<T>(b[off + 2], b[off + 3], b[off + 4]), e1 = C3<T>(b[off + 5], b[off + 6], b[off + 7]), e2 = C3<T>(b[off + 8], b[off + 9], b[off + 10]);
     V3T<T> n0 = C3<T>(b[off + 11], b[off + 12], b[off + 13]), n1 = C3<T>(b[off + 14], b[off + 15], b[off + 16]), n2 = C3<T>(b[off + 17], b[off + 18], b[off + 19]);
@@ -263,7 +303,7 @@ LMC_HD void IntersectT(const In &b, int off, const V3T<T> &org, const V3T<T> &di
 
 // SampleDirect on a triangle, trianglemesh.cpp:291-305 with ADEpsilon = 1e-6
 template <class T, class In>
-LMC_HD void SampleShapeT(const In &b, int off, const T &r0, const T &r1, V3T<T> &pos, V3T<T> &nrm, float &pdf) {
+LMC_PF void SampleShapeT(const In &b, int off, const T &r0, const T &r1, V3T<T> &pos, V3T<T> &nrm, float &pdf) {
     V3T<T> p0 = C3<T>(b[off + 2], b[off + 3], b[off + 4]), e1 = C3<T>(b[off + 5], b[off + 6], b[off + 7]), e2 = C3<T>(b[off + 8], b[off + 9], b[off + 10]);
     V3T<T> n0 = C3<T>(b[off + 11], b[off + 12], b[off + 13]), n1 = C3<T>(b[off + 14], b[off + 15], b[off + 16]), n2 = C3<T>(b[off + 17], b[off + 18], b[off + 19]);
     T a = Sqrt((1.0f + 1e-6f) - r0);
@@ -388,7 +428,7 @@ LMC_HD void PhongTermsT(const In &b, int off, const T &alpha, const T &cosWi, co
 
 // EvaluateBSDF, bsdf.cpp:13-63.  Unknown types produce zeros like the generated else-branch.
 template <class T, class In>
-LMC_HD void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
+LMC_PF void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
                           T &pdf, T &revPdf) {
     const float type = b[off];
     if (type == (float)0 /*Lambertian*/) {  // lambertian.cpp:95-122
@@ -458,7 +498,7 @@ LMC_HD void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, 
 }
 // SampleBSDF, bsdf.cpp:65-171 (fixDiscrete = false)
 template <class T, class In>
-LMC_HD void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const T &r0, const T &r1, float uDiscrete,
+LMC_PF void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const T &r0, const T &r1, float uDiscrete,
                         V3T<T> &wo, V3T<T> &contrib, T &cosWo, T &pdf, T &revPdf) {
     const float type = b[off];
     if (type == (float)0) {  // lambertian.cpp:124-151
@@ -617,7 +657,7 @@ LMC_HD void EnvSampleDirectionT(const EnvBlk &e, const T &r0, const T &r1, V3T<T
 
 // SampleDirect dispatcher, light.cpp:12-138
 template <class T, class In>
-LMC_HD void SampleDirectT(const In &b, int off, const SceneBlk &sc, const V3T<T> &pos, const T &r0, const T &r1, V3T<T> &dirToLight, V3T<T> &lightContrib,
+LMC_PF void SampleDirectT(const In &b, int off, const SceneBlk &sc, const V3T<T> &pos, const T &r0, const T &r1, V3T<T> &dirToLight, V3T<T> &lightContrib,
                           T &cosAtLight, T &directPdf, T &emissionPdf) {
     const float type = b[off];
     if (type == 0.0f) {  // point, pointlight.cpp:20-31,74-93
@@ -659,7 +699,7 @@ LMC_HD void SampleDirectT(const In &b, int off, const SceneBlk &sc, const V3T<T>
 
 // Emission dispatcher, light.cpp:140-185
 template <class T, class In>
-LMC_HD void EmissionT(const In &b, int off, const SceneBlk &sc, const V3T<T> &dirToLight, const V3T<T> &normalOnLight, V3T<T> &emission, T &directPdf,
+LMC_PF void EmissionT(const In &b, int off, const SceneBlk &sc, const V3T<T> &dirToLight, const V3T<T> &normalOnLight, V3T<T> &emission, T &directPdf,
                       T &emissionPdf) {
     const float type = b[off];
     if (type == 1.0f) {  // arealight.cpp:157-174
@@ -705,7 +745,7 @@ LMC_HD void SampleConcentricDiscT(const T &p0, const T &p1, T &ox, T &oy) {  // 
 
 // Emit dispatcher, light.cpp:187-324
 template <class T, class In>
-LMC_HD void EmitT(const In &b, int off, const SceneBlk &sc, const T &p0, const T &p1, const T &d0, const T &d1, V3T<T> &org, V3T<T> &dir, V3T<T> &emission,
+LMC_PF void EmitT(const In &b, int off, const SceneBlk &sc, const T &p0, const T &p1, const T &d0, const T &d1, V3T<T> &org, V3T<T> &dir, V3T<T> &emission,
                   T &cosAtLight, T &emissionPdf, T &directPdf) {
     const float type = b[off];
     if (type == 0.0f) {  // pointlight.cpp:95-116
@@ -961,6 +1001,35 @@ LMC_HD void PathFuncGrad(int c, int l, const float *primary, const float *scene,
     if (dim <= 8) PathFuncGradN<8>(c, l, primary, scene, vp, logLum, grad);
     else if (dim <= 12) PathFuncGradN<12>(c, l, primary, scene, vp, logLum, grad);
     else PathFuncGradN<16>(c, l, primary, scene, vp, logLum, grad);
+}
+
+// evaluate_path_bidir_<c>_<l>_static_derv (H2MC library, pathlibbidir.so): gradient and Hessian of logLum with respect to
+// primary[1..2L]; row i of the Hessian at hess[i * 2L] (path.h:122-123, mutation_h2mc.h:76-79).  One pass per row with a
+// dual number whose scalar is itself a Dual<N> (value, gradient, and their derivative along direction i).
+template <int N, class In>
+LMC_HD void PathFuncHessN(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    typedef DualS<1, Dual<N>> T2;
+    for (int i = 0; i < dim && i < N; i++) {
+        T2 p[2 * 8 + 1];
+        p[0] = Lift<T2>::Of(primary[0]);
+        for (int k = 0; k < dim; k++) {
+            p[k + 1] = Lift<T2>::Of(primary[k + 1]);
+            if (k < N) p[k + 1].v.d[k] = 1.0f;
+            if (k == i) p[k + 1].d[0].v = 1.0f;
+        }
+        T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
+        if (i == 0 && logLum) *logLum = r.v.v;
+        if (grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
+        for (int k = 0; k < dim && k < N; k++) hess[i * dim + k] = r.d[0].d[k];
+    }
+}
+template <class In>
+LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    // two widths only: every instantiation of the nested-dual program costs about a minute of compile time
+    if (dim <= 8) PathFuncHessN<8>(c, l, primary, scene, vp, logLum, grad, hess);
+    else PathFuncHessN<16>(c, l, primary, scene, vp, logLum, grad, hess);
 }
 
 // The chain loop only differentiates states with dim <= PSS_MAX_LENGTH = 12 (mutation_mala.h:94-96): no Dual<16> copy of

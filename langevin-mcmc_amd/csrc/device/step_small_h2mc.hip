@@ -1,0 +1,60 @@
+// k_step_h2mc: every small step of an H2MC render (dh2step.h), and k_hess_batch, the batched form of the H2MC plugin symbols.
+// Both call ONE out-of-line copy of the second-order path program (PathFuncHessDevice); its building blocks are outlined too
+// (LMC_PF_OUTLINE, pathfunc.h): this translation unit compiles in about two minutes instead of twenty-five.
+#define LMC_PF_OUTLINE
+#include "dh2step.h"
+#include "step_kernel.h"
+
+using namespace lmcd;
+
+__global__ void __launch_bounds__(128) k_step_h2mc(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
+                                                  NextLists next, float *gradBuf, int gradStride) {
+    StepStats st;
+    const int total = *listCount;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
+        const int i = list[j];
+        Rng rng;
+        rng.state = A.rngState[i];
+        rng.tab = A.rngTab + (size_t)i * 64;
+        rng.ticks = 0;
+        GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
+        LocalStackT<true> stk;
+        StepChainH2MC(S, A, film, P, i, rng, gw, st, stk);
+        QueueNext(S, *cache, A, P, i, rng);
+        A.rngState[i] = rng.state;
+    }
+    __shared__ int sStats[9];
+    BlockReduceStats(st, A.counters, A.weightSum, sStats);
+}
+
+// lmc_hess_batch: value, gradient and Hessian (row i of item j at hessSoA[(i * dim + k) * n + j])
+__global__ void __launch_bounds__(64) k_hess_batch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum,
+                                                  float *gradSoA, float *hessSoA) {
+    __shared__ float sScene[38];
+    if (threadIdx.x < 38) sScene[threadIdx.x] = scene[threadIdx.x];
+    __syncthreads();
+    const int L = c + l - 1 > 2 ? c + l - 1 : 2;
+    const int dim = 2 * L;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float primary[2 * 8 + 1];
+        for (int k = 0; k < dim + 1; k++) primary[k] = primarySoA[(size_t)k * n + i];
+        StridedIn vin{vertSoA + i, (size_t)n};
+        float ll, g[16], h[256];
+        PathFuncHessDevice(c, l, primary, sScene, vin, &ll, g, h);
+        if (logLum) logLum[i] = ll;
+        if (gradSoA)
+            for (int k = 0; k < dim; k++) gradSoA[(size_t)k * n + i] = g[k];
+        for (int k = 0; k < dim * dim; k++) hessSoA[(size_t)k * n + i] = h[k];
+    }
+}
+
+
+void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, float *hessSoA,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_hess_batch, dim3((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096), dim3(64), 0, s, c, l, n, primarySoA, scene, vertSoA, logLum, gradSoA, hessSoA);
+}
+void LaunchStepSmallH2MC(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
+                         const NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_step_h2mc, dim3(gridBlocks * 2), dim3(128), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+}

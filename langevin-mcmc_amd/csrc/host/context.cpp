@@ -2,6 +2,7 @@
 // global-cache maintenance around the gfx950 kernels.  Host logic only -- every numeric result returned by this
 // library is produced by the HIP kernels in device/kernels.hip; there is no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -83,6 +84,8 @@ struct CacheDimHost {
 
 }  // namespace
 
+static int GetRcclDestroy(void *comm);  // RCCL is bound lazily (below)
+
 struct lmc_ctx {
     std::unique_ptr<lmc::Scene> scene;
     int device = 0;
@@ -109,18 +112,19 @@ struct lmc_ctx {
     int bvhDepth = 0;
     // film
     DevBuf<float> film, directFilm;
+    void *comm = nullptr;  // ncclComm_t of lmc_comm_init (multi-GPU: one process per GPU, chains sharded by id range)
     // chains
     int N = 0, numChainsTotal = 0, chainBegin = 0;
     ChainArrays A;
     DevBuf<uint64_t> rngState;
     DevBuf<uint32_t> rngTab;
-    DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
+    DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, gaussian1, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
         lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum;
     DevBuf<unsigned char> nextKind;
     DevBuf<int> flags, curSplatCount, adjacentReject, sampleIdx, numSamples, pushDim;
     DevBuf<unsigned long long> counters;
     DevBuf<double> weightSum;
-    DevBuf<float> gradBuf;
+    DevBuf<float> gradBuf, h2Gauss;
     int gradStride = 0, stepGrid = 0;
     // launch shape of the lean small-step kernel and the technique sort of its work list; LMC_LEAN_BLOCK / LMC_SORT_PLAIN
     // override them for A/B runs (profiles/)
@@ -155,6 +159,12 @@ struct lmc_ctx {
         for (auto *v : {&events, &eventPool})
             for (auto &ev : *v)
                 for (auto e : ev.e) (void)hipEventDestroy(e);
+        if (comm) {
+            try {
+                (void)GetRcclDestroy(comm);
+            } catch (...) {
+            }
+        }
         if (hostCounts) (void)hipHostFree(hostCounts);
         for (auto e : {forkEvent, joinEvent[0], joinEvent[1]})
             if (e) (void)hipEventDestroy(e);
@@ -288,13 +298,13 @@ static void UploadScene(lmc_ctx *c) {
 static void SyncOptions(lmc_ctx *c) {
     const lmc::DptOptions &o = c->scene->options;
     DOptions &d = c->S.opt;
-    d.minDepth = o.minDepth, d.maxDepth = o.maxDepth, d.mala = o.mala ? 1 : 0;
+    d.minDepth = o.minDepth, d.maxDepth = o.maxDepth, d.mala = o.mala ? 1 : 0, d.h2mc = o.h2mc ? 1 : 0;
     d.roughnessThreshold = o.roughnessThreshold, d.largeStepProbability = o.largeStepProbability, d.largeStepProbScale = o.largeStepProbScale;
     d.malaGN = o.malaGN, d.malaStepsize = o.malaStepsize, d.malaStdDev = o.malaStdDev, d.perturbStdDev = o.perturbStdDev;
     d.discreteStdDev = o.discreteStdDev, d.uniformMixingProbability = o.uniformMixingProbability, d.seedOffset = o.seedOffset;
     if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 12] on the MI355X back end");
-    if (o.largeStepMultiplexed || o.sampleFromGlobalCache || o.useLightCoordinateSampling || o.h2mc)
-        throw std::runtime_error("largestepmultiplexed / samplecache / uselightcoordinatesampling / h2mc are out of scope (SURVEY.md §8f)");
+    if (o.largeStepMultiplexed || o.sampleFromGlobalCache || o.useLightCoordinateSampling)
+        throw std::runtime_error("largestepmultiplexed / samplecache / uselightcoordinatesampling are out of scope (SURVEY.md §8f)");
 }
 
 static void UploadCacheStruct(lmc_ctx *c) {
@@ -359,6 +369,7 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     if (n == "largestepprob") o.largeStepProbability = (float)v;
     else if (n == "largestepscale") o.largeStepProbScale = (float)v;
     else if (n == "mala") o.mala = v != 0;
+    else if (n == "h2mc") o.h2mc = v != 0;
     else if (n == "uniformmixprob") o.uniformMixingProbability = (float)v;
     else if (n == "mala-stepsize") o.malaStepsize = (float)v;
     else if (n == "mala-gn") o.malaGN = (float)v;
@@ -503,7 +514,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     }
     // ---- chain arrays
     c->rngState.Alloc(N), c->rngTab.Alloc(N * 64, false);
-    c->curPath.Alloc(N * DPATH_WORDS), c->pathBuf1.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS);
+    c->curPath.Alloc(N * DPATH_WORDS), c->pathBuf1.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS), c->gaussian1.Alloc(N * GAUSS_WORDS);
     c->curSplat.Alloc(N * MAXCONTRIB * SPLAT_WORDS), c->curSplatCount.Alloc(N);
     c->chV1.Alloc(N * MAXPSS), c->chV2.Alloc(N * MAXPSS), c->chCurrNewV2.Alloc(N * MAXPSS), c->chPropNewV1.Alloc(N * MAXPSS),
         c->chPropNewV2.Alloc(N * MAXPSS), c->chPss.Alloc(N * MAXPSS), c->chLastPss.Alloc(N * MAXPSS);
@@ -513,7 +524,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     ChainArrays &A = c->A;
     A.N = (int)N;
     A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.pathBuf1 = c->pathBuf1.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
-    A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
+    A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.gaussian1 = c->gaussian1.p, A.h2Gauss = nullptr, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
     A.chV1 = c->chV1.p, A.chV2 = c->chV2.p, A.chCurrNewV2 = c->chCurrNewV2.p, A.chPropNewV1 = c->chPropNewV1.p, A.chPropNewV2 = c->chPropNewV2.p,
     A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
     A.pathWeight = c->pathWeight.p, A.lastScoreSum = c->lastScoreSum.p, A.lastScore = c->lastScore.p;
@@ -552,6 +563,11 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     UploadCacheStruct(c);
     c->allCachesReady = false;
     c->needGeneric = true;
+    if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
+        c->allCachesReady = true;
+        c->h2Gauss.Alloc(N * (size_t)(16 + 2 * 256 + 1), false);
+        c->A.h2Gauss = c->h2Gauss.p;
+    }
     for (int b = 0; b < 2; b++) {
         for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
         c->listCounts[b].Alloc(4);
@@ -650,7 +666,9 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
         // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
-        if (c->needGeneric)
+        if (c->needGeneric && c->S.opt.h2mc)
+            LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
+        else if (c->needGeneric)
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
@@ -784,6 +802,89 @@ int lmc_direct_read(lmc_ctx *c, float *rgb) {
     LMC_CATCH(-1)
 }
 
+// ---- multi-GPU: the one data-path collective of the LMC path is a sum of the per-GPU films.  RCCL is
+// bound at run time (dlopen) so that single-GPU users and the CPU-side tests do not need it.
+extern "C++" {
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, const void * /* ncclUniqueId by value: 128 bytes, passed in memory */, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct UniqueId {
+    char internal[128];
+};
+Rccl &GetRccl() {
+    static Rccl r;
+    if (r.h) return r;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+    }
+    if (!r.h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
+    r.GetUniqueId = (int (*)(void *))dlsym(r.h, "ncclGetUniqueId");
+    r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.h, "ncclAllReduce");
+    r.CommDestroy = (int (*)(void *))dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (const char *(*)(int))dlsym(r.h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !dlsym(r.h, "ncclCommInitRank") || !r.AllReduce) throw std::runtime_error("RCCL symbols missing");
+    return r;
+}
+// ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank): the id struct travels by value
+typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
+void RcclCheck(int rc, const char *what) {
+    if (rc != 0) {
+        Rccl &r = GetRccl();
+        throw std::runtime_error(std::string("RCCL error in ") + what + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+static int GetRcclDestroy(void *comm) { return GetRccl().CommDestroy ? GetRccl().CommDestroy(comm) : 0; }
+
+int lmc_comm_unique_id(unsigned char *out128) {
+    LMC_TRY
+    UniqueId id;
+    memset(&id, 0, sizeof(id));
+    RcclCheck(GetRccl().GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out128, id.internal, 128);
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_comm_init(lmc_ctx *c, int nranks, int rank, const unsigned char *id128) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (c->comm) throw std::runtime_error("lmc_comm_init: communicator already initialised");
+    UniqueId id;
+    memcpy(id.internal, id128, 128);
+    CommInitRankFn init = (CommInitRankFn)dlsym(GetRccl().h, "ncclCommInitRank");
+    RcclCheck(init(&c->comm, nranks, id, rank), "ncclCommInitRank");
+    return 0;
+    LMC_CATCH(-1)
+}
+
+int lmc_film_allreduce(lmc_ctx *c) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->comm) throw std::runtime_error("lmc_film_allreduce before lmc_comm_init");
+    // in place on the device film, on the stream the step kernels run on: ordered after the last splat, no host staging
+    RcclCheck(GetRccl().AllReduce(c->film.p, c->film.p, c->film.n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->stream), "ncclAllReduce(film)");
+    // the scalars that normalise the merged image: sum of splat weights (double) -- `normalization` itself is identical on
+    // every rank (each runs the same MLTInit), so it is not reduced
+    RcclCheck(GetRccl().AllReduce(c->weightSum.p, c->weightSum.p, 1, /*ncclFloat64*/ 8, 0, c->comm, c->stream), "ncclAllReduce(weightSum)");
+    return 0;
+    LMC_CATCH(-1)
+}
+
+void *lmc_film_device_ptr(lmc_ctx *c, long long *nFloats) {
+    if (nFloats) *nFloats = (long long)c->film.n;
+    return c->film.p;
+}
+
 int lmc_film_clear(lmc_ctx *c) {
     LMC_TRY
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), c->stream));
@@ -866,6 +967,27 @@ int lmc_grad_batch(int c, int l, int n, const float *primarySoA, const float *sc
     HIP_CHECK(hipDeviceSynchronize());
     if (loglum) HIP_CHECK(hipMemcpy(loglum, dLL.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (gradSoA) HIP_CHECK(hipMemcpy(gradSoA, dGrad.p, (size_t)2 * L * n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// gradient + Hessian batch (H2MC): hess_soa[(2L)^2 * n], entry (i,k) of item j at [(i * 2L + k) * n + j]
+int lmc_hess_batch(int c, int l, int n, const float *primarySoA, const float *scene38, const float *vertSoA, float *loglum, float *gradSoA, float *hessSoA) {
+    LMC_TRY
+    if (!(c >= 1 && l >= 0 && c + l >= 3 && c + l - 1 <= 8)) throw std::runtime_error("lmc_hess_batch: technique (c,l) out of range");
+    if (!hessSoA) throw std::runtime_error("lmc_hess_batch: null output");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) EnsureDevice(0);
+    else EnsureDevice(dev);
+    const int L = std::max(c + l - 1, 2), V = 238 + 59 * (c + l - 3), dim = 2 * L;
+    DevBuf<float> dPrim, dScene, dVert, dLL, dGrad, dHess;
+    dPrim.Upload(primarySoA, (size_t)(2 * L + 1) * n), dScene.Upload(scene38, 38), dVert.Upload(vertSoA, (size_t)V * n);
+    dLL.Alloc(n), dGrad.Alloc((size_t)dim * n), dHess.Alloc((size_t)dim * dim * n);
+    LaunchHessBatch(c, l, n, dPrim.p, dScene.p, dVert.p, dLL.p, dGrad.p, dHess.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (loglum) HIP_CHECK(hipMemcpy(loglum, dLL.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (gradSoA) HIP_CHECK(hipMemcpy(gradSoA, dGrad.p, (size_t)dim * n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hessSoA, dHess.p, (size_t)dim * dim * n * 4, hipMemcpyDeviceToHost));
     return 0;
     LMC_CATCH(-1)
 }
@@ -963,12 +1085,31 @@ static void PluginEval(int c, int l, const float *primary, const float *scene, c
     if (grad)
         for (int k = 0; k < 2 * L; k++) grad[k] = g[k];
 }
+static void PluginEvalHess(int c, int l, const float *primary, const float *scene, const float *vertParams, float *grad, float *hess) {
+    const int L = std::max(c + l - 1, 2), dim = 2 * L;
+    float ll = NAN, g[16], h[256];
+    for (int k = 0; k < 16; k++) g[k] = NAN;
+    for (int k = 0; k < 256; k++) h[k] = NAN;
+    int r = lmc_hess_batch(c, l, 1, primary, scene, vertParams, &ll, g, h);
+    if (r != 0) fprintf(stderr, "lmc: H2MC path program (%d,%d) failed: %s\n", c, l, g_err.c_str());
+    if (grad)
+        for (int k = 0; k < dim; k++) grad[k] = g[k];
+    if (hess)
+        for (int k = 0; k < dim * dim; k++) hess[k] = h[k];
+}
 #define LMC_PLUGIN(C, Lg)                                                                                                                          \
     void evaluate_path_bidir_mala_##C##_##Lg##_static(const float *, const float *primary, const float *scene, const float *vp, float *logLum) {   \
         PluginEval(C, Lg, primary, scene, vp, logLum, nullptr);                                                                                    \
     }                                                                                                                                              \
     void evaluate_path_bidir_mala_##C##_##Lg##_static_derv(const float *, const float *primary, const float *scene, const float *vp, float *grad) { \
         PluginEval(C, Lg, primary, scene, vp, nullptr, grad);                                                                                      \
+    }                                                                                                                                              \
+    /* H2MC library (pathlibbidir.so, chad.cpp:884-895; caller mutation_h2mc.h:74-79): same forward program, derivative with Hessian */          \
+    void evaluate_path_bidir_##C##_##Lg##_static(const float *, const float *primary, const float *scene, const float *vp, float *logLum) {        \
+        PluginEval(C, Lg, primary, scene, vp, logLum, nullptr);                                                                                    \
+    }                                                                                                                                              \
+    void evaluate_path_bidir_##C##_##Lg##_static_derv(const float *, const float *primary, const float *scene, const float *vp, float *grad, float *hess) { \
+        PluginEvalHess(C, Lg, primary, scene, vp, grad, hess);                                                                                     \
     }
 // (c,l) with 1<=c<=9, 0<=l<=8, 3<=c+l<=9 (path.cpp:3955-3959)
 LMC_PLUGIN(1, 2) LMC_PLUGIN(1, 3) LMC_PLUGIN(1, 4) LMC_PLUGIN(1, 5) LMC_PLUGIN(1, 6) LMC_PLUGIN(1, 7) LMC_PLUGIN(1, 8)

@@ -386,7 +386,13 @@ Image3f ReadImage(const std::string &fn, bool *is8bit) {
     if (is8bit) *is8bit = false;
     if (ext == ".exr") return ReadEXR(fn);
     if (ext == ".png") return ReadPNG(fn, is8bit);
-    throw std::runtime_error("Unsupported image format (EXR and PNG are implemented; JPEG is SURVEY.md §8f): " + fn);
+    std::string ext5 = fn.size() >= 5 ? fn.substr(fn.size() - 5) : "";
+    std::transform(ext5.begin(), ext5.end(), ext5.begin(), ::tolower);
+    if (ext == ".jpg" || ext5 == ".jpeg") {
+        if (is8bit) *is8bit = true;  // 8-bit file: gamma 2.2 in the texture lookup (bitmaptexture.h:135-144)
+        return ReadJPEG(fn);
+    }
+    throw std::runtime_error("Unsupported image format (EXR, PNG and JPEG are implemented): " + fn);
 }
 
 }  // namespace lmc

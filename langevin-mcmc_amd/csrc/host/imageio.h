@@ -1,4 +1,4 @@
-// Minimal EXR / PNG I/O for the drop-in front end (see imageio.cpp).
+// Minimal EXR / PNG / JPEG I/O for the drop-in front end (see imageio.cpp).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -17,6 +17,7 @@ uint16_t FloatToHalf(float f);
 Image3f ReadEXR(const std::string &fn);
 void WriteEXRHalf(const std::string &fn, const float *rgb, int W, int H);
 Image3f ReadPNG(const std::string &fn, bool *is8bit = nullptr);
+Image3f ReadJPEG(const std::string &fn);  // jpeg.cpp: baseline + progressive, libjpeg-compatible reconstruction
 Image3f ReadImage(const std::string &fn, bool *is8bit = nullptr);
 
 }  // namespace lmc

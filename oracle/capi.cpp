@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "mlt.h"
+#include "../langevin-mcmc_amd/csrc/device/dh2mc.h"
 
 using namespace orc;
 
@@ -63,6 +64,7 @@ int orc_set_option(void *h, const char *name, double v) {
     if (n == "largestepprob") o.largeStepProbability = (float)v;
     else if (n == "largestepscale") o.largeStepProbScale = (float)v;
     else if (n == "mala") o.mala = v != 0;
+    else if (n == "h2mc") o.h2mc = v != 0;
     else if (n == "uniformmixprob") o.uniformMixingProbability = (float)v;
     else if (n == "mala-stepsize") o.malaStepsize = (float)v;
     else if (n == "mala-gn") o.malaGN = (float)v;
@@ -291,6 +293,14 @@ void orc_compute_gaussian(int dim, const float *v1, const float *M, float ss, fl
     for (int i = 0; i < dim; i++) out[i] = g.mean[i], out[dim + i] = g.covL_d[i], out[2 * dim + i] = g.invCov_d[i];
     out[3 * dim] = g.logDet;
     out[3 * dim + 1] = GaussianLogPdf(off, g, false);
+}
+
+// H2MC Gaussian of one state (h2mc.cpp:70-142 through the shared header device/dh2mc.h): out = mean[dim], covL[dim*dim],
+// invCov[dim*dim], logDet
+void orc_h2mc_gaussian(int dim, float sigma, float sc, const float *grad, const float *hess, float *out) {
+    lmcd::H2MCParam p = lmcd::MakeH2MCParam(sigma);
+    std::vector<float> work((size_t)2 * dim * dim + 4 * dim);
+    lmcd::ComputeGaussianH2MC(p, dim, sc, grad, hess, out, out + dim, out + dim + dim * dim, out[dim + 2 * dim * dim], work.data());
 }
 
 // ---- CPU baseline (bench.py): the chain loop on `threads` host threads, chains handed out in contiguous

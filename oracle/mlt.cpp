@@ -8,6 +8,7 @@
 // cache pushes of a step after the step, in chain-id order -- one legal interleaving of the reference,
 // made deterministic; it is the contract the HIP back end is compared against.
 #include "mlt.h"
+#include "../langevin-mcmc_amd/csrc/device/dh2mc.h"  // H2MC Gaussian + Jacobi eigen-solver, shared with the device (see the header)
 
 #include <dlfcn.h>
 
@@ -19,6 +20,7 @@ namespace orc {
 // ============================================================================================ gaussian.cpp
 void IsotropicGaussian(const int dim, const Float sigma, Gaussian &gaussian) {  // gaussian.cpp:4-22
     gaussian.isDiagonal = false;
+    gaussian.dense = false;  // the dense matrices the reference fills here are diagonal: the diagonal arithmetic below is the same
     gaussian.mean.assign(dim, Float(0.0));
     gaussian.covL_d.assign(dim, sigma);
     gaussian.invCov_d.assign(dim, Float(1.0) / (sigma * sigma));
@@ -27,6 +29,7 @@ void IsotropicGaussian(const int dim, const Float sigma, Gaussian &gaussian) {  
 
 Float GaussianLogPdf(const std::vector<Float> &offset, const Gaussian &gaussian, bool negate) {  // gaussian.cpp:24-36
     const int dim = (int)gaussian.mean.size();
+    if (gaussian.dense) return lmcd::DenseGaussianLogPdf(dim, offset.data(), negate, gaussian.mean.data(), gaussian.invCov.data(), gaussian.logDet);
     Float logPdf = dim * (-Float(0.9189385332046727));
     logPdf += Float(0.5) * gaussian.logDet;
     // d^T (invCov d); Eigen's reduction order is unpinned -- summed left to right here.
@@ -42,6 +45,11 @@ Float GaussianLogPdf(const std::vector<Float> &offset, const Gaussian &gaussian,
 void GenerateSample(Gaussian &gaussian, std::vector<Float> &x, RNG &rng) {  // gaussian.cpp:38-55
     std::normal_distribution<Float> normDist(Float(0.0), Float(1.0));
     for (size_t i = 0; i < x.size(); i++) x[i] = normDist(rng);
+    if (gaussian.dense) {
+        std::vector<Float> z(x);
+        lmcd::DenseGaussianMap((int)x.size(), z.data(), gaussian.mean.data(), gaussian.covL.data(), x.data());
+        return;
+    }
     for (size_t i = 0; i < x.size(); i++) x[i] = gaussian.covL_d[i] * x[i] + gaussian.mean[i];
 }
 
@@ -361,6 +369,8 @@ bool PathFuncLib::Load(const char *soPath, int maxDepth_) {  // path.cpp:4021-40
                 funcMap[{c, l}] = (PathFunc)f;
                 dervMap[{c, l}] = (PathFuncDerv)d;
             }
+            snprintf(name, sizeof(name), "evaluate_path_bidir_%d_%d_static_derv", c, l);
+            if (void *h2 = dlsym(handle, name)) hessMap[{c, l}] = (PathFuncDerv)h2;
         }
     return true;
 }
@@ -672,6 +682,68 @@ Float MLT::MALAMutate(ChainCtx &c) {  // mutation_mala.h:35-278
     return a;
 }
 
+Float MLT::H2MCMutate(ChainCtx &c) {  // mutation_h2mc.h:38-128
+    const RScene *sc = scene.get();
+    MarkovState &currentState = c.currentState, &proposalState = c.proposalState;
+    std::uniform_real_distribution<Float> uniDist(Float(0.0), Float(1.0));
+    if (uniDist(c.rng) < sc->options->uniformMixingProbability) {
+        Float a = SmallStepMutate(c);
+        c.lastSmallType = MutationType::Small;
+        return a;
+    }
+    std::vector<SubpathContrib> spContribs;
+    Float a = Float(1.0);
+    c.lastSmallType = MutationType::H2MCSmall;
+    const int dim = GetDimension(currentState.path);
+    const lmcd::H2MCParam param = lmcd::MakeH2MCParam(sc->options->perturbStdDev);  // H2MCSmallStep(scene, maxDervDepth, perturbStdDev), mlt.cpp:76-79
+    auto initGaussian = [&](MarkovState &state) {
+        const SubpathContrib &csp = state.spContrib;
+        auto funcIt = lib.hessMap.find({csp.camDepth, csp.lightDepth});
+        const int d = GetDimension(state.path);
+        if (funcIt != lib.hessMap.end()) {
+            std::vector<Float> vGrad(d, Float(0.0)), vHess((size_t)d * d, Float(0.0));
+            if (csp.ssScore > Float(1e-15)) {
+                SerializedSubpath ssubPath;
+                ssubPath.primary.assign(GetPrimaryParamSize(lib.maxDepth, lib.maxDepth), Float(0.0));
+                ssubPath.vertParams.assign(GetVertParamSize(lib.maxDepth, lib.maxDepth), Float(0.0));
+                Serialize(sc, state.path, ssubPath);
+                funcIt->second(&csp.screenPos[0], &ssubPath.primary[0], sc->sceneParams, &ssubPath.vertParams[0], &vGrad[0], &vHess[0]);
+                c.st->gradCalls++;
+                if (!IsFiniteVec(vGrad) || !IsFiniteVec(vHess)) {
+                    std::fill(vGrad.begin(), vGrad.end(), Float(0.0));
+                    std::fill(vHess.begin(), vHess.end(), Float(0.0));
+                }
+            }
+            Gaussian &g = state.gaussian;
+            g.dense = true, g.isDiagonal = false;
+            g.mean.assign(d, 0.f), g.covL.assign((size_t)d * d, 0.f), g.invCov.assign((size_t)d * d, 0.f);
+            std::vector<Float> work((size_t)2 * d * d + 4 * d);
+            lmcd::ComputeGaussianH2MC(param, d, csp.ssScore, vGrad.data(), vHess.data(), g.mean.data(), g.covL.data(), g.invCov.data(), g.logDet, work.data());
+        } else {
+            IsotropicGaussian(d, param.sigma, state.gaussian);
+        }
+        state.gaussianInitialized = true;
+    };
+    if (!currentState.gaussianInitialized) initGaussian(currentState);
+    std::vector<Float> offset(dim);
+    GenerateSample(currentState.gaussian, offset, c.rng);
+    proposalState.path = currentState.path;
+    PerturbPathBidir(sc, offset, proposalState.path, spContribs, c.rng);
+    if (spContribs.size() > 0) {
+        proposalState.spContrib = spContribs[0];
+        initGaussian(proposalState);
+        Float py = GaussianLogPdf(offset, currentState.gaussian, false);
+        Float px = GaussianLogPdf(offset, proposalState.gaussian, true);
+        a = Clamp(std::exp(px - py) * proposalState.spContrib.ssScore / currentState.spContrib.ssScore, Float(0.0), Float(1.0));
+        proposalState.toSplat.clear();
+        for (const auto &spContrib : spContribs)
+            proposalState.toSplat.push_back(SplatSample{spContrib.screenPos, spContrib.contrib * (normalization / spContrib.lsScore)});
+    } else {
+        a = Float(0.0);
+    }
+    return a;
+}
+
 // mutation.h:5-8
 #define OUTLIER_WEAK_REJECT_CNT 10000
 #define OUTLIER_STRONG_REJECT_CNT 1000
@@ -693,8 +765,9 @@ void MLT::StepChain(ChainCtx &c, std::vector<PendingPush> &pushes) {  // body of
         a = LargeStepMutate(c);
         c.st->largeSteps++;
     } else {
-        a = sc->options->mala ? MALAMutate(c) : SmallStepMutate(c);
-        if (!sc->options->mala) c.lastSmallType = MutationType::Small;
+        // mlt.cpp:74-85: H2MC takes precedence over LMC, plain isotropic steps otherwise
+        a = sc->options->h2mc ? H2MCMutate(c) : sc->options->mala ? MALAMutate(c) : SmallStepMutate(c);
+        if (!sc->options->h2mc && !sc->options->mala) c.lastSmallType = MutationType::Small;
     }
     c.st->steps++;
     c.st->weightSum += currentState.valid ? 1.0 : (a > Float(0.0) ? (double)a : 0.0);

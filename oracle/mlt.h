@@ -14,6 +14,9 @@ struct Gaussian {
     std::vector<Float> mean, covL_d, invCov_d;
     Float logDet = 0;
     bool isDiagonal = false;
+    // H2MC (h2mc.cpp): dense covL / invCov, row-major dim x dim; `dense` selects them in GaussianLogPdf / GenerateSample
+    bool dense = false;
+    std::vector<Float> covL, invCov;
 };
 void IsotropicGaussian(const int dim, const Float sigma, Gaussian &gaussian);
 Float GaussianLogPdf(const std::vector<Float> &offset, const Gaussian &gaussian, bool negate);
@@ -105,6 +108,7 @@ struct PathFuncLib {
     void *handle = nullptr;
     std::map<std::pair<int, int>, PathFunc> funcMap;
     std::map<std::pair<int, int>, PathFuncDerv> dervMap;
+    std::map<std::pair<int, int>, PathFuncDerv> hessMap;  // H2MC library (pathlibbidir.so): evaluate_path_bidir_<c>_<l>_static_derv(..., grad, hess)
     int maxDepth = 8;
     bool Load(const char *soPath, int maxDepth);
 };
@@ -156,6 +160,7 @@ struct MLT {
     Float LargeStepMutate(ChainCtx &c);
     Float SmallStepMutate(ChainCtx &c);
     Float MALAMutate(ChainCtx &c);
+    Float H2MCMutate(ChainCtx &c);  // mutation_h2mc.h:38-128
     void InitGaussianFor(ChainCtx &c, MarkovState &state, bool isProposal);
     void Splat(std::vector<Float> &film, const Vector2 screenPos, const Vector3 &contrib);
 };

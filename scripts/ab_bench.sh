@@ -5,7 +5,7 @@ OUT=$1; : > "$OUT"
 STEPS=${2:-64}; WARM=${3:-40}
 run() {
   echo "== $*" >&2
-  env "$@" python bench.py --no-cpu-baseline --steps $STEPS --warmup $WARM 2>/dev/null | tail -1 | python -c "
+  env "$@" timeout 240 python bench.py --no-cpu-baseline --steps $STEPS --warmup $WARM 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({'variant': '$*', 'steps': $STEPS, 'warmup': $WARM, 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'k_step_small_ms': d['step_ms']['k_step_small'], 'large_ms': d['step_ms']['large_and_generic'], 'roofline_frac': d['roofline']['frac'], 'accept_rate': d['accept_rate']}))" | tee -a "$OUT"

@@ -15,13 +15,13 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ SQ_INSTS_BRANCH" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python "$REPO/bench.py" --no-cpu-baseline --steps 32 --warmup 40 "$@" > "$OUT/pass$i.log" 2>&1
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python "$REPO/bench.py" --no-cpu-baseline --steps 32 --warmup 40 "$@" > "$OUT/pass$i.log" 2>&1
 done
 python "$REPO/scripts/pmc_summary.py" "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"
 # counter calibration on a known byte count (1 GiB read + 1 GiB written per launch, dword-per-lane pattern)
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/calib_$grp" -- python -c "
+  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/calib_$grp" -- python -c "
 import importlib,sys
 sys.path.insert(0,'$REPO')
 p=importlib.import_module('langevin-mcmc_amd')

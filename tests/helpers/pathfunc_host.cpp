@@ -13,6 +13,11 @@ extern "C" void lmc_test_pathfunc_host(int c, int l, const float *primary, const
     }
 }
 
+extern "C" void lmc_test_pathfunc_hess_host(int c, int l, const float *primary, const float *scene, const float *vert, float *logLum, float *grad, float *hess) {
+    lmcd::ContigIn in{vert};
+    lmcd::PathFuncHess(c, l, primary, scene, in, logLum, grad, hess);
+}
+
 // The reference's plugin symbol names over the same host instantiation: lets the CPU oracle (test infrastructure) take
 // its gradients from the product's path program instead of the reference's generated code.
 #define LMC_HOST_PLUGIN(C, Lg)                                                                                                                      \
@@ -21,6 +26,10 @@ extern "C" void lmc_test_pathfunc_host(int c, int l, const float *primary, const
     }                                                                                                                                               \
     extern "C" void evaluate_path_bidir_mala_##C##_##Lg##_static_derv(const float *, const float *primary, const float *scene, const float *vp, float *g) { \
         lmc_test_pathfunc_host(C, Lg, primary, scene, vp, nullptr, g);                                                                              \
+    }                                                                                                                                               \
+    extern "C" void evaluate_path_bidir_##C##_##Lg##_static_derv(const float *, const float *primary, const float *scene, const float *vp, float *g, float *h) { \
+        float ll;                                                                                                                                   \
+        lmc_test_pathfunc_hess_host(C, Lg, primary, scene, vp, &ll, g, h);                                                                          \
     }
 LMC_HOST_PLUGIN(1, 2) LMC_HOST_PLUGIN(1, 3) LMC_HOST_PLUGIN(1, 4) LMC_HOST_PLUGIN(1, 5) LMC_HOST_PLUGIN(1, 6) LMC_HOST_PLUGIN(1, 7) LMC_HOST_PLUGIN(1, 8)
 LMC_HOST_PLUGIN(2, 1) LMC_HOST_PLUGIN(2, 2) LMC_HOST_PLUGIN(2, 3) LMC_HOST_PLUGIN(2, 4) LMC_HOST_PLUGIN(2, 5) LMC_HOST_PLUGIN(2, 6) LMC_HOST_PLUGIN(2, 7)

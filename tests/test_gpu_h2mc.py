@@ -1,0 +1,127 @@
+"""`-m gpu` tier, H2MC (BASELINE.json configs[4]): the second-order path program on the device against the reference's generated
+gradient + Hessian programs, the H2MC chain loop against the CPU oracle, and the end-to-end image of the shipped veach-door
+h2mc.xml against the render the reference ships."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc
+from tests import gpu_checks as gc
+from tests._orc import P
+
+pytestmark = pytest.mark.gpu
+DOOR_H2 = os.path.join(gc.ROOT, "scenes", "veachdoor", "h2mc.xml")
+
+
+@pytest.fixture(scope="module")
+def L():
+    return gc.oracle_lib()
+
+
+def _hess_batch(c, l, prim, sp, vert):
+    lib = gc.pkg().lib()
+    lib.lmc_hess_batch.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+    n = len(prim)
+    dim = 2 * max(c + l - 1, 2)
+    ps, vs = np.ascontiguousarray(prim.T, np.float32), np.ascontiguousarray(vert.T, np.float32)
+    ll, g, h = np.zeros(n, np.float32), np.zeros((dim, n), np.float32), np.zeros((dim * dim, n), np.float32)
+    r = lib.lmc_hess_batch(c, l, n, P(ps), P(sp), P(vs), P(ll), P(g), P(h))
+    assert r == 0, lib.lmc_last_error()
+    return ll, g.T.copy(), h.T.reshape(n, dim, dim).copy()
+
+
+def test_hessian_kernel_matches_reference_programs(L):
+    """lmc_hess_batch (HIP) vs evaluate_path_bidir_<c>_<l>_static_derv of the reference (oracle/_ref) on Lambertian states of the
+    torus: gradient and Hessian within 1e-2 relative for every state; plus the dlsym'd plugin symbol on single paths."""
+    if not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    ref = ctypes.CDLL(gc.pathref())
+    if not hasattr(ref, "evaluate_path_bidir_3_1_static_derv"):
+        pytest.skip("oracle/_ref built without the H2MC programs")
+    orc = _orc.Oracle(L, gc.TORUS, 1, 6, 160, 120, 0, gc.pathref())
+    orc.init(30000, 512, 8)
+    sp = orc.scene_params()
+    inp = gc.collect_grad_inputs(orc, 512)
+    lens = np.zeros(2, np.float32)
+    lib = gc.pkg().lib()
+    checked = 0
+    for (c, l), (prim, vert) in sorted(inp.items()):
+        if c + l > 7:
+            continue
+        dim = 2 * max(c + l - 1, 2)
+        ll, g, h = _hess_batch(c, l, prim, sp, vert)
+        f = getattr(ref, "evaluate_path_bidir_%d_%d_static_derv" % (c, l))
+        for i in range(min(len(prim), 64)):
+            g1, h1 = np.zeros(16, np.float32), np.zeros(256, np.float32)
+            f(P(lens), P(prim[i]), P(sp), P(vert[i]), P(g1), P(h1))
+            H1 = h1[: dim * dim].reshape(dim, dim)
+            if not (np.isfinite(H1).all() and np.isfinite(g1).all()):
+                continue
+            assert np.linalg.norm(g1[:dim] - g[i]) <= 1e-2 * max(np.linalg.norm(g1[:dim]), 1e-2), (c, l, i)
+            assert np.linalg.norm(H1 - h[i]) <= 1e-2 * max(np.linalg.norm(H1), 1e-1), (c, l, i)
+            checked += 1
+        # the plugin symbol the reference would dlsym from pathlibbidir.so: 6 pointer arguments, one path per call
+        d = getattr(lib, "evaluate_path_bidir_%d_%d_static_derv" % (c, l))
+        g2, h2 = np.zeros(16, np.float32), np.zeros(256, np.float32)
+        d(P(lens), P(prim[0]), P(sp), P(vert[0]), P(g2), P(h2))
+        assert np.allclose(g2[:dim], g[0], rtol=1e-5, atol=1e-6) and np.allclose(h2[: dim * dim].reshape(dim, dim), h[0], rtol=1e-5, atol=1e-5)
+    orc.close()
+    assert checked > 150
+
+
+def test_h2mc_chain_parity_diffuse():
+    """MLTInit + 30 lock-step H2MC mutations of 256 chains, Lambertian torus: same PCG streams, same Jacobi solver on both sides.
+    The Hessian is ill-conditioned input to an eigen-solve, so a last-bit difference of the device libm can move an acceptance
+    test: 1 % on the accept count, film 5 %."""
+    r = gc.run_pair(160, 120, 40000, 256, 8, 400, 30, use_gradient=1, opts={"h2mc": 1, "largestepprob": 0.2, "perturbstddev": 0.01}, oracle_grad="product")
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["init_cl_match"] == 1.0
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == 256 * 30
+    assert sg["largeSteps"] == so["largeSteps"] or abs(sg["largeSteps"] - so["largeSteps"]) <= 2
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"] + 2
+    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * so["gradCalls"] + 2 and sg["gradCalls"] > 256 * 10
+    assert r["film_rel_l2"] < 0.05
+    assert r["final_state_match"] > 0.95
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+
+
+def test_h2mc_chain_parity_full_materials():
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 30, use_gradient=1, max_depth=8, force_diffuse=0,
+                    opts={"h2mc": 1, "largestepprob": 0.2, "perturbstddev": 0.01}, oracle_grad="product")
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == 256 * 30
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.03 * so["accepted"]
+    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.03 * so["gradCalls"]
+    assert r["film_rel_l2"] < 0.25
+    assert r["final_state_match"] > 0.9
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+
+
+def test_h2mc_door_render_matches_reference_image():
+    """scenes/veachdoor/h2mc.xml as shipped (largestepprob 0.2, sigma 0.01) at 320x180 with 4096 chains x 450 mutations (32 spp, half
+    the shipped budget: every mutation costs two Hessians) against the reference authors' H2MC render: image mean 5 %, 3x4 region
+    grid 20 %.  (H2MC chains mix faster than
+    LMC ones; the door scene has no strongly peaked glass transport in most regions.)"""
+    p = gc.pkg()
+    ref = np.load(os.path.join(gc.ROOT, "tests", "golden", "veachdoor_ref_images_320x180.npz"))["h2mc"]
+    lum = lambda x: x @ np.array([0.212671, 0.715160, 0.072169])
+    lr = lum(ref)
+    W, H, dspp, spp, chains = 320, 180, 32, 32, 4096
+    ren = p.Renderer(DOOR_H2, width=W, height=H, seed_offset=0)
+    assert ren.get_option("h2mc") == 1
+    direct = ren.direct_lighting(dspp)
+    per = spp * W * H // chains
+    ren.init_chains(300000, chains, 8192, per, per % chains)
+    ren.step(per + 1)
+    lg = lum(direct / dspp + ren.film() / spp)
+    st = ren.stats()
+    ren.close()
+    assert st["gradCalls"] > 0.5 * st["steps"]
+    assert np.isfinite(lg).all()
+    assert abs(lg.mean() / lr.mean() - 1) < 0.05
+    for gy in range(3):
+        for gx in range(4):
+            a, b = lg[gy * 60:(gy + 1) * 60, gx * 80:(gx + 1) * 80].mean(), lr[gy * 60:(gy + 1) * 60, gx * 80:(gx + 1) * 80].mean()
+            assert abs(a / b - 1) < 0.20, (gy, gx, a / b)

@@ -395,6 +395,27 @@ def test_sharded_chains_match_unsharded():
     assert np.allclose(films[0], films[1], rtol=1e-4, atol=1e-7)
 
 
+def test_film_allreduce_in_library_single_rank():
+    """The multi-GPU collective of the path through the C ABI: RCCL communicator from a 128-byte id, in-place
+    all-reduce of the device film on the step stream.  One GPU here, so the communicator has one rank and the sum is the
+    identity; the N-rank arithmetic (chain ranges, film sum) is covered by tests/test_dist_gloo.py on CPU."""
+    p = gc.pkg()
+    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=96, height=72, seed_offset=0, use_gradient=0)
+    ren.init_chains(20000, 256, 4, 100)
+    ren.step(10)
+    before = ren.film()
+    w0 = ren.stats()["weightSum"]
+    ren.comm_init(1, 0, p.comm_unique_id())
+    ren.film_allreduce()
+    after = ren.film()
+    assert before.sum() > 0 and np.array_equal(before, after)
+    assert ren.stats()["weightSum"] == w0
+    n = ctypes.c_longlong()
+    ptr = p.lib().lmc_film_device_ptr(ren.h, ctypes.byref(n))
+    assert ptr and n.value == 96 * 72 * 3
+    ren.close()
+
+
 def test_bad_inputs_fail_cleanly():
     p = gc.pkg()
     with pytest.raises(RuntimeError):

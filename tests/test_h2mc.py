@@ -1,0 +1,125 @@
+"""CPU tier, H2MC (BASELINE.json configs[4]; /root/reference/src/mutation_h2mc.h, h2mc.cpp): the second-order path program
+against the reference's own generated gradient + Hessian programs, the eigen-solve / Gaussian construction against numpy, and
+the oracle's H2MC render against the image the reference ships."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc
+from tests import gpu_checks as gc
+from tests._orc import P
+
+H2XML = os.path.join(gc.ROOT, "scenes", "torus", "h2mc.xml")
+
+
+@pytest.fixture(scope="module")
+def L():
+    return gc.oracle_lib()
+
+
+def test_h2mc_gaussian_against_numpy(L):
+    """ComputeGaussian(H2MCParam, ...) (h2mc.cpp:3-142): the Jacobi eigen-solver stands in for Eigen's; everything the
+    mutation uses is invariant to the eigenvector convention and is compared with a float64 numpy.linalg.eigh recomputation:
+    invCov, mean, covL covL^T (= the covariance the samples have), logDet."""
+    rng = np.random.default_rng(11)
+    sigma = 0.01
+    Lc = np.pi / 2
+    posS, posO = (0.5 * (np.exp(Lc) - np.exp(-Lc))) ** 2, 0.5 * (np.exp(Lc) + np.exp(-Lc) - 1.0)
+    negS, negO = np.sin(Lc) ** 2, -(np.cos(Lc) - 1.0)
+    L.orc_h2mc_gaussian.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    for dim in (4, 6, 8, 12, 16):
+        for trial in range(20):
+            B = rng.normal(0, 1, (dim, dim))
+            H = ((B + B.T) * rng.choice([3e3, 3e4, 3e5])).astype(np.float32)  # indefinite, well above the 0.5 / sigma^2 = 5000 switch
+            g = rng.normal(0, 30, dim).astype(np.float32)
+            out = np.zeros(dim + 2 * dim * dim + 1, np.float32)
+            L.orc_h2mc_gaussian(dim, sigma, 1.0, P(g), P(H), P(out))
+            mean, covL, invCov, logDet = out[:dim], out[dim:dim + dim * dim].reshape(dim, dim), out[dim + dim * dim:-1].reshape(dim, dim), out[-1]
+            w, V = np.linalg.eigh(H.astype(np.float64))
+            eb = 1.0 / np.abs(w)
+            ob = eb * (V.T @ g.astype(np.float64))
+            s2 = np.where(w > 0, posS, negS)
+            o = ob * np.where(w > 0, posO, negO)
+            eb = 1.0 / (eb * s2)
+            post = eb + 1.0 / sigma ** 2
+            ic = V @ np.diag(post) @ V.T
+            m = V @ ((eb / post) * o)
+            cov = V @ np.diag(1.0 / post) @ V.T
+            assert np.allclose(invCov, ic, rtol=2e-4, atol=2e-4 * np.abs(ic).max()), (dim, trial)
+            assert np.allclose(mean, m, rtol=2e-3, atol=2e-4 * max(np.abs(m).max(), 1e-6)), (dim, trial)
+            assert np.allclose(covL @ covL.T, cov, rtol=2e-3, atol=2e-4 * np.abs(cov).max()), (dim, trial)
+            assert abs(logDet - np.log(post).sum()) < 1e-3 * abs(np.log(post).sum())
+        # below the switch (or a dead state): isotropic N(0, sigma^2), h2mc.cpp:84-92
+        out = np.zeros(dim + 2 * dim * dim + 1, np.float32)
+        L.orc_h2mc_gaussian(dim, sigma, 1.0, P(np.ones(dim, np.float32)), P(np.eye(dim, dtype=np.float32).ravel() * 10), P(out))
+        assert np.allclose(out[dim:dim + dim * dim].reshape(dim, dim), np.eye(dim) * sigma) and np.all(out[:dim] == 0)
+
+
+def test_hessian_program_matches_reference_h2mc_programs(L):
+    """The product's path program differentiated twice (nested duals, pathfunc.h PathFuncHess; host instantiation of the same
+    header the kernels compile) against the reference's generated H2MC programs evaluate_path_bidir_<c>_<l>_static_derv
+    (oracle/_ref, built from the reference's .ispc in place) on states of the torus scene.  Lambertian: every state within 1e-2
+    relative (Frobenius) for the Hessian and for the gradient.  Full materials: the rough-dielectric derivative programs of the
+    reference are not the true derivatives (chad's adjoint overwrite), >= 75 % of the states must still agree."""
+    if not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    ref = ctypes.CDLL(gc.pathref())
+    if not hasattr(ref, "evaluate_path_bidir_3_1_static_derv"):
+        pytest.skip("oracle/_ref built without the H2MC programs")
+    mine = ctypes.CDLL(gc.host_pathfunc_lib())
+    lens = np.zeros(2, np.float32)
+    for fd, depth, bar in ((1, 6, 1.0), (0, 8, 0.75)):
+        orc = _orc.Oracle(L, gc.TORUS, fd, depth, 160, 120, 0, gc.pathref())
+        orc.init(30000, 384, 8)
+        sp = orc.scene_params()
+        ok = tot = 0
+        seen = set()
+        for i in range(384):
+            r = orc.serialize_init_state(i)
+            if r is None:
+                continue
+            c, l, prim, vert = r
+            if c + l > 7:
+                continue
+            dim = 2 * max(c + l - 1, 2)
+            g1, h1, g2, h2, ll = np.zeros(16, np.float32), np.zeros(256, np.float32), np.zeros(16, np.float32), np.zeros(256, np.float32), np.zeros(1, np.float32)
+            getattr(ref, "evaluate_path_bidir_%d_%d_static_derv" % (c, l))(P(lens), P(prim), P(sp), P(vert), P(g1), P(h1))
+            mine.lmc_test_pathfunc_hess_host(c, l, P(prim), P(sp), P(vert), P(ll), P(g2), P(h2))
+            H1, H2 = h1[: dim * dim].reshape(dim, dim), h2[: dim * dim].reshape(dim, dim)
+            if not (np.isfinite(H1).all() and np.isfinite(g1).all()):
+                continue
+            tot += 1
+            seen.add((c, l))
+            assert np.linalg.norm(H2 - H2.T) <= 2e-2 * max(np.linalg.norm(H2), 1e-1)  # a Hessian
+            eg = np.linalg.norm(g1[:dim] - g2[:dim]) / max(np.linalg.norm(g1[:dim]), 1e-2)
+            eh = np.linalg.norm(H1 - H2) / max(np.linalg.norm(H1), 1e-1)
+            ok += (eg < 1e-2) and (eh < 1e-2)
+        orc.close()
+        assert tot > 100 and len(seen) >= 4
+        assert ok >= bar * tot, (fd, ok, tot)
+
+
+def test_oracle_h2mc_render_matches_reference_image(L):
+    """scenes/torus/h2mc.xml (largestepprob 0.2, sigma 0.01) through the oracle's H2MC mutation with the product's second-order
+    path program, 64 chains x 51 k mutations at 256x192, against the reference authors' H2MC render: whole-image mean 3 %, floor
+    3 %, glass regions 15 % (one seed; the sweep of the LMC renders shows +-5 % seed scatter at this budget)."""
+    ref = np.load(os.path.join(gc.ROOT, "tests", "golden", "torus_ref_images_256x192.npz"))["h2mc"]
+    lum = lambda x: x @ np.array([0.212671, 0.715160, 0.072169])
+    lr = lum(ref)
+    W, H, spp, chains = 256, 192, 67, 64
+    orc = _orc.Oracle(L, H2XML, 0, 8, W, H, 0, gc.host_pathfunc_lib())
+    direct = orc.direct(8) / 8
+    orc.init(300000, chains, 32)
+    per = spp * W * H // chains
+    orc.setup_chains(per, per % chains)
+    orc.run_async(os.cpu_count() or 1)
+    st = orc.stats()
+    lg = lum(direct + orc.film() / spp)
+    orc.close()
+    assert st["gradCalls"] > 0.5 * st["steps"]  # Hessians were evaluated
+    assert abs(lg.mean() / lr.mean() - 1) < 0.03
+    assert abs(lg[75:125, 5:50].mean() / lr[75:125, 5:50].mean() - 1) < 0.03
+    for k, (x0, x1, y0, y1) in {"left face": (100, 120, 60, 100), "front face": (175, 225, 62, 112), "torus": (140, 170, 65, 100)}.items():
+        assert abs(lg[y0:y1, x0:x1].mean() / lr[y0:y1, x0:x1].mean() - 1) < 0.15, k

@@ -52,8 +52,8 @@ int main(int argc, char *argv[]) {
             return 1;
         }
         lmc_set_option(ctx, "max-derivatives-depth", maxDervDepth);
-        if (Opt(ctx, "mala") == 0 || Opt(ctx, "h2mc") != 0) {
-            fprintf(stderr, "dpt_amd serves the LMC path only (<dpt> integrator=mcmc, mala=true)\n");
+        if (Opt(ctx, "mala") == 0 && Opt(ctx, "h2mc") == 0) {
+            fprintf(stderr, "dpt_amd serves the LMC path only (<dpt> integrator=mcmc with mala=true or h2mc=true)\n");
             return 1;
         }
         int info[8];
