@@ -73,6 +73,9 @@ int lmc_chains_init(lmc_ctx *ctx, long long num_init_samples, int n_chains_total
                     long long samples_per_chain, long long chains_need_extra);
 /* normalization = avgScore (mlt.cpp:46-47), number of init contributions */
 int lmc_init_result(lmc_ctx *ctx, float *normalization, long long *num_contribs);
+/* parity probe: every contribution MLTInit collected, in stream order: index of the init sample that produced it, technique as
+ * c * 16 + l, lsScore; returns the total count (at most `cap` entries are written) */
+long long lmc_init_contribs(lmc_ctx *ctx, long long cap, long long *sample, int *cl, float *ls);
 /* advances every resident chain by n_steps mutations (the loop body mlt.cpp:91-170), lock step */
 int lmc_chains_step(lmc_ctx *ctx, int n_steps);
 /* blocks until all queued work is done */

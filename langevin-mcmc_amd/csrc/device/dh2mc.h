@@ -84,9 +84,18 @@ LMC_HD void JacobiEigenSym(int n, float *A, float *V, float *w) {
     }
 }
 
-// Dense Gaussian of one state: mean[n], covL[n*n], invCov[n*n] (row-major, stride n), logDet.
-// `hess` is the n x n matrix as the derivative program delivers it (row i at hess[i*n]); `work` needs 2*n*n + 4*n floats.
-LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const float *grad, const float *hess, float *mean, float *covL, float *invCov,
+// An n x n matrix (row-major, entry (i,j) = word i*n+j) behind a stride: contiguous on the CPU, one word per chain-stride in the
+// device's SoA arrays -- the device keeps covL / invCov in HBM and never holds a dense matrix of the Gaussian in private memory.
+struct MatRef {
+    float *p;
+    size_t stride;
+    LMC_HD float &operator[](int k) const { return p[(size_t)k * stride]; }
+};
+
+// Dense Gaussian of one state: mean[n], covL, invCov (n x n), logDet.
+// `hess` is the n x n matrix as the derivative program delivers it (row i at hess[i*n]); it is symmetrised IN PLACE and destroyed
+// by the eigen-solve; `work` needs n*n + 4*n floats.
+LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL, MatRef invCov,
                                 float &logDet, float *work) {
     const float sigma = param.sigma, invSigmaSq = 1.0f / (sigma * sigma);
     float hnorm = 0.f;
@@ -101,9 +110,9 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
         for (int i = 0; i < n; i++) logDet += logd(invSigmaSq);
         return;
     }
-    float *A = work, *V = work + n * n, *w = work + 2 * n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
+    float *A = hess, *V = work, *w = work + n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) A[i * n + j] = 0.5f * (hess[i * n + j] + hess[j * n + i]);  // the solver reads one triangle; symmetrise
+        for (int j = i; j < n; j++) A[i * n + j] = A[j * n + i] = 0.5f * (hess[i * n + j] + hess[j * n + i]);  // Eigen reads one triangle; symmetrise
     JacobiEigenSym(n, A, V, w);
     for (int i = 0; i < n; i++) eigenBuff[i] = fabsf(w[i]) > 1e-10f ? 1.0f / fabsf(w[i]) : 0.0f;
     for (int i = 0; i < n; i++) {  // offsetBuff = diag(eigenBuff) (V^T grad)
@@ -143,7 +152,7 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
 }
 
 // gaussian.cpp:24-36 / :38-55, dense branch
-LMC_HD float DenseGaussianLogPdf(int n, const float *offset, bool negate, const float *mean, const float *invCov, float logDet) {
+LMC_HD float DenseGaussianLogPdf(int n, const float *offset, bool negate, const float *mean, MatRef invCov, float logDet) {
     float logPdf = n * (-0.9189385332046727f);
     logPdf += 0.5f * logDet;
     float q = 0.f;
@@ -155,7 +164,7 @@ LMC_HD float DenseGaussianLogPdf(int n, const float *offset, bool negate, const 
     logPdf -= 0.5f * q;
     return logPdf;
 }
-LMC_HD void DenseGaussianMap(int n, const float *z, const float *mean, const float *covL, float *x) {  // x = covL z + mean
+LMC_HD void DenseGaussianMap(int n, const float *z, const float *mean, MatRef covL, float *x) {  // x = covL z + mean
     for (int i = 0; i < n; i++) {
         float r = 0.f;
         for (int j = 0; j < n; j++) r += covL[i * n + j] * z[j];

@@ -10,13 +10,21 @@
 
 namespace lmcd {
 
-constexpr int H2_GAUSS_WORDS = H2_MAXDIM + 2 * H2_MAXDIM * H2_MAXDIM + 1;
+constexpr int H2_GAUSS_WORDS = H2_MAXDIM + 2 * H2_MAXDIM * H2_MAXDIM + 1;  // mean | covL | invCov | logDet
 
-struct DenseGauss {
-    float mean[H2_MAXDIM], covL[H2_MAXDIM * H2_MAXDIM], invCov[H2_MAXDIM * H2_MAXDIM];
-    float logDet;
-    bool dense;  // false: IsotropicGaussian(sigma) (no derivative program for this technique), diagonal stored in covL / invCov all the same
+// The dense Gaussian of a state, in HBM: two buffers of H2_GAUSS_WORDS words per chain (A.h2Gauss, SoA), the current state's
+// and the proposal's, selected by F_GSEL like the path buffers by F_SEL (acceptance flips the bit).  Only the mean and the
+// log-determinant are ever held in private memory: with both matrices of both Gaussians on the stack the kernel needed more
+// than 16 KB of scratch per lane, which faults on gfx950 (scripts/debug).
+struct H2Slot {
+    float *base;  // word 0 of this chain in the selected buffer
+    size_t stride;
+    LMC_D float &Mean(int k) const { return base[(size_t)k * stride]; }
+    LMC_D MatRef CovL() const { return MatRef{base + (size_t)H2_MAXDIM * stride, stride}; }
+    LMC_D MatRef InvCov() const { return MatRef{base + (size_t)(H2_MAXDIM + H2_MAXDIM * H2_MAXDIM) * stride, stride}; }
+    LMC_D float &LogDet() const { return base[(size_t)(H2_GAUSS_WORDS - 1) * stride]; }
 };
+LMC_D H2Slot H2Buf(const ChainArrays &A, int i, bool second) { return H2Slot{A.h2Gauss + (second ? (size_t)H2_GAUSS_WORDS * A.N : 0) + i, (size_t)A.N}; }
 
 #ifdef __HIPCC__
 template <class In>
@@ -25,64 +33,52 @@ __device__ __noinline__ void PathFuncHessDevice(int c, int l, const float *prima
 }
 #endif
 
-// initGaussian lambda of H2MCSmallStep::Mutate (mutation_h2mc.h:60-93)
-LMC_D void InitGaussianH2MC(const DScene &S, const StepParams &P, const H2MCParam &param, const DPath &path, const Contrib &sp, DenseGauss &g, GradWork &gw,
-                            StepStats &st) {
+#ifdef __HIPCC__
+// out of line: its eigen-solve work space then shares stack with the (already returned) path program instead of adding to it
+__device__ __noinline__ void ComputeGaussianH2MCDevice(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL,
+                                                       MatRef invCov, float &logDet) {
+    float work[H2_MAXDIM * H2_MAXDIM + 4 * H2_MAXDIM];
+    ComputeGaussianH2MC(param, n, sc, grad, hess, mean, covL, invCov, logDet, work);
+}
+#endif
+
+// initGaussian lambda of H2MCSmallStep::Mutate (mutation_h2mc.h:60-93): fills `slot` (HBM) and returns mean / logDet
+LMC_D void InitGaussianH2MC(const DScene &S, const StepParams &P, const H2MCParam &param, const DPath &path, const Contrib &sp, const H2Slot &slot, float *mean,
+                            float &logDet, GradWork &gw, StepStats &st) {
     const int dim = PathDimension(path.camDepth, path.lgtDepth);
     const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth) && path.camDepth + path.lgtDepth - 1 <= P.maxDervDepth && dim <= H2_MAXDIM;
+    MatRef covL = slot.CovL(), invCov = slot.InvCov();
     if (!haveDerv) {  // IsotropicGaussian(dim, sigma), gaussian.cpp:4-22
         const float sigma = param.sigma;
         for (int i = 0; i < dim; i++) {
-            g.mean[i] = 0.f;
-            for (int j = 0; j < dim; j++) g.covL[i * dim + j] = (i == j) ? sigma : 0.f, g.invCov[i * dim + j] = (i == j) ? 1.0f / (sigma * sigma) : 0.f;
+            mean[i] = 0.f;
+            for (int j = 0; j < dim; j++) covL[i * dim + j] = (i == j) ? sigma : 0.f, invCov[i * dim + j] = (i == j) ? 1.0f / (sigma * sigma) : 0.f;
         }
-        g.logDet = dim * fastlog(1.0f / (sigma * sigma));
-        g.dense = false;
-        return;
-    }
-    float vGrad[H2_MAXDIM], vHess[H2_MAXDIM * H2_MAXDIM];
-    for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
-    for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
-    if (sp.ssScore > 1e-15f) {
-        float primary[2 * MAXD + 1];
-        StridedOut o{gw.buf + gw.slot, gw.stride, 0};
-        SerializePath(S, path, primary, o);
-        StridedIn vin{gw.buf + gw.slot, gw.stride};
-        float logLum;
-        PathFuncHessDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
-        st.gradCalls++;
-        bool finite = true;
-        for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);
-        for (int k = 0; k < dim * dim; k++) finite = finite && isfinite(vHess[k]);
-        if (!finite) {
-            for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
-            for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
+        logDet = dim * fastlog(1.0f / (sigma * sigma));
+    } else {
+        float vGrad[H2_MAXDIM], vHess[H2_MAXDIM * H2_MAXDIM];
+        for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
+        for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
+        if (sp.ssScore > 1e-15f) {
+            float primary[2 * MAXD + 1];
+            StridedOut o{gw.buf + gw.slot, gw.stride, 0};
+            SerializePath(S, path, primary, o);
+            StridedIn vin{gw.buf + gw.slot, gw.stride};
+            float logLum;
+            PathFuncHessDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
+            st.gradCalls++;
+            bool finite = true;
+            for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);
+            for (int k = 0; k < dim * dim; k++) finite = finite && isfinite(vHess[k]);
+            if (!finite) {
+                for (int k = 0; k < dim; k++) vGrad[k] = 0.f;
+                for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
+            }
         }
+        ComputeGaussianH2MCDevice(param, dim, sp.ssScore, vGrad, vHess, mean, covL, invCov, logDet);
     }
-    float work[2 * H2_MAXDIM * H2_MAXDIM + 4 * H2_MAXDIM];
-    ComputeGaussianH2MC(param, dim, sp.ssScore, vGrad, vHess, g.mean, g.covL, g.invCov, g.logDet, work);
-    g.dense = true;
-}
-
-LMC_D void LoadDense(const ChainArrays &A, int i, int dim, DenseGauss &g) {
-    const size_t N = A.N;
-    const float *G = A.h2Gauss;
-    for (int k = 0; k < dim; k++) g.mean[k] = G[(size_t)k * N + i];
-    for (int k = 0; k < dim * dim; k++) {
-        g.covL[k] = G[(size_t)(H2_MAXDIM + k) * N + i];
-        g.invCov[k] = G[(size_t)(H2_MAXDIM + H2_MAXDIM * H2_MAXDIM + k) * N + i];
-    }
-    g.logDet = G[(size_t)(H2_GAUSS_WORDS - 1) * N + i];
-}
-LMC_D void StoreDense(const ChainArrays &A, int i, int dim, const DenseGauss &g) {
-    const size_t N = A.N;
-    float *G = A.h2Gauss;
-    for (int k = 0; k < dim; k++) G[(size_t)k * N + i] = g.mean[k];
-    for (int k = 0; k < dim * dim; k++) {
-        G[(size_t)(H2_MAXDIM + k) * N + i] = g.covL[k];
-        G[(size_t)(H2_MAXDIM + H2_MAXDIM * H2_MAXDIM + k) * N + i] = g.invCov[k];
-    }
-    G[(size_t)(H2_GAUSS_WORDS - 1) * N + i] = g.logDet;
+    for (int k = 0; k < dim; k++) slot.Mean(k) = mean[k];
+    slot.LogDet() = logDet;
 }
 
 template <class Stk>
@@ -104,35 +100,39 @@ LMC_D void StepChainH2MC(const DScene &S, const ChainArrays &A, const Film &film
     float offset[MAXPSS];
     const bool h2 = !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_h2mc.h:49-55
     const H2MCParam param = MakeH2MCParam(S.opt.perturbStdDev);
-    DenseGauss cg, pg;
+    float mean[H2_MAXDIM], logDet = 0.f, py = 0.f;  // of the Gaussian in use: the current state's until py is known, then the proposal's
+    const bool gsel = (flags & F_GSEL) != 0;
     const bool useDense = dim <= H2_MAXDIM;  // longer states have no derivative program: isotropic, nothing stored
     if (!h2) {  // SmallStep::Mutate, mutation_small.h:16-56
         NormalDist nd(0.0f, S.opt.perturbStdDev);
         for (int k = 0; k < dim; k++) offset[k] = nd(rng);
     } else {
+        const H2Slot cs = H2Buf(A, i, gsel);
         if (useDense) {
             if (!(flags & F_GAUSS)) {
-                InitGaussianH2MC(S, P, param, prop, cur, cg, gw, st);
-                StoreDense(A, i, dim, cg);
+                InitGaussianH2MC(S, P, param, prop, cur, cs, mean, logDet, gw, st);
                 flags |= F_GAUSS;
             } else {
-                LoadDense(A, i, dim, cg);
+                for (int k = 0; k < dim; k++) mean[k] = cs.Mean(k);
+                logDet = cs.LogDet();
             }
         }
         NormalDist nd(0.0f, 1.0f);  // GenerateSample, gaussian.cpp:38-55
         float z[MAXPSS];
         for (int k = 0; k < dim; k++) z[k] = nd(rng);
-        if (useDense) DenseGaussianMap(dim, z, cg.mean, cg.covL, offset);
-        else
+        if (useDense) {
+            DenseGaussianMap(dim, z, mean, cs.CovL(), offset);
+            py = DenseGaussianLogPdf(dim, offset, false, mean, cs.InvCov(), logDet);  // GaussianLogPdf(offset, currentState.gaussian): draws nothing, so it can be taken now
+        } else
             for (int k = 0; k < dim; k++) offset[k] = param.sigma * z[k] + 0.0f;
     }
     if (PerturbPathBidir(S, offset, prop, pc, rng, stk)) {
         if (h2) {
-            float py, px;
+            float px;
             if (useDense) {
-                InitGaussianH2MC(S, P, param, prop, pc, pg, gw, st);
-                py = DenseGaussianLogPdf(dim, offset, false, cg.mean, cg.invCov, cg.logDet);
-                px = DenseGaussianLogPdf(dim, offset, true, pg.mean, pg.invCov, pg.logDet);
+                const H2Slot ps = H2Buf(A, i, !gsel);
+                InitGaussianH2MC(S, P, param, prop, pc, ps, mean, logDet, gw, st);
+                px = DenseGaussianLogPdf(dim, offset, true, mean, ps.InvCov(), logDet);
             } else {  // both isotropic with the same sigma: the dense form with a diagonal matrix, written out
                 const float inv = 1.0f / (param.sigma * param.sigma), logDet = dim * fastlog(inv);
                 float q = 0.f;
@@ -174,7 +174,7 @@ LMC_D void StepChainH2MC(const DScene &S, const ChainArrays &A, const Film &film
         p[0] = pc.screenPos.x, p[N] = pc.screenPos.y, p[2 * N] = smallSplat.x, p[3 * N] = smallSplat.y, p[4 * N] = smallSplat.z;
         A.curSplatCount[i] = 1;
         if (h2) {  // std::swap(currentState, proposalState): the proposal's Gaussian is the current one now
-            if (useDense) StoreDense(A, i, dim, pg);
+            if (useDense) flags ^= F_GSEL;  // the proposal's buffer is the current one now
             flags |= F_GAUSS;
         } else {
             flags &= ~F_GAUSS;  // mutation_small.h:39

@@ -1004,32 +1004,30 @@ LMC_HD void PathFuncGrad(int c, int l, const float *primary, const float *scene,
 }
 
 // evaluate_path_bidir_<c>_<l>_static_derv (H2MC library, pathlibbidir.so): gradient and Hessian of logLum with respect to
-// primary[1..2L]; row i of the Hessian at hess[i * 2L] (path.h:122-123, mutation_h2mc.h:76-79).  One pass per row with a
-// dual number whose scalar is itself a Dual<N> (value, gradient, and their derivative along direction i).
-template <int N, class In>
-LMC_HD void PathFuncHessN(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
-    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
-    typedef DualS<1, Dual<N>> T2;
-    for (int i = 0; i < dim && i < N; i++) {
-        T2 p[2 * 8 + 1];
-        p[0] = Lift<T2>::Of(primary[0]);
-        for (int k = 0; k < dim; k++) {
-            p[k + 1] = Lift<T2>::Of(primary[k + 1]);
-            if (k < N) p[k + 1].v.d[k] = 1.0f;
-            if (k == i) p[k + 1].d[0].v = 1.0f;
-        }
-        T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
-        if (i == 0 && logLum) *logLum = r.v.v;
-        if (grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
-        for (int k = 0; k < dim && k < N; k++) hess[i * dim + k] = r.d[0].d[k];
-    }
-}
+// primary[1..2L]; row i of the Hessian at hess[i * 2L] (path.h:122-123, mutation_h2mc.h:76-79).  One pass per row and per
+// chunk of HC columns with a dual number whose scalar is itself a Dual<HC> (value, HC gradient components, and their
+// derivative along direction i).  Chunking keeps the working set of the second-order type at 2 (HC + 1) floats per value
+// whatever the dimension: the 16-wide form needed 22 KB of private memory per lane and faulted on gfx950, the 8-wide one
+// 12.6 KB; one instantiation also halves the compile time.
+constexpr int HC = 8;
 template <class In>
 LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
-    // two widths only: every instantiation of the nested-dual program costs about a minute of compile time
-    if (dim <= 8) PathFuncHessN<8>(c, l, primary, scene, vp, logLum, grad, hess);
-    else PathFuncHessN<16>(c, l, primary, scene, vp, logLum, grad, hess);
+    typedef DualS<1, Dual<HC>> T2;
+    for (int i = 0; i < dim; i++)
+        for (int c0 = 0; c0 < dim; c0 += HC) {
+            T2 p[2 * 8 + 1];
+            p[0] = Lift<T2>::Of(primary[0]);
+            for (int k = 0; k < dim; k++) {
+                p[k + 1] = Lift<T2>::Of(primary[k + 1]);
+                if (k >= c0 && k < c0 + HC) p[k + 1].v.d[k - c0] = 1.0f;
+                if (k == i) p[k + 1].d[0].v = 1.0f;
+            }
+            T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
+            if (i == 0 && c0 == 0 && logLum) *logLum = r.v.v;
+            if (c0 == 0 && grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
+            for (int k = c0; k < dim && k < c0 + HC; k++) hess[i * dim + k] = r.d[0].d[k - c0];
+        }
 }
 
 // The chain loop only differentiates states with dim <= PSS_MAX_LENGTH = 12 (mutation_mala.h:94-96): no Dual<16> copy of

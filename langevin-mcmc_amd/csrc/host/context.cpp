@@ -146,6 +146,9 @@ struct lmc_ctx {
     // init results
     float normalization = 0.f;
     long long numInitContribs = 0;
+    std::vector<unsigned char> initCL;            // MLTInit contributions in stream order (parity probe lmc_init_contribs)
+    std::vector<float> initLs;
+    std::vector<unsigned long long> initOffsets;  // first contribution of every init sample
     // timing
     struct StepEvents {
         hipEvent_t e[8];  // main stream: step begin | lean launch begin | lean launch end | step end;  side streams: large begin / end, generic begin / end
@@ -467,6 +470,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     HIP_CHECK(hipStreamSynchronize(s));
     std::vector<unsigned char> hCL = outCL.Download();
     std::vector<float> hLs = outLs.Download();
+    c->initCL = hCL, c->initLs = hLs, c->initOffsets = hOff;
     // ---- equal-spaced seeding (mlt.h:107-148), sequential float arithmetic on the host like the reference
     float totalScore = 0.f;
     for (unsigned long long i = 0; i < total; i++) totalScore += hLs[i];
@@ -565,7 +569,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->needGeneric = true;
     if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
         c->allCachesReady = true;
-        c->h2Gauss.Alloc(N * (size_t)(16 + 2 * 256 + 1), false);
+        c->h2Gauss.Alloc(2 * N * (size_t)(16 + 2 * 256 + 1), false);  // current + proposal buffer (F_GSEL)
         c->A.h2Gauss = c->h2Gauss.p;
     }
     for (int b = 0; b < 2; b++) {
@@ -585,6 +589,16 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     HIP_CHECK(hipStreamSynchronize(s));
     return 0;
     LMC_CATCH(-1)
+}
+
+long long lmc_init_contribs(lmc_ctx *c, long long cap, long long *sample, int *cl, float *ls) {
+    const long long n = (long long)c->initCL.size();
+    size_t g = 0;
+    for (long long i = 0; i < n && i < cap; i++) {
+        while (g + 1 < c->initOffsets.size() && c->initOffsets[g + 1] <= (unsigned long long)i) g++;
+        sample[i] = (long long)g, cl[i] = c->initCL[i], ls[i] = c->initLs[i];
+    }
+    return n;
 }
 
 int lmc_init_result(lmc_ctx *c, float *normalization, long long *numContribs) {

@@ -84,6 +84,14 @@ int orc_init(void *h, long long numInitSamples, int numChains, int initThreads, 
     ORC_CATCH(-1)
 }
 
+// parity probe: every MLTInit contribution in stream order (global sample index, c * 16 + l, lsScore); returns the count
+long long orc_init_contribs(void *h, long long cap, long long *sample, int *cl, float *ls) {
+    MLT *m = (MLT *)h;
+    const long long n = (long long)m->initContribCL.size();
+    for (long long i = 0; i < n && i < cap; i++) sample[i] = m->initContribSample[i], cl[i] = m->initContribCL[i], ls[i] = m->initContribLs[i];
+    return n;
+}
+
 int orc_setup_chains(void *h, long long samplesPerChain, long long chainsNeedExtra) {
     ORC_TRY((MLT *)h)->SetupChains(samplesPerChain, chainsNeedExtra);
     return 0;
@@ -299,8 +307,8 @@ void orc_compute_gaussian(int dim, const float *v1, const float *M, float ss, fl
 // invCov[dim*dim], logDet
 void orc_h2mc_gaussian(int dim, float sigma, float sc, const float *grad, const float *hess, float *out) {
     lmcd::H2MCParam p = lmcd::MakeH2MCParam(sigma);
-    std::vector<float> work((size_t)2 * dim * dim + 4 * dim);
-    lmcd::ComputeGaussianH2MC(p, dim, sc, grad, hess, out, out + dim, out + dim + dim * dim, out[dim + 2 * dim * dim], work.data());
+    std::vector<float> work((size_t)dim * dim + 4 * dim), h(hess, hess + (size_t)dim * dim);
+    lmcd::ComputeGaussianH2MC(p, dim, sc, grad, h.data(), out, lmcd::MatRef{out + dim, 1}, lmcd::MatRef{out + dim + dim * dim, 1}, out[dim + 2 * dim * dim], work.data());
 }
 
 // ---- CPU baseline (bench.py): the chain loop on `threads` host threads, chains handed out in contiguous

@@ -29,7 +29,7 @@ void IsotropicGaussian(const int dim, const Float sigma, Gaussian &gaussian) {  
 
 Float GaussianLogPdf(const std::vector<Float> &offset, const Gaussian &gaussian, bool negate) {  // gaussian.cpp:24-36
     const int dim = (int)gaussian.mean.size();
-    if (gaussian.dense) return lmcd::DenseGaussianLogPdf(dim, offset.data(), negate, gaussian.mean.data(), gaussian.invCov.data(), gaussian.logDet);
+    if (gaussian.dense) return lmcd::DenseGaussianLogPdf(dim, offset.data(), negate, gaussian.mean.data(), lmcd::MatRef{const_cast<Float *>(gaussian.invCov.data()), 1}, gaussian.logDet);
     Float logPdf = dim * (-Float(0.9189385332046727));
     logPdf += Float(0.5) * gaussian.logDet;
     // d^T (invCov d); Eigen's reduction order is unpinned -- summed left to right here.
@@ -47,7 +47,7 @@ void GenerateSample(Gaussian &gaussian, std::vector<Float> &x, RNG &rng) {  // g
     for (size_t i = 0; i < x.size(); i++) x[i] = normDist(rng);
     if (gaussian.dense) {
         std::vector<Float> z(x);
-        lmcd::DenseGaussianMap((int)x.size(), z.data(), gaussian.mean.data(), gaussian.covL.data(), x.data());
+        lmcd::DenseGaussianMap((int)x.size(), z.data(), gaussian.mean.data(), lmcd::MatRef{gaussian.covL.data(), 1}, x.data());
         return;
     }
     for (size_t i = 0; i < x.size(); i++) x[i] = gaussian.covL_d[i] * x[i] + gaussian.mean[i];
@@ -404,6 +404,8 @@ Float MLT::Init(int64_t numInitSamples, int numChains, int initThreads_) {  // m
     const int minPathLength = std::max(sc->options->minDepth, 3);
     std::vector<SubpathContrib> spContribs;
     Path path;
+    initContribSample.clear(), initContribCL.clear(), initContribLs.clear();
+    int64_t globalSample = 0;
     for (int threadId = 0; threadId < initThreads; threadId++) {
         const uint64_t seed = (uint64_t)(threadId + sc->options->seedOffset);
         RNG rng(seed);
@@ -423,7 +425,9 @@ Float MLT::Init(int64_t numInitSamples, int numChains, int initThreads_) {  // m
                 if (pathLength >= int(lengthContrib.size())) lengthContrib.resize(pathLength + 1, Float(0.0));
                 lengthContrib[pathLength] += spContrib.lsScore;
                 mStates.push_back(LightMarkovState{threadId, stateCheckpoint, ticksCheckpoint, spContrib.camDepth, spContrib.lightDepth, spContrib.lsScore});
+                initContribSample.push_back(globalSample), initContribCL.push_back(spContrib.camDepth * 16 + spContrib.lightDepth), initContribLs.push_back(spContrib.lsScore);
             }
+            globalSample++;
         }
     }
     numInitContribs = (int64_t)mStates.size();
@@ -717,8 +721,9 @@ Float MLT::H2MCMutate(ChainCtx &c) {  // mutation_h2mc.h:38-128
             Gaussian &g = state.gaussian;
             g.dense = true, g.isDiagonal = false;
             g.mean.assign(d, 0.f), g.covL.assign((size_t)d * d, 0.f), g.invCov.assign((size_t)d * d, 0.f);
-            std::vector<Float> work((size_t)2 * d * d + 4 * d);
-            lmcd::ComputeGaussianH2MC(param, d, csp.ssScore, vGrad.data(), vHess.data(), g.mean.data(), g.covL.data(), g.invCov.data(), g.logDet, work.data());
+            std::vector<Float> work((size_t)d * d + 4 * d);
+            lmcd::ComputeGaussianH2MC(param, d, csp.ssScore, vGrad.data(), vHess.data(), g.mean.data(), lmcd::MatRef{g.covL.data(), 1}, lmcd::MatRef{g.invCov.data(), 1},
+                                      g.logDet, work.data());
         } else {
             IsotropicGaussian(d, param.sigma, state.gaussian);
         }

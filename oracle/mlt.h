@@ -150,6 +150,9 @@ struct MLT {
     StepStats stats;
     int initThreads = 1;
     int64_t numInitContribs = 0;
+    std::vector<int64_t> initContribSample;  // MLTInit contributions in stream order: global sample index, technique, lsScore (parity probe)
+    std::vector<int> initContribCL;
+    std::vector<Float> initContribLs;
 
     // mlt.h:41-154 with NumSystemCores() := initThreads (deterministic order: thread-major)
     Float Init(int64_t numInitSamples, int numChains, int initThreads);

@@ -218,6 +218,10 @@ def run_pair(width, height, num_init, n_chains, init_threads, per_chain, steps, 
     same = (co[:, 0] == cg[:, 0]) & (co[:, 1] == cg[:, 1]) & (co[:, 2] == cg[:, 2])
     close = same & (np.abs(co[:, 3] - cg[:, 3]) <= 1e-3 * np.abs(co[:, 3]) + 1e-12)
     res["final_state_match"] = float(close.mean())
+    # technique histograms of the final states (c * 16 + l -> fraction): a comparison that survives re-seeded chains
+    for name, cs in (("hist_oracle", co), ("hist_gpu", cg)):
+        keys, cnt = np.unique((cs[:, 1] * 16 + cs[:, 2]).astype(int), return_counts=True)
+        res[name] = {int(k): float(v) / len(cs) for k, v in zip(keys, cnt)}
     res["nonfinite_gpu"] = int((~np.isfinite(fg)).sum())
     orc.close()
     ren.close()

