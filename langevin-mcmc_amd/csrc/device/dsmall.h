@@ -200,7 +200,7 @@ enum : int { VS_ISOTROPIC = 0, VS_REUSE = 1, VS_BLEND = 2 };
 
 // First half of InitGaussianFor for a state whose pss is in L.Q: bookkeeping writes, re-use test, cache query.
 LMC_D void PrepareGaussianLean(const DCache &cache, const ChainArrays &A, int i, int dim, float lsScore, int flags, const LdsView &L, VSource &vs,
-                               StepStats &st) {
+                               StepStats &st, bool skipQuery = false) {
     const size_t N = A.N;
     vs.mode = VS_ISOTROPIC;
     vs.nMatches = 0;
@@ -210,6 +210,7 @@ LMC_D void PrepareGaussianLean(const DCache &cache, const ChainArrays &A, int i,
 #pragma unroll 1
     for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = L.Q(k);  // GetPathPss(path, chain->pss)
     if (dim < PSS_MIN_LENGTH || !cache.d[dim].ready) return;
+    if (skipQuery) return;
     if (flags & F_QUERIED) {
         float dist_sqr = 0.f;
 #pragma unroll 1
@@ -348,7 +349,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 for (int d = 0; d < camCount - 1; d++) qs.Push(cur[(size_t)VertWord(false, d, 3) * N + i]), qs.Push(cur[(size_t)VertWord(false, d, 4) * N + i]);
                 if (l == 1) qs.Push(cur[(size_t)VertWord(false, camCount - 1, 10) * N + i]), qs.Push(cur[(size_t)VertWord(false, camCount - 1, 11) * N + i]);
             }
-            PrepareGaussianLean(cache, A, i, dim, curLs, flags, L, vs, st);
+            PrepareGaussianLean(cache, A, i, dim, curLs, flags, L, vs, st, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags |= F_QUERIED;
             flags |= F_GAUSS;
         }
@@ -522,7 +523,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         if (mala) {
             float *G = PropGaussBuf(A, flags);
             VSource vs;
-            PrepareGaussianLean(cache, A, i, dim, pc.lsScore, flags, L, vs, st);
+            PrepareGaussianLean(cache, A, i, dim, pc.lsScore, flags, L, vs, st, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags |= F_QUERIED;
             float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
 #pragma unroll 1
@@ -544,7 +545,8 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     }
 
     // ---- splats, mlt.cpp:103-112
-    if (curValid && a < 1.0f) {
+    const bool doSplat = !(P.expFlags & 1);
+    if (curValid && a < 1.0f && doSplat) {
         const int n = A.curSplatCount[i];
         for (int k = 0; k < n; k++) {
             const float *p = A.curSplat + ((size_t)k * SPLAT_WORDS) * N + i;
@@ -552,7 +554,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         }
     }
     const V3 smallSplat = mala ? (pc.contrib * P.normalization) / pc.lsScore : pc.contrib * (P.normalization / pc.lsScore);
-    if (a > 0.0f) Splat(film, pc.screenPos, a * smallSplat);
+    if (a > 0.0f && doSplat) Splat(film, pc.screenPos, a * smallSplat);
     st.wsum += curValid ? 1.0f : (a > 0.0f ? a : 0.0f);
 
     // ---- accept / reject, mlt.cpp:113-170

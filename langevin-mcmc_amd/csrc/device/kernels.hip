@@ -315,24 +315,26 @@ __global__ void k_first_kind(DScene S, const DCache *cache, ChainArrays A, StepP
 //     kernel retraces ONE technique -- same ray count, same terminal strategy -- instead of the 5 different ones a wave of
 //     64 consecutive chains holds on average (profiles/r02_*).  A wave's chains still come from one 1024-chain tile: its
 //     state accesses stay within a few cache lines per word.
+template <int CPT>  // chains per thread: the tile is 256 * CPT consecutive chains
 __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next, int sortPlain) {
     __shared__ unsigned long long sWave[4];
     __shared__ int sBase[3];
     __shared__ int sHist[64], sStart[64];
     if (threadIdx.x < 64) sHist[threadIdx.x] = 0;
     __syncthreads();
-    const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
-    unsigned char k[4] = {0, 0, 0, 0};
-    if (first + 3 < A.N) {
+    const int first = (blockIdx.x * 256 + threadIdx.x) * CPT;
+    unsigned char k[CPT];
+    for (int j = 0; j < CPT; j++) k[j] = 0;
+    if (CPT == 4 && first + 3 < A.N) {
         const uchar4 v = *reinterpret_cast<const uchar4 *>(A.nextKind + first);
-        k[0] = v.x, k[1] = v.y, k[2] = v.z, k[3] = v.w;
+        k[0] = v.x, k[1 % CPT] = v.y, k[2 % CPT] = v.z, k[3 % CPT] = v.w;
     } else {
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < CPT; j++)
             if (first + j < A.N) k[j] = A.nextKind[first + j];
     }
     // three 21-bit counters packed into one word: [large | generic << 21 | plain << 42]
     unsigned long long mine = 0;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < CPT; j++) {
         const int kind = k[j] & 3;
         if (kind) mine += 1ull << (21 * (kind - 1));
         if (kind == NEXT_SMALL_PLAIN && sortPlain) atomicAdd(&sHist[k[j] >> 2], 1);
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
     const unsigned long long excl = before + incl - mine;
     int pos[3] = {sBase[0] + (int)(excl & 0x1fffff), sBase[1] + (int)((excl >> 21) & 0x1fffff), sBase[2] + (int)((excl >> 42) & 0x1fffff)};
     int *lists[3] = {next.large, next.smallGrad, next.smallPlain};
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < CPT; j++) {
         const int kind = k[j] & 3;
         if (!kind) continue;
         if (kind == NEXT_SMALL_PLAIN && sortPlain) next.smallPlain[sBase[2] + atomicAdd(&sStart[k[j] >> 2], 1)] = first + j;
@@ -565,7 +567,11 @@ void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }
 void LaunchBuildLists(const ChainArrays &A, const NextLists &next, int sortPlain, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_lists, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next, sortPlain);
+    // sortPlain: 0 = id order; 1 = technique sort inside 1024-chain tiles; 2 = inside 256-chain tiles (one tile = one 256-thread
+    // block of the lean kernel, so the tile's cache lines are shared through that CU's L1)
+    if (sortPlain == 2) hipLaunchKernelGGL(k_build_lists<1>, dim3((A.N + 255) / 256), dim3(256), 0, s, A, next, 1);
+    else
+        hipLaunchKernelGGL(k_build_lists<4>, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next, sortPlain);
 }
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lists, dim3(GridFor(n, 256)), dim3(256), 0, s, n, large, counts);

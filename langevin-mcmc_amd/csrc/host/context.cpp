@@ -91,6 +91,7 @@ struct lmc_ctx {
     int device = 0;
     int useGradient = 1;
     int maxDervDepth = 8;  // --max-derivatives-depth default, main.cpp:46
+    int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
     hipStream_t stream = nullptr;
     // The three step launches of one iteration touch disjoint chains, so they run concurrently: large steps and the generic
     // (gradient) small steps on two side streams, the lean small steps on the main stream, joined before k_build_lists.
@@ -344,6 +345,8 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -542,7 +545,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
     c->gradStride = c->stepGrid * 256;
     if (const char *e = getenv("LMC_LEAN_BLOCK")) c->leanBlock = std::max(64, std::min(256, atoi(e) / 64 * 64));
-    if (const char *e = getenv("LMC_SORT_PLAIN")) c->sortPlain = atoi(e) != 0;
+    if (const char *e = getenv("LMC_SORT_PLAIN")) c->sortPlain = atoi(e);  // 0 | 1 (1024-chain tiles) | 2 (256-chain tiles)
     c->leanGrid = (int)std::min<size_t>((N + c->leanBlock - 1) / c->leanBlock, (size_t)4096 * 256 / c->leanBlock);
     c->gradBuf.Alloc(c->useGradient ? (size_t)c->gradStride * 640 : 1, false);  // V <= 238 + 59*6 = 592 words for c+l <= 9
     // global cache: dims 2L for L in [3, maxDepth], capped by PSS_MAX_LENGTH
@@ -579,7 +582,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->parity = 0;
     if (c->seedChains) {  // chains start valid: the first step's kind is drawn like any other (mlt.cpp:96-97)
         StepParams P;
-        P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth;
+        P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
         LaunchFirstKind(c->S, c->cacheDev.p, c->A, P, s);
         NextLists first{c->lists[0][0].p, c->lists[0][1].p, c->lists[0][2].p, c->listCounts[0].p};
         LaunchBuildLists(c->A, first, c->sortPlain, s);
@@ -652,7 +655,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
     hipStream_t s = c->stream;
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
     StepParams P;
-    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth;
+    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
     for (int it = 0; it < nSteps; it++) {
         lmc_ctx::StepEvents ev;
         if (c->timing) {
