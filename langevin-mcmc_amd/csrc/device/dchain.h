@@ -26,6 +26,14 @@ constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
 constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
 
 constexpr int KD_LDS_DEPTH = 22;  // deepest tree the lean small-step kernel searches with its frames in LDS (dsmall.h)
+LMC_HD int CacheGridG(int dim) {  // cells per axis: the largest G with 1 / G >= radius = sqrt(dim) * PSS_QUERY_DIST
+    int G = (int)(1.0f / (sqrtf((float)dim) * PSS_QUERY_DIST));
+    return G < 1 ? 1 : (G > 64 ? 64 : G);
+}
+LMC_HD int CacheGridCell(float x, int G) {
+    int c = (int)(x * (float)G);
+    return c < 0 ? 0 : (c > G - 1 ? G - 1 : c);
+}
 constexpr int KD_STACK = 160;  // deepest kd-tree the in-kernel search accepts (the host refuses deeper ones)
 
 struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly like nanoflann's divideTree)
@@ -42,6 +50,16 @@ struct DCacheDim {
     const int *vind;
     const float *pts, *v1, *v2;  // PSS_MAX_SIZE x dim, row-major
     const float *ptsLeaf;        // the points again, in leaf order (row i = pts[vind[i]]): the lean kernel scans leaves from it
+    // Exact existence test in front of the radius query (lean kernel): a uniform grid over the first gridM coordinates with
+    // cells no smaller than the query radius (G = floor(1 / sqrt(dim) / 0.01)).  Every cell lists the points of its 3^gridM
+    // neighbourhood (rows copied: gridRows[gridStart[c] .. gridStart[c+1]) x dim), so a point within the radius of a query is
+    // among the candidates of the query's own cell: two adjacent loads find them, and testing them with the search's own
+    // distance arithmetic decides "any match?" exactly.  Only then (0.015 % of the queries on the torus) is the
+    // nanoflann-ordered search needed.  The search itself cost 40 % of the lean kernel
+    // (profiles/r02_f_ablation_splat_query.jsonl): in 6-12 dimensions its split planes prune little.
+    const int *gridStart;
+    const float *gridRows;
+    int gridG, gridM;
     float rootLow[MAXPSS], rootHigh[MAXPSS];
 };
 struct DCache {

@@ -224,8 +224,34 @@ LMC_D void PrepareGaussianLean(const DCache &cache, const ChainArrays &A, int i,
         }
     }
     st.cacheQueries++;
+    const DCacheDim &C = cache.d[dim];
+    const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
+    if (C.gridStart) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
+        float q[MD];
+#pragma unroll
+        for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
+        int cell = 0;
+        for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(q[k], C.gridG);
+        const int s0 = C.gridStart[cell], s1 = C.gridStart[cell + 1];
+        bool any = false;
+        for (int j = s0; j < s1; j++) {
+            const float2 *row = reinterpret_cast<const float2 *>(C.gridRows + (size_t)j * dim);
+            float d = 0.f;  // same arithmetic, same order as the leaf scan of the search
+#pragma unroll
+            for (int k = 0; k < MD / 2; ++k)
+                if (2 * k < dim) {
+                    const float2 p = row[k];
+                    const float diff0 = q[2 * k] - p.x;
+                    d += diff0 * diff0;
+                    const float diff1 = q[2 * k + 1] - p.y;
+                    d += diff1 * diff1;
+                }
+            any = any || d < radiusSq;
+        }
+        if (!any) return;
+    }
     float dist[5];
-    const int n = KdRadiusSearchLds(cache.d[dim], dim, L, dim * (PSS_QUERY_DIST * PSS_QUERY_DIST), 5, vs.idx, dist);
+    const int n = KdRadiusSearchLds(C, dim, L, radiusSq, 5, vs.idx, dist);
     if (n > 0) {  // global_cache.h:106-123
         st.cacheHits++;
         vs.mode = VS_BLEND;

@@ -388,6 +388,61 @@ struct KdBuilder {
 };
 }  // namespace
 
+CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m) {
+    using namespace lmcd;
+    CacheGrid g;
+    g.G = CacheGridG(dim), g.m = std::min(m, dim);
+    const int G = g.G;
+    size_t cells = 1;
+    for (int k = 0; k < g.m; k++) cells *= G;
+    int nbrs = 1;
+    for (int k = 0; k < g.m; k++) nbrs *= 3;
+    // (cell, point) pairs of the dilation, counting-sorted by cell
+    std::vector<int> pairCell;
+    pairCell.reserve((size_t)n * nbrs);
+    g.start.assign(cells + 1, 0);
+    auto forNeighbours = [&](const float *p, auto &&fn) {
+        int c[8];
+        for (int k = 0; k < g.m; k++) c[k] = CacheGridCell(p[k], G);
+        for (int o = 0; o < nbrs; o++) {
+            int cell = 0, t = o;
+            bool inside = true;
+            for (int k = 0; k < g.m; k++, t /= 3) {
+                const int ck = c[k] + (t % 3) - 1;
+                inside = inside && ck >= 0 && ck < G;
+                cell = cell * G + ck;
+            }
+            if (inside) fn(cell);
+        }
+    };
+    for (int i = 0; i < n; i++) forNeighbours(pts + (size_t)i * dim, [&](int cell) { g.start[cell + 1]++; });
+    for (size_t c = 0; c < cells; c++) g.start[c + 1] += g.start[c];
+    g.rows.resize((size_t)g.start[cells] * dim);
+    std::vector<int> cursor(g.start.begin(), g.start.end() - 1);
+    for (int i = 0; i < n; i++)
+        forNeighbours(pts + (size_t)i * dim, [&](int cell) {
+            std::copy(pts + (size_t)i * dim, pts + (size_t)(i + 1) * dim, g.rows.begin() + (size_t)cursor[cell]++ * dim);
+        });
+    return g;
+}
+bool CacheGrid::Exists(const float *q, int dim) const {
+    using namespace lmcd;
+    const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
+    int cell = 0;
+    for (int k = 0; k < m; k++) cell = cell * G + CacheGridCell(q[k], G);
+    bool any = false;
+    for (int j = start[cell]; j < start[cell + 1]; j++) {
+        const float *p = rows.data() + (size_t)j * dim;
+        float d = 0.f;
+        for (int k = 0; k < dim; k++) {
+            const float diff = q[k] - p[k];
+            d += diff * diff;
+        }
+        any = any || d < radiusSq;
+    }
+    return any;
+}
+
 KdTreeResult BuildKdTree(const float *pts, int n, int dim) {
     KdBuilder B;
     B.pts = pts, B.dim = dim;

@@ -30,5 +30,14 @@ struct KdTreeResult {
     int depth = 0;
 };
 KdTreeResult BuildKdTree(const float *pts, int n, int dim);
+// dilated uniform grid over the first m coordinates of the cache points (DCacheDim::gridStart / gridRows):
+// start[G^m + 1]; rows = the points of every cell's 3^m neighbourhood, dim floats each
+struct CacheGrid {
+    int G = 0, m = 0;
+    std::vector<int> start;
+    std::vector<float> rows;
+    bool Exists(const float *q, int dim) const;  // the kernel's test, on the host
+};
+CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m);
 
 }  // namespace lmc

@@ -77,6 +77,8 @@ void EnsureDevice(int device) {
 struct CacheDimHost {
     DevBuf<float> pss, v1, v2, weight, ptsLeaf;
     DevBuf<KdNode> nodes;
+    DevBuf<int> gridStart;
+    DevBuf<float> gridRows;
     DevBuf<int> vind;
     bool ready = false;
     bool relevant = false;
@@ -91,6 +93,8 @@ struct lmc_ctx {
     int device = 0;
     int useGradient = 1;
     int maxDervDepth = 8;  // --max-derivatives-depth default, main.cpp:46
+    bool useOccFilter = true;  // LMC_OCC_FILTER=0: A/B switch for the existence test in front of the cache query
+    int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
     hipStream_t stream = nullptr;
     // The three step launches of one iteration touch disjoint chains, so they run concurrently: large steps and the generic
@@ -345,6 +349,8 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
+    if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
     if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
     if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
     UploadScene(c.get());
@@ -638,7 +644,10 @@ static void MaintainCache(lmc_ctx *c) {
         std::vector<float> leafOrder((size_t)PSS_MAX_SIZE * d);
         for (int i = 0; i < PSS_MAX_SIZE; i++) memcpy(&leafOrder[(size_t)i * d], &pts[(size_t)t.vind[i] * d], d * sizeof(float));
         cd.ptsLeaf.Upload(leafOrder);
+        lmc::CacheGrid grid = lmc::BuildCacheGrid(pts.data(), PSS_MAX_SIZE, d, c->gridDims);
+        cd.gridStart.Upload(grid.start), cd.gridRows.Upload(grid.rows);
         DCacheDim &D = c->cacheHost.d[d];
+        D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = grid.G, D.gridM = grid.m;
         D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
         D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
         for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
@@ -1074,6 +1083,22 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
     HIP_CHECK(hipMemcpy(outN, dOutN.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(outIdx, dOutI.p, (size_t)nq * knn * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(outDist, dOutD.p, (size_t)nq * knn * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+// host-only probe of the existence test in front of the cache query (accel.cpp BuildCacheGrid + the kernel's candidate loop):
+// out[i] = 1 iff some cache point lies within the radius of query i.  No device needed.
+int lmc_cache_filter_probe(int dim, int npts, const float *pts, int nq, const float *q, int *out) {
+    LMC_TRY
+    if (dim < 3 || dim > MAXPSS) throw std::runtime_error("lmc_cache_filter_probe: bad dim");
+    for (int m = 3; m <= 4; m++) {  // both grid ranks the kernel can be configured with must agree
+        lmc::CacheGrid g = lmc::BuildCacheGrid(pts, npts, dim, m);
+        for (int i = 0; i < nq; i++) {
+            const int e = g.Exists(q + (size_t)i * dim, dim) ? 1 : 0;
+            if (m > 3 && e != out[i]) throw std::runtime_error("lmc_cache_filter_probe: grid ranks disagree");
+            out[i] = e;
+        }
+    }
     return 0;
     LMC_CATCH(-1)
 }

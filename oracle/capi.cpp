@@ -303,6 +303,17 @@ void orc_compute_gaussian(int dim, const float *v1, const float *M, float ss, fl
     out[3 * dim + 1] = GaussianLogPdf(off, g, false);
 }
 
+// parity / analysis probe: the points of the global cache of one dim (row-major n x dim); returns n
+int orc_cache_points(void *h, int dim, float *out, int cap) {
+    MLT *m = (MLT *)h;
+    if (dim < 2 || dim > 16) return 0;
+    const CacheDim &c = m->cache.dims[dim];
+    const int n = c.is_ready ? PSS_MAX_SIZE : c.data_idx;
+    for (int i = 0; i < n && i < cap; i++)
+        for (int k = 0; k < dim; k++) out[(size_t)i * dim + k] = c.pss[(size_t)i * dim + k];
+    return n;
+}
+
 // H2MC Gaussian of one state (h2mc.cpp:70-142 through the shared header device/dh2mc.h): out = mean[dim], covL[dim*dim],
 // invCov[dim*dim], logDet
 void orc_h2mc_gaussian(int dim, float sigma, float sc, const float *grad, const float *hess, float *out) {

@@ -208,3 +208,31 @@ def test_golden_gradient_vectors(oracle):
     H.lmc_test_pathfunc_host(2, 1, P(k[0].copy()), P(k[1].copy()), P(k[2].copy()), P(ll2), P(g2))
     assert abs(ll2[0] - (-2.53792)) < 1e-4
     assert np.allclose(g2[:4], [0.513756, 1.54127, 0, 0], atol=2e-4)
+
+
+def test_cache_query_existence_test_is_exact():
+    """The lean kernel runs the kd-tree search only when a grid over the first three coordinates finds a cache point within the
+    query radius (dchain.h, dsmall.h).  Exactness in BOTH directions against the reference's radius search (restated nanoflann,
+    the oracle): "found something" <=> "the search returns at least one match", on clustered clouds with queries ON, NEAR,
+    just inside the radius of, and far from the points, for the smallest and the largest radius."""
+    lib = _product_lib()
+    L = gc.oracle_lib()
+    rng = np.random.default_rng(4)
+    for dim in (6, 8, 12):
+        pts = rng.random((3000, dim)).astype(np.float32)
+        pts[:600] = (pts[rng.integers(600, 3000, 600)] + rng.normal(0, 0.01, (600, dim))).astype(np.float32)  # clusters
+        pts = np.clip(pts, 0, np.nextafter(np.float32(1), np.float32(0)))
+        r2 = np.float32(dim * 0.01 * 0.01)
+        q_near = (pts[rng.integers(0, 3000, 4000)] + rng.normal(0, 0.012, (4000, dim))).astype(np.float32)
+        q_edge = pts[rng.integers(0, 3000, 2000)].copy()
+        q_edge[:, :3] += (rng.choice([-1, 1], (2000, 3)) * np.sqrt(r2 / 3) * rng.uniform(0.98, 1.02, (2000, 1))).astype(np.float32)
+        q_far = rng.random((4000, dim)).astype(np.float32)
+        q = np.clip(np.concatenate([q_near, q_edge, q_far]), 0, np.nextafter(np.float32(1), np.float32(0))).astype(np.float32)
+        n = np.zeros(len(q), np.int32)
+        idx = np.zeros((len(q), 5), np.int32)
+        dist = np.zeros((len(q), 5), np.float32)
+        L.orc_kd_query(dim, 3000, P(pts), len(q), P(q), ctypes.c_float(r2), 5, P(n), P(idx), P(dist))
+        found = np.zeros(len(q), np.int32)
+        assert lib.lmc_cache_filter_probe(dim, 3000, P(pts), len(q), P(q), P(found)) == 0
+        assert 500 < (n > 0).sum() < len(q) - 500  # both answers occur
+        assert np.array_equal(found == 1, n > 0), dim
