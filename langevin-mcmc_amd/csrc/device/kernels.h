@@ -47,3 +47,5 @@ void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, i
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 // pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
 void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);
+// dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
+void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s);

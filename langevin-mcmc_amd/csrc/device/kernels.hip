@@ -556,6 +556,104 @@ void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal,
 void LaunchFirstKind(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, hipStream_t s) {
     hipLaunchKernelGGL(k_first_kind, dim3((A.N + 255) / 256), dim3(256), 0, s, S, cache, A, P);
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Dilated grid of one cache dim (DCacheDim::gridStart / gridRows, dchain.h), built on the device from the point rows that are
+// already there: count the (point, neighbour cell) pairs, scan the counts, scatter the rows.  (On the host the same build
+// cost 8-26 ms per dim, lmc::BuildCacheGrid in accel.cpp, which stays as the checker.)  The order of the rows inside a cell
+// depends on the atomics; the existence test ORs over a cell's rows, so it does not see it.
+struct GridShape {
+    int G, m, nbrs, dim, n;
+};
+__device__ inline bool GridNeighbourCell(const GridShape &g, const float *p, int o, int &cell) {
+    cell = 0;
+    bool inside = true;
+    for (int k = 0; k < g.m; k++, o /= 3) {
+        const int ck = CacheGridCell(p[k], g.G) + (o % 3) - 1;
+        inside = inside && ck >= 0 && ck < g.G;
+        cell = cell * g.G + ck;
+    }
+    return inside;
+}
+__global__ void __launch_bounds__(256) k_grid_count(GridShape g, const float *pts, int *start) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.n * g.nbrs) return;
+    int cell;
+    if (GridNeighbourCell(g, pts + (size_t)(t / g.nbrs) * g.dim, t % g.nbrs, cell)) atomicAdd(&start[cell + 1], 1);
+}
+constexpr int SCAN_ITEMS = 8, SCAN_TILE = 256 * SCAN_ITEMS;
+// inclusive scan of v[0..n) in three launches: tiles of 2048, the tile totals (one block), the carry-in
+__global__ void __launch_bounds__(256) k_scan_tiles(int *v, int n, int *tileSums) {
+    __shared__ int warpSums[4];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int x[SCAN_ITEMS], run = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) x[k] = run += (base + k < n ? v[base + k] : 0);
+    int incl = run;  // inclusive scan of the thread totals: wave shuffle, then the four wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) warpSums[wave] = incl;
+    __syncthreads();
+    int carry = incl - run;
+    for (int w = 0; w < wave; w++) carry += warpSums[w];
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < n) v[base + k] = x[k] + carry;
+    if (threadIdx.x == 255) tileSums[blockIdx.x] = carry + run;
+}
+__global__ void __launch_bounds__(256) k_scan_sums(int *tileSums, int nTiles) {  // one block; nTiles is a few thousand at most
+    __shared__ int warpSums[4];
+    __shared__ int carryIn;
+    if (threadIdx.x == 0) carryIn = 0;
+    __syncthreads();
+    for (int b = 0; b < nTiles; b += 256) {
+        const int i = b + threadIdx.x, val = i < nTiles ? tileSums[i] : 0;
+        int incl = val;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) warpSums[wave] = incl;
+        __syncthreads();
+        int carry = carryIn;
+        for (int w = 0; w < wave; w++) carry += warpSums[w];
+        if (i < nTiles) tileSums[i] = incl + carry;
+        __syncthreads();
+        if (threadIdx.x == 255) carryIn = incl + carry;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_scan_carry(int *v, int n, const int *tileSums) {
+    if (blockIdx.x == 0) return;
+    const int carry = tileSums[blockIdx.x - 1], base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < n) v[base + k] += carry;
+}
+__global__ void __launch_bounds__(256) k_grid_scatter(GridShape g, const float *pts, const int *start, int *cursor, float *rows) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.n * g.nbrs) return;
+    const float *p = pts + (size_t)(t / g.nbrs) * g.dim;
+    int cell;
+    if (!GridNeighbourCell(g, p, t % g.nbrs, cell)) return;
+    float *dst = rows + (size_t)(start[cell] + atomicAdd(&cursor[cell], 1)) * g.dim;
+    for (int k = 0; k < g.dim; k++) dst[k] = p[k];
+}
+// start: cells + 1 ints; cursor: cells ints; rows: n * 3^m * dim floats; tileSums: ceil((cells + 1) / 2048) ints
+void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s) {
+    GridShape g{G, m, 1, dim, n};
+    size_t cells = 1;
+    for (int k = 0; k < m; k++) cells *= G, g.nbrs *= 3;
+    (void)hipMemsetAsync(start, 0, (cells + 1) * sizeof(int), s);
+    (void)hipMemsetAsync(cursor, 0, cells * sizeof(int), s);
+    const int pairs = n * g.nbrs, nScan = (int)cells + 1, nTiles = (nScan + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_grid_count, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, start);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nTiles), dim3(256), 0, s, start, nScan, tileSums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, tileSums, nTiles);
+    hipLaunchKernelGGL(k_scan_carry, dim3(nTiles), dim3(256), 0, s, start, nScan, tileSums);
+    hipLaunchKernelGGL(k_grid_scatter, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, start, cursor, rows);
+}
+
 void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s) {
     const int nTiles = (A.N + 1023) / 1024;
     hipLaunchKernelGGL(k_push_count, dim3(nTiles), dim3(256), 0, s, A, tileCounts);

@@ -77,8 +77,9 @@ void EnsureDevice(int device) {
 struct CacheDimHost {
     DevBuf<float> pss, v1, v2, weight, ptsLeaf;
     DevBuf<KdNode> nodes;
-    DevBuf<int> gridStart;
+    DevBuf<int> gridStart, gridCursor, gridTileSums;
     DevBuf<float> gridRows;
+    int gridG = 0, gridM = 0;
     DevBuf<int> vind;
     bool ready = false;
     bool relevant = false;
@@ -644,10 +645,16 @@ static void MaintainCache(lmc_ctx *c) {
         std::vector<float> leafOrder((size_t)PSS_MAX_SIZE * d);
         for (int i = 0; i < PSS_MAX_SIZE; i++) memcpy(&leafOrder[(size_t)i * d], &pts[(size_t)t.vind[i] * d], d * sizeof(float));
         cd.ptsLeaf.Upload(leafOrder);
-        lmc::CacheGrid grid = lmc::BuildCacheGrid(pts.data(), PSS_MAX_SIZE, d, c->gridDims);
-        cd.gridStart.Upload(grid.start), cd.gridRows.Upload(grid.rows);
+        {  // the existence-test grid, on the device (no host time, nothing to upload)
+            cd.gridG = CacheGridG(d), cd.gridM = std::min(c->gridDims, d);
+            size_t cells = 1, nbrs = 1;
+            for (int k = 0; k < cd.gridM; k++) cells *= cd.gridG, nbrs *= 3;
+            cd.gridStart.Alloc(cells + 1, false), cd.gridCursor.Alloc(cells, false), cd.gridTileSums.Alloc((cells + 1) / 2048 + 1, false);
+            cd.gridRows.Alloc((size_t)PSS_MAX_SIZE * nbrs * d, false);
+            LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, d, cd.gridG, cd.gridM, cd.gridStart.p, cd.gridCursor.p, cd.gridRows.p, cd.gridTileSums.p, s);
+        }
         DCacheDim &D = c->cacheHost.d[d];
-        D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = grid.G, D.gridM = grid.m;
+        D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
         D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
         D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
         for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
@@ -1086,6 +1093,38 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
     return 0;
     LMC_CATCH(-1)
 }
+// checker of the device-built grid of one cache dim against the host build (accel.cpp): returns the number of cells whose row
+// sets differ (0 = identical), -1 on error, -2 when that dim's cache is not ready
+int lmc_cache_grid_check(lmc_ctx *c, int dim) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (dim < 0 || dim > PSS_MAX_LENGTH || !c->cacheDims[dim].ready) return -2;
+    CacheDimHost &cd = c->cacheDims[dim];
+    std::vector<float> pts = cd.pss.Download();
+    lmc::CacheGrid g = lmc::BuildCacheGrid(pts.data(), PSS_MAX_SIZE, dim, cd.gridM);
+    if (g.G != cd.gridG) return 1 << 30;
+    std::vector<int> start = cd.gridStart.Download();
+    std::vector<float> rows = cd.gridRows.Download();
+    int bad = 0;
+    const size_t cells = g.start.size() - 1;
+    for (size_t cell = 0; cell < cells; cell++) {
+        if (start[cell] != g.start[cell] || start[cell + 1] != g.start[cell + 1]) {
+            bad++;
+            continue;
+        }
+        auto sorted = [&](const std::vector<float> &r) {
+            std::vector<std::vector<float>> v;
+            for (int j = g.start[cell]; j < g.start[cell + 1]; j++) v.emplace_back(r.begin() + (size_t)j * dim, r.begin() + (size_t)(j + 1) * dim);
+            std::sort(v.begin(), v.end());
+            return v;
+        };
+        if (g.start[cell + 1] > g.start[cell] && sorted(rows) != sorted(g.rows)) bad++;
+    }
+    return bad;
+    LMC_CATCH(-1)
+}
+
 // host-only probe of the existence test in front of the cache query (accel.cpp BuildCacheGrid + the kernel's candidate loop):
 // out[i] = 1 iff some cache point lies within the radius of query i.  No device needed.
 int lmc_cache_filter_probe(int dim, int npts, const float *pts, int nq, const float *q, int *out) {

@@ -361,6 +361,29 @@ def test_cache_phase_parity():
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
+def test_cache_grid_device_build_matches_host():
+    """The existence-test grid in front of the cache query is built on the device (kernels.hip LaunchBuildCacheGrid: count,
+    scan, scatter); the host build of accel.cpp (whose exactness tests/test_host.py proves against the oracle's nanoflann
+    restatement) is the checker: same cell starts, same set of rows in every cell, for every cache dim that filled."""
+    import ctypes
+
+    p = gc.pkg()
+    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, seed_offset=0, use_gradient=1)
+    ren.init_chains(1 << 20, 1 << 17, 16384, 64)
+    ren.step(40)
+    mask = ren.stats()["cacheReadyMask"]
+    assert mask != 0, "test set-up: no cache filled"
+    checked = 0
+    for dim in range(2, 13):
+        r = p.lib().lmc_cache_grid_check(ren.h, dim)
+        if (mask >> dim) & 1:
+            assert r == 0, (dim, r)
+            checked += 1
+        else:
+            assert r == -2, (dim, r)
+    assert checked >= 2
+
+
 def test_full_size_energy_conservation():
     """BASELINE-size chain count: film luminance == normalization * sum of splat weights (every step deposits exactly
     `normalization`, mlt.cpp:103-112) -- a size-independent property, no oracle run needed."""
