@@ -13,8 +13,15 @@
 //     the new primary-sample vector) lives in LDS, laid out [word][thread].
 // Same arithmetic, same RNG order as the generic StepChain (dstep.h), which remains the implementation for
 // large steps and for gradient-evaluating small steps and which the parity tests cross-check against this one.
+//
+// LMC_LEAN_GRAD (step_small_leangrad.hip) compiles the same body with the gradient branch of InitGaussianFor in
+// (mutation_mala.h:94-130): the launch that serves the chains whose cache is still filling.  The path program runs in a
+// non-inlined function on the path record the step has just streamed to HBM, so its private memory does not touch the body.
 #pragma once
 #include "dstep.h"
+#ifdef LMC_LEAN_GRAD
+#include "dgrad.h"
+#endif
 
 namespace lmcd {
 
@@ -196,11 +203,32 @@ struct VSource {
     float w[5];
     double sum_w;
 };
-enum : int { VS_ISOTROPIC = 0, VS_REUSE = 1, VS_BLEND = 2 };
+enum : int { VS_ISOTROPIC = 0, VS_REUSE = 1, VS_BLEND = 2, VS_GRAD = 3 };  // VS_GRAD: clipped gradient in LDS words [0, dim), nMatches = `first`
+
+// What the gradient branch needs to know about the state whose Gaussian is being initialised
+struct GradState {
+    const float *pathBuf;  // its path record (current or proposal buffer of the chain)
+    int c, l;
+    float ssScore;
+    bool isProposal;
+    float *workBuf;  // serialisation buffer (dgrad.h GradWork)
+    size_t workStride, workSlot;
+};
+#ifdef LMC_LEAN_GRAD
+__device__ __noinline__ void LeanStateGradient(const DScene &S, const float *pathBuf, int N, int i, float *workBuf, size_t workStride, size_t workSlot, float *grad) {
+    DPath path;
+    LoadPath(pathBuf, N, i, path);
+    GradWork gw{workBuf, workStride, workSlot};
+    Contrib unused;
+    unused.camDepth = path.camDepth, unused.lightDepth = path.lgtDepth;
+    ComputeGradient(S, path, unused, grad, gw);
+}
+#endif
 
 // First half of InitGaussianFor for a state whose pss is in L.Q: bookkeeping writes, re-use test, cache query.
-LMC_D void PrepareGaussianLean(const DCache &cache, const ChainArrays &A, int i, int dim, float lsScore, int flags, const LdsView &L, VSource &vs,
-                               StepStats &st, bool skipQuery = false) {
+template <bool WITH_GRAD>
+LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, int dim, float lsScore, int flags,
+                               const LdsView &L, VSource &vs, StepStats &st, const GradState &gs, bool skipQuery = false) {
     const size_t N = A.N;
     vs.mode = VS_ISOTROPIC;
     vs.nMatches = 0;
@@ -209,7 +237,36 @@ LMC_D void PrepareGaussianLean(const DCache &cache, const ChainArrays &A, int i,
     if (dim > MD) return;  // PSS_MAX_LENGTH: no cache, chain->pss is never read for such a state
 #pragma unroll 1
     for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = L.Q(k);  // GetPathPss(path, chain->pss)
-    if (dim < PSS_MIN_LENGTH || !cache.d[dim].ready) return;
+    if (dim < PSS_MIN_LENGTH) return;
+#ifdef LMC_LEAN_GRAD
+    if (WITH_GRAD && !cache.d[dim].ready && P.useGradient && GradAvailable(gs.c, gs.l) && gs.c + gs.l - 1 <= P.maxDervDepth) {  // mutation_mala.h:94-130
+        float g[MD];
+#pragma unroll
+        for (int k = 0; k < MD; k++) g[k] = 0.f;
+        if (gs.ssScore > 1e-10f) {
+            if (!(P.expFlags & 4)) LeanStateGradient(S, gs.pathBuf, (int)N, i, gs.workBuf, gs.workStride, gs.workSlot, g);
+            st.gradCalls++;
+            bool finite = true;
+            for (int k = 0; k < dim; k++) finite = finite && isfinite(g[k]);
+            if (!finite)
+                for (int k = 0; k < dim; k++) g[k] = 0.f;
+        }
+        float norm = 0.f;
+        const float drift = S.opt.malaGN;
+        for (int k = 0; k < dim; k++) norm += g[k] * g[k];
+        norm = sqrtf(norm);
+        const float *newV2 = gs.isProposal ? A.chPropNewV2 : A.chCurrNewV2;
+        bool first = true;
+        for (int k = 0; k < dim; k++) {
+            L.U(k) = g[k] * (drift / fmaxf(drift, norm));
+            if (first && newV2[(size_t)k * N + i] > 1e-10f) first = false;
+        }
+        vs.mode = VS_GRAD;
+        vs.nMatches = first ? 1 : 0;
+        return;
+    }
+#endif
+    if (!cache.d[dim].ready) return;
     if (skipQuery) return;
     if (flags & F_QUERIED) {
         float dist_sqr = 0.f;
@@ -271,7 +328,7 @@ struct GaussK {
     float mean, covL, invCov;
 };
 LMC_D GaussK GaussianDim(const DScene &S, const DCacheDim &C, const ChainArrays &A, int i, int dim, int k, const VSource &vs, float ssScore, const LdsView &L,
-                         float &logDet) {
+                         float &logDet, bool isProposal) {
     const size_t N = A.N;
     const float ss = S.opt.malaStepsize, shk = S.opt.malaStdDev;
     GaussK g;
@@ -282,6 +339,13 @@ LMC_D GaussK GaussianDim(const DScene &S, const DCacheDim &C, const ChainArrays 
     float v1, v2;
     if (vs.mode == VS_REUSE) {
         v1 = A.chV1[(size_t)k * N + i], v2 = A.chV2[(size_t)k * N + i];
+    } else if (vs.mode == VS_GRAD) {  // first / second moment update of the clipped gradient, mutation_mala.h:108-128 and :199-221
+        const float gk = L.U(k), ov1 = A.chV1[(size_t)k * N + i], ov2 = A.chV2[(size_t)k * N + i];
+        const bool first = vs.nMatches != 0;
+        v1 = first ? gk : 0.9f * ov1 + 0.1f * gk;
+        v2 = first ? gk * gk : 0.999f * ov2 + 0.001f * gk * gk;
+        (isProposal ? A.chPropNewV2 : A.chCurrNewV2)[(size_t)k * N + i] = v2;
+        if (isProposal) A.chPropNewV1[(size_t)k * N + i] = v1;
     } else {
         v1 = 0.f, v2 = 0.f;
 #pragma unroll
@@ -318,9 +382,9 @@ LMC_D float ClosedFormLogDet(const DScene &S, const VSource &vs, int dim) {
 }
 
 // One plain small step of chain i.  Returns nothing; all state changes go to HBM.
-template <class Stk>
+template <bool WITH_GRAD, class Stk>
 LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, Rng &rng,
-                         const LdsView &L, Stk &stk, StepStats &st) {
+                         const LdsView &L, Stk &stk, StepStats &st, float *workBuf = nullptr, size_t workStride = 0, size_t workSlot = 0) {
     const size_t N = A.N;
     int flags = A.flags[i];
     const int sel = (flags & F_SEL) ? 1 : 0;
@@ -375,7 +439,8 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 for (int d = 0; d < camCount - 1; d++) qs.Push(cur[(size_t)VertWord(false, d, 3) * N + i]), qs.Push(cur[(size_t)VertWord(false, d, 4) * N + i]);
                 if (l == 1) qs.Push(cur[(size_t)VertWord(false, camCount - 1, 10) * N + i]), qs.Push(cur[(size_t)VertWord(false, camCount - 1, 11) * N + i]);
             }
-            PrepareGaussianLean(cache, A, i, dim, curLs, flags, L, vs, st, (P.expFlags & 2) != 0);
+            const GradState gs{cur, c, l, curSs, false, workBuf, workStride, workSlot};
+            PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags |= F_QUERIED;
             flags |= F_GAUSS;
         }
@@ -387,7 +452,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             if (stored) {
                 g.mean = G[(size_t)k * N + i], g.covL = G[(size_t)(MAXPSS + k) * N + i], g.invCov = G[(size_t)(2 * MAXPSS + k) * N + i];
             } else {
-                g = GaussianDim(S, C, A, i, dim, k, vs, curSs, L, logDet);
+                g = GaussianDim(S, C, A, i, dim, k, vs, curSs, L, logDet, false);
                 if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
             }
             const float o = g.covL * nd(rng) + g.mean;
@@ -549,12 +614,13 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         if (mala) {
             float *G = PropGaussBuf(A, flags);
             VSource vs;
-            PrepareGaussianLean(cache, A, i, dim, pc.lsScore, flags, L, vs, st, (P.expFlags & 2) != 0);
+            const GradState gs{prop, c, l, pc.ssScore, true, workBuf, workStride, workSlot};
+            PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags |= F_QUERIED;
             float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
 #pragma unroll 1
             for (int k = 0; k < dim; k++) {
-                const GaussK g = GaussianDim(S, C, A, i, dim, k, vs, pc.ssScore, L, logDet);
+                const GaussK g = GaussianDim(S, C, A, i, dim, k, vs, pc.ssScore, L, logDet, true);
                 if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
                 const float d = -L.U(offBase + k) - g.mean;
                 q += d * (g.invCov * d);

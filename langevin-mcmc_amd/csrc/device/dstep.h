@@ -59,7 +59,7 @@ LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArra
         if (sp.ssScore > 1e-10f) {
             // chains are only dispatched to a launch without the gradient code once the cache of their dim is
             // ready (NeedsGradient below), so this branch is unreachable there; NaN -> zeroed keeps it defined
-            if (WITH_GRAD) ComputeGradient(S, path, sp, vGrad, gw);
+            if (WITH_GRAD && !(P.expFlags & 4)) ComputeGradient(S, path, sp, vGrad, gw);
             else
                 for (int k = 0; k < dim; k++) vGrad[k] = NAN;
             st.gradCalls++;
@@ -172,7 +172,7 @@ LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A,
         } else {
             const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
             if (S.opt.h2mc) nk = NEXT_SMALL_GENERIC;  // every H2MC small step runs k_step_h2mc (the "generic" slot of the launch plan)
-            else if (S.opt.mala && NeedsGeneric(cache, P, c, l)) nk = NEXT_SMALL_GENERIC;
+            else if (S.opt.mala && NeedsGeneric(cache, P, c, l)) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // key: k_build_lists may still re-route it
             else nk = (unsigned char)(NEXT_SMALL_PLAIN | (TechniqueKey(c, l) << 2));
         }
     }

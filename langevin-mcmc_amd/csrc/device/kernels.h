@@ -32,6 +32,8 @@ void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
+void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list,
+                             const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                           const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads,
                           hipStream_t s);
@@ -43,9 +45,11 @@ void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *
                      hipStream_t s);
 // id-ordered work lists of the next step from A.nextKind (coalescing: a wave's 64 list entries are (nearly) consecutive chains)
 // sortPlain: group the plain small steps of every 1024-chain tile by technique (QueueNext's key)
-void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, int sortPlain, hipStream_t s);
+void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, int sortPlain, unsigned leanDims, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 // pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
 void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);
+// groups the entries of a work list by the technique key of A.nextKind (bins: 128 ints of scratch)
+void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
 void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s);

@@ -316,7 +316,7 @@ __global__ void k_first_kind(DScene S, const DCache *cache, ChainArrays A, StepP
 //     64 consecutive chains holds on average (profiles/r02_*).  A wave's chains still come from one 1024-chain tile: its
 //     state accesses stay within a few cache lines per word.
 template <int CPT>  // chains per thread: the tile is 256 * CPT consecutive chains
-__global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next, int sortPlain) {
+__global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next, int sortPlain, unsigned leanDims) {
     __shared__ unsigned long long sWave[4];
     __shared__ int sBase[3];
     __shared__ int sHist[64], sStart[64];
@@ -332,6 +332,10 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
         for (int j = 0; j < CPT; j++)
             if (first + j < A.N) k[j] = A.nextKind[first + j];
     }
+    // a generic entry whose cache became ready after the chain queued it (leanDims, context.cpp) is a plain one now; its
+    // technique key gives the dimension: 2 * path length
+    for (int j = 0; j < CPT; j++)
+        if ((k[j] & 3) == NEXT_SMALL_GENERIC && ((leanDims >> (2 * (3 + (k[j] >> 2) / 6))) & 1u)) k[j] = (unsigned char)(k[j] | NEXT_SMALL_PLAIN);
     // three 21-bit counters packed into one word: [large | generic << 21 | plain << 42]
     unsigned long long mine = 0;
     for (int j = 0; j < CPT; j++) {
@@ -664,12 +668,48 @@ void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned l
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }
-void LaunchBuildLists(const ChainArrays &A, const NextLists &next, int sortPlain, hipStream_t s) {
+// Global counting sort of the generic small-step list by technique key.  The generic kernel evaluates a gradient program per
+// chain: a wave whose 64 chains follow different techniques (c,l) runs their programs one after the other, so (unlike the lean
+// kernel, where the coalescing of the state loads mattered more, profiles/r02_b_*) grouping equal techniques pays.  The order
+// inside a group is left to the atomics: no result depends on the order of a list.
+constexpr int SORT_GRID = 128;
+__global__ void __launch_bounds__(256) k_sort_hist(const unsigned char *nextKind, const int *in, const int *count, int *bins) {
+    __shared__ int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = *count;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SORT_GRID * 256) atomicAdd(&h[nextKind[in[i]] >> 2], 1);
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(64) k_sort_scan(int *bins) {  // bins[0..64) counts -> bins[64..128) cursors (exclusive prefix)
+    const int h = bins[threadIdx.x];
+    int inc = h;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if ((int)threadIdx.x >= off) inc += o;
+    }
+    bins[64 + threadIdx.x] = inc - h;
+}
+__global__ void __launch_bounds__(256) k_sort_scatter(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins) {
+    const int n = *count;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SORT_GRID * 256) {
+        const int chain = in[i];
+        out[atomicAdd(&bins[64 + (nextKind[chain] >> 2)], 1)] = chain;
+    }
+}
+void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins, hipStream_t s) {
+    (void)hipMemsetAsync(bins, 0, 128 * sizeof(int), s);
+    hipLaunchKernelGGL(k_sort_hist, dim3(SORT_GRID), dim3(256), 0, s, nextKind, in, count, bins);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(64), 0, s, bins);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(SORT_GRID), dim3(256), 0, s, nextKind, in, out, count, bins);
+}
+void LaunchBuildLists(const ChainArrays &A, const NextLists &next, int sortPlain, unsigned leanDims, hipStream_t s) {
     // sortPlain: 0 = id order; 1 = technique sort inside 1024-chain tiles; 2 = inside 256-chain tiles (one tile = one 256-thread
     // block of the lean kernel, so the tile's cache lines are shared through that CU's L1)
-    if (sortPlain == 2) hipLaunchKernelGGL(k_build_lists<1>, dim3((A.N + 255) / 256), dim3(256), 0, s, A, next, 1);
+    if (sortPlain == 2) hipLaunchKernelGGL(k_build_lists<1>, dim3((A.N + 255) / 256), dim3(256), 0, s, A, next, 1, leanDims);
     else
-        hipLaunchKernelGGL(k_build_lists<4>, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next, sortPlain);
+        hipLaunchKernelGGL(k_build_lists<4>, dim3((A.N + 1023) / 1024), dim3(256), 0, s, A, next, sortPlain, leanDims);
 }
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lists, dim3(GridFor(n, 256)), dim3(256), 0, s, n, large, counts);

@@ -1,0 +1,42 @@
+// The cache-filling launch: small steps of the chains whose dimension's cache is not ready yet, i.e. whose Gaussians come
+// from the gradient of the path program (mutation_mala.h:94-130).  Same streamed body as the hot launch (dsmall.h) with the
+// gradient branch compiled in; the program itself runs in a non-inlined function over the path record in HBM.  It replaces
+// k_step<false, true, true, true> (step_small_grad.hip) on this list -- that kernel keeps the whole path in private memory
+// and took 3.6 ms per wave even with the gradient program skipped (profiles/r02_h_*) -- which remains the fallback for BVHs
+// deeper than the LDS traversal stack and for cache trees deeper than the LDS search frames.
+#define LMC_LEAN_GRAD
+#include "dsmall.h"
+#include "step_kernel.h"
+
+using namespace lmcd;
+
+template <bool GLOSSY>
+__global__ void __launch_bounds__(256) k_step_small_grad(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
+                                                      const int *listCount, NextLists next, float *gradBuf, int gradStride) {
+    extern __shared__ float lds[];
+    StepStats st;
+    const int total = *listCount;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const LdsView L{lds + threadIdx.x, (int)blockDim.x};
+    for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
+        const int i = list[j];
+        Rng rng;
+        rng.state = A.rngState[i];
+        rng.tab = A.rngTab + (size_t)i * 64;
+        rng.ticks = 0;
+        LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
+        SmallStepLean<true>(S, *cache, A, film, P, i, rng, L, stk, st, gradBuf, (size_t)gradStride, (size_t)tid);
+        QueueNext(S, *cache, A, P, i, rng);
+        A.rngState[i] = rng.state;
+    }
+    BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
+}
+
+// gridBlocks * blockThreads must not exceed gradStride (one serialisation slot per thread)
+void LaunchStepSmallLeanGrad(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
+                             const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, hipStream_t s) {
+    const size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float);
+    if (glossy) hipLaunchKernelGGL((k_step_small_grad<true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+    else
+        hipLaunchKernelGGL((k_step_small_grad<false>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+}

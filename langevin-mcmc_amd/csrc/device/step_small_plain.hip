@@ -22,10 +22,10 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
         rng.ticks = 0;
         if (USE_LDS_STACK) {
             LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
-            SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
+            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st);
         } else {
             LocalStackT<GLOSSY> stk;
-            SmallStepLean(S, *cache, A, film, P, i, rng, L, stk, st);
+            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st);
         }
         QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;

@@ -96,6 +96,10 @@ struct lmc_ctx {
     int maxDervDepth = 8;  // --max-derivatives-depth default, main.cpp:46
     bool useOccFilter = true;  // LMC_OCC_FILTER=0: A/B switch for the existence test in front of the cache query
     int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
+    bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
+    bool anyDeepCache = false;  // some ready cache tree is deeper than the lean kernels' LDS search frames
+    bool sortGeneric = true;   // LMC_SORT_GENERIC=0: A/B switch for the technique sort of the gradient launch
+    DevBuf<int> listScratch, sortBins;
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
     hipStream_t stream = nullptr;
     // The three step launches of one iteration touch disjoint chains, so they run concurrently: large steps and the generic
@@ -351,9 +355,12 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
+    if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
+    if (const char *e = getenv("LMC_SORT_GENERIC")) c->sortGeneric = atoi(e) != 0;
     if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
     if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
     if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
+    if (const char *e = getenv("LMC_EXP_NOGRAD")) c->expFlags |= atoi(e) ? 4 : 0;
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -577,6 +584,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     UploadCacheStruct(c);
     c->allCachesReady = false;
     c->needGeneric = true;
+    c->anyDeepCache = false;
     if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
         c->allCachesReady = true;
         c->h2Gauss.Alloc(2 * N * (size_t)(16 + 2 * 256 + 1), false);  // current + proposal buffer (F_GSEL)
@@ -586,13 +594,14 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
         for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
         c->listCounts[b].Alloc(4);
     }
+    c->listScratch.Alloc(N, false), c->sortBins.Alloc(128);
     c->parity = 0;
     if (c->seedChains) {  // chains start valid: the first step's kind is drawn like any other (mlt.cpp:96-97)
         StepParams P;
         P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
         LaunchFirstKind(c->S, c->cacheDev.p, c->A, P, s);
         NextLists first{c->lists[0][0].p, c->lists[0][1].p, c->lists[0][2].p, c->listCounts[0].p};
-        LaunchBuildLists(c->A, first, c->sortPlain, s);
+        LaunchBuildLists(c->A, first, c->sortPlain, 0u, s);
     } else
         LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
@@ -620,6 +629,14 @@ int lmc_init_result(lmc_ctx *c, float *normalization, long long *numContribs) {
 // After every step, until all caches in use are full: apply the step's pushes (three small launches for all dims), read the
 // four fill counts back and build the kd-tree of a dim that has just reached PSS_MAX_SIZE (global_cache.h:85-92), so
 // that the next step already queries it -- the lock-step contract the oracle implements too.
+// bit d: small steps of dimension d run the lean launch (MALA with that dim's cache ready and shallow enough for the LDS search)
+static unsigned LeanDims(const lmc_ctx *c) {
+    unsigned m = 0;
+    if (c->S.opt.h2mc || !c->S.opt.mala) return 0;
+    for (int d = PSS_MIN_LENGTH; d <= PSS_MAX_LENGTH; d++)
+        if (c->cacheDims[d].ready && !c->cacheHost.d[d].deep) m |= 1u << d;
+    return m;
+}
 static void MaintainCache(lmc_ctx *c) {
     hipStream_t s = c->stream;
     bool anyPending = false;
@@ -656,6 +673,7 @@ static void MaintainCache(lmc_ctx *c) {
         DCacheDim &D = c->cacheHost.d[d];
         D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
         D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
+        c->anyDeepCache = c->anyDeepCache || D.deep;
         D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
         for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
         cd.ready = true;
@@ -701,6 +719,8 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
         if (c->needGeneric && c->S.opt.h2mc)
             LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
+        else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && c->bvhDepth <= BVH_LDS_STACK)
+            LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, sG);
         else if (c->needGeneric)
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
@@ -715,13 +735,19 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
                 HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[1], 0));
             }
         }
-        LaunchBuildLists(c->A, next, c->sortPlain, s);
+        // a cache that becomes ready at the end of this step (mlt.cpp: push() flips is_ready inside the step) is seen by the
+        // list build: chains whose next step no longer needs a gradient go to the lean launch right away
+        if (!c->allCachesReady) MaintainCache(c);
+        LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c), s);
+        if (c->sortGeneric && c->needGeneric && c->S.opt.mala && !c->S.opt.h2mc) {  // group the gradient launch's chains by technique
+            LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, s);
+            std::swap(c->lists[nxt][1].p, c->listScratch.p);
+        }
         c->parity = nxt;
         if (c->timing) {
             HIP_CHECK(hipEventRecord(ev.e[3], s));
             c->events.push_back(ev);
         }
-        if (!c->allCachesReady) MaintainCache(c);
     }
     HIP_CHECK(hipGetLastError());
     return 0;
