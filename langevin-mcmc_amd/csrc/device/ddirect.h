@@ -13,9 +13,63 @@ LMC_D float MISWeight(float pdfA, float pdfB) {  // path.cpp:23-27
     return 1.0f / (1.0f + ratioSq);
 }
 
-// one GeneratePath(scene, (x,y), minDepth, maxDepth) call; contributions go straight to the film (direct.cpp:42-45)
-template <class Stk>
-LMC_D void DirectSample(const DScene &S, const Film &film, int px, int py, int minDepth, int maxDepth, Rng &rng, Stk &stk) {
+// where a sample's contributions go (direct.cpp:42-45): straight to the film ...
+struct FilmSink {
+    Film film;
+    LMC_D void operator()(V2 screenPos, V3 contrib) const { Splat(film, screenPos, contrib); }
+};
+// ... or into the lane's registers, to be committed in stream order by k_direct_wave.  With maxDepth <= 2 (the pre-pass) a
+// sample makes at most two contributions (direct-light sample at the first hit, emitter found by the BSDF sample), both at
+// the sample's own screen position.
+struct LaneSink {
+    V2 screenPos;
+    V3 c[2];
+    int n;
+    LMC_D void operator()(V2 sp, V3 contrib) {
+        screenPos = sp;
+        if (n < 2) c[n] = contrib;
+        n++;
+    }
+};
+
+// pcg32_k64 read-only: a lane that evaluates a sample ahead of the committed stream position must not advance the stream's
+// extension table; it reports the case instead (`crossed`, once per 2^32 draws) and counts its draws
+struct SpecRng {
+    uint64_t state;
+    const uint32_t *tab;
+    uint32_t draws;
+    bool crossed;
+    LMC_D uint32_t Next() {
+        const uint64_t s = state;
+        if ((s & 0xFFFFFFFFull) == 0ull) crossed = true;
+        const uint32_t rhs = tab[(unsigned)(s & 63u)];
+        state = s * PCG_MULT + PCG_INC;
+        draws++;
+        return PcgOutputXshRs(s) ^ rhs;
+    }
+    LMC_D float Uniform() {
+        float r = (float)Next() * 2.3283064365386963e-10f;
+        return r >= 1.0f ? 0.99999994f : r;
+    }
+};
+// the LCG `delta` steps ahead (pcg_random.hpp:522-541, advance())
+LMC_HD uint64_t PcgAdvance(uint64_t state, uint64_t delta) {
+    uint64_t accMult = 1u, accPlus = 0u, curMult = PCG_MULT, curPlus = PCG_INC;
+    while (delta > 0) {
+        if (delta & 1) {
+            accMult *= curMult;
+            accPlus = accPlus * curMult + curPlus;
+        }
+        curPlus = (curMult + 1) * curPlus;
+        curMult *= curMult;
+        delta >>= 1;
+    }
+    return accMult * state + accPlus;
+}
+
+// one GeneratePath(scene, (x,y), minDepth, maxDepth) call
+template <class Stk, class R, class Sink>
+LMC_D void DirectSample(const DScene &S, Sink &sink, int px, int py, int minDepth, int maxDepth, R &rng, Stk &stk) {
     constexpr bool G = Stk::kGlossy;
     (void)rng.Uniform();  // time
     // Vector2(f(u), g(u)): gcc evaluates the second argument first
@@ -50,7 +104,7 @@ LMC_D void DirectSample(const DScene &S, const Film &film, int px, int py, int m
                     const float lightPickProb = PickLightProb(S, light);
                     contrib = contrib * MISWeight(lastBsdfPdf, directPdf * lightPickProb);
                 }
-                if (Luminance(contrib) > 0.0f) Splat(film, screenPos, contrib);
+                if (Luminance(contrib) > 0.0f) sink(screenPos, contrib);
             }
             return;
         }
@@ -74,7 +128,7 @@ LMC_D void DirectSample(const DScene &S, const Film &film, int px, int py, int m
                     V3 contrib = cmul(throughput, bsdfContrib);
                     contrib = cmul(contrib, lightContrib) * inverse(lightPickProb);
                     if (!LightIsDelta(S, dl)) contrib = contrib * MISWeight(directPdf * lightPickProb, bsdfPdf);
-                    if (Luminance(contrib) > 0.0f) Splat(film, screenPos, contrib);
+                    if (Luminance(contrib) > 0.0f) sink(screenPos, contrib);
                 }
             }
         }

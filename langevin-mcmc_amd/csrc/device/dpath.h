@@ -106,7 +106,8 @@ LMC_D float ShadingNormalCorrection(V3 wi, const Isect &isect, V3 wo) {  // path
 }
 
 // Vector2(uniDist(rng), uniDist(rng)): gcc evaluates the arguments right to left (see oracle/path.cpp)
-LMC_D V2 RndVec2(Rng &rng) {
+template <class R>
+LMC_D V2 RndVec2(R &rng) {
     float first = rng.Uniform();
     float second = rng.Uniform();
     return V2{second, first};
@@ -350,7 +351,8 @@ LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS 
     return false;
 }
 
-LMC_D bool RussianRoulette(int depth, V3 bsdfContrib, float &rrWeight, V3 &throughput, Rng &rng) {  // path.cpp:388-404
+template <class R>
+LMC_D bool RussianRoulette(int depth, V3 bsdfContrib, float &rrWeight, V3 &throughput, R &rng) {  // path.cpp:388-404
     float rrProb = 1.0f;
     if (depth >= 3) rrProb = fminf(MaxCoeff(bsdfContrib), 0.95f);
     if (rng.Uniform() > rrProb) return false;

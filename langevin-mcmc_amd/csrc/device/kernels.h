@@ -21,7 +21,9 @@ void LaunchInitRegen(const lmcd::DScene &S, int numChains, long long perThread, 
                      uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
                      float *initScoreSum, hipStream_t s);
 // direct.cpp:4-54; tabScratch: 64 words per 16x16 tile
-void LaunchDirect(const lmcd::DScene &S, const lmcd::Film &film, int directSpp, int minDepth, int maxDepth, uint32_t *tabScratch, hipStream_t s);
+// waveKernel: one wave per tile with speculative stream positions (kernels.hip) when maxDepth <= 2 and the BVH fits the LDS stack
+void LaunchDirect(const lmcd::DScene &S, const lmcd::Film &film, int directSpp, int minDepth, int maxDepth, int bvhDepth, bool waveKernel, uint32_t *tabScratch,
+                  hipStream_t s);
 void LaunchBidirMC(const lmcd::DScene &S, const lmcd::Film &film, int nThreads, int samplesPerThread, uint32_t *tabScratch, float *contribScratch, hipStream_t s);
 void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
                        float normalization, hipStream_t s);

@@ -231,7 +231,103 @@ __global__ void k_direct(DScene S, Film film, int directSpp, int minDepth, int m
     LocalStackT<GLOSSY> stk;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++)
-            for (int s = 0; s < directSpp; s++) DirectSample(S, film, x, y, minDepth, maxDepth, rng, stk);
+            for (int s = 0; s < directSpp; s++) {
+                FilmSink sink{film};
+                DirectSample(S, sink, x, y, minDepth, maxDepth, rng, stk);
+            }
+}
+
+// The same pass with one WAVE per tile.  The reference consumes one RNG stream per tile, sample after sample, and a sample's
+// number of draws depends on what its rays hit -- but inside a tile it is nearly always the same (3 when the primary ray
+// escapes, 10 on a surface), so the lanes evaluate 64 consecutive samples at once, lane j from the stream position
+// "committed position + j * K" (K = the draw count of the last committed sample; the LCG is jumped ahead, the extension table
+// is only read).  Lane 0's position is exact by construction; lane j's is exact iff every lane before it drew exactly K
+// numbers.  The wave commits that prefix -- plus the first lane that drew a different number, whose position was still right
+// -- in stream order into a tile accumulator in LDS, moves the committed position, and repeats.  Same numbers, same order of
+// the float sums as the one-thread-per-tile kernel above (the parity test is unchanged), 17 s -> well under a second at
+// 1024 x 768 x 256 spp.  Needs maxDepth <= 2 (LaneSink) and a BVH no deeper than the LDS stack.
+template <bool GLOSSY>
+__global__ void __launch_bounds__(64) k_direct_wave(DScene S, Film film, int directSpp, int minDepth, int maxDepth, int nXTiles, uint32_t *tabScratch) {
+    __shared__ float sTile[16 * 16 * 3];
+    __shared__ int sStack[BVH_LDS_STACK * 64];
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int tx = tile % nXTiles, ty = tile / nXTiles;
+    const int x0 = tx * 16, x1 = min(x0 + 16, S.cam.width), y0 = ty * 16, y1 = min(y0 + 16, S.cam.height);
+    const int tw = x1 - x0, th = y1 - y0;
+    for (int k = lane; k < 16 * 16 * 3; k += 64) sTile[k] = 0.f;
+    uint32_t *tab = tabScratch + (size_t)tile * 64;
+    uint64_t committed = 0;  // stream state at the first uncommitted sample (same value in every lane)
+    if (lane == 0) committed = PcgSeed((uint64_t)(tile + S.opt.seedOffset), tab);
+    committed = ((uint64_t)__shfl((unsigned)(committed >> 32), 0) << 32) | __shfl((unsigned)committed, 0);
+    __syncthreads();
+    LdsStackT<GLOSSY> stk{sStack + lane, 64, 0};
+    const int total = tw * th * directSpp;
+    int n0 = 0;
+    unsigned K = 10;
+    auto commit = [&](const LaneSink &ls) {  // Splat (dchain.h), into the tile accumulator when the pixel is the tile's
+        for (int k = 0; k < ls.n && k < 2; k++) {
+            if (!AllFinite(ls.c[k])) continue;
+            const int ix = Clampi((int)(ls.screenPos.x * film.W), 0, film.W - 1), iy = Clampi((int)(ls.screenPos.y * film.H), 0, film.H - 1);
+            if (ix >= x0 && ix < x1 && iy >= y0 && iy < y1) {
+                float *px = sTile + ((iy - y0) * 16 + (ix - x0)) * 3;
+                px[0] += ls.c[k].x, px[1] += ls.c[k].y, px[2] += ls.c[k].z;
+            } else {
+                float *px = film.rgb + ((size_t)iy * film.W + ix) * 3;
+                unsafeAtomicAdd(px + 0, ls.c[k].x), unsafeAtomicAdd(px + 1, ls.c[k].y), unsafeAtomicAdd(px + 2, ls.c[k].z);
+            }
+        }
+    };
+    while (n0 < total) {
+        const int active = min(64, total - n0);
+        LaneSink ls;
+        ls.n = 0;
+        SpecRng rng{PcgAdvance(committed, (uint64_t)lane * K), tab, 0u, false};
+        if (lane < active) {
+            const int n = n0 + lane, pix = n / directSpp;
+            DirectSample(S, ls, x0 + pix % tw, y0 + pix / tw, minDepth, maxDepth, rng, stk);
+        }
+        const unsigned long long bad = __ballot(lane < active && (rng.draws != K || rng.crossed));
+        const int m = bad ? __ffsll((long long)bad) - 1 : active;  // lanes [0, m) consumed exactly K draws each
+        int nCommit = m;
+        uint64_t advance = (uint64_t)m * K;
+        bool sequential = false;
+        if (m < active) {
+            if (__shfl((int)rng.crossed, m)) sequential = true;  // the table advances inside sample n0 + m: run it for real
+            else {
+                const unsigned drawsM = __shfl(rng.draws, m);
+                nCommit = m + 1, advance += drawsM, K = drawsM;
+            }
+        }
+        for (int j = 0; j < nCommit; j++)  // stream order
+            if (lane == j) commit(ls);
+        committed = PcgAdvance(committed, advance);
+        n0 += nCommit;
+        if (sequential) {
+            __syncthreads();
+            uint64_t st = 0;
+            if (lane == 0) {
+                Rng real;
+                real.state = committed, real.tab = tab, real.ticks = 0;
+                LaneSink one;
+                one.n = 0;
+                const int pix = n0 / directSpp;
+                DirectSample(S, one, x0 + pix % tw, y0 + pix / tw, minDepth, maxDepth, real, stk);
+                commit(one);
+                st = real.state;
+            }
+            committed = ((uint64_t)__shfl((unsigned)(st >> 32), 0) << 32) | __shfl((unsigned)st, 0);
+            n0 += 1;
+            __syncthreads();  // the advanced table is visible to every lane
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < 16 * 16; k += 64) {
+        const int ix = x0 + k % 16, iy = y0 + k / 16;
+        if (ix < x1 && iy < y1) {
+            float *px = film.rgb + ((size_t)iy * film.W + ix) * 3;
+            unsafeAtomicAdd(px + 0, sTile[k * 3 + 0]), unsafeAtomicAdd(px + 1, sTile[k * 3 + 1]), unsafeAtomicAdd(px + 2, sTile[k * 3 + 2]);
+        }
+    }
 }
 
 // cross-check estimator: plain Monte Carlo over GeneratePathBidir samples (uniform screen positions), every contribution
@@ -541,8 +637,14 @@ void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long l
         hipLaunchKernelGGL(k_init_regen<false>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
                        contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
 }
-void LaunchDirect(const DScene &S, const Film &film, int directSpp, int minDepth, int maxDepth, uint32_t *tabScratch, hipStream_t s) {
+void LaunchDirect(const DScene &S, const Film &film, int directSpp, int minDepth, int maxDepth, int bvhDepth, bool waveKernel, uint32_t *tabScratch, hipStream_t s) {
     const int nX = (S.cam.width + 15) / 16, nY = (S.cam.height + 15) / 16;
+    if (waveKernel && maxDepth >= 0 && maxDepth <= 2 && bvhDepth <= BVH_LDS_STACK) {
+        if (S.glossy) hipLaunchKernelGGL(k_direct_wave<true>, dim3(nX * nY), dim3(64), 0, s, S, film, directSpp, minDepth, maxDepth, nX, tabScratch);
+        else
+            hipLaunchKernelGGL(k_direct_wave<false>, dim3(nX * nY), dim3(64), 0, s, S, film, directSpp, minDepth, maxDepth, nX, tabScratch);
+        return;
+    }
     if (S.glossy) hipLaunchKernelGGL(k_direct<true>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, minDepth, maxDepth, nX, nY, tabScratch);
     else
         hipLaunchKernelGGL(k_direct<false>, dim3((nX * nY + 63) / 64), dim3(64), 0, s, S, film, directSpp, minDepth, maxDepth, nX, nY, tabScratch);

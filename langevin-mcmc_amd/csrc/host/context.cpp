@@ -350,7 +350,16 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     ov.maxDepth = desc->max_depth, ov.width = desc->width, ov.height = desc->height, ov.seedOffset = desc->seed_offset;
     c->scene = lmc::ParseScene(desc->scene_xml, ov);
     HIP_CHECK(hipStreamCreate(&c->stream));
-    for (auto &st : c->sideStream) HIP_CHECK(hipStreamCreate(&st));
+    {
+        // the side launches (large steps, cache-filling small steps) are short lists of long-running waves: with a higher
+        // queue priority their workgroups are placed before the hot launch's, which would otherwise hold every CU's LDS
+        // until it retires (LMC_STREAM_PRIO=0: A/B switch)
+        int lo = 0, hi = 0;  // hi = the numerically lowest value = greatest priority
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char *e = getenv("LMC_STREAM_PRIO");
+        const bool prio = !e || atoi(e) != 0;
+        for (auto &st : c->sideStream) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio ? hi : 0));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
@@ -845,7 +854,8 @@ static int PathTracePass(lmc_ctx *c, int directSpp, int minDepth, int maxDepth) 
     DevBuf<uint32_t> tab;
     tab.Alloc((size_t)nTiles * 64, false);
     Film film{c->directFilm.p, W, H};
-    LaunchDirect(c->S, film, directSpp, minDepth, maxDepth, tab.p, c->stream);
+    const char *e = getenv("LMC_DIRECT_WAVE");  // =0: the one-thread-per-tile kernel (A/B, and the checker of the wave kernel)
+    LaunchDirect(c->S, film, directSpp, minDepth, maxDepth, c->bvhDepth, !e || atoi(e) != 0, tab.p, c->stream);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     HIP_CHECK(hipGetLastError());
     return 0;

@@ -236,6 +236,41 @@ def test_direct_lighting_prepass_parity(L, force_diffuse):
     assert np.linalg.norm(la - lb) <= (1e-4 if force_diffuse else 2e-2) * np.linalg.norm(la)
 
 
+@pytest.mark.parametrize("force_diffuse", [1, 0])
+def test_direct_prepass_wave_kernel_equals_tile_thread_kernel(force_diffuse, monkeypatch):
+    """The pre-pass runs one wave per 16x16 tile with speculative stream positions (kernels.hip k_direct_wave); the
+    one-thread-per-tile kernel, which walks the tile's RNG stream sample by sample like direct.cpp:23-47, is its checker:
+    same random numbers and the same order of the float sums, so the images agree bit for bit inside the tiles.  (A
+    contribution whose screen position rounds into the neighbouring tile is added atomically in both kernels: 1-ulp slack
+    on a handful of border pixels.)  Ragged size: the last tile column / row is partial."""
+    out = []
+    for wave in ("0", "1"):
+        monkeypatch.setenv("LMC_DIRECT_WAVE", wave)
+        ren = gc.pkg().Renderer(gc.TORUS, force_diffuse=force_diffuse, max_depth=8, width=200, height=120, seed_offset=3)
+        out.append(ren.direct_lighting(24))
+        ren.close()
+    a, b = out
+    assert np.isfinite(b).all() and a.sum() > 0
+    same = a == b
+    assert same.mean() > 0.999
+    assert np.allclose(a, b, rtol=1e-6, atol=0)
+
+
+def test_direct_prepass_full_size_time():
+    """the 1024x768 pre-pass at the scene's own 256 spp took 17 s with one thread per tile."""
+    import time
+
+    ren = gc.pkg().Renderer(gc.TORUS, force_diffuse=0, max_depth=8, seed_offset=0)
+    ren.direct_lighting(1)  # warm-up (module load)
+    t0 = time.time()
+    d = ren.direct_lighting(256)
+    dt = time.time() - t0
+    ren.close()
+    print("direct pre-pass 1024x768x256spp: %.3f s" % dt)
+    assert np.isfinite(d).all() and d.sum() > 0
+    assert dt < 2.0
+
+
 def test_full_render_matches_reference_image():
     """End to end against the reference authors' own render of the shipped scene file (tests/golden/torus_ref_images_256x192.npz =
     scenes/torus/lmc_timeuse_44.689152s.exr, 245 spp, box-downsampled 4x) with the reference's own semantics -- no option the
