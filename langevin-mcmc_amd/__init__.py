@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "liblmc_hip.so")
+LIB_PATH = os.environ.get("LMC_LIB") or os.path.join(_HERE, "liblmc_hip.so")  # LMC_LIB: A/B builds of the same library (scripts/)
 vp = ctypes.c_void_p
 c_ll = ctypes.c_longlong
 

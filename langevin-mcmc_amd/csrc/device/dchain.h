@@ -97,6 +97,7 @@ struct ChainArrays {
     float *initPath, *initContrib, *initScoreSum;
     // per-launch counters: [0] steps, [1] large, [2] accepted, [3] gradCalls, [4] cacheQueries, [5] cacheHits, [6] resets
     unsigned long long *counters;
+    unsigned long long *prof;  // region cycle sums of the profiling instantiation of the lean kernel (dsmall.h WaveProf), 16 words
     double *weightSum;
 };
 

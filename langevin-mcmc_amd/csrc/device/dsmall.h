@@ -29,18 +29,17 @@ namespace lmcd {
 // PSS_MAX_LENGTH always get IsotropicGaussian(malaStdDev), which needs no per-dimension storage at all.
 constexpr int MD = PSS_MAX_LENGTH;
 
-// LDS words per thread (80 = 320 B; 20 KB per wave, 8 waves per CU):
-//   [0, 56)   union of the BVH stack (32 entries) and the kd search state (MD per-dimension distances + KD_LDS_DEPTH
-//             two-word frames)
-//   [56, 68)  the proposal offsets of a state with dim <= MD; they must survive the kd search of the proposal state.
-//             A state with dim > MD (up to 2 * MAXD offsets) is never searched for: its offsets use [32, 56)
-//   [68, 80)  the new primary-sample vector (first MD entries; longer ones are never looked up)
-constexpr int LDS_KD_FRAMES = MD;
-constexpr int LDS_UNION_WORDS = LDS_KD_FRAMES + 2 * KD_LDS_DEPTH;  // 56
-static_assert(LDS_UNION_WORDS >= BVH_LDS_STACK + MAXPSS, "long offset vectors sit above the BVH stack inside the union region");
-constexpr int LDS_OFF_SHORT = LDS_UNION_WORDS, LDS_OFF_LONG = BVH_LDS_STACK;
+// LDS words per thread (56 = 224 B; 14 KB per wave, 11 waves per CU):
+//   [0, 32)   the BVH stack; between traversals the clipped gradient of the cache-filling launch (dim <= MD words)
+//   [32, 44)  the proposal offsets of a state with dim <= MD
+//   [44, 56)  its new primary-sample vector
+//   [32, 56)  the offsets of a state with dim > MD (up to 2 * MAXD): such a state is never looked up, it has no Q
+// The kd-tree search frames used to live here too (80 words, 8 waves per CU).  Since the existence test (dchain.h) the search
+// runs for 0.015 % of the queries: it now keeps its frames in private memory, out of line (KdRadiusSearchRare).
+constexpr int LDS_OFF_SHORT = BVH_LDS_STACK, LDS_OFF_LONG = BVH_LDS_STACK;
 constexpr int LDS_Q_WORD = LDS_OFF_SHORT + MD;
-constexpr int LDS_WORDS_PER_THREAD = LDS_Q_WORD + MD;  // 80
+constexpr int LDS_WORDS_PER_THREAD = LDS_OFF_LONG + MAXPSS;  // 56
+static_assert(LDS_Q_WORD + MD <= LDS_WORDS_PER_THREAD, "short states: offsets + new pss fit the region of the long offsets");
 
 struct LdsView {
     float *base;  // &lds[threadIdx.x]
@@ -79,119 +78,22 @@ struct OffsetCursor {
     int w;  // next word
     LMC_D float Pop() { return L.U(w++); }
 };
-// the new primary-sample vector: only its first MD entries are ever looked up (cache query / reuse test)
+// the new primary-sample vector of a state with dim <= MD (cache query / reuse test / chain->pss); longer states are never
+// looked up and their offsets occupy the words Q would use
 struct PssSink {
     const LdsView &L;
+    bool keep;
     int n = 0;
     LMC_D void Push(float v) {
-        if (n < MD) L.Q(n) = v;
+        if (keep && n < MD) L.Q(n) = v;
         n++;
     }
 };
 
-// kd-tree radius search with all run-time indexed state in LDS: the traversal of KdRadiusSearch (dchain.h), i.e.
-// nanoflann's searchLevel with the reference's stop-after-knn result set, reorganised for a wave:
-//   * "while-while": every lane first walks its frame stack until its top frame is a leaf (or the search is over), then
-//     all lanes scan their leaf's points together.  As one loop with a leaf branch, a wave spent most of its
-//     vector-memory instructions scanning leaves with 2-3 active lanes (profiles/r01_e);
-//   * the points are read from a copy stored in leaf order (C.ptsLeaf), two coordinates per load, the query from
-//     registers.
-// Per lane the sequence of visited nodes, tested points and matches is unchanged.
-LMC_D int KdRadiusSearchLds(const DCacheDim &C, int dim, const LdsView &L, float radiusSq, int knn, int *idx, float *dist) {
-    // union layout: [0,MD) dists, then KD_LDS_DEPTH x (node | phase << 30, mindistsq until phase 2 / saved dists[id] afterwards)
-    float q[MD];
-    float distsq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MD; i++) {
-        q[i] = 0.f;
-        if (i < dim) {
-            q[i] = L.Q(i);
-            float d = 0.f;
-            if (q[i] < C.rootLow[i]) d = (q[i] - C.rootLow[i]) * (q[i] - C.rootLow[i]);
-            if (q[i] > C.rootHigh[i]) d = (q[i] - C.rootHigh[i]) * (q[i] - C.rootHigh[i]);
-            L.U(i) = d;
-            distsq += d;
-        }
-    }
-    int sp = 0;
-    int count = 0;
-    auto FN = [&](int lvl) -> float & { return L.U(LDS_KD_FRAMES + 2 * lvl); };
-    auto FM = [&](int lvl) -> float & { return L.U(LDS_KD_FRAMES + 2 * lvl + 1); };
-    FN(0) = __int_as_float(0), FM(0) = distsq;  // node 0, phase 0 (phase in the top 2 bits)
-    sp = 1;
-    for (;;) {
-        // ---- walk until the top frame is a leaf
-        int leafLeft = 0, leafRight = 0;
-        bool atLeaf = false;
-        while (sp > 0) {
-            const int lvl = sp - 1;
-            const int packed = __float_as_int(FN(lvl));
-            const int node = packed & 0x3fffffff, phase = (unsigned)packed >> 30;
-            const KdNode nd = C.nodes[node];
-            if (nd.child1 < 0 && nd.child2 < 0) {
-                leafLeft = nd.left, leafRight = nd.right;
-                atLeaf = true;
-                break;
-            }
-            const int id = nd.divfeat;
-            const float val = L.Q(id);
-            const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
-            int bestChild, otherChild;
-            float cut_dist;
-            if ((diff1 + diff2) < 0) {
-                bestChild = nd.child1, otherChild = nd.child2;
-                cut_dist = (val - nd.divhigh) * (val - nd.divhigh);
-            } else {
-                bestChild = nd.child2, otherChild = nd.child1;
-                cut_dist = (val - nd.divlow) * (val - nd.divlow);
-            }
-            if (phase == 0) {
-                FN(lvl) = __int_as_float(node | (1 << 30));
-                if (sp >= KD_LDS_DEPTH) return -1;  // the host routes deeper trees to the generic kernel
-                FM(sp) = FM(lvl), FN(sp) = __int_as_float(bestChild);
-                sp++;
-                continue;
-            }
-            if (phase == 1) {
-                const float dst = L.U(id);
-                const float mindistsq = FM(lvl) + cut_dist - dst;
-                FM(lvl) = dst;  // the frame's mindistsq is dead from here on: the word now keeps dists[id] for the restore
-                L.U(id) = cut_dist;
-                FN(lvl) = __int_as_float(node | (2 << 30));
-                if (mindistsq * 1.0f <= radiusSq) {
-                    if (sp >= KD_LDS_DEPTH) return -1;
-                    FM(sp) = mindistsq, FN(sp) = __int_as_float(otherChild);
-                    sp++;
-                    continue;
-                }
-            }
-            L.U(id) = FM(lvl);
-            sp--;
-        }
-        if (!atLeaf) break;
-        // ---- scan the leaf
-        for (int i = leafLeft; i < leafRight; ++i) {
-            const float2 *row = reinterpret_cast<const float2 *>(C.ptsLeaf + (size_t)i * dim);
-            float d = 0.f;
-#pragma unroll
-            for (int k = 0; k < MD / 2; ++k)
-                if (2 * k < dim) {
-                    const float2 p = row[k];
-                    const float diff0 = q[2 * k] - p.x;
-                    d += diff0 * diff0;
-                    const float diff1 = q[2 * k + 1] - p.y;
-                    d += diff1 * diff1;
-                }
-            if (d < radiusSq) {
-                idx[count] = C.vind[i];
-                dist[count] = d;
-                count++;
-                if (count >= knn) return count;
-            }
-        }
-        sp--;
-    }
-    return count;
+// The nanoflann-ordered radius search (dchain.h KdRadiusSearch) for the rare query that has a point within its radius.
+// Out of line: its frame stack lives in private memory that the common path never touches.
+__device__ __noinline__ int KdRadiusSearchRare(const DCacheDim &C, int dim, const float *q, float radiusSq, int *idx, float *dist) {
+    return KdRadiusSearch(C, dim, q, radiusSq, 5, idx, dist);
 }
 
 // Where the moment vectors (v1, v2) behind a state's Gaussian come from (mutation_mala.h:131-164 and :224-257, cache /
@@ -283,10 +185,10 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     st.cacheQueries++;
     const DCacheDim &C = cache.d[dim];
     const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
-    if (C.gridStart) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
-        float q[MD];
+    float q[MD];
 #pragma unroll
-        for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
+    for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
+    if (C.gridStart) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
         int cell = 0;
         for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(q[k], C.gridG);
         const int s0 = C.gridStart[cell], s1 = C.gridStart[cell + 1];
@@ -308,7 +210,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         if (!any) return;
     }
     float dist[5];
-    const int n = KdRadiusSearchLds(C, dim, L, radiusSq, 5, vs.idx, dist);
+    const int n = KdRadiusSearchRare(C, dim, q, radiusSq, vs.idx, dist);
     if (n > 0) {  // global_cache.h:106-123
         st.cacheHits++;
         vs.mode = VS_BLEND;
@@ -381,10 +283,30 @@ LMC_D float ClosedFormLogDet(const DScene &S, const VSource &vs, int dim) {
     return vs.mode == VS_ISOTROPIC ? dim * fastlog(1.0f / (shk * shk)) : dim * fastlog(inverse(shk * shk));
 }
 
+// Region timer of the profiling instantiation (LMC_PROF=1 selects it at run time; the production kernel is compiled with
+// NoProf): the shader clock is read at marks placed at wave-convergent and divergent points of the step; the cycles since the
+// previous mark -- as the WAVE experienced them -- are charged to the region the mark names.  Scalar registers only.
+enum : int { PR_PROLOGUE = 0, PR_GAUSS_CUR, PR_OFFSETS, PR_VERTEX_LOAD, PR_TRAVERSE, PR_SHADE, PR_LOOP_EXIT, PR_SHADOW, PR_GAUSS_PROP, PR_SPLAT, PR_ACCEPT, PR_QUEUE, PR_COUNT };
+struct NoProf {
+    LMC_D void Mark(int) {}
+};
+struct WaveProf {
+    unsigned long long last, acc[PR_COUNT];
+    LMC_D void Start() {
+        for (int r = 0; r < PR_COUNT; r++) acc[r] = 0;
+        last = __builtin_readcyclecounter();
+    }
+    LMC_D void Mark(int r) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        acc[r] += now - last;
+        last = now;
+    }
+};
+
 // One plain small step of chain i.  Returns nothing; all state changes go to HBM.
-template <bool WITH_GRAD, class Stk>
+template <bool WITH_GRAD, class Stk, class Prof>
 LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, Rng &rng,
-                         const LdsView &L, Stk &stk, StepStats &st, float *workBuf = nullptr, size_t workStride = 0, size_t workSlot = 0) {
+                         const LdsView &L, Stk &stk, StepStats &st, Prof &prof, float *workBuf = nullptr, size_t workStride = 0, size_t workSlot = 0) {
     const size_t N = A.N;
     int flags = A.flags[i];
     const int sel = (flags & F_SEL) ? 1 : 0;
@@ -401,6 +323,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     st.steps++;
     st.lean++;
 
+    prof.Mark(PR_PROLOGUE);
     // ---- proposal offsets
     const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51
     float py = 0.f;
@@ -428,7 +351,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         float logDet = 0.f;
         if (!(flags & F_GAUSS)) {
             // GetPathPss(currentState.path) into LDS, path.cpp:2588-2632
-            PssSink qs{L};
+            PssSink qs{L, shortState};
             if (l > 1) {
                 qs.Push(cur[(size_t)PW_LGTPOS0 * N + i]), qs.Push(cur[(size_t)PW_LGTPOS1 * N + i]);
                 qs.Push(cur[(size_t)PW_LGTDIR0 * N + i]), qs.Push(cur[(size_t)PW_LGTDIR1 * N + i]);
@@ -443,6 +366,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags |= F_QUERIED;
             flags |= F_GAUSS;
+            prof.Mark(PR_GAUSS_CUR);
         }
         NormalDist nd(0.0f, 1.0f);
         float q = 0.f;
@@ -471,6 +395,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         py -= 0.5f * q;
     }
 
+    prof.Mark(PR_OFFSETS);
     // ---- PerturbPathBidir, path.cpp:1953-2160, streamed.  Light and camera sub-path share one loop so that the closest-hit
     // traversal (and the hit reconstruction behind it) is instantiated once; the connection strategies defer their shadow ray
     Contrib pc;
@@ -482,7 +407,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     DeferOcclusion occ;
     {
         OffsetCursor off{L, offBase};
-        PssSink qs{L};
+        PssSink qs{L, shortState};
         NormalDist normDist(0.0f, S.opt.discreteStdDev);
         const float time = Modulo1(cur[(size_t)PW_TIME * N + i] + normDist(rng));
         prop[(size_t)PW_TIME * N + i] = time;
@@ -529,13 +454,16 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         int depth = 0;  // vertex index inside the current sub-path
         // every iteration = one path segment; `break` = the step's contribution is decided (ok) or the path died
         while (lightPhase || depth < camCount) {
+            prof.Mark(PR_SHADE);  // the previous segment's vertex work (the first time: the sub-path head)
             DVertex sv = LoadVertex(cur, N, i, lightPhase, depth);
             SurfHit hit;
             hit.tri = -1;
             hit.st = V2{0.f, 0.f};
             Isect isect;
             isect.position = isect.shadingNormal = isect.geomNormal = V3{0.f, 0.f, 0.f};
+            prof.Mark(PR_VERTEX_LOAD);
             const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk);
+            prof.Mark(PR_TRAVERSE);
             if (lightPhase) {
                 if (!hitSurface) break;
                 lps.isect = isect;
@@ -605,8 +533,10 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         }
         prop[(size_t)PW_ENVPRIM * N + i] = __int_as_float(envPrim);
     }
+    prof.Mark(PR_LOOP_EXIT);  // the last segment's vertex work: connection strategy / emitter hit
     // the one shadow ray of the step (scene.cpp:128-149), cast after its strategy has been evaluated
     if (ok && occ.pending) ok = !Occluded(S, occ.org, occ.dir, occ.dist, stk);
+    prof.Mark(PR_SHADOW);
 
     // ---- proposal Gaussian + acceptance probability (mutation_mala.h:174-267)
     float a = 0.0f;
@@ -636,6 +566,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         }
     }
 
+    prof.Mark(PR_GAUSS_PROP);
     // ---- splats, mlt.cpp:103-112
     const bool doSplat = !(P.expFlags & 1);
     if (curValid && a < 1.0f && doSplat) {
@@ -649,6 +580,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     if (a > 0.0f && doSplat) Splat(film, pc.screenPos, a * smallSplat);
     st.wsum += curValid ? 1.0f : (a > 0.0f ? a : 0.0f);
 
+    prof.Mark(PR_SPLAT);
     // ---- accept / reject, mlt.cpp:113-170
     const int sampleIdx = A.sampleIdx[i];
     A.pushDim[i] = 0;
@@ -696,6 +628,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     }
     A.flags[i] = flags;
     A.sampleIdx[i] = sampleIdx + 1;
+    prof.Mark(PR_ACCEPT);
 }
 
 }  // namespace lmcd

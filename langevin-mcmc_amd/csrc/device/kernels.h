@@ -38,7 +38,7 @@ void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, c
                              const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                           const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads,
-                          hipStream_t s);
+                          bool profile, hipStream_t s);
 // all small steps of an H2MC render (device/step_small_h2mc.hip)
 void LaunchStepSmallH2MC(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);

@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(256) k_step_small_grad(DScene S, const DCache 
         rng.tab = A.rngTab + (size_t)i * 64;
         rng.ticks = 0;
         LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
-        SmallStepLean<true>(S, *cache, A, film, P, i, rng, L, stk, st, gradBuf, (size_t)gradStride, (size_t)tid);
+        NoProf prof;
+        SmallStepLean<true>(S, *cache, A, film, P, i, rng, L, stk, st, prof, gradBuf, (size_t)gradStride, (size_t)tid);
         QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;
     }

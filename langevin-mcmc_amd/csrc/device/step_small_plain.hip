@@ -1,19 +1,27 @@
 // The hot launch: plain small steps (dsmall.h) of the chains on the smallPlain list.  Everything indexed at run time
 // lives in LDS (80 words per thread), the path is streamed through registers: no scratch memory.
 // USE_LDS_STACK = false is the fallback for scenes whose LBVH is deeper than the 32-entry LDS traversal stack.
+#include <cstdlib>
+#include <type_traits>
+
 #include "dsmall.h"
 #include "step_kernel.h"
 
 using namespace lmcd;
 
-template <bool USE_LDS_STACK, bool GLOSSY>
-__global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
+template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false>
+#ifndef LMC_LEAN_WAVES
+#define LMC_LEAN_WAVES 2  // waves per SIMD the register allocation aims at
+#endif
+__global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                     const int *listCount, NextLists next) {
     extern __shared__ float lds[];
     StepStats st;
     const int total = *listCount;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const LdsView L{lds + threadIdx.x, (int)blockDim.x};
+    typename std::conditional<PROF, WaveProf, NoProf>::type prof;
+    if constexpr (PROF) prof.Start();
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
         Rng rng;
@@ -22,23 +30,33 @@ __global__ void __launch_bounds__(256, 2) k_step_small(DScene S, const DCache *c
         rng.ticks = 0;
         if (USE_LDS_STACK) {
             LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
-            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st);
+            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         } else {
             LocalStackT<GLOSSY> stk;
-            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st);
+            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         }
         QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;
+        prof.Mark(PR_QUEUE);
+    }
+    if constexpr (PROF) {  // one lane per wave adds the wave's region totals (A.prof: PR_COUNT cycle sums + the number of waves)
+        if ((threadIdx.x & 63) == 0) {
+            for (int r = 0; r < PR_COUNT; r++) atomicAdd(&A.prof[r], prof.acc[r]);
+            atomicAdd(&A.prof[PR_COUNT], 1ull);
+        }
     }
     BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
 }
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                          const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, hipStream_t s) {
-    const size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float);
+                          const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, bool profile, hipStream_t s) {
+    size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float);
+    if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code
     const bool lds = bvhDepth <= BVH_LDS_STACK;
 #define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next)
-    if (lds && !glossy) LMC_LAUNCH_SMALL(true, false);
+    if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+    else if (lds && !glossy)
+        LMC_LAUNCH_SMALL(true, false);
     else if (lds && glossy)
         LMC_LAUNCH_SMALL(true, true);
     else if (!glossy)

@@ -132,7 +132,8 @@ struct lmc_ctx {
         lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum;
     DevBuf<unsigned char> nextKind;
     DevBuf<int> flags, curSplatCount, adjacentReject, sampleIdx, numSamples, pushDim;
-    DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> counters, prof;
+    bool profileLean = false;  // LMC_PROF=1: the lean launch runs its region-timer instantiation (lmc_prof_read)
     DevBuf<double> weightSum;
     DevBuf<float> gradBuf, h2Gauss;
     int gradStride = 0, stepGrid = 0;
@@ -364,6 +365,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
+    if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
     if (const char *e = getenv("LMC_SORT_GENERIC")) c->sortGeneric = atoi(e) != 0;
     if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
@@ -550,7 +552,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
         c->chPropNewV2.Alloc(N * MAXPSS), c->chPss.Alloc(N * MAXPSS), c->chLastPss.Alloc(N * MAXPSS);
     c->pathWeight.Alloc(N), c->lastScoreSum.Alloc(N), c->lastScore.Alloc(N), c->contribList.Alloc(N * MAXCONTRIB * CONTRIB_WORDS, false);
     c->pushData.Alloc(N * GAUSS_WORDS), c->flags.Alloc(N), c->nextKind.Alloc(N + 4), c->adjacentReject.Alloc(N), c->sampleIdx.Alloc(N), c->numSamples.Alloc(N), c->pushDim.Alloc(N);
-    c->counters.Alloc(8), c->weightSum.Alloc(1);
+    c->counters.Alloc(8), c->weightSum.Alloc(1), c->prof.Alloc(16);
     ChainArrays &A = c->A;
     A.N = (int)N;
     A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.pathBuf1 = c->pathBuf1.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
@@ -561,7 +563,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     A.adjacentReject = c->adjacentReject.p, A.sampleIdx = c->sampleIdx.p, A.numSamples = c->numSamples.p;
     A.contribList = c->contribList.p, A.nextKind = c->nextKind.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p;
-    A.counters = c->counters.p, A.weightSum = c->weightSum.p;
+    A.counters = c->counters.p, A.weightSum = c->weightSum.p, A.prof = c->prof.p;
     LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
     LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, c->seedChains ? 1 : 0, c->normalization, s);
     // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
@@ -734,7 +736,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
             LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
-        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, s);
+        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));
         if (c->overlap) {
             HIP_CHECK(hipEventRecord(c->joinEvent[0], sL));
@@ -800,6 +802,20 @@ int lmc_kernel_timing(lmc_ctx *c, double *out3) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     out3[0] = c->smallMs, out3[1] = c->largeMs;
     out3[2] = (double)c->counters.Download()[7];
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// region cycle sums of the lean kernel's profiling instantiation since the last call (LMC_PROF=1): out16[0..12) = wave cycles per
+// region (dsmall.h PR_*), out16[12] = waves
+int lmc_prof_read(lmc_ctx *c, unsigned long long *out16) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->prof.n == 0) throw std::runtime_error("lmc_prof_read before lmc_chains_init");
+    std::vector<unsigned long long> h = c->prof.Download();
+    for (int k = 0; k < 16; k++) out16[k] = h[k];
+    HIP_CHECK(hipMemset(c->prof.p, 0, 16 * sizeof(unsigned long long)));
     return 0;
     LMC_CATCH(-1)
 }
