@@ -14,7 +14,9 @@ constexpr int SPLAT_WORDS = 5;
 // F_SEL: which of the two path buffers holds the chain's current path (the other receives the proposal; acceptance
 // flips the bit instead of copying the path)
 // F_GSEL: the same for the two Gaussian buffers (the lean kernel streams the proposal's Gaussian into the other buffer)
-enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64 };
+// F_VSYNC: chain->v1 / v2 are known to equal prop_new_v1 / prop_new_v2 word for word, so the copy that follows an accepted
+// MALA step (mlt.cpp:133-142) has nothing to move.  Maintained by the lean kernel; every other kernel just clears it.
+enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64, F_VSYNC = 128 };
 enum : int { KIND_SMALL = 0, KIND_LARGE = 1 };
 enum : unsigned char { NEXT_DONE = 0, NEXT_LARGE = 1, NEXT_SMALL_GENERIC = 2, NEXT_SMALL_PLAIN = 3 };
 

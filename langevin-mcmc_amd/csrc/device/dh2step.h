@@ -201,7 +201,7 @@ LMC_D void StepChainH2MC(const DScene &S, const ChainArrays &A, const Film &film
             st.resets++;
         }
     }
-    A.flags[i] = flags;
+    A.flags[i] = flags & ~F_VSYNC;
     A.sampleIdx[i] = sampleIdx + 1;
 }
 

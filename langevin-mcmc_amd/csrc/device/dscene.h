@@ -16,6 +16,17 @@ struct alignas(16) BvhNode {
     int left, right;
     int pad[2];
 };
+// The tree the kernels walk: the binary tree collapsed to four children per node (host/accel.cpp CollapseToBvh4), 128 B = one
+// fetch round for four slab tests.  A ray visits about half as many nodes as in the binary tree, and each visit is one
+// dependent memory round trip, which is what the step kernels wait on (profiles/r02_h_lean_regions.json: 32 % of a wave's
+// cycles inside the closest-hit traversal).  child: >= 0 inner node, < 0 leaf code as above, BVH4_EMPTY = no child.
+constexpr int BVH4_EMPTY = 0x7fffffff;
+struct alignas(16) BvhNode4 {
+    float bmin[4][3], bmax[4][3];  // child k: bmin[k], bmax[k]
+    int child[4];
+    int pad[4];
+};
+static_assert(sizeof(BvhNode4) == 128, "one node = two cache lines of 64 B");
 // triangle in BVH leaf order, 48 B: Moeller-Trumbore operands + global triangle id
 struct alignas(16) LeafTri {
     float p0[3];
@@ -85,7 +96,7 @@ struct DOptions {
 };
 
 struct DScene {
-    const BvhNode *nodes;
+    const BvhNode4 *nodes;
     const LeafTri *leafTris;
     const TriData *tris;
     const DMesh *meshes;
@@ -178,6 +189,50 @@ struct LdsStackT {
 // finished), then all test their leaf's triangles together.  With the node test and the leaf test as two branches of
 // one loop a wave executed both bodies on almost every iteration (profiles/r01_d: 5270 vector-memory instructions per
 // wave-step for ~800 per lane); the visiting order, hence the result, is the same depth-first order.
+// one inner-node visit: slab-tests the four children; returns the nearest hit child (or BVH4_EMPTY) and pushes the others,
+// farthest first, so that they are popped nearest first (ORDERED = false: any order, for the any-hit query)
+template <bool ORDERED, class Stk>
+LMC_D int VisitNode4(const BvhNode4 &nd, V3 org, V3 invd, float tnear, float tfar, Stk &stk) {
+    float t[4];
+    bool h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = nd.child[k] != BVH4_EMPTY && SlabTest(nd.bmin[k], nd.bmax[k], org, invd, tnear, tfar, t[k]);
+    int next = BVH4_EMPTY;
+    if (!ORDERED) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (h[k]) {
+                if (next == BVH4_EMPTY) next = nd.child[k];
+                else
+                    stk.Push(nd.child[k]);
+            }
+        return next;
+    }
+    // sort the (up to four) hits by entry distance with a 5-comparator network on (t, child) pairs; misses carry +inf
+    float tk[4];
+    int ck[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tk[k] = h[k] ? t[k] : INFINITY, ck[k] = h[k] ? nd.child[k] : BVH4_EMPTY;
+    auto cswap = [&](int a, int b) {
+        if (tk[b] < tk[a]) {
+            const float tt = tk[a];
+            tk[a] = tk[b], tk[b] = tt;
+            const int cc = ck[a];
+            ck[a] = ck[b], ck[b] = cc;
+        }
+    };
+    cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+    if (ck[3] != BVH4_EMPTY) stk.Push(ck[3]);
+    if (ck[2] != BVH4_EMPTY) stk.Push(ck[2]);
+    if (ck[1] != BVH4_EMPTY) stk.Push(ck[1]);
+    return ck[0];
+}
+
+// closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer).
+// "while-while" traversal: all lanes of a wave first descend through inner nodes until each has reached a leaf (or
+// finished), then all test their leaf's triangles together.  With the node test and the leaf test as two branches of
+// one loop a wave executed both bodies on almost every iteration (profiles/r01_d: 5270 vector-memory instructions per
+// wave-step for ~800 per lane).  A leaf's triangles (up to four) are fetched in one round and tested in leaf order.
 template <class Stk>
 LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stk &stk) {
     if (S.numNodes == 0) return -1;
@@ -185,41 +240,33 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     stk.Reset();
     int best = -1;
     float bestT = tfar;
-    int cur = 0;  // root is an inner node (or a single-leaf wrapper)
-    bool alive = true;
-    while (alive) {
+    int cur = 0;  // root is an inner node
+    for (;;) {
         while (cur >= 0) {
-            const BvhNode nd = S.nodes[cur];
-            float tl, tr;
-            const bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, bestT, tl);
-            const bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, bestT, tr);
-            if (hl && hr) {
-                int nearC = nd.left, farC = nd.right;
-                if (tr < tl) nearC = nd.right, farC = nd.left;
-                stk.Push(farC);
-                cur = nearC;
-            } else if (hl) {
-                cur = nd.left;
-            } else if (hr) {
-                cur = nd.right;
-            } else {
+            const BvhNode4 nd = S.nodes[cur];
+            cur = VisitNode4<true>(nd, org, invd, tnear, bestT, stk);
+            if (cur == BVH4_EMPTY) {
                 if (stk.Empty()) {
-                    alive = false;
-                    break;
+                    tHit = bestT;
+                    return best;
                 }
                 cur = stk.Pop();
             }
         }
-        if (!alive) break;
         const unsigned code = (unsigned)~cur;
         const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
-        for (int i = 0; i < cnt; i++) {
-            const LeafTri tr = S.leafTris[first + i];
-            float t;
-            if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, bestT, t)) {
-                if (best < 0 || t < bestT || (t == bestT && tr.id < best)) {
-                    bestT = t;
-                    best = tr.id;
+        for (int base = 0; base < cnt; base += 4) {
+            LeafTri tr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) tr[i] = S.leafTris[first + min(base + i, cnt - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float t;
+                if (base + i < cnt && TriTest(tr[i].p0, tr[i].e1, tr[i].e2, org, dir, tnear, bestT, t)) {
+                    if (best < 0 || t < bestT || (t == bestT && tr[i].id < best)) {
+                        bestT = t;
+                        best = tr[i].id;
+                    }
                 }
             }
         }
@@ -236,40 +283,32 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
     stk.Reset();
     int cur = 0;
-    bool alive = true, hit = false;
-    while (alive) {
+    for (;;) {
         while (cur >= 0) {
-            const BvhNode nd = S.nodes[cur];
-            float tl, tr;
-            const bool hl = SlabTest(nd.lmin, nd.lmax, org, invd, tnear, tfar, tl);
-            const bool hr = SlabTest(nd.rmin, nd.rmax, org, invd, tnear, tfar, tr);
-            if (hl && hr) {
-                stk.Push(nd.right);
-                cur = nd.left;
-            } else if (hl) {
-                cur = nd.left;
-            } else if (hr) {
-                cur = nd.right;
-            } else {
-                if (stk.Empty()) {
-                    alive = false;
-                    break;
-                }
+            const BvhNode4 nd = S.nodes[cur];
+            cur = VisitNode4<false>(nd, org, invd, tnear, tfar, stk);
+            if (cur == BVH4_EMPTY) {
+                if (stk.Empty()) return false;
                 cur = stk.Pop();
             }
         }
-        if (!alive) break;
         const unsigned code = (unsigned)~cur;
         const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
-        for (int i = 0; i < cnt; i++) {
-            const LeafTri tr = S.leafTris[first + i];
-            float t;
-            if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, tfar, t)) hit = true;
+        bool hit = false;
+        for (int base = 0; base < cnt; base += 4) {
+            LeafTri tr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) tr[i] = S.leafTris[first + min(base + i, cnt - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float t;
+                if (base + i < cnt && TriTest(tr[i].p0, tr[i].e1, tr[i].e2, org, dir, tnear, tfar, t)) hit = true;
+            }
         }
-        if (hit || stk.Empty()) break;
+        if (hit) return true;
+        if (stk.Empty()) return false;
         cur = stk.Pop();
     }
-    return hit;
 }
 
 // scene.cpp:128-149

@@ -338,7 +338,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 size_t o = (size_t)k * N + i;
                 A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
             }
-            flags |= F_BUFFERED;
+            flags |= F_BUFFERED | F_VSYNC;  // all four vectors are zero
             flags &= ~F_QUERIED;
         }
         // currentState.gaussian: stored (F_GAUSS) or initialised now from the cache / isotropic (mutation_mala.h:83-166);
@@ -364,7 +364,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             }
             const GradState gs{cur, c, l, curSs, false, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
-            if (vs.mode == VS_BLEND) flags |= F_QUERIED;
+            if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;  // the blend rewrote chain->v1 / v2
             flags |= F_GAUSS;
             prof.Mark(PR_GAUSS_CUR);
         }
@@ -546,7 +546,8 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             VSource vs;
             const GradState gs{prop, c, l, pc.ssScore, true, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
-            if (vs.mode == VS_BLEND) flags |= F_QUERIED;
+            if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;
+            if (vs.mode == VS_GRAD) flags &= ~F_VSYNC;  // the moment update rewrote prop_new_v1 / v2
             float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
 #pragma unroll 1
             for (int k = 0; k < dim; k++) {
@@ -592,13 +593,15 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         float *p = A.curSplat + i;
         p[0] = pc.screenPos.x, p[N] = pc.screenPos.y, p[2 * N] = smallSplat.x, p[3 * N] = smallSplat.y, p[4 * N] = smallSplat.z;
         A.curSplatCount[i] = 1;
-        if (mala) {  // mlt.cpp:133-142
-#pragma unroll 1
-            for (int k = 0; k < MAXPSS; k++) {
-                A.chV1[(size_t)k * N + i] = A.chPropNewV1[(size_t)k * N + i];
-                A.chV2[(size_t)k * N + i] = A.chPropNewV2[(size_t)k * N + i];
+        if (mala) {  // mlt.cpp:133-142: chain.v1 / v2 = prop_new_v1 / v2 (whole vectors) -- unless they are known to be equal
+            if (!(flags & F_VSYNC)) {
+#pragma unroll 4
+                for (int k = 0; k < MAXPSS; k++) {
+                    A.chV1[(size_t)k * N + i] = A.chPropNewV1[(size_t)k * N + i];
+                    A.chV2[(size_t)k * N + i] = A.chPropNewV2[(size_t)k * N + i];
+                }
             }
-            flags |= F_BUFFERED | F_GAUSS;
+            flags |= F_BUFFERED | F_GAUSS | F_VSYNC;
             flags ^= F_GSEL;  // the proposal's Gaussian (streamed into the other buffer above) becomes the current one
         } else {
             flags &= ~F_GAUSS;

@@ -367,7 +367,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             st.resets++;
         }
     }
-    A.flags[i] = flags;
+    A.flags[i] = flags & ~F_VSYNC;  // this kernel does not track the v1 / v2 equality (dchain.h)
     A.sampleIdx[i] = sampleIdx + 1;
 }
 

@@ -245,6 +245,65 @@ LbvhResult BuildSceneBvh(const std::vector<lmcd::TriData> &tris) {
     return BuildSahBvh(tris, leaf);
 }
 
+namespace {
+struct Child2 {
+    int ref;  // >= 0 inner node of the binary tree, < 0 leaf code
+    float bmin[3], bmax[3];
+};
+float HalfArea(const Child2 &c) {
+    const float dx = c.bmax[0] - c.bmin[0], dy = c.bmax[1] - c.bmin[1], dz = c.bmax[2] - c.bmin[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+void ChildrenOf(const LbvhResult &bvh, int node, Child2 out[2]) {
+    const lmcd::BvhNode &nd = bvh.nodes[node];
+    out[0].ref = nd.left, out[1].ref = nd.right;
+    for (int k = 0; k < 3; k++) out[0].bmin[k] = nd.lmin[k], out[0].bmax[k] = nd.lmax[k], out[1].bmin[k] = nd.rmin[k], out[1].bmax[k] = nd.rmax[k];
+}
+// returns the index of the wide node made from binary node `node`; `pending` = stack entries above this node's own visit
+int Collapse(const LbvhResult &bvh, int node, Bvh4Result &out, int depth, int pending) {
+    Child2 ch[4];
+    int n = 2;
+    ChildrenOf(bvh, node, ch);
+    if (ch[1].ref == ch[0].ref && ch[0].ref < 0) n = 1;  // WrapSingleLeaf: the scene is one leaf, stored twice
+    while (n < 4) {
+        int pick = -1;
+        for (int k = 0; k < n; k++)
+            if (ch[k].ref >= 0 && (pick < 0 || HalfArea(ch[k]) > HalfArea(ch[pick]))) pick = k;
+        if (pick < 0) break;
+        Child2 two[2];
+        ChildrenOf(bvh, ch[pick].ref, two);
+        ch[pick] = two[0];
+        ch[n++] = two[1];
+    }
+    const int me = (int)out.nodes.size();
+    out.nodes.emplace_back();
+    out.depth = std::max(out.depth, depth);
+    out.stackNeed = std::max(out.stackNeed, pending + n - 1);
+    lmcd::BvhNode4 nd;
+    memset(&nd, 0, sizeof(nd));
+    for (int k = 0; k < 4; k++) {
+        nd.child[k] = lmcd::BVH4_EMPTY;
+        for (int a = 0; a < 3; a++) nd.bmin[k][a] = INFINITY, nd.bmax[k][a] = -INFINITY;
+    }
+    for (int k = 0; k < n; k++) {
+        for (int a = 0; a < 3; a++) nd.bmin[k][a] = ch[k].bmin[a], nd.bmax[k][a] = ch[k].bmax[a];
+        // while child k is being walked, at most the n - 1 siblings are pending (fewer in practice: upper bound)
+        nd.child[k] = ch[k].ref >= 0 ? Collapse(bvh, ch[k].ref, out, depth + 1, pending + n - 1) : ch[k].ref;
+    }
+    out.nodes[me] = nd;
+    return me;
+}
+}  // namespace
+
+Bvh4Result CollapseToBvh4(const LbvhResult &bvh) {
+    Bvh4Result out;
+    out.leafTris = bvh.leafTris;
+    if (bvh.nodes.empty()) return out;
+    Collapse(bvh, 0, out, 1, 0);
+    if (out.stackNeed > lmcd::BVH_STACK) throw std::runtime_error("BVH needs a deeper traversal stack than BVH_STACK");
+    return out;
+}
+
 LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris) {
     Builder B;
     B.tris = &tris;

@@ -20,8 +20,17 @@ struct LbvhResult {
 LbvhResult BuildLbvh(const std::vector<lmcd::TriData> &tris);
 // same node / leaf format from a top-down binned-SAH build (fewer node visits per ray than the Morton tree)
 LbvhResult BuildSahBvh(const std::vector<lmcd::TriData> &tris, int maxLeaf = 4);
-// the tree the renderer uploads: SAH unless LMC_BVH=lbvh (A/B switch; hits do not depend on the tree)
+// the binary tree behind the scene's: SAH unless LMC_BVH=lbvh (A/B switch; hits do not depend on the tree)
 LbvhResult BuildSceneBvh(const std::vector<lmcd::TriData> &tris);
+// the tree the renderer uploads: the binary tree with (up to) four children per node.  Every node takes its two children and
+// keeps replacing the inner child with the largest surface area by that child's own two children until it has four.
+// stackNeed = the largest number of entries the depth-first traversal can have pending.
+struct Bvh4Result {
+    std::vector<lmcd::BvhNode4> nodes;
+    std::vector<lmcd::LeafTri> leafTris;
+    int depth = 0, stackNeed = 0;
+};
+Bvh4Result CollapseToBvh4(const LbvhResult &bvh);
 
 struct KdTreeResult {
     std::vector<lmcd::KdNode> nodes;

@@ -109,7 +109,7 @@ struct lmc_ctx {
     hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
     bool overlap = true;
     // scene buffers
-    DevBuf<BvhNode> nodes;
+    DevBuf<BvhNode4> nodes;
     DevBuf<LeafTri> leafTris;
     DevBuf<TriData> tris;
     DevBuf<DMesh> meshes;
@@ -230,8 +230,8 @@ static void UploadScene(lmc_ctx *c) {
         triBase += dm.numTris;
         meshes.push_back(dm);
     }
-    lmc::LbvhResult bvh = lmc::BuildSceneBvh(tris);
-    c->bvhDepth = bvh.depth;
+    const lmc::Bvh4Result bvh = lmc::CollapseToBvh4(lmc::BuildSceneBvh(tris));
+    c->bvhDepth = bvh.stackNeed;  // what the traversal stack must hold (the LDS stack has BVH_LDS_STACK entries)
     std::vector<DMaterial> mats;
     int glossy = 0;
     for (const lmc::Material &m : sc.materials) {

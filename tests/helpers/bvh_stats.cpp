@@ -1,5 +1,6 @@
-// Host-only check + statistics of the two BVH builders (host/accel.cpp): traverses the node arrays exactly like
-// device/dscene.h:BvhIntersect (same slab test, same near-child-first order, same tie rule) on rays that resemble the
+// Host-only check + statistics of the BVH builders (host/accel.cpp): traverses the binary trees (Morton, SAH) and the
+// four-wide tree the renderer uploads (CollapseToBvh4) like device/dscene.h:BvhIntersect (same slab test, same
+// nearest-child-first order, same tie rule) on rays that resemble the
 // renderer's (camera rays and cosine-distributed bounces off the hit points) and reports inner-node visits and triangle
 // tests per ray.  Exit code 1 if the two trees disagree on any (triangle id, t).
 // build: hipcc -x hip tests/helpers/bvh_stats.cpp <objs of the product> (see tests/test_host.py)
@@ -14,7 +15,7 @@
 using namespace lmcd;
 
 struct Stats {
-    long long rays = 0, nodes = 0, tris = 0, hits = 0, maxStack = 0;
+    long long rays = 0, nodes = 0, tris = 0, hits = 0, maxStack = 0, leaves = 0;
 };
 
 static bool Slab(const float *bmin, const float *bmax, V3 org, V3 invd, float tnear, float tfar, float &tEntry) {  // = dscene.h:SlabTest
@@ -58,6 +59,60 @@ static int Traverse(const lmc::LbvhResult &B, V3 org, V3 dir, float tnear, float
         if (!alive) break;
         const unsigned code = (unsigned)~cur;
         const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+        st.leaves++;
+        for (int i = 0; i < cnt; i++) {
+            const LeafTri &tr = B.leafTris[first + i];
+            st.tris++;
+            float t;
+            if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, bestT, t))
+                if (best < 0 || t < bestT || (t == bestT && tr.id < best)) bestT = t, best = tr.id;
+        }
+        if (!sp) break;
+        cur = stack[--sp];
+    }
+    tHit = bestT;
+    if (best >= 0) st.hits++;
+    return best;
+}
+
+// device/dscene.h: VisitNode4<true> + BvhIntersect on the four-wide tree
+static int Traverse4(const lmc::Bvh4Result &B, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stats &st) {
+    V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    int stack[BVH_STACK], sp = 0, best = -1, cur = 0;
+    float bestT = tfar;
+    st.rays++;
+    for (;;) {
+        bool done = false;
+        while (cur >= 0) {
+            const BvhNode4 &nd = B.nodes[cur];
+            st.nodes++;
+            float tk[4];
+            int ck[4];
+            for (int k = 0; k < 4; k++) {
+                float t;
+                const bool h = nd.child[k] != BVH4_EMPTY && Slab(nd.bmin[k], nd.bmax[k], org, invd, tnear, bestT, t);
+                tk[k] = h ? t : INFINITY, ck[k] = h ? nd.child[k] : BVH4_EMPTY;
+            }
+            auto cswap = [&](int a, int b) {
+                if (tk[b] < tk[a]) std::swap(tk[a], tk[b]), std::swap(ck[a], ck[b]);
+            };
+            cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+            for (int k = 3; k >= 1; k--)
+                if (ck[k] != BVH4_EMPTY) stack[sp++] = ck[k];
+            if (sp > st.maxStack) st.maxStack = sp;
+            cur = ck[0];
+            if (cur == BVH4_EMPTY) {
+                if (!sp) {
+                    done = true;
+                    break;
+                }
+                cur = stack[--sp];
+            }
+        }
+        if (done) break;
+        const unsigned code = (unsigned)~cur;
+        const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+        st.leaves++;
         for (int i = 0; i < cnt; i++) {
             const LeafTri &tr = B.leafTris[first + i];
             st.tris++;
@@ -90,8 +145,9 @@ int main(int argc, char **argv) {
         }
     }
     lmc::LbvhResult trees[2] = {lmc::BuildLbvh(tris), lmc::BuildSahBvh(tris, 4)};
-    const char *names[2] = {"lbvh", "sah"};
-    Stats st[2];
+    const lmc::Bvh4Result wide = lmc::CollapseToBvh4(trees[1]);
+    const char *names[3] = {"lbvh", "sah", "sah_4wide"};
+    Stats st[3];
     std::mt19937 gen(7);
     std::uniform_real_distribution<float> U(0.f, 1.f);
     const lmc::Camera &cam = scene->camera;
@@ -115,6 +171,9 @@ int main(int argc, char **argv) {
             int id[2];
             for (int k = 0; k < 2; k++) id[k] = Traverse(trees[k], org, dir, tnear, INFINITY, t[k], st[k]);
             if (id[0] != id[1] || (id[0] >= 0 && t[0] != t[1])) mismatches++;
+            float t4;
+            const int id4 = Traverse4(wide, org, dir, tnear, INFINITY, t4, st[2]);
+            if (id4 != id[1] || (id4 >= 0 && t4 != t[1])) mismatches++;
             if (id[0] < 0) break;
             const TriData &T = tris[id[0]];
             V3 e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
@@ -129,9 +188,11 @@ int main(int argc, char **argv) {
             tnear = 5e-4f;
         }
     }
-    for (int k = 0; k < 2; k++)
-        printf("{\"tree\": \"%s\", \"nodes\": %zu, \"depth\": %d, \"rays\": %lld, \"node_visits_per_ray\": %.2f, \"tri_tests_per_ray\": %.2f, \"max_stack\": %lld}\n", names[k],
-               trees[k].nodes.size(), trees[k].depth, st[k].rays, (double)st[k].nodes / st[k].rays, (double)st[k].tris / st[k].rays, st[k].maxStack);
+    for (int k = 0; k < 3; k++)
+        printf("{\"tree\": \"%s\", \"nodes\": %zu, \"depth\": %d, \"rays\": %lld, \"node_visits_per_ray\": %.2f, \"leaf_visits_per_ray\": %.2f, \"tri_tests_per_ray\": %.2f, \"max_stack\": %lld, \"stack_bound\": %d}\n",
+               names[k], k < 2 ? trees[k].nodes.size() : wide.nodes.size(), k < 2 ? trees[k].depth : wide.depth, st[k].rays, (double)st[k].nodes / st[k].rays,
+               (double)st[k].leaves / st[k].rays, (double)st[k].tris / st[k].rays, st[k].maxStack, k < 2 ? trees[k].depth : wide.stackNeed);
+    if (st[2].maxStack > wide.stackNeed) mismatches++;  // the bound the host sizes the traversal stack with must hold
     printf("{\"mismatches\": %lld}\n", mismatches);
     return mismatches ? 1 : 0;
 }

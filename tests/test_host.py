@@ -236,3 +236,26 @@ def test_cache_query_existence_test_is_exact():
         assert lib.lmc_cache_filter_probe(dim, 3000, P(pts), len(q), P(q), P(found)) == 0
         assert 500 < (n > 0).sum() < len(q) - 500  # both answers occur
         assert np.array_equal(found == 1, n > 0), dim
+
+
+def test_bvh_builders_agree_and_stack_bound_holds(tmp_path):
+    """tests/helpers/bvh_stats.cpp: Morton tree, binned-SAH tree and the four-wide tree the renderer uploads
+    (accel.cpp CollapseToBvh4) return the same (triangle id, t) for every ray of a camera-rays-plus-bounces workload on the
+    torus scene (the closest hit is defined tree-independently: smallest t, ties to the lower id), and the wide traversal
+    never holds more pending entries than the bound the host sizes the stack with."""
+    import json, subprocess
+
+    build = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "_build")
+    objs = [os.path.join(build, o) for o in ("accel.o", "scene.o", "imageio.o", "jpeg.o")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("product objects not built")
+    exe = str(tmp_path / "bvh_stats")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-x", "hip", os.path.join(ROOT, "tests", "helpers", "bvh_stats.cpp"),
+                    "-x", "none"] + objs + ["-lz", "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe, os.path.join(ROOT, "scenes", "torus", "lmc.xml"), "30000"], capture_output=True, text=True)
+    rows = [json.loads(l) for l in r.stdout.splitlines()]
+    assert r.returncode == 0, r.stdout
+    assert rows[-1] == {"mismatches": 0}
+    wide = rows[2]
+    assert wide["tree"] == "sah_4wide" and wide["max_stack"] <= wide["stack_bound"] <= 32
+    assert wide["node_visits_per_ray"] < 0.65 * rows[1]["node_visits_per_ray"]
