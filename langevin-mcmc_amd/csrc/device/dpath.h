@@ -363,7 +363,7 @@ LMC_D bool RussianRoulette(int depth, V3 bsdfContrib, float &rrWeight, V3 &throu
 
 LMC_D int HitLightOf(const DScene &S, bool hitSurface, int tri) {  // GetHitLight, path.cpp:105-120; -1 = none
     if (!hitSurface) return S.envLight;
-    return S.meshes[S.tris[tri].mesh].areaLight;
+    return S.tris[tri].areaLight;
 }
 
 // GeneratePathBidir, path.cpp:1237-1449 with screenPosi = (-1,-1)

@@ -40,9 +40,10 @@ struct alignas(16) LeafTri {
 struct alignas(16) TriData {
     float p0[3], e1[3], e2[3];
     float n0[3], n1[3], n2[3];
-    float st[6];  // per-vertex st (valid iff mesh.hasST)
+    float st[6];  // per-vertex st (valid iff hasST)
     int mesh;
-    int pad[3];
+    // copies of the mesh's fields: what a hit needs sits in the triangle's own record, one fetch instead of a chain of dependent ones
+    int hasST, material, areaLight;
 };
 struct DMesh {
     int material, areaLight, hasST, triBase, numTris;

@@ -21,7 +21,7 @@ LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float 
     float tB;
     int id = BvhIntersect(S, org, dir, tnear, tfar, tB, stk);
     if (id < 0) return false;
-    const TriData &T = S.tris[id];
+    const TriData T = S.tris[id];  // the whole record at once (by value: one round of loads, not one per early-out below)
     V3 p0{T.p0[0], T.p0[1], T.p0[2]}, e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
     isect.geomNormal = Normalize(Cross(e1, e2));
     V3 s1 = Cross(dir, e2);
@@ -40,7 +40,7 @@ LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float 
     isect.shadingNormal = Normalize(w * n0 + u * n1 + v * n2);
     if (Dot(isect.geomNormal, isect.shadingNormal) < 0.0f) isect.geomNormal = -isect.geomNormal;
     hit.tri = id;
-    if (S.meshes[T.mesh].hasST) {
+    if (T.hasST) {
         hit.st.x = (1.0f - u - v) * T.st[0] + u * T.st[2] + v * T.st[4];
         hit.st.y = (1.0f - u - v) * T.st[1] + u * T.st[3] + v * T.st[5];
     } else {
@@ -69,7 +69,7 @@ LMC_D int PickLight(const DScene &S, float u, float &prob) { return SampleDiscre
 LMC_D float PickLightProb(const DScene &S, int light) { return S.lights[light].samplingWeight / S.lightWeightSum; }
 
 // ---------------------------------------------------------------------------------------------- BSDF
-LMC_D const DMaterial &MaterialOfTri(const DScene &S, int tri) { return S.materials[S.meshes[S.tris[tri].mesh].material]; }
+LMC_D const DMaterial &MaterialOfTri(const DScene &S, int tri) { return S.materials[S.tris[tri].material]; }
 
 // Texture::Eval.  Bitmaps: periodic bilinear lookup standing in for OIIO's TextureSystem::texture() with zero filter
 // width, then fastpow(max(v,0), gamma) (bitmaptexture.h:72-97); the same arithmetic as host/scene.cpp:EvalTexture.

@@ -172,10 +172,16 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     if (skipQuery) return;
     if (flags & F_QUERIED) {
         float dist_sqr = 0.f;
-#pragma unroll 1
-        for (int k = 0; k < dim; k++) {
-            const float diff = L.Q(k) - A.chLastPss[(size_t)k * N + i];
-            dist_sqr += diff * diff;
+        for (int k0 = 0; k0 < dim; k0 += 4) {  // chain->last_pss in branch-free groups of four; the sum keeps its order
+            float lp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) lp[j] = A.chLastPss[(size_t)min(k0 + j, dim - 1) * N + i];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (k0 + j < dim) {
+                    const float diff = L.Q(k0 + j) - lp[j];
+                    dist_sqr += diff * diff;
+                }
         }
         if (dist_sqr < dim * (PSS_REUSE_DIST * PSS_REUSE_DIST)) {
             vs.mode = VS_REUSE;
@@ -224,6 +230,22 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     }
 }
 
+// chain->v1 / v2 of a re-using state into LDS words [0, 2 MD) (the BVH stack is idle whenever a Gaussian is built): all loads
+// in flight together instead of one HBM round trip per dimension in GaussianDim's loop
+LMC_D void StageReuseVectors(const ChainArrays &A, int i, int dim, const LdsView &L) {
+    const size_t N = A.N;
+    for (int k0 = 0; k0 < dim; k0 += 4) {  // branch-free groups of four (see the stored-Gaussian staging in SmallStepLean)
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const size_t kk = (size_t)min(k0 + j, dim - 1);
+            a[j] = A.chV1[kk * N + i], b[j] = A.chV2[kk * N + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) L.U(k0 + j) = a[j], L.U(MD + k0 + j) = b[j];
+    }
+}
+
 // Second half, one dimension at a time: (v1[k], v2[k]) -> M -> ComputeGaussian (mala.cpp:7-52) or the isotropic values.
 // A blend also performs query()'s writes of chain->v1 / v2 and last_pss (global_cache.h:107-123, mutation_mala.h:147-151).
 struct GaussK {
@@ -240,7 +262,7 @@ LMC_D GaussK GaussianDim(const DScene &S, const DCacheDim &C, const ChainArrays 
     }
     float v1, v2;
     if (vs.mode == VS_REUSE) {
-        v1 = A.chV1[(size_t)k * N + i], v2 = A.chV2[(size_t)k * N + i];
+        v1 = L.U(k), v2 = L.U(MD + k);  // staged by StageReuseVectors
     } else if (vs.mode == VS_GRAD) {  // first / second moment update of the clipped gradient, mutation_mala.h:108-128 and :199-221
         const float gk = L.U(k), ov1 = A.chV1[(size_t)k * N + i], ov2 = A.chV2[(size_t)k * N + i];
         const bool first = vs.nMatches != 0;
@@ -286,7 +308,7 @@ LMC_D float ClosedFormLogDet(const DScene &S, const VSource &vs, int dim) {
 // Region timer of the profiling instantiation (LMC_PROF=1 selects it at run time; the production kernel is compiled with
 // NoProf): the shader clock is read at marks placed at wave-convergent and divergent points of the step; the cycles since the
 // previous mark -- as the WAVE experienced them -- are charged to the region the mark names.  Scalar registers only.
-enum : int { PR_PROLOGUE = 0, PR_GAUSS_CUR, PR_OFFSETS, PR_VERTEX_LOAD, PR_TRAVERSE, PR_SHADE, PR_LOOP_EXIT, PR_SHADOW, PR_GAUSS_PROP, PR_SPLAT, PR_ACCEPT, PR_QUEUE, PR_COUNT };
+enum : int { PR_PROLOGUE = 0, PR_GAUSS_CUR, PR_OFFSETS, PR_VERTEX_LOAD, PR_TRAVERSE, PR_SHADE, PR_LOOP_EXIT, PR_SHADOW, PR_GAUSS_PROP, PR_SPLAT, PR_ACCEPT, PR_QUEUE, PR_ISO, PR_RESET, PR_STAGE, PR_COUNT };
 struct NoProf {
     LMC_D void Mark(int) {}
 };
@@ -323,6 +345,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     st.steps++;
     st.lean++;
 
+    DVertex nextV = LoadVertex(cur, N, i, l > 1, 0);  // first vertex of the walk below, requested before the Gaussian work
     prof.Mark(PR_PROLOGUE);
     // ---- proposal offsets
     const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51
@@ -331,6 +354,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         NormalDist nd(0.0f, S.opt.perturbStdDev);
 #pragma unroll 1
         for (int k = 0; k < dim; k++) L.U(offBase + k) = nd(rng);
+        prof.Mark(PR_ISO);
     } else {
         if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81
 #pragma unroll 1
@@ -341,6 +365,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             flags |= F_BUFFERED | F_VSYNC;  // all four vectors are zero
             flags &= ~F_QUERIED;
         }
+        prof.Mark(PR_RESET);
         // currentState.gaussian: stored (F_GAUSS) or initialised now from the cache / isotropic (mutation_mala.h:83-166);
         // GenerateSample (gaussian.cpp:38-55) and GaussianLogPdf(offset, currentState.gaussian) (gaussian.cpp:24-36) are
         // fused into the same pass over the dimensions (the affine map draws nothing)
@@ -370,11 +395,33 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         }
         NormalDist nd(0.0f, 1.0f);
         float q = 0.f;
+        float storedLogDet = 0.f;
+        if (stored) {
+            // The stored Gaussian is streamed from HBM: every load is a full memory round trip, so all of them are put in
+            // flight together (independent iterations, staged through LDS words that are free here: Q and the BVH stack)
+            // instead of one round trip per dimension inside the loop below, whose RNG calls the loads cannot be moved across.
+            storedLogDet = G[(size_t)(3 * MAXPSS) * N + i];
+            // branch-free groups of four dimensions (indices clamped, surplus slots written with duplicates): with a test
+            // per element the compiler emits "load, wait, write" once per word
+            for (int k0 = 0; k0 < dim; k0 += 4) {
+                float m[4], c[4], v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const size_t kk = (size_t)min(k0 + j, dim - 1);
+                    m[j] = G[kk * N + i], c[j] = G[(MAXPSS + kk) * N + i], v[j] = G[(2 * MAXPSS + kk) * N + i];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) L.Q(k0 + j) = m[j], L.U(k0 + j) = c[j], L.U(MD + k0 + j) = v[j];
+            }
+        } else if (vs.mode == VS_REUSE) {
+            StageReuseVectors(A, i, dim, L);
+        }
+        prof.Mark(PR_STAGE);
 #pragma unroll 1
         for (int k = 0; k < dim; k++) {
             GaussK g;
             if (stored) {
-                g.mean = G[(size_t)k * N + i], g.covL = G[(size_t)(MAXPSS + k) * N + i], g.invCov = G[(size_t)(2 * MAXPSS + k) * N + i];
+                g.mean = L.Q(k), g.covL = L.U(k), g.invCov = L.U(MD + k);
             } else {
                 g = GaussianDim(S, C, A, i, dim, k, vs, curSs, L, logDet, false);
                 if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
@@ -385,7 +432,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             q += d * (g.invCov * d);
         }
         if (stored) {
-            logDet = G[(size_t)(3 * MAXPSS) * N + i];
+            logDet = storedLogDet;
         } else {
             if (LogDetIsClosedForm(vs, curSs)) logDet = ClosedFormLogDet(S, vs, dim);
             if (shortState) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
@@ -455,7 +502,14 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         // every iteration = one path segment; `break` = the step's contribution is decided (ok) or the path died
         while (lightPhase || depth < camCount) {
             prof.Mark(PR_SHADE);  // the previous segment's vertex work (the first time: the sub-path head)
-            DVertex sv = LoadVertex(cur, N, i, lightPhase, depth);
+            DVertex sv = nextV;
+            {   // the record of the vertex the next iteration perturbs (if the path goes on) is requested now: the path is
+                // streamed from HBM, and its round trip then runs behind this segment's traversal instead of in front of the next
+                bool nl = lightPhase;
+                int nd = depth + 1;
+                if (lightPhase && depth == lgtCount - 1) nl = false, nd = 0;
+                if (nl ? nd < lgtCount : nd < camCount) nextV = LoadVertex(cur, N, i, nl, nd);
+            }
             SurfHit hit;
             hit.tri = -1;
             hit.st = V2{0.f, 0.f};
@@ -548,6 +602,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;
             if (vs.mode == VS_GRAD) flags &= ~F_VSYNC;  // the moment update rewrote prop_new_v1 / v2
+            if (vs.mode == VS_REUSE) StageReuseVectors(A, i, dim, L);
             float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
 #pragma unroll 1
             for (int k = 0; k < dim; k++) {

@@ -31,7 +31,7 @@ void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 // one of the three step launches (device/step_*.hip): chains of `list` (count read on the device) run one mutation and
 // append themselves to the lists of the next step
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
+                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list,
@@ -51,6 +51,8 @@ void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, i
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 // pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
 void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);
+// measurement aid: state-layout probe (kernels.hip k_layout_probe)
+void LaunchLayoutProbe(int N, int words, int mode, int batch, const float *in, float *out, hipStream_t s);
 // groups the entries of a work list by the technique key of A.nextKind (bins: 128 ints of scratch)
 void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip

@@ -50,6 +50,29 @@ __global__ void k_stream_probe(long long n, const float *in, float *out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = in[i] + 1.0f;
 }
 
+// Layout probe: every thread reads `words` words of "its chain's state" and writes half as many back, in batches of `batch`
+// independent loads (a step kernel's access pattern without the arithmetic).  mode 0: struct of arrays over all chains, word w
+// of chain i at [w * N + i] (a wave's load = 256 contiguous bytes, consecutive words 4 N bytes apart); mode 1: tiles of 64
+// chains, [tile][w][lane] (a wave's state = one contiguous block).
+template <int BATCH>
+__global__ void __launch_bounds__(64) k_layout_probe(int N, int words, int mode, const float *in, float *out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= N) return;
+    const size_t wordStride = mode == 0 ? (size_t)N : 64, base = mode == 0 ? (size_t)i : (size_t)(i / 64) * 64 * words + (i % 64);
+    float acc = 0.f;
+    for (int w0 = 0; w0 < words; w0 += BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) v[k] = w0 + k < words ? in[base + (size_t)(w0 + k) * wordStride] : 0.f;
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) acc += v[k];
+        // dependent on the batch: the next batch's addresses wait for this one (acc is folded into the store below)
+#pragma unroll
+        for (int k = 0; k < BATCH; k += 2)
+            if (w0 + k < words) out[base + (size_t)(w0 + k) * wordStride] = acc;
+        if (acc == 123456.789f) w0 += 1;  // keeps the batches ordered without changing anything
+    }
+}
 __global__ void k_trace(DScene S, int n, const float *rays, int *prim, float *t, int anyHit) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *r = rays + (size_t)i * 8;
@@ -587,6 +610,13 @@ __global__ void __launch_bounds__(256) k_push_finish(const unsigned long long *t
 
 // ================================================================================================ launch glue
 using namespace lmcd;
+
+void LaunchLayoutProbe(int N, int words, int mode, int batch, const float *in, float *out, hipStream_t s) {
+    if (batch >= 12) hipLaunchKernelGGL(k_layout_probe<12>, dim3((N + 63) / 64), dim3(64), 0, s, N, words, mode, in, out);
+    else
+        hipLaunchKernelGGL(k_layout_probe<4>, dim3((N + 63) / 64), dim3(64), 0, s, N, words, mode, in, out);
+}
+
 
 static inline int GridFor(long long n, int block, int maxBlocks = 2048) {
     long long g = (n + block - 1) / block;

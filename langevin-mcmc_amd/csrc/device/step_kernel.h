@@ -38,9 +38,11 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
     }
 }
 
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY>
+// LDS_STACK: the BVH traversal stack in dynamic LDS ([entry][thread], BVH_LDS_STACK entries per thread) instead of private memory
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false>
 __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
+    extern __shared__ int ldsStack[];
     StepStats st;
     const int total = *listCount;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,8 +54,13 @@ __global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, Cha
         rng.ticks = 0;
         GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
         const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
-        LocalStackT<GLOSSY> stk;
-        StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
+        if constexpr (LDS_STACK) {
+            LdsStackT<GLOSSY> stk{ldsStack + threadIdx.x, (int)blockDim.x, 0};
+            StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
+        } else {
+            LocalStackT<GLOSSY> stk;
+            StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
+        }
         QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;
     }

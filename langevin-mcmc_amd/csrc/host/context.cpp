@@ -96,6 +96,8 @@ struct lmc_ctx {
     int maxDervDepth = 8;  // --max-derivatives-depth default, main.cpp:46
     bool useOccFilter = true;  // LMC_OCC_FILTER=0: A/B switch for the existence test in front of the cache query
     int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
+    bool largeLdsStack = true;  // LMC_LARGE_LDS=0: A/B switch for the LDS traversal stack of the large-step launch
+    int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // some ready cache tree is deeper than the lean kernels' LDS search frames
     bool sortGeneric = true;   // LMC_SORT_GENERIC=0: A/B switch for the technique sort of the gradient launch
@@ -224,7 +226,7 @@ static void UploadScene(lmc_ctx *c) {
             if (dm.hasST) {
                 T.st[0] = m.ST[i0].x, T.st[1] = m.ST[i0].y, T.st[2] = m.ST[i1].x, T.st[3] = m.ST[i1].y, T.st[4] = m.ST[i2].x, T.st[5] = m.ST[i2].y;
             }
-            T.mesh = (int)mi;
+            T.mesh = (int)mi, T.hasST = dm.hasST, T.material = dm.material, T.areaLight = dm.areaLight;
             tris.push_back(T);
         }
         triBase += dm.numTris;
@@ -365,6 +367,8 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
+    if (const char *e = getenv("LMC_LARGE_LDS")) c->largeLdsStack = atoi(e) != 0;
+    if (const char *e = getenv("LMC_LARGE_BLOCK")) c->largeBlock = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
     if (const char *e = getenv("LMC_SORT_GENERIC")) c->sortGeneric = atoi(e) != 0;
@@ -372,6 +376,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
     if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
     if (const char *e = getenv("LMC_EXP_NOGRAD")) c->expFlags |= atoi(e) ? 4 : 0;
+    if (const char *e = getenv("LMC_EXP_NOSTATS")) c->expFlags |= atoi(e) ? 8 : 0;
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -723,7 +728,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
             if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
         }
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
-        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sL);
+        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
         // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
         // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
@@ -806,8 +811,8 @@ int lmc_kernel_timing(lmc_ctx *c, double *out3) {
     LMC_CATCH(-1)
 }
 
-// region cycle sums of the lean kernel's profiling instantiation since the last call (LMC_PROF=1): out16[0..12) = wave cycles per
-// region (dsmall.h PR_*), out16[12] = waves
+// region cycle sums of the lean kernel's profiling instantiation since the last call (LMC_PROF=1): out16[0..PR_COUNT) = wave cycles per
+// region (dsmall.h PR_*), out16[PR_COUNT] = waves
 int lmc_prof_read(lmc_ctx *c, unsigned long long *out16) {
     LMC_TRY
     HIP_CHECK(hipSetDevice(c->device));
@@ -1120,6 +1125,28 @@ int lmc_stream_probe(long long nWords, int reps) {
     a.Alloc((size_t)nWords), b.Alloc((size_t)nWords, false);
     for (int r = 0; r < reps; r++) LaunchStreamProbe(nWords, a.p, b.p, 0);
     HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+    LMC_CATCH(-1)
+}
+// measurement aid: milliseconds per launch of the state-layout probe (kernels.hip k_layout_probe)
+int lmc_layout_probe(int nChains, int words, int mode, int batch, int reps, double *msPerLaunch) {
+    LMC_TRY
+    EnsureDevice(0);
+    DevBuf<float> a, b;
+    a.Alloc((size_t)nChains * words), b.Alloc((size_t)nChains * words, false);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    LaunchLayoutProbe(nChains, words, mode, batch, a.p, b.p, 0);
+    HIP_CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; r++) LaunchLayoutProbe(nChains, words, mode, batch, a.p, b.p, 0);
+    HIP_CHECK(hipEventRecord(e1, 0));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *msPerLaunch = ms / reps;
+    HIP_CHECK(hipEventDestroy(e0));
+    HIP_CHECK(hipEventDestroy(e1));
     return 0;
     LMC_CATCH(-1)
 }

@@ -22,7 +22,7 @@ ren.step(32)
 kernel_ms, launches = ren.step_timing()
 small_ms, large_ms, lean = ren.kernel_timing()
 assert p.lib().lmc_prof_read(ren.h, out) == 0
-names = ["prologue", "gauss_current", "offsets", "vertex_load", "traverse", "shade", "loop_exit", "shadow_ray", "gauss_proposal", "splat", "accept", "queue_next"]
-tot = sum(out[:12])
-print(json.dumps({"waves": out[12], "lean_ms_per_launch": small_ms / launches, "cycles_per_wave": tot / max(out[12], 1),
+names = ["prologue", "gauss_current", "offsets", "vertex_load", "traverse", "shade", "loop_exit", "shadow_ray", "gauss_proposal", "splat", "accept", "queue_next", "isotropic_offsets", "buffered_reset", "gauss_stage"]
+tot = sum(out[:15])
+print(json.dumps({"waves": out[15], "lean_ms_per_launch": small_ms / launches, "cycles_per_wave": tot / max(out[15], 1),
                   "share": {n: round(out[k] / tot, 4) for k, n in enumerate(names)}}, indent=1))
