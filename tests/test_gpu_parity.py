@@ -437,7 +437,9 @@ def test_full_size_energy_conservation():
 
 
 def test_sharded_chains_match_unsharded():
-    """Two chain ranges on one GPU == the unsharded run (seeds are global chain ids)."""
+    """Two chain ranges on one GPU == the unsharded run (seeds are global chain ids).  use_gradient=0 and too few steps for the
+    gradient cache to fill: this is the regime in which shards are EXACTLY the unsharded run.  Once a cache fills, every rank
+    has built it from its own chains' pushes, so only statistical agreement is claimed: the next test."""
     p = gc.pkg()
     films = []
     for rng_ in ([(0, 256)], [(0, 128), (128, 256)]):
@@ -451,6 +453,42 @@ def test_sharded_chains_match_unsharded():
             ren.close()
         films.append(acc)
     assert np.allclose(films[0], films[1], rtol=1e-4, atol=1e-7)
+
+
+def test_sharded_chains_cache_phase_statistical():
+    """Sharded run that reaches the cache phase: each shard fills its own gradient cache from its own chains
+    (global_cache.h is per process in the reference too), so shard films are not the unsharded film.  What must hold: the same
+    energy identity per shard, the same cache dims ready, acceptance / large-step / hit rates within the run-to-run spread, and
+    film agreement at the Monte-Carlo noise level measured from two unsharded runs with different seed offsets."""
+    p = gc.pkg()
+    n, steps = 1 << 16, 60
+
+    def run(ranges, seed):
+        film, st = None, []
+        for b, e in ranges:
+            ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=96, height=72, seed_offset=seed, use_gradient=1)
+            norm, _ = ren.init_chains(1 << 19, n, 4096, steps, 0, b, e)
+            ren.step(steps)
+            s_ = ren.stats()
+            f = ren.film()
+            assert gc.lum(f).sum() == pytest.approx(norm * s_["weightSum"], rel=5e-4)
+            film = f if film is None else film + f
+            st.append(s_)
+            ren.close()
+        tot = {k: sum(s_[k] for s_ in st) for k in ("steps", "accepted", "largeSteps", "cacheQueries", "cacheHits", "gradCalls")}
+        return gc.lum(film), tot, [s_["cacheReadyMask"] for s_ in st]
+
+    whole, sw, mw = run([(0, n)], 0)
+    other, so, _ = run([(0, n)], 1000003)  # seeds are chain id + offset: a small offset would only shift the same streams
+    shard, ss, ms = run([(0, n // 2), (n // 2, n)], 0)
+    assert mw[0] != 0 and all(m == mw[0] for m in ms), (mw, ms)  # both shards reach the cache phase with the same dims
+    assert ss["steps"] == sw["steps"] == n * steps
+    assert ss["cacheQueries"] > 0 and ss["gradCalls"] > sw["gradCalls"]  # two caches to fill: more gradient evaluations
+    for k in ("accepted", "largeSteps"):
+        assert abs(ss[k] - sw[k]) <= 3 * max(abs(so[k] - sw[k]), 2e-3 * sw[k]), k
+    noise = np.linalg.norm(other - whole) / np.linalg.norm(whole)
+    assert np.linalg.norm(shard - whole) / np.linalg.norm(whole) <= 1.5 * noise
+    assert shard.sum() == pytest.approx(whole.sum(), rel=3 * max(abs(other.sum() / whole.sum() - 1), 2e-3))
 
 
 def test_film_allreduce_in_library_single_rank():
