@@ -119,12 +119,25 @@ def equal_time_rmse(args, p, gc, gpu_rate, cpu_rate, cores):
     }
 
 
+def kernel_source_sha():
+    """Fingerprint of the sources the dominant kernel is compiled from (device headers + its translation unit)."""
+    import glob, hashlib
+
+    dev = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "device")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(dev, "*.h"))) + [os.path.join(dev, "step_small_plain.hip")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc summary, if any."""
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc summary (scripts/pmc_to_json.py) -- only if
+    that summary was measured on the kernel sources of this tree; otherwise null (a stale counter figure is worse than none)."""
     p = os.path.join(ROOT, "profiles", "pmc_step_kernel.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
+            d = json.load(open(p))
+            return d.get("hbm_bytes_per_launch") if d.get("kernel_source_sha16") == kernel_source_sha() else None
         except Exception:
             return None
     return None
@@ -198,6 +211,19 @@ def main():
     kernel_ms, launches = ren.step_timing()
     small_ms, large_ms, lean_after = ren.kernel_timing()
     stats = ren.stats()
+    # outside the timed region: the dominant kernel with the GPU to itself (the large-step launch normally runs beside it on
+    # another stream and stretches its bracket); only meaningful once the start-up launches are over
+    standalone = None
+    if world == 1 and args.warmup + args.steps >= 48:
+        ren.set_option("overlap", 0)
+        ren.step(4)
+        ren.step_timing()
+        lean0 = ren.kernel_timing()[2]
+        ren.step(16)
+        _, n_sa = ren.step_timing()
+        sa_small_ms, _, lean1 = ren.kernel_timing()
+        ren.set_option("overlap", 1)
+        standalone = (sa_small_ms / max(n_sa, 1), (lean1 - lean0) / max(n_sa, 1))
     if rank == 0:
         value = args.steps * total / dt
         # dominant kernel: k_step_small (plain small steps); its own HIP-event bracket on the launch stream
@@ -236,6 +262,7 @@ def main():
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "chain_steps_per_launch": lean_steps_per_launch,
                 "algorithmic_bytes_per_step": ALGO_BYTES_PER_STEP,
+                "concurrent_launches": "k_step<large> runs beside this kernel on a second stream inside the bracket",
             },
             "step_ms": {"all_launches": kernel_ms / max(launches, 1), "k_step_small": small_ms / max(launches, 1),
                         "large_and_generic": large_ms / max(launches, 1)},
@@ -244,6 +271,10 @@ def main():
             "accept_rate": stats["accepted"] / max(stats["steps"], 1),
             "large_step_frac": stats["largeSteps"] / max(stats["steps"], 1),
         }
+        if standalone is not None and standalone[0] > 0:
+            sa_ach = ALGO_BYTES_PER_STEP * standalone[1] / (standalone[0] * 1e-3) / 1e9
+            out["roofline"]["standalone"] = {"avg_launch_ms": standalone[0], "chain_steps_per_launch": standalone[1], "achieved": sa_ach,
+                                             "frac": sa_ach / HBM_PEAK_GBS, "note": "same kernel, 16 launches after the timed region with the side launches serialised"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

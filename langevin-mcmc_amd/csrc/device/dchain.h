@@ -138,6 +138,22 @@ LMC_D void StorePath(float *base, int N, int i, const DPath &p) {
             base[(size_t)o * N + i] = w[o];
         }
 }
+// chain.buffered = false (mlt.cpp:121-132 after an accepted large step, :147-169 outlier reset).  The reference zeroes the
+// chain's MALA vectors at the NEXT MALA step (mutation_mala.h:59-81); nothing reads them in between (the cache push that may
+// precede this call is the last reader), so they are zeroed here instead, where the stores of a wave are dense: inside the hot
+// small-step kernel the same zeroing ran as 168 sparsely populated store instructions in almost every wave-step and made up a
+// third of the kernel's stores.  Invariant: F_BUFFERED clear => the seven vectors are zero.
+LMC_D void ClearBuffered(const ChainArrays &A, int i, int &flags) {
+    if (flags & F_BUFFERED) {
+        const size_t N = A.N;
+#pragma unroll 4
+        for (int k = 0; k < MAXPSS; k++) {
+            const size_t o = (size_t)k * N + i;
+            A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
+        }
+    }
+    flags &= ~F_BUFFERED;
+}
 LMC_D float *CurPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.pathBuf1 : A.curPath; }
 LMC_D float *PropPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.curPath : A.pathBuf1; }
 LMC_D float *CurGaussBuf(const ChainArrays &A, int flags) { return (flags & F_GSEL) ? A.gaussian1 : A.gaussian; }

@@ -356,12 +356,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         for (int k = 0; k < dim; k++) L.U(offBase + k) = nd(rng);
         prof.Mark(PR_ISO);
     } else {
-        if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81
-#pragma unroll 1
-            for (int k = 0; k < MAXPSS; k++) {
-                size_t o = (size_t)k * N + i;
-                A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
-            }
+        if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81; the vectors are zero already (dchain.h ClearBuffered)
             flags |= F_BUFFERED | F_VSYNC;  // all four vectors are zero
             flags &= ~F_QUERIED;
         }
@@ -680,7 +675,8 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             for (int w = 0; w < CONTRIB_WORDS; w++) A.curContrib[(size_t)w * N + i] = A.initContrib[(size_t)w * P.numChains + chainId];
             A.scoreSum[i] = A.initScoreSum[chainId];
             A.curSplatCount[i] = 0;
-            flags &= ~(F_VALID | F_GAUSS | F_BUFFERED);
+            flags &= ~(F_VALID | F_GAUSS);
+            ClearBuffered(A, i, flags);
             st.resets++;
         }
     }

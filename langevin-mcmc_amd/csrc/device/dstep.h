@@ -235,11 +235,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             for (int k = 0; k < dim; k++) offset[k] = nd(rng);
         } else {
             lastMala = true;
-            if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81
-                for (int k = 0; k < MAXPSS; k++) {
-                    size_t o = (size_t)k * N + i;
-                    A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
-                }
+            if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81; the vectors are zero already (dchain.h ClearBuffered)
                 flags |= F_BUFFERED;
                 flags &= ~F_QUERIED;
             }
@@ -329,7 +325,8 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             }
             A.lastScoreSum[i] = propScoreSum;
             A.lastScore[i] = pc.lsScore;
-            flags &= ~(F_GAUSS | F_BUFFERED);
+            flags &= ~F_GAUSS;
+            ClearBuffered(A, i, flags);
         } else {
             float *p = A.curSplat + i;
             p[0] = pc.screenPos.x, p[N] = pc.screenPos.y, p[2 * N] = smallSplat.x, p[3 * N] = smallSplat.y, p[4 * N] = smallSplat.z;
@@ -363,7 +360,8 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, P.numChains, chainId));
             A.scoreSum[i] = A.initScoreSum[chainId];
             A.curSplatCount[i] = 0;
-            flags &= ~(F_VALID | F_GAUSS | F_BUFFERED);
+            flags &= ~(F_VALID | F_GAUSS);
+            ClearBuffered(A, i, flags);
             st.resets++;
         }
     }

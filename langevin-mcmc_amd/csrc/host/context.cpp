@@ -360,8 +360,8 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
         int lo = 0, hi = 0;  // hi = the numerically lowest value = greatest priority
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char *e = getenv("LMC_STREAM_PRIO");
-        const bool prio = !e || atoi(e) != 0;
-        for (auto &st : c->sideStream) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio ? hi : 0));
+        const int mode = e ? atoi(e) : 1;  // 1: side launches first (highest priority), 0: equal, -1: side launches last
+        for (auto &st : c->sideStream) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
     }
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -402,6 +402,10 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     LMC_TRY
     lmc::DptOptions &o = c->scene->options;
     std::string n(name);
+    if (n == "overlap") {  // run-time switch of the concurrent side launches (same results either way; bench.py measures both)
+        c->overlap = v != 0;
+        return 0;
+    }
     if (n == "largestepprob") o.largeStepProbability = (float)v;
     else if (n == "largestepscale") o.largeStepProbScale = (float)v;
     else if (n == "mala") o.mala = v != 0;

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""profiles/pmc_step_kernel.json from the output directory of scripts/pmc_passes.sh: HBM bytes per launch of the lean step
+kernel with the guide's corrections (FETCH_SIZE / WRITE_SIZE are in KB; the read counter is calibrated against a kernel that
+streams a known byte count, lmc_stream_probe), stamped with the fingerprint of the kernel sources it was measured on
+(bench.py only reports `traffic` when the fingerprint matches the tree).
+usage: python scripts/pmc_to_json.py <pmc outdir> <label of the profile files in profiles/>"""
+import json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+out, label = sys.argv[1], sys.argv[2]
+summ = json.load(open(os.path.join(out, "summary.json")))
+cal = json.load(open(os.path.join(out, "calib.json")))
+probe = next(v for k, v in cal.items() if "stream_probe" in k)
+GiB_KB = (1 << 30) / 1024.0
+read_corr = GiB_KB / probe["FETCH_SIZE"]   # the probe reads exactly 1 GiB per launch
+write_corr = GiB_KB / probe["WRITE_SIZE"]  # ... and writes 1 GiB
+k = next(v for name, v in summ.items() if "k_step_small<true, false>" in name or "k_step_small<true,false>" in name)
+fetch = k["FETCH_SIZE"] * 1024.0 * read_corr
+write = k["WRITE_SIZE"] * 1024.0 * write_corr
+d = {
+    "kernel": "k_step_small<true,false>",
+    "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-rmse --steps 32 --warmup 40`, last third of the launches)" % label,
+    "fetch_bytes_per_launch": fetch,
+    "write_bytes_per_launch": write,
+    "hbm_bytes_per_launch": fetch + write,
+    "corrections": "FETCH_SIZE KB x 1024 x %.3f, WRITE_SIZE KB x 1024 x %.3f (profiles/%s_pmc_calibration.json: lmc_stream_probe moves 1 GiB each way per launch)" % (read_corr, write_corr, label),
+    "kernel_source_sha16": bench.kernel_source_sha(),
+}
+json.dump(d, open(os.path.join(ROOT, "profiles", "pmc_step_kernel.json"), "w"), indent=1)
+json.dump(summ, open(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % label), "w"), indent=1)
+json.dump(cal, open(os.path.join(ROOT, "profiles", "%s_pmc_calibration.json" % label), "w"), indent=1)
+print(json.dumps(d, indent=1))
