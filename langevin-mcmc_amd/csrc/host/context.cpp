@@ -100,7 +100,7 @@ struct lmc_ctx {
     int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // some ready cache tree is deeper than the lean kernels' LDS search frames
-    bool sortGeneric = true;   // LMC_SORT_GENERIC=0: A/B switch for the technique sort of the gradient launch
+    bool sortGeneric = false;  // LMC_SORT_GENERIC=1: technique sort of the gradient launch (A/B: its scatter costs more than the grouping saves, profiles/r02_final_kernel_stats.csv)
     DevBuf<int> listScratch, sortBins;
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
     hipStream_t stream = nullptr;

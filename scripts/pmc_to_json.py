@@ -17,7 +17,7 @@ probe = next(v for k, v in cal.items() if "stream_probe" in k)
 GiB_KB = (1 << 30) / 1024.0
 read_corr = GiB_KB / probe["FETCH_SIZE"]   # the probe reads exactly 1 GiB per launch
 write_corr = GiB_KB / probe["WRITE_SIZE"]  # ... and writes 1 GiB
-k = next(v for name, v in summ.items() if "k_step_small<true, false>" in name or "k_step_small<true,false>" in name)
+k = next(v for name, v in summ.items() if name.replace(" ", "").startswith("voidk_step_small<true,false,false>"))
 fetch = k["FETCH_SIZE"] * 1024.0 * read_corr
 write = k["WRITE_SIZE"] * 1024.0 * write_corr
 d = {
