@@ -457,16 +457,38 @@ LMC_D V3 EnvRepAt(const DEnv &E, int x, int y) {
     const float *p = E.image + ((long)Moduloi(y, E.H) * E.W + Moduloi(x, E.W)) * 3;
     return V3{p[0], p[1], p[2]};
 }
-LMC_D int EnvUToIndex(const float *cdf, int size, float &u) {  // std::lower_bound, envlight.cpp:128-133
-    int lo = 0, len = size + 1;
-    while (len > 0) {
-        int half = len >> 1;
-        if (cdf[lo + half] < u) {
-            lo += half + 1;
-            len -= half + 1;
-        } else
-            len = half;
+// std::lower_bound(cdf, cdf + n, u): the first index whose entry is not below u (n if none).  A CDF is non-decreasing, so that
+// index does not depend on which entries a search probes: eight independent probes per round (one memory round trip) shrink
+// the range ninefold, against one dependent probe per halving -- 3 round trips instead of 9-10 for the env map's 257 / 513 entries.
+LMC_D int LowerBoundMonotone(const float *cdf, int n, float u) {
+    int lo = 0, hi = n;  // entries before lo are below u, entries from hi on are not
+    while (hi - lo > 8) {
+        const int span = hi - lo;
+        int p[8];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j] = lo + ((j + 1) * span) / 9, v[j] = cdf[p[j]];
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) c += v[j] < u ? 1 : 0;
+        int nlo = lo, nhi = hi;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j == c - 1) nlo = p[j] + 1;
+            if (j == c) nhi = p[j];
+        }
+        lo = nlo, hi = nhi;
     }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = cdf[min(lo + j, n - 1)];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) c += (lo + j < hi && v[j] < u) ? 1 : 0;
+    return lo + c;
+}
+LMC_D int EnvUToIndex(const float *cdf, int size, float &u) {  // std::lower_bound, envlight.cpp:128-133
+    const int lo = LowerBoundMonotone(cdf, size + 1, u);
     int index = lo - 1;
     if (index < 0) index = 0;
     if (index > size - 1) index = size - 1;
