@@ -51,6 +51,10 @@ struct SpecRng {
         float r = (float)Next() * 2.3283064365386963e-10f;
         return r >= 1.0f ? 0.99999994f : r;
     }
+    LMC_D void Uniform2(float &a, float &b) {
+        a = Uniform();
+        b = Uniform();
+    }
 };
 // the LCG `delta` steps ahead (pcg_random.hpp:522-541, advance())
 LMC_HD uint64_t PcgAdvance(uint64_t state, uint64_t delta) {

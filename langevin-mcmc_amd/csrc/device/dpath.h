@@ -108,8 +108,8 @@ LMC_D float ShadingNormalCorrection(V3 wi, const Isect &isect, V3 wo) {  // path
 // Vector2(uniDist(rng), uniDist(rng)): gcc evaluates the arguments right to left (see oracle/path.cpp)
 template <class R>
 LMC_D V2 RndVec2(R &rng) {
-    float first = rng.Uniform();
-    float second = rng.Uniform();
+    float first, second;
+    rng.Uniform2(first, second);
     return V2{second, first};
 }
 

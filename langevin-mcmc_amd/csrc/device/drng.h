@@ -95,6 +95,22 @@ struct Rng {
         float r = (float)Next() * 2.3283064365386963e-10f;
         return r >= 1.0f ? 0.99999994f : r;
     }
+    // Two consecutive draws (a first, then b) with both table look-ups in flight together: the second state is one LCG step
+    // away, so its table slot is known before the first value has arrived.  Same stream as two Uniform() calls; the
+    // once-per-2^32 table advance takes the sequential path.
+    LMC_HD void Uniform2(float &a, float &b) {
+        const uint64_t s0 = state, s1 = s0 * PCG_MULT + PCG_INC;
+        if ((s0 & 0xFFFFFFFFull) == 0ull || (s1 & 0xFFFFFFFFull) == 0ull) {
+            a = Uniform();
+            b = Uniform();
+            return;
+        }
+        const uint32_t r0 = tab[(unsigned)(s0 & 63u)], r1 = tab[(unsigned)(s1 & 63u)];
+        state = s1 * PCG_MULT + PCG_INC;
+        const float fa = (float)(PcgOutputXshRs(s0) ^ r0) * 2.3283064365386963e-10f, fb = (float)(PcgOutputXshRs(s1) ^ r1) * 2.3283064365386963e-10f;
+        a = fa >= 1.0f ? 0.99999994f : fa;
+        b = fb >= 1.0f ? 0.99999994f : fb;
+    }
 };
 
 // one normal_distribution<float> object (the saved variate lives as long as the object)
@@ -110,8 +126,10 @@ struct NormalDist {
         } else {
             float x, y, r2;
             do {
-                x = 2.0f * rng.Uniform() - 1.0f;
-                y = 2.0f * rng.Uniform() - 1.0f;
+                float u0, u1;
+                rng.Uniform2(u0, u1);
+                x = 2.0f * u0 - 1.0f;
+                y = 2.0f * u1 - 1.0f;
                 r2 = x * x + y * y;
             } while (r2 > 1.0f || r2 == 0.0f);
             float mult = sqrtf(-2.0f * logf(r2) / r2);

@@ -11,7 +11,10 @@
 using namespace lmcd;
 
 template <bool GLOSSY>
-__global__ void __launch_bounds__(256) k_step_small_grad(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
+#ifndef LMC_LEANGRAD_WAVES
+#define LMC_LEANGRAD_WAVES 2  // registers for two waves per SIMD: a wave of this launch then fits beside a resident wave of the hot launch
+#endif
+__global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                       const int *listCount, NextLists next, float *gradBuf, int gradStride) {
     extern __shared__ float lds[];
     StepStats st;
