@@ -36,6 +36,7 @@ LMC_HD int CacheGridCell(float x, int G) {
     int c = (int)(x * (float)G);
     return c < 0 ? 0 : (c > G - 1 ? G - 1 : c);
 }
+constexpr int KD_MAX_NODES = 6144;  // 3000 points: a binary tree has fewer than 2 * 3000 nodes whatever the split (the host checks)
 constexpr int KD_STACK = 160;  // deepest kd-tree the in-kernel search accepts (the host refuses deeper ones)
 
 struct KdNode {  // nanoflann Node flattened (host/kdtree.cpp builds it exactly like nanoflann's divideTree)
@@ -51,7 +52,6 @@ struct DCacheDim {
     const KdNode *nodes;
     const int *vind;
     const float *pts, *v1, *v2;  // PSS_MAX_SIZE x dim, row-major
-    const float *ptsLeaf;        // the points again, in leaf order (row i = pts[vind[i]]): the lean kernel scans leaves from it
     // Exact existence test in front of the radius query (lean kernel): a uniform grid over the first gridM coordinates with
     // cells no smaller than the query radius (G = floor(1 / sqrt(dim) / 0.01)).  Every cell lists the points of its 3^gridM
     // neighbourhood (rows copied: gridRows[gridStart[c] .. gridStart[c+1]) x dim), so a point within the radius of a query is

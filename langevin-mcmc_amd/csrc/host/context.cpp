@@ -75,7 +75,7 @@ void EnsureDevice(int device) {
 }
 
 struct CacheDimHost {
-    DevBuf<float> pss, v1, v2, weight, ptsLeaf;
+    DevBuf<float> pss, v1, v2, weight;
     DevBuf<KdNode> nodes;
     DevBuf<int> gridStart, gridCursor, gridTileSums;
     DevBuf<float> gridRows;
@@ -590,6 +590,14 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
         if (cd.relevant) {
             cd.pss.Alloc((size_t)PSS_MAX_SIZE * d), cd.v1.Alloc((size_t)PSS_MAX_SIZE * d), cd.v2.Alloc((size_t)PSS_MAX_SIZE * d);
             cd.weight.Alloc(PSS_MAX_SIZE);
+            // everything the "cache became ready" event needs is allocated here: hipMalloc inside the step loop costs more than
+            // the kd-tree build it would sit next to
+            cd.gridG = CacheGridG(d), cd.gridM = std::min(c->gridDims, d);
+            size_t cells = 1, nbrs = 1;
+            for (int k = 0; k < cd.gridM; k++) cells *= cd.gridG, nbrs *= 3;
+            cd.gridStart.Alloc(cells + 1, false), cd.gridCursor.Alloc(cells, false), cd.gridTileSums.Alloc((cells + 1) / 2048 + 1, false);
+            cd.gridRows.Alloc((size_t)PSS_MAX_SIZE * nbrs * d, false);
+            cd.nodes.Alloc(KD_MAX_NODES, false), cd.vind.Alloc(PSS_MAX_SIZE, false);
         }
     }
     c->cacheCounts.Alloc(CACHE_SLOTS), c->pushTiles.Alloc((N + 1023) / 1024);
@@ -678,23 +686,17 @@ static void MaintainCache(lmc_ctx *c) {
         if (!cd.relevant || cd.ready || c->hostCounts[sl] < PSS_MAX_SIZE) continue;
         std::vector<float> pts = cd.pss.Download();
         lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
-        cd.nodes.Upload(t.nodes), cd.vind.Upload(t.vind);
-        std::vector<float> leafOrder((size_t)PSS_MAX_SIZE * d);
-        for (int i = 0; i < PSS_MAX_SIZE; i++) memcpy(&leafOrder[(size_t)i * d], &pts[(size_t)t.vind[i] * d], d * sizeof(float));
-        cd.ptsLeaf.Upload(leafOrder);
-        {  // the existence-test grid, on the device (no host time, nothing to upload)
-            cd.gridG = CacheGridG(d), cd.gridM = std::min(c->gridDims, d);
-            size_t cells = 1, nbrs = 1;
-            for (int k = 0; k < cd.gridM; k++) cells *= cd.gridG, nbrs *= 3;
-            cd.gridStart.Alloc(cells + 1, false), cd.gridCursor.Alloc(cells, false), cd.gridTileSums.Alloc((cells + 1) / 2048 + 1, false);
-            cd.gridRows.Alloc((size_t)PSS_MAX_SIZE * nbrs * d, false);
-            LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, d, cd.gridG, cd.gridM, cd.gridStart.p, cd.gridCursor.p, cd.gridRows.p, cd.gridTileSums.p, s);
-        }
+        if (t.nodes.size() > KD_MAX_NODES) throw std::runtime_error("kd-tree larger than its preallocated node buffer");
+        HIP_CHECK(hipMemcpyAsync(cd.nodes.p, t.nodes.data(), t.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(cd.vind.p, t.vind.data(), t.vind.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        // the existence-test grid, on the device (no host time, nothing to upload)
+        LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, d, cd.gridG, cd.gridM, cd.gridStart.p, cd.gridCursor.p, cd.gridRows.p, cd.gridTileSums.p, s);
+        HIP_CHECK(hipStreamSynchronize(s));  // t goes out of scope below: the pageable copies above must have left the host
         DCacheDim &D = c->cacheHost.d[d];
         D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
         D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
         c->anyDeepCache = c->anyDeepCache || D.deep;
-        D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.ptsLeaf = cd.ptsLeaf.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
+        D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
         for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
         cd.ready = true;
         changed = true;
@@ -1166,7 +1168,7 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
     dOutN.Alloc(nq), dOutI.Alloc((size_t)nq * knn), dOutD.Alloc((size_t)nq * knn);
     DCacheDim C;
     memset(&C, 0, sizeof(C));
-    C.ready = 1, C.nodes = dN.p, C.vind = dV.p, C.pts = dP.p, C.ptsLeaf = nullptr, C.v1 = dP.p, C.v2 = dP.p;
+    C.ready = 1, C.nodes = dN.p, C.vind = dV.p, C.pts = dP.p, C.v1 = dP.p, C.v2 = dP.p;
     for (int k = 0; k < dim; k++) C.rootLow[k] = t.rootLow[k], C.rootHigh[k] = t.rootHigh[k];
     LaunchKdProbe(C, dim, nq, dQ.p, radiusSq, knn, dOutN.p, dOutI.p, dOutD.p, 0);
     HIP_CHECK(hipDeviceSynchronize());
