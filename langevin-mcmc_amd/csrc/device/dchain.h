@@ -27,7 +27,6 @@ constexpr float PCD_MIN = 0.01f, PCD_MAX = 100.f, MTM_MIN = -5.0f, MTM_MAX = 5.0
 constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
 constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
 
-constexpr int KD_LDS_DEPTH = 22;  // deepest tree the lean small-step kernel searches with its frames in LDS (dsmall.h)
 LMC_HD int CacheGridG(int dim) {  // cells per axis: the largest G with 1 / G >= radius = sqrt(dim) * PSS_QUERY_DIST
     int G = (int)(1.0f / (sqrtf((float)dim) * PSS_QUERY_DIST));
     return G < 1 ? 1 : (G > 64 ? 64 : G);

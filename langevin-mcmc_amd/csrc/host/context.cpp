@@ -99,7 +99,7 @@ struct lmc_ctx {
     bool largeLdsStack = true;  // LMC_LARGE_LDS=0: A/B switch for the LDS traversal stack of the large-step launch
     int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
-    bool anyDeepCache = false;  // some ready cache tree is deeper than the lean kernels' LDS search frames
+    bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
     bool sortGeneric = false;  // LMC_SORT_GENERIC=1: technique sort of the gradient launch (A/B: its scatter costs more than the grouping saves, profiles/r02_final_kernel_stats.csv)
     DevBuf<int> listScratch, sortBins;
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
@@ -694,7 +694,8 @@ static void MaintainCache(lmc_ctx *c) {
         HIP_CHECK(hipStreamSynchronize(s));  // t goes out of scope below: the pageable copies above must have left the host
         DCacheDim &D = c->cacheHost.d[d];
         D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
-        D.deep = t.depth > KD_LDS_DEPTH ? 1 : 0;
+        if (t.depth >= KD_STACK) throw std::runtime_error("kd-tree deeper than the search stack (KD_STACK)");
+        D.deep = 0;  // every kernel searches with KD_STACK private frames now; the field routed deep trees away from the former LDS search
         c->anyDeepCache = c->anyDeepCache || D.deep;
         D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
         for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
