@@ -136,6 +136,8 @@ int lmc_occluded(lmc_ctx *ctx, int n, const float *rays, int *occluded);
  * out: n_seeds x (n + 66) words, the last 66 = RNG state after the draws [lo, hi, table 64] */
 int lmc_rng_probe(int n_seeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, unsigned *out);
 int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, float radius_sq, int knn, int *out_n, int *out_idx, float *out_dist);
+/* test hook: first index of cdf[0..n) that is not below u[i] (the device's search behind the env-map CDF look-ups; = std::lower_bound) */
+int lmc_lower_bound_probe(int n, const float *cdf, int nq, const float *u, int *out);
 /* measurement aid: ms per launch of a kernel that streams `words` state words per chain in batches of `batch` loads; mode 0 = [word][chain], 1 = [tile of 64][word][lane] */
 int lmc_layout_probe(int nChains, int words, int mode, int batch, int reps, double *msPerLaunch);
 /* measurement hook (LMC_PROF=1): wave cycles per region of the lean small-step kernel since the last call, out16[12] = waves */

@@ -6,6 +6,7 @@
 #include "dstep_params.h"
 
 void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s);
+void LaunchLowerBoundProbe(int n, const float *cdf, int nq, const float *u, int *out, hipStream_t s);
 void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out, hipStream_t s);
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s);
 void LaunchTrace(const lmcd::DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s);

@@ -15,6 +15,12 @@ __global__ void k_seed_rng(int n, long long firstSeed, uint64_t *state, uint32_t
 }
 
 // test probe: draws from RNG(seed): mode 0 raw u32, 1 uniform, 2 one normal object (mean, stddev), 3 mixed rounds
+// test hook: LowerBoundMonotone (dshade.h) against std::lower_bound on the host side of the test
+__global__ void k_lower_bound_probe(int n, const float *cdf, int nq, const float *u, int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) out[i] = LowerBoundMonotone(cdf, n, u[i]);
+}
+
 __global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nSeeds) return;
@@ -630,6 +636,9 @@ void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, h
 }
 void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_rng_probe, dim3((nSeeds + 63) / 64), dim3(64), 0, s, nSeeds, seeds, mode, n, mean, stddev, tabScratch, out);
+}
+void LaunchLowerBoundProbe(int n, const float *cdf, int nq, const float *u, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_lower_bound_probe, dim3((nq + 63) / 64), dim3(64), 0, s, n, cdf, nq, u, out);
 }
 void LaunchTrace(const DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s) {
     hipLaunchKernelGGL(k_trace, dim3(GridFor(n, 256)), dim3(256), 0, s, S, n, rays, prim, t, anyHit);

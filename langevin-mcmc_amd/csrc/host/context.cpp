@@ -1125,6 +1125,19 @@ int lmc_rng_probe(int nSeeds, const unsigned long long *seeds, int mode, int n, 
     return 0;
     LMC_CATCH(-1)
 }
+// test hook: the device's nine-way monotone search over cdf[0..n) for nq keys (tests compare with numpy.searchsorted)
+int lmc_lower_bound_probe(int n, const float *cdf, int nq, const float *u, int *out) {
+    LMC_TRY
+    EnsureDevice(0);
+    DevBuf<float> dC, dU;
+    DevBuf<int> dO;
+    dC.Upload(cdf, n), dU.Upload(u, nq), dO.Alloc(nq);
+    LaunchLowerBoundProbe(n, dC.p, nq, dU.p, dO.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dO.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
 int lmc_stream_probe(long long nWords, int reps) {
     LMC_TRY
     EnsureDevice(0);

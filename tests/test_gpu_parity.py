@@ -379,6 +379,28 @@ def test_isotropic_small_step_only():
     assert r["film_rel_l2"] < 1e-3
 
 
+def test_env_cdf_search_equals_lower_bound():
+    """The env-map CDF look-ups use a nine-way search (dshade.h LowerBoundMonotone: three memory round trips instead of ten).
+    For a non-decreasing array its answer is std::lower_bound's whatever it probes: checked against numpy.searchsorted(side="left")
+    on CDFs with plateaus and repeated end values, sizes around the search's range boundaries (1..9, 10, 73, 82, 257, 513, 4097),
+    keys on, between, below and above the entries, and NaN."""
+    p = gc.pkg()
+    L = p.lib()
+    rng = np.random.default_rng(11)
+    for n in list(range(1, 12)) + [72, 73, 74, 81, 82, 83, 257, 513, 729, 730, 4097]:
+        w = rng.random(n).astype(np.float32)
+        w[rng.random(n) < 0.3] = 0.0  # plateaus
+        cdf = np.cumsum(w, dtype=np.float32)
+        cdf = (cdf / max(cdf[-1], np.float32(1e-30))).astype(np.float32)
+        u = np.concatenate([cdf, np.nextafter(cdf, np.float32(-1)), np.nextafter(cdf, np.float32(2)), rng.random(2000).astype(np.float32),
+                            np.array([-1.0, 0.0, 1.0, 2.0, np.nan], np.float32)]).astype(np.float32)
+        out = np.zeros(len(u), np.int32)
+        assert L.lmc_lower_bound_probe(n, P(cdf), len(u), P(u), P(out)) == 0
+        want = np.searchsorted(cdf, u, side="left")
+        want[np.isnan(u)] = 0  # comparisons with NaN are false: std::lower_bound never moves right
+        assert np.array_equal(out, want), n
+
+
 def test_cache_phase_parity():
     """Enough chains and steps for the global gradient cache to fill (3000 entries per dim) and be queried:
     exercises the deferred, chain-ordered push, the host kd-tree build and the in-kernel radius search."""
