@@ -65,7 +65,7 @@ LMC_D void InitGaussianH2MC(const DScene &S, const StepParams &P, const H2MCPara
             SerializePath(S, path, primary, o);
             StridedIn vin{gw.buf + gw.slot, gw.stride};
             float logLum;
-            PathFuncHessDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
+            if (!(P.expFlags & 16)) PathFuncHessDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
             st.gradCalls++;
             bool finite = true;
             for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);
@@ -75,7 +75,7 @@ LMC_D void InitGaussianH2MC(const DScene &S, const StepParams &P, const H2MCPara
                 for (int k = 0; k < dim * dim; k++) vHess[k] = 0.f;
             }
         }
-        ComputeGaussianH2MCDevice(param, dim, sp.ssScore, vGrad, vHess, mean, covL, invCov, logDet);
+        ComputeGaussianH2MCDevice(param, dim, (P.expFlags & 32) ? 0.f : sp.ssScore, vGrad, vHess, mean, covL, invCov, logDet);  // sc = 0: isotropic early-out, no eigen-solve
     }
     for (int k = 0; k < dim; k++) slot.Mean(k) = mean[k];
     slot.LogDet() = logDet;

@@ -7,7 +7,7 @@ struct StepParams {
     int numChains;   // all chains of the job (stride of the init-state arrays)
     int chainBegin;  // global id of this rank's chain 0
     int useGradient;  // 0: derivative library "absent" (isotropic until the cache is ready, path.cpp:4042-4053), 1: in-kernel gradient
-    int expFlags;      // measurement aids, never set in production: bit 0 = skip the film splats of the lean kernel (LMC_EXP_NOSPLAT), bit 1 = skip its cache queries, bit 2 = skip the gradient program of the generic kernel (LMC_EXP_NOGRAD)
+    int expFlags;      // measurement aids, never set in production: bit 0 = skip the film splats of the lean kernel (LMC_EXP_NOSPLAT), bit 1 = skip its cache queries, bit 2 = skip the gradient program of the generic kernel (LMC_EXP_NOGRAD), bit 3 = no statistics reduction in the lean kernel, bits 4 / 5 = H2MC without the Hessian program / without the eigen-solve
     int maxDervDepth;  // --max-derivatives-depth (main.cpp:46,59-60): derivative programs exist for path lengths c + l - 1 <= this (path.cpp:4030-4037)
 };
 

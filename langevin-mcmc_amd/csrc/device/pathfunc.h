@@ -1009,7 +1009,10 @@ LMC_HD void PathFuncGrad(int c, int l, const float *primary, const float *scene,
 // derivative along direction i).  Chunking keeps the working set of the second-order type at 2 (HC + 1) floats per value
 // whatever the dimension: the 16-wide form needed 22 KB of private memory per lane and faulted on gfx950, the 8-wide one
 // 12.6 KB; one instantiation also halves the compile time.
-constexpr int HC = 8;
+#ifndef LMC_HESS_CHUNK
+#define LMC_HESS_CHUNK 8
+#endif
+constexpr int HC = LMC_HESS_CHUNK;
 template <class In>
 LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);

@@ -100,6 +100,7 @@ struct lmc_ctx {
     int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
+    bool sortH2mc = true;
     bool sortGeneric = false;  // LMC_SORT_GENERIC=1: technique sort of the gradient launch (A/B: its scatter costs more than the grouping saves, profiles/r02_final_kernel_stats.csv)
     DevBuf<int> listScratch, sortBins;
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
@@ -371,12 +372,15 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_LARGE_BLOCK")) c->largeBlock = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
+    if (const char *e = getenv("LMC_SORT_H2MC")) c->sortH2mc = atoi(e) != 0;
     if (const char *e = getenv("LMC_SORT_GENERIC")) c->sortGeneric = atoi(e) != 0;
     if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
     if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
     if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
     if (const char *e = getenv("LMC_EXP_NOGRAD")) c->expFlags |= atoi(e) ? 4 : 0;
     if (const char *e = getenv("LMC_EXP_NOSTATS")) c->expFlags |= atoi(e) ? 8 : 0;
+    if (const char *e = getenv("LMC_EXP_NOHESS")) c->expFlags |= atoi(e) ? 16 : 0;    // H2MC: skip the second-order path program
+    if (const char *e = getenv("LMC_EXP_NOEIGEN")) c->expFlags |= atoi(e) ? 32 : 0;   // H2MC: skip the eigen-solve (isotropic Gaussian)
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -762,7 +766,9 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         // list build: chains whose next step no longer needs a gradient go to the lean launch right away
         if (!c->allCachesReady) MaintainCache(c);
         LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c), s);
-        if (c->sortGeneric && c->needGeneric && c->S.opt.mala && !c->S.opt.h2mc) {  // group the gradient launch's chains by technique
+        // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
+        // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
+        if (c->needGeneric && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
             LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, s);
             std::swap(c->lists[nxt][1].p, c->listScratch.p);
         }
