@@ -27,8 +27,15 @@ for name, xml, kw, n, warm, steps in cases:
         ren.sync()
         dt = time.time() - t0
         st = ren.stats()
+        # kernel split of a few more steps, side launches serialised (not part of the rate above)
+        ren.set_option("timing", 1)
+        ren.set_option("overlap", 0)
+        ren.step(4)
+        _, nl = ren.step_timing()
+        small_ms, large_ms, _ = ren.kernel_timing()
         print(json.dumps({"config": name, "chains": n, "steps": steps, "after_warmup_steps": warm, "chain_steps_per_s": n * steps / dt, "ms_per_step": dt * 1e3 / steps,
-                          "accept_rate": st["accepted"] / max(st["steps"], 1), "cache_ready_mask": st["cacheReadyMask"]}), flush=True)
+                          "accept_rate": st["accepted"] / max(st["steps"], 1), "large_step_frac": st["largeSteps"] / max(st["steps"], 1),
+                          "serial_ms": {"lean": small_ms / max(nl, 1), "large_and_generic": large_ms / max(nl, 1)}, "cache_ready_mask": st["cacheReadyMask"]}), flush=True)
         ren.close()
     except Exception as e:  # a configuration that cannot run is reported, not hidden
         print(json.dumps({"config": name, "error": str(e)}), flush=True)
