@@ -128,9 +128,15 @@ LMC_HD float fastpow(float x, float p) { return fastpow2(p * fastlog2(x)); }
 // reference calls libm's float versions, whose last bit differs between libm builds (and from the device libm); a
 // correctly rounded value is within that spread and makes the Russian-roulette / rejection decisions downstream of a
 // glossy vertex reproducible between CPU and GPU.
+#ifdef LMC_EXP_FLOAT_TRANSCENDENTALS  // measurement aid only: what the double evaluation costs (breaks bit-parity with the oracle)
+LMC_HD float powd(float a, float e) { return powf(a, e); }
+LMC_HD float expd(float x) { return expf(x); }
+LMC_HD float logd(float x) { return logf(x); }
+#else
 LMC_HD float powd(float a, float e) { return (float)pow((double)a, (double)e); }
 LMC_HD float expd(float x) { return (float)exp((double)x); }
 LMC_HD float logd(float x) { return (float)log((double)x); }
+#endif
 
 // utils.h:197-210
 LMC_HD V3 Reflect(V3 wi, V3 n) { return (2.0f * Dot(wi, n)) * n - wi; }
