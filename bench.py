@@ -169,6 +169,8 @@ def main():
     norm, ncontrib = ren.init_chains(init_samples, total, args.init_threads, args.samples_per_chain, 0, rank * per_gpu, (rank + 1) * per_gpu)
     t_init = time.time() - t_init
 
+    collective = "in-library RCCL all-reduce of the device film (lmc_film_allreduce)"
+
     def barrier():
         ren.sync()
         if dist is not None:
@@ -185,7 +187,17 @@ def main():
         if rank == 0:
             idt = torch.tensor(list(p.comm_unique_id()), dtype=torch.uint8, device="cuda")
         dist.broadcast(idt, 0)
-        ren.comm_init(world, rank, bytes(idt.cpu().tolist()))
+        # If the in-library communicator cannot be created on this node, the film sum still runs over RCCL, through
+        # torch.distributed on a staged copy -- reported in the JSON line ("collective"), never silently.
+        try:
+            ren.comm_init(world, rank, bytes(idt.cpu().tolist()))
+        except Exception as e:  # noqa: BLE001
+            collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed: %s)" % str(e)[:200]
+            sys.stderr.write("bench.py rank %d: %s\n" % (rank, collective))
+        ok_t = torch.tensor([1 if collective.startswith("in-library") else 0], device="cuda")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if int(ok_t.item()) == 0 and collective.startswith("in-library"):
+            collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed on another rank)"
     ren.set_option("timing", 1)  # per-step HIP events on the launch stream (lmc_step_timing / lmc_kernel_timing)
     ren.step(args.warmup)
     ren.step_timing()  # discard warm-up launches
@@ -199,7 +211,11 @@ def main():
 
         # the single data-path collective: the device films are summed in place by the library (RCCL over xGMI, on the step
         # stream, no host staging); `normalization` is identical on all ranks (every rank runs the same MLTInit)
-        ren.film_allreduce()
+        if collective.startswith("in-library"):
+            ren.film_allreduce()
+        else:
+            ft = torch.from_numpy(ren.film()).cuda()
+            dist.all_reduce(ft)
     barrier()
     dt = time.time() - t0
     if dist is not None:
@@ -250,6 +266,7 @@ def main():
                 "samples_per_chain": args.samples_per_chain,
                 "film": [ren.width, ren.height],
                 "parallelism": "chains sharded x%d" % world,
+                "collective": collective if world > 1 else "none (one GPU)",
             },
             "roofline": {
                 "bound": "hbm",
