@@ -28,14 +28,17 @@ LMC_D H2Slot H2Buf(const ChainArrays &A, int i, bool second) { return H2Slot{A.h
 
 #ifdef __HIPCC__
 template <class In>
-__device__ __noinline__ void PathFuncHessDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
+#ifndef LMC_PF_ATTR
+#define LMC_PF_ATTR
+#endif
+__device__ __noinline__ LMC_PF_ATTR void PathFuncHessDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     PathFuncHess(c, l, primary, scene, vp, logLum, grad, hess);
 }
 #endif
 
 #ifdef __HIPCC__
 // out of line: its eigen-solve work space then shares stack with the (already returned) path program instead of adding to it
-__device__ __noinline__ void ComputeGaussianH2MCDevice(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL,
+__device__ __noinline__ LMC_PF_ATTR void ComputeGaussianH2MCDevice(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL,
                                                        MatRef invCov, float &logDet) {
     float work[H2_MAXDIM * H2_MAXDIM + 4 * H2_MAXDIM];
     ComputeGaussianH2MC(param, n, sc, grad, hess, mean, covL, invCov, logDet, work);

@@ -17,7 +17,10 @@
 // unit that instantiates the second-order (nested dual) type defines LMC_PF_OUTLINE first: one out-of-line copy per block keeps
 // the compile time of that instantiation to minutes (inlined at every call site it took 8 min per Hessian width).
 #if defined(LMC_PF_OUTLINE) && defined(__HIPCC__)
-#define LMC_PF __host__ __device__ inline __attribute__((noinline))
+#ifndef LMC_PF_ATTR
+#define LMC_PF_ATTR  // build experiments: extra attributes of the out-of-line blocks (e.g. a register budget)
+#endif
+#define LMC_PF __host__ __device__ inline __attribute__((noinline)) LMC_PF_ATTR
 #else
 #define LMC_PF LMC_HD
 #endif

@@ -54,7 +54,8 @@ void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArray
     if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code
     const bool lds = bvhDepth <= BVH_LDS_STACK;
 #define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next)
-    if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+    if (profile && lds && glossy) hipLaunchKernelGGL((k_step_small<true, true, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+    else if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
     else if (lds && !glossy)
         LMC_LAUNCH_SMALL(true, false);
     else if (lds && glossy)
