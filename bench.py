@@ -230,7 +230,7 @@ def main():
     # outside the timed region: the dominant kernel with the GPU to itself (the large-step launch normally runs beside it on
     # another stream and stretches its bracket); only meaningful once the start-up launches are over
     standalone = None
-    if world == 1 and args.warmup + args.steps >= 48:
+    if world == 1 and args.warmup + args.steps >= 48 and args.warmup + args.steps + 20 <= args.samples_per_chain:
         ren.set_option("overlap", 0)
         ren.step(4)
         ren.step_timing()
