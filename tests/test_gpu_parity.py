@@ -371,6 +371,22 @@ def test_maxdepth_12_diffuse_long_paths_exact():
     assert r["final_state_match"] > 0.98
 
 
+@pytest.mark.parametrize("n_chains", [1, 65, 1000])
+def test_ragged_chain_counts_and_finished_chains(n_chains):
+    """Edge cases of the launch plan: chain counts that fill no wave / tile (1, 65, 1000 against 64-lane waves and 1024-chain
+    list tiles), a film whose sides are not multiples of the 16-pixel tiles, and more steps requested than a chain has
+    samples (chains finish: NEXT_DONE, empty work lists).  Same checks as the chain-loop parity test."""
+    ug = 1 if gc.pathref() else 0
+    r = gc.run_pair(97, 61, 4000, n_chains, 8, 5, 9, use_gradient=ug)
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert so["steps"] == sg["steps"] == n_chains * 5  # every chain ran exactly its own 5 mutations, then stopped
+    assert sg["largeSteps"] == so["largeSteps"] and sg["accepted"] == so["accepted"]
+    assert r["init_cl_match"] == 1.0
+    assert r["film_rel_l2"] < 1e-3
+    assert abs(r["energy_gpu"] - 1.0) < 1e-4
+    assert r["final_state_match"] == 1.0
+
+
 def test_isotropic_small_step_only():
     """mala = false: plain Kelemen small steps (mutation_small.h) + large steps."""
     r = gc.run_pair(96, 72, 20000, 128, 4, 300, 30, use_gradient=0, mala=False)
