@@ -54,7 +54,7 @@ void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);
 // measurement aid: state-layout probe (kernels.hip k_layout_probe)
 void LaunchLayoutProbe(int N, int words, int mode, int batch, const float *in, float *out, hipStream_t s);
-// groups the entries of a work list by the technique key of A.nextKind (bins: 128 ints of scratch)
-void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins, hipStream_t s);
+// groups the entries of a work list by the technique key of A.nextKind (blockHist: 64 ints per 2048 entries of the longest list)
+void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *blockHist, int maxEntries, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
 void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s);

@@ -809,41 +809,56 @@ void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned l
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }
-// Global counting sort of the generic small-step list by technique key.  The generic kernel evaluates a gradient program per
-// chain: a wave whose 64 chains follow different techniques (c,l) runs their programs one after the other, so (unlike the lean
-// kernel, where the coalescing of the state loads mattered more, profiles/r02_b_*) grouping equal techniques pays.  The order
-// inside a group is left to the atomics: no result depends on the order of a list.
-constexpr int SORT_GRID = 128;
-__global__ void __launch_bounds__(256) k_sort_hist(const unsigned char *nextKind, const int *in, const int *count, int *bins) {
+// Global counting sort of the generic small-step list by technique key.  The generic launches evaluate a path program per
+// chain (gradient of the cache-filling launch, Hessian of H2MC): a wave whose 64 chains follow different techniques (c,l) runs
+// their programs one after the other, so -- unlike the lean kernel, where the coalescing of the state loads mattered more
+// (profiles/r02_b_*) -- grouping equal techniques pays (H2MC: +85 %).  Two levels: every block of SORT_CHUNK entries counts its
+// keys in LDS, one small block turns the (block, key) counts into offsets, every block scatters its entries with LDS cursors.
+// The order inside a (block, key) group is left to the LDS atomics: no result depends on the order of a list.
+constexpr int SORT_CHUNK = 2048;
+__global__ void __launch_bounds__(256) k_sort_hist(const unsigned char *nextKind, const int *in, const int *count, int *blockHist) {
     __shared__ int h[64];
+    const int n = *count, base = blockIdx.x * SORT_CHUNK;
+    if (base >= n) return;
     if (threadIdx.x < 64) h[threadIdx.x] = 0;
     __syncthreads();
-    const int n = *count;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SORT_GRID * 256) atomicAdd(&h[nextKind[in[i]] >> 2], 1);
+    for (int i = base + threadIdx.x; i < min(base + SORT_CHUNK, n); i += 256) atomicAdd(&h[nextKind[in[i]] >> 2], 1);
     __syncthreads();
-    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < 64) blockHist[blockIdx.x * 64 + threadIdx.x] = h[threadIdx.x];
 }
-__global__ void __launch_bounds__(64) k_sort_scan(int *bins) {  // bins[0..64) counts -> bins[64..128) cursors (exclusive prefix)
-    const int h = bins[threadIdx.x];
-    int inc = h;
+__global__ void __launch_bounds__(64) k_sort_scan(const int *count, int *blockHist) {  // counts -> first output index of every (block, key) group
+    const int nBlocks = (*count + SORT_CHUNK - 1) / SORT_CHUNK, key = threadIdx.x;
+    int total = 0;
+    for (int b = 0; b < nBlocks; b++) total += blockHist[b * 64 + key];
+    int incl = total;
     for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if ((int)threadIdx.x >= off) inc += o;
+        const int o = __shfl_up(incl, off);
+        if (key >= off) incl += o;
     }
-    bins[64 + threadIdx.x] = inc - h;
+    int run = incl - total;  // entries with smaller keys
+    for (int b = 0; b < nBlocks; b++) {
+        const int c = blockHist[b * 64 + key];
+        blockHist[b * 64 + key] = run;
+        run += c;
+    }
 }
-__global__ void __launch_bounds__(256) k_sort_scatter(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins) {
-    const int n = *count;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SORT_GRID * 256) {
+__global__ void __launch_bounds__(256) k_sort_scatter(const unsigned char *nextKind, const int *in, int *out, const int *count, const int *blockHist) {
+    __shared__ int cursor[64];
+    const int n = *count, base = blockIdx.x * SORT_CHUNK;
+    if (base >= n) return;
+    if (threadIdx.x < 64) cursor[threadIdx.x] = blockHist[blockIdx.x * 64 + threadIdx.x];
+    __syncthreads();
+    for (int i = base + threadIdx.x; i < min(base + SORT_CHUNK, n); i += 256) {
         const int chain = in[i];
-        out[atomicAdd(&bins[64 + (nextKind[chain] >> 2)], 1)] = chain;
+        out[atomicAdd(&cursor[nextKind[chain] >> 2], 1)] = chain;
     }
 }
-void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *bins, hipStream_t s) {
-    (void)hipMemsetAsync(bins, 0, 128 * sizeof(int), s);
-    hipLaunchKernelGGL(k_sort_hist, dim3(SORT_GRID), dim3(256), 0, s, nextKind, in, count, bins);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(64), 0, s, bins);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(SORT_GRID), dim3(256), 0, s, nextKind, in, out, count, bins);
+// blockHist: 64 ints per SORT_CHUNK entries of the longest possible list (maxEntries)
+void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *blockHist, int maxEntries, hipStream_t s) {
+    const int nBlocks = (maxEntries + SORT_CHUNK - 1) / SORT_CHUNK;
+    hipLaunchKernelGGL(k_sort_hist, dim3(nBlocks), dim3(256), 0, s, nextKind, in, count, blockHist);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(64), 0, s, count, blockHist);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(nBlocks), dim3(256), 0, s, nextKind, in, out, count, blockHist);
 }
 void LaunchBuildLists(const ChainArrays &A, const NextLists &next, int sortPlain, unsigned leanDims, hipStream_t s) {
     // sortPlain: 0 = id order; 1 = technique sort inside 1024-chain tiles; 2 = inside 256-chain tiles (one tile = one 256-thread

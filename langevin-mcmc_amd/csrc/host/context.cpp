@@ -101,7 +101,7 @@ struct lmc_ctx {
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
     bool sortH2mc = true;
-    bool sortGeneric = false;  // LMC_SORT_GENERIC=1: technique sort of the gradient launch (A/B: its scatter costs more than the grouping saves, profiles/r02_final_kernel_stats.csv)
+    bool sortGeneric = true;   // LMC_SORT_GENERIC=0: A/B switch for the technique sort of the cache-filling launch
     DevBuf<int> listScratch, sortBins;
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
     hipStream_t stream = nullptr;
@@ -626,7 +626,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
         for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
         c->listCounts[b].Alloc(4);
     }
-    c->listScratch.Alloc(N, false), c->sortBins.Alloc(128);
+    c->listScratch.Alloc(N, false), c->sortBins.Alloc(((size_t)N / 2048 + 2) * 64);
     c->parity = 0;
     if (c->seedChains) {  // chains start valid: the first step's kind is drawn like any other (mlt.cpp:96-97)
         StepParams P;
@@ -769,7 +769,7 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
         // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
         // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
         if (c->needGeneric && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
-            LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, s);
+            LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
             std::swap(c->lists[nxt][1].p, c->listScratch.p);
         }
         c->parity = nxt;
