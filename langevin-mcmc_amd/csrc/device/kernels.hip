@@ -440,6 +440,9 @@ __global__ void k_first_kind(DScene S, const DCache *cache, ChainArrays A, StepP
 //     kernel retraces ONE technique -- same ray count, same terminal strategy -- instead of the 5 different ones a wave of
 //     64 consecutive chains holds on average (profiles/r02_*).  A wave's chains still come from one 1024-chain tile: its
 //     state accesses stay within a few cache lines per word.
+// bin of a plain entry inside its tile: the full technique key (sortPlain 1, 2) or just "path length >= 5" (sortPlain 3: two
+// classes, so that a wave's lanes stay almost as dense in chain order as unsorted ones)
+__device__ inline int PlainSortBin(unsigned char nk, int sortPlain) { return sortPlain == 3 ? ((nk >> 2) / 6 >= 2 ? 1 : 0) : (nk >> 2); }
 template <int CPT>  // chains per thread: the tile is 256 * CPT consecutive chains
 __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists next, int sortPlain, unsigned leanDims) {
     __shared__ unsigned long long sWave[4];
@@ -461,12 +464,18 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
     // technique key gives the dimension: 2 * path length
     for (int j = 0; j < CPT; j++)
         if ((k[j] & 3) == NEXT_SMALL_GENERIC && ((leanDims >> (2 * (3 + (k[j] >> 2) / 6))) & 1u)) k[j] = (unsigned char)(k[j] | NEXT_SMALL_PLAIN);
-    // three 21-bit counters packed into one word: [large | generic << 21 | plain << 42]
+    // four 16-bit counters packed into one word: [large | generic | plain A | plain B]; B = the "long path" class of sortPlain 3
+    // (a STABLE two-way partition: inside a class the entries keep their chain order, so a wave's lanes stay dense)
+    auto fieldOf = [&](unsigned char nk) {
+        const int kind = nk & 3;
+        return kind == NEXT_SMALL_PLAIN ? (sortPlain == 3 && PlainSortBin(nk, 3) ? 3 : 2) : kind - 1;
+    };
+    const bool histSort = sortPlain == 1 || sortPlain == 2;
     unsigned long long mine = 0;
     for (int j = 0; j < CPT; j++) {
         const int kind = k[j] & 3;
-        if (kind) mine += 1ull << (21 * (kind - 1));
-        if (kind == NEXT_SMALL_PLAIN && sortPlain) atomicAdd(&sHist[k[j] >> 2], 1);
+        if (kind) mine += 1ull << (16 * fieldOf(k[j]));
+        if (kind == NEXT_SMALL_PLAIN && histSort) atomicAdd(&sHist[PlainSortBin(k[j], sortPlain)], 1);
     }
     unsigned long long incl = mine;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -481,8 +490,9 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
         if (w < wave) before += sWave[w];
         total += sWave[w];
     }
+    const int totalA = (int)((total >> 32) & 0xffff), totalB = (int)((total >> 48) & 0xffff);
     if (threadIdx.x < 3) {
-        const int n = (int)((total >> (21 * threadIdx.x)) & 0x1fffff);
+        const int n = threadIdx.x < 2 ? (int)((total >> (16 * threadIdx.x)) & 0xffff) : totalA + totalB;
         sBase[threadIdx.x] = n ? atomicAdd(&next.counts[threadIdx.x], n) : 0;
     }
     if (wave == 1) {  // exclusive prefix of the key histogram; the bins then serve as cursors
@@ -495,14 +505,17 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
     }
     __syncthreads();
     const unsigned long long excl = before + incl - mine;
-    int pos[3] = {sBase[0] + (int)(excl & 0x1fffff), sBase[1] + (int)((excl >> 21) & 0x1fffff), sBase[2] + (int)((excl >> 42) & 0x1fffff)};
-    int *lists[3] = {next.large, next.smallGrad, next.smallPlain};
+    int pos[4] = {sBase[0] + (int)(excl & 0xffff), sBase[1] + (int)((excl >> 16) & 0xffff), sBase[2] + (int)((excl >> 32) & 0xffff),
+                  sBase[2] + totalA + (int)((excl >> 48) & 0xffff)};
+    int *lists[4] = {next.large, next.smallGrad, next.smallPlain, next.smallPlain};
     for (int j = 0; j < CPT; j++) {
         const int kind = k[j] & 3;
         if (!kind) continue;
-        if (kind == NEXT_SMALL_PLAIN && sortPlain) next.smallPlain[sBase[2] + atomicAdd(&sStart[k[j] >> 2], 1)] = first + j;
-        else
-            lists[kind - 1][pos[kind - 1]++] = first + j;
+        if (kind == NEXT_SMALL_PLAIN && histSort) next.smallPlain[sBase[2] + atomicAdd(&sStart[PlainSortBin(k[j], sortPlain)], 1)] = first + j;
+        else {
+            const int f = fieldOf(k[j]);
+            lists[f][pos[f]++] = first + j;
+        }
     }
 }
 
