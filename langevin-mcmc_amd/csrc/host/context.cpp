@@ -97,7 +97,7 @@ struct lmc_ctx {
     bool useOccFilter = true;  // LMC_OCC_FILTER=0: A/B switch for the existence test in front of the cache query
     int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
     bool largeLdsStack = true;  // LMC_LARGE_LDS=0: A/B switch for the LDS traversal stack of the large-step launch
-    int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256)
+    int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256); 128 disturbs the lean launch less (its bracket 2.4 instead of 2.7 ms) but the step and the start-up end 1-2 % later (profiles/r02_j_ab_block_sizes.jsonl)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
     bool sortH2mc = true;
