@@ -149,7 +149,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LMC_BENCH_FORCE_DIST"):  # the env switch runs the multi-rank code path with one rank (launch under torch.distributed.run)
         import torch
         import torch.distributed as dist_
 
