@@ -62,3 +62,20 @@ def test_dpt_amd_refuses_what_it_does_not_serve(tmp_path):
     p.write_text(xml)
     r = subprocess.run([CLI, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode != 0 and "LMC path only" in r.stdout
+
+
+def test_bench_multi_rank_code_path_with_one_rank():
+    """bench.py's N > 1 branch (torch.distributed bootstrap of the 128-byte id, the library's own RCCL communicator, in-place film
+    all-reduce, max-over-ranks timing) launched the way the driver launches it, with one rank: the 8-GPU run is the driver's, this
+    keeps the code path from rotting."""
+    import json, subprocess, sys
+
+    env = dict(os.environ, LMC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(gc.ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--chains", "65536", "--no-cpu-baseline", "--no-rmse"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=gc.ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 1e6
+    assert d["roofline"]["avg_launch_ms"] > 0
