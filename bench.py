@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time bound of the CPU baseline sample")
     ap.add_argument("--no-rmse", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json workloads (the `configs` array of the JSON line)")
     ap.add_argument("--rmse-seconds", type=float, default=2.0, help="GPU wall time of the equal-time RMSE leg")
     ap.add_argument("--rmse-gt-spp", type=int, default=8192)
     return ap.parse_args()
@@ -119,6 +120,75 @@ def equal_time_rmse(args, p, gc, gpu_rate, cpu_rate, cores):
     }
 
 
+def algorithmic_bytes(L, h2mc=False):
+    """SURVEY.md §8(d)'s per-chain-step figure for maximum path length L (dim = 2L): read + write of {RNG 264 B; path record
+    52 (L + 1) + 64 B; SubpathContrib 44 B; proposal Gaussian; adaptive vectors; one pending splat 20 B} + 48 B of splat traffic.
+    Gaussian: diagonal (3 dim + 1) floats, plus v1, v2, g, M = 4 dim floats (LMC); dense mean + covL + invCov + logDet =
+    (dim + 2 dim^2 + 1) floats and no adaptive vectors (H2MC).  L = 6 gives the headline's 2240 B."""
+    dim = 2 * L
+    path = 52 * (L + 1) + 64
+    gauss = (dim + 2 * dim * dim + 1) * 4 if h2mc else (3 * dim + 1) * 4 + 4 * dim * 4
+    return 2 * (264 + path + 44 + gauss + 20) + 48
+
+
+def other_configs(args, p, gc):
+    """The other BASELINE.json workloads, driver-observed: each runs after the headline's timed region on its
+    own chain population (fresh Renderer), `warm` untimed steps to get past the start-up (cache fill), then `steps` timed steps
+    bracketed by stream syncs.  `frac` = that workload's algorithmic bytes (algorithmic_bytes(L) with its own L) x the chain-steps
+    its dominant kernel ran per launch / that kernel's HIP-event bracket / 8 TB/s."""
+    door = os.path.join(ROOT, "scenes", "veachdoor")
+    cfgs = [
+        dict(name="torus, full BSDF set (Phong, rough dielectric, bitmap texture), max path length 12, LMC (BASELINE.json configs[2])",
+             xml=gc.TORUS, kw=dict(force_diffuse=0, max_depth=12), chains=args.chains, L=12, h2mc=False, warm=40, steps=40),
+        dict(name="veach-door, shipped lmc.xml (area light, textures, max path length 8), LMC (BASELINE.json configs[3], one GPU's shard)",
+             xml=os.path.join(door, "lmc.xml"), kw={}, chains=args.chains, L=8, h2mc=False, warm=40, steps=40),
+        dict(name="veach-door, shipped h2mc.xml, H2MC (BASELINE.json configs[4], one GPU's shard)",
+             xml=os.path.join(door, "h2mc.xml"), kw={}, chains=min(args.chains, 1 << 18), L=8, h2mc=True, warm=6, steps=12),
+    ]
+    out = []
+    for c in cfgs:
+        try:
+            ren = p.Renderer(c["xml"], seed_offset=0, use_gradient=1, **c["kw"])
+            t0 = time.time()
+            ren.init_chains(8 * c["chains"], c["chains"], args.init_threads, args.samples_per_chain, 0)
+            t_init = time.time() - t0
+            ren.set_option("timing", 1)
+            ren.step(c["warm"])
+            ren.step_timing()
+            k0 = ren.kernel_timing_split()
+            s0 = ren.stats()
+            ren.sync()
+            t0 = time.time()
+            ren.step(c["steps"])
+            ren.sync()
+            dt = time.time() - t0
+            _, launches = ren.step_timing()
+            k1 = ren.kernel_timing_split()
+            s1 = ren.stats()
+            ren.close()
+            steps_total = s1["steps"] - s0["steps"]
+            large_steps = s1["largeSteps"] - s0["largeSteps"]
+            lean_steps = k1["lean_steps"] - k0["lean_steps"]
+            ker = {"k_step_small (plain small steps)": (k1["lean_ms"], lean_steps), "k_step<large>": (k1["large_ms"], large_steps),
+                   ("k_step_h2mc (all small steps)" if c["h2mc"] else "k_step_small_grad (cache-filling small steps)"): (k1["generic_ms"], steps_total - large_steps - lean_steps)}
+            dom = max(ker, key=lambda k: ker[k][0])
+            ab = algorithmic_bytes(c["L"], c["h2mc"])
+            dom_ms, dom_steps = ker[dom][0] / max(launches, 1), ker[dom][1] / max(launches, 1)
+            ach = ab * dom_steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            out.append({
+                "workload": c["name"], "chains": c["chains"], "value": steps_total / dt, "unit": "chain-steps/s", "ms_per_step": dt * 1e3 / c["steps"],
+                "steps": c["steps"], "warmup": c["warm"], "init_seconds": t_init,
+                "kernel_ms_per_step": {k: v[0] / max(launches, 1) for k, v in ker.items()},
+                "roofline": {"bound": "hbm", "kernel": dom, "avg_launch_ms": dom_ms, "chain_steps_per_launch": dom_steps, "algorithmic_bytes_per_step": ab,
+                             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "concurrent_launches": "the three step launches share the GPU inside each bracket"},
+                "accept_rate": (s1["accepted"] - s0["accepted"]) / max(steps_total, 1), "large_step_frac": large_steps / max(steps_total, 1),
+            })
+        except Exception as e:  # noqa: BLE001 -- the headline line must still come out
+            out.append({"workload": c["name"], "failed": str(e)[:300]})
+    return out
+
+
 def kernel_source_sha():
     """Fingerprint of the sources the dominant kernel is compiled from (device headers + its translation unit)."""
     import glob, hashlib
@@ -141,6 +211,20 @@ def pmc_traffic():
         except Exception:
             return None
     return None
+
+
+def pmc_traffic_meta():
+    """what the committed counter figure was measured on: chain-steps per launch of that run (the wasted-traffic ratio is
+    traffic / (algorithmic bytes x THESE steps), not x the steps of the window timed here) and the profile it comes from"""
+    pth = os.path.join(ROOT, "profiles", "pmc_step_kernel.json")
+    try:
+        d = json.load(open(pth))
+        if d.get("kernel_source_sha16") != kernel_source_sha():
+            return None
+        spl = d.get("chain_steps_per_launch")
+        return {"chain_steps_per_launch": spl, "traffic_over_algorithmic": (d["hbm_bytes_per_launch"] / (ALGO_BYTES_PER_STEP * spl)) if spl else None, "source": d.get("source")}
+    except Exception:
+        return None
 
 
 def main():
@@ -279,6 +363,7 @@ def main():
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "chain_steps_per_launch": lean_steps_per_launch,
                 "algorithmic_bytes_per_step": ALGO_BYTES_PER_STEP,
+                "traffic_measured_at": pmc_traffic_meta(),
                 "concurrent_launches": "k_step<large> runs beside this kernel on a second stream inside the bracket",
             },
             "step_ms": {"all_launches": kernel_ms / max(launches, 1), "k_step_small": small_ms / max(launches, 1),
@@ -292,6 +377,9 @@ def main():
             sa_ach = ALGO_BYTES_PER_STEP * standalone[1] / (standalone[0] * 1e-3) / 1e9
             out["roofline"]["standalone"] = {"avg_launch_ms": standalone[0], "chain_steps_per_launch": standalone[1], "achieved": sa_ach,
                                              "frac": sa_ach / HBM_PEAK_GBS, "note": "same kernel, 16 launches after the timed region with the side launches serialised"}
+        if not args.no_configs and world == 1:
+            ren.close()
+            out["configs"] = other_configs(args, p, gc)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

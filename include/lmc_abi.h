@@ -52,9 +52,8 @@ int lmc_info(lmc_ctx *ctx, int *out8);
 /* the 38-float scene block of the plugin ABI (scene.cpp:160-169) */
 int lmc_scene_params(lmc_ctx *ctx, float *out38);
 /* <dpt> float options by XML name: largestepprob, largestepscale, mala, uniformmixprob, mala-stepsize, mala-gn,
- * perturbstddev, mindepth (parsescene.cpp:538-585); plus one key the reference does not have: seedchains = 1 starts every
- * chain in the state MLTInit resampled for it (the reference discards those, mlt.h:121, and begins with a forced large
- * step): removes the start-up bias of the short chains a GPU runs */
+ * perturbstddev, mindepth, h2mc (parsescene.cpp:538-585).  mala / h2mc select the mutation the chain state is laid out for:
+ * they can only change before lmc_chains_init (afterwards the call fails; re-initialise the chains) */
 int lmc_set_option(lmc_ctx *ctx, const char *name, double value);
 /* <dpt> options as parsed: spp, numinitsamples, numchains, directspp, mindepth, maxdepth, largestepprob, largestepscale,
  * mala, h2mc, seedoffset (dptoptions.h:7-34) */
@@ -107,6 +106,9 @@ int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);
  * (k_step_small, the dominant kernel), out3[1] = ms inside the large-step + generic small-step launches,
  * out3[2] = chain-steps the lean kernel has run since lmc_chains_init (cumulative). */
 int lmc_kernel_timing(lmc_ctx *ctx, double *out3);
+/* the same interval, the three step launches separately: out4 = [lean small-step ms, large-step ms, generic small-step ms
+ * (cache-filling gradient steps; every small step of an H2MC render), cumulative chain-steps of the lean kernel] */
+int lmc_kernel_timing_split(lmc_ctx *ctx, double *out4);
 
 /* ---- multi-GPU (one process per GPU; chains sharded by contiguous global id range through lmc_chains_init).
  * The only data-path collective is the sum of the per-GPU films: rank 0 calls lmc_comm_unique_id and the host program
@@ -140,7 +142,9 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
 int lmc_lower_bound_probe(int n, const float *cdf, int nq, const float *u, int *out);
 /* measurement aid: ms per launch of a kernel that streams `words` state words per chain in batches of `batch` loads; mode 0 = [word][chain], 1 = [tile of 64][word][lane] */
 int lmc_layout_probe(int nChains, int words, int mode, int batch, int reps, double *msPerLaunch);
-/* measurement hook (LMC_PROF=1): wave cycles per region of the lean small-step kernel since the last call, out16[12] = waves */
+/* measurement hook (LMC_PROF=1): wave cycles per region of the lean small-step kernel since the last call: out16[0 .. LMC_PROF_REGIONS-1]
+ * = cycle sums of the regions (dsmall.h PR_*), out16[LMC_PROF_REGIONS] = number of waves */
+#define LMC_PROF_REGIONS 15
 int lmc_prof_read(lmc_ctx *ctx, unsigned long long *out16);
 /* test hook: compares the device-built existence-test grid of one cache dim with the host build; number of differing cells (0 = same), -2 = that cache is not ready */
 int lmc_cache_grid_check(lmc_ctx *ctx, int dim);

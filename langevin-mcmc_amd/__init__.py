@@ -58,6 +58,7 @@ def lib():
         L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.lmc_step_timing.argtypes = [vp, vp, vp]
         L.lmc_kernel_timing.argtypes = [vp, vp]
+        L.lmc_kernel_timing_split.argtypes = [vp, vp]
         L.lmc_get_option.argtypes = [vp, ctypes.c_char_p, vp]
         L.lmc_output_name.argtypes = [vp]
         L.lmc_output_name.restype = ctypes.c_char_p
@@ -218,6 +219,15 @@ class Renderer:
         if lib().lmc_kernel_timing(self.h, out) != 0:
             raise RuntimeError(_err())
         return out[0], out[1], int(out[2])
+
+    def kernel_timing_split(self):
+        """the three step launches separately over the interval of the last step_timing() call: ms in the lean small-step kernel,
+        in the large-step launch and in the generic small-step launch (cache-filling gradient steps / every H2MC small step), plus
+        the cumulative number of chain-steps the lean kernel has run"""
+        out = (ctypes.c_double * 4)()
+        if lib().lmc_kernel_timing_split(self.h, out) != 0:
+            raise RuntimeError(_err())
+        return {"lean_ms": out[0], "large_ms": out[1], "generic_ms": out[2], "lean_steps": int(out[3])}
 
     def trace(self, rays):
         rays = np.ascontiguousarray(rays, np.float32)

@@ -93,7 +93,7 @@ struct MatRef {
 };
 
 // Dense Gaussian of one state: mean[n], covL, invCov (n x n), logDet.
-// `hess` is the n x n matrix as the derivative program delivers it (row i at hess[i*n]); it is symmetrised IN PLACE and destroyed
+// `hess` is the n x n matrix as the derivative program delivers it (row i at hess[i*n]); its upper triangle is mirrored IN PLACE and it is destroyed
 // by the eigen-solve; `work` needs n*n + 4*n floats.
 LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL, MatRef invCov,
                                 float &logDet, float *work) {
@@ -111,8 +111,10 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
         return;
     }
     float *A = hess, *V = work, *w = work + n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
+    // Eigen maps the row-major program output as a COLUMN-major matrix (h2mc.cpp:78) and SelfAdjointEigenSolver reads its lower
+    // triangle only: entry (r, c), r >= c, of that view is hess[c * n + r], i.e. the UPPER triangle of the rows as delivered.
     for (int i = 0; i < n; i++)
-        for (int j = i; j < n; j++) A[i * n + j] = A[j * n + i] = 0.5f * (hess[i * n + j] + hess[j * n + i]);  // Eigen reads one triangle; symmetrise
+        for (int j = i + 1; j < n; j++) A[j * n + i] = hess[i * n + j];
     JacobiEigenSym(n, A, V, w);
     for (int i = 0; i < n; i++) eigenBuff[i] = fabsf(w[i]) > 1e-10f ? 1.0f / fabsf(w[i]) : 0.0f;
     for (int i = 0; i < n; i++) {  // offsetBuff = diag(eigenBuff) (V^T grad)

@@ -147,6 +147,18 @@ LMC_D bool SlabTest(const float *bmin, const float *bmax, V3 org, V3 invd, float
     return t0 * 0.9999996f <= t1 * 1.0000004f;  // 2*gamma(3) widening, as in the oracle
 }
 
+// The host numbers the top of the four-wide tree breadth first (accel.cpp TopLevelsFirst): nodes [0, BVH_TOP_NODES) are the root,
+// its children and grandchildren ... (1 + 4 + 16 + 64 = 85 when every node is full).
+constexpr int BVH_TOP_NODES = 85;
+// LMC_BVH_LDS_TOP = K > 0 (build experiment, profiles/r03_*_ab_bvh_lds_top.jsonl): the lean kernel stages nodes [0, K) in LDS at
+// launch and the traversal reads them from there.  Node stride in LDS: 9 x 16 B (144 B) instead of 128 B, so that lanes reading
+// the same word of different nodes fall on different banks (128 B = one full turn of the 32 banks: every node would start on bank 0).
+#ifndef LMC_BVH_LDS_TOP
+#define LMC_BVH_LDS_TOP 0
+#endif
+static_assert(LMC_BVH_LDS_TOP <= BVH_TOP_NODES, "the host only guarantees breadth-first numbering for BVH_TOP_NODES nodes");
+constexpr int BVH_LDS_NODE_QUADS = 9;
+
 constexpr int BVH_STACK = 64;      // host-checked bound on the LBVH depth
 constexpr int BVH_LDS_STACK = 32;  // entries of the per-thread LDS stack (the host refuses deeper trees for LDS kernels)
 
@@ -161,6 +173,8 @@ struct LocalStackT {
     static constexpr bool kGlossy = GLOSSY;
     int s[BVH_STACK];
     int sp = 0;
+    LMC_D const uint4 *Top() const { return nullptr; }
+    LMC_D int TopCount() const { return 0; }
     LMC_D void Reset() { sp = 0; }
     LMC_D bool Empty() const { return sp == 0; }
     LMC_D void Push(int v) {
@@ -174,6 +188,10 @@ struct LdsStackT {
     int *base;   // &lds[threadIdx.x]
     int stride;  // blockDim.x
     int sp;
+    const uint4 *top = nullptr;  // LMC_BVH_LDS_TOP: the staged top of the tree, topCount nodes of BVH_LDS_NODE_QUADS x 16 B
+    int topCount = 0;
+    LMC_D const uint4 *Top() const { return top; }
+    LMC_D int TopCount() const { return topCount; }
     LMC_D void Reset() { sp = 0; }
     LMC_D bool Empty() const { return sp == 0; }
     LMC_D void Push(int v) {
@@ -229,6 +247,29 @@ LMC_D int VisitNode4(const BvhNode4 &nd, V3 org, V3 invd, float tnear, float tfa
     return ck[0];
 }
 
+// one node: from the LDS copy of the top of the tree when the kernel staged one (LMC_BVH_LDS_TOP), from memory otherwise
+template <class Stk>
+LMC_D BvhNode4 FetchNode4(const DScene &S, int cur, const Stk &stk) {
+#if LMC_BVH_LDS_TOP > 0
+    if (cur < stk.TopCount()) {
+        union {
+            BvhNode4 nd;
+            uint4 q[8];
+        } u;
+        const uint4 *p = stk.Top() + cur * BVH_LDS_NODE_QUADS;
+#pragma unroll
+        for (int k = 0; k < 8; k++) u.q[k] = p[k];
+        return u.nd;
+    }
+#endif
+    return S.nodes[cur];
+}
+// cooperative copy of the top of the tree into LDS (all threads of the block; the caller synchronises)
+LMC_D void StageTopNodes(const DScene &S, uint4 *dst, int count) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(S.nodes);
+    for (int k = threadIdx.x; k < count * 8; k += blockDim.x) dst[(k >> 3) * BVH_LDS_NODE_QUADS + (k & 7)] = src[k];
+}
+
 // closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer).
 // "while-while" traversal: all lanes of a wave first descend through inner nodes until each has reached a leaf (or
 // finished), then all test their leaf's triangles together.  With the node test and the leaf test as two branches of
@@ -244,7 +285,7 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     int cur = 0;  // root is an inner node
     for (;;) {
         while (cur >= 0) {
-            const BvhNode4 nd = S.nodes[cur];
+            const BvhNode4 nd = FetchNode4(S, cur, stk);
             cur = VisitNode4<true>(nd, org, invd, tnear, bestT, stk);
             if (cur == BVH4_EMPTY) {
                 if (stk.Empty()) {
@@ -286,7 +327,7 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     int cur = 0;
     for (;;) {
         while (cur >= 0) {
-            const BvhNode4 nd = S.nodes[cur];
+            const BvhNode4 nd = FetchNode4(S, cur, stk);
             cur = VisitNode4<false>(nd, org, invd, tnear, tfar, stk);
             if (cur == BVH4_EMPTY) {
                 if (stk.Empty()) return false;

@@ -309,6 +309,7 @@ LMC_D float ClosedFormLogDet(const DScene &S, const VSource &vs, int dim) {
 // NoProf): the shader clock is read at marks placed at wave-convergent and divergent points of the step; the cycles since the
 // previous mark -- as the WAVE experienced them -- are charged to the region the mark names.  Scalar registers only.
 enum : int { PR_PROLOGUE = 0, PR_GAUSS_CUR, PR_OFFSETS, PR_VERTEX_LOAD, PR_TRAVERSE, PR_SHADE, PR_LOOP_EXIT, PR_SHADOW, PR_GAUSS_PROP, PR_SPLAT, PR_ACCEPT, PR_QUEUE, PR_ISO, PR_RESET, PR_STAGE, PR_COUNT };
+static_assert(PR_COUNT < 16, "lmc_prof_read hands out 16 words: the regions + the wave count (include/lmc_abi.h LMC_PROF_REGIONS)");
 struct NoProf {
     LMC_D void Mark(int) {}
 };

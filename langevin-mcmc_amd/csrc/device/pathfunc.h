@@ -212,6 +212,7 @@ template <class T> LMC_HD V3T<T> NormalizeT(const V3T<T> &a) {
 template <class T> LMC_HD V3T<T> CrossT(const V3T<T> &a, const V3T<T> &b) {
     return V3T<T>{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+template <class T> LMC_HD V3T<T> DetachW3(const V3T<T> &a) { return V3T<T>{DetachW(a.x), DetachW(a.y), DetachW(a.z)}; }
 template <class T> LMC_HD T LumT(const V3T<T> &v) { return v.x * 0.212671f + v.y * 0.715160f + v.z * 0.072169f; }
 
 template <class T> LMC_HD V3T<T> C3(float a, float b, float c) { return V3T<T>{Lift<T>::Of(a), Lift<T>::Of(b), Lift<T>::Of(c)}; }
@@ -326,7 +327,10 @@ LMC_HD void CoordinateSystemT(const V3T<T> &n, V3T<T> &b1, V3T<T> &b2) {  // uti
     }
     T a = 1.0f / (1.0f + n.z);
     T b = -n.x * n.y * a;
-    b1 = V3T<T>{1.0f - n.x * n.x * a, b, -n.x};
+    // `b` leaves the reference's conditional through TWO outputs (b1.y and b2.x, utils.h:268-271); chad's reverse sweep assigns
+    // the adjoint of each output to the expression it passes through (chad.cpp:283-284), so the second assignment replaces the
+    // first: b1.y reaches the derivative programs as a constant.
+    b1 = V3T<T>{1.0f - n.x * n.x * a, DetachW(b), -n.x};
     b2 = V3T<T>{b, 1.0f - n.y * n.y * a, -n.y};
 }
 
@@ -431,7 +435,7 @@ LMC_HD void PhongTermsT(const In &b, int off, const T &alpha, const T &cosWi, co
 
 // EvaluateBSDF, bsdf.cpp:13-63.  Unknown types produce zeros like the generated else-branch.
 template <class T, class In>
-LMC_PF void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
+LMC_PF void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, V3T<T> &normal, const V3T<T> &wo, V3T<T> &contrib, T &cosWo,
                           T &pdf, T &revPdf) {
     const float type = b[off];
     if (type == (float)0 /*Lambertian*/) {  // lambertian.cpp:95-122
@@ -440,6 +444,8 @@ LMC_PF void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, 
         if (!(Val(cosWi) > 0.0f)) {
             n = -normal;
             cosWi = -cosWi;
+        } else {
+            normal = DetachW3(normal);  // passed through the two-sided conditional (lambertian.cpp:109-113): its later uses see a constant
         }
         cosWo = DotT(n, wo);
         T fwdScalar = cosWo * c_INVPI;
@@ -452,6 +458,8 @@ LMC_PF void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, 
         if (!(Val(cosWi) > 0.0f)) {
             n = -normal;
             cosWi = -cosWi;
+        } else {
+            normal = DetachW3(normal);  // phong.cpp:192-196, as in the Lambertian case
         }
         cosWo = DotT(n, wo);
         T alpha = DotT(ReflectT(wi, n), wo);
@@ -501,7 +509,7 @@ LMC_PF void EvaluateBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, 
 }
 // SampleBSDF, bsdf.cpp:65-171 (fixDiscrete = false)
 template <class T, class In>
-LMC_PF void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, const V3T<T> &normal, const T &r0, const T &r1, float uDiscrete,
+LMC_PF void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, V3T<T> &normal, const T &r0, const T &r1, float uDiscrete,
                         V3T<T> &wo, V3T<T> &contrib, T &cosWo, T &pdf, T &revPdf) {
     const float type = b[off];
     if (type == (float)0) {  // lambertian.cpp:124-151
@@ -510,6 +518,8 @@ LMC_PF void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, co
         if (!(Val(cosWi) > 0.0f)) {
             n = -normal;
             cosWi = -cosWi;
+        } else {
+            normal = DetachW3(normal);  // lambertian.cpp:140-144
         }
         V3T<T> b0, b1;
         CoordinateSystemT(n, b0, b1);
@@ -526,6 +536,8 @@ LMC_PF void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, co
         if (!(Val(cosWi) > 0.0f)) {
             n = -normal;
             cosWi = -cosWi;
+        } else {
+            normal = DetachW3(normal);  // phong.cpp:284-288
         }
         V3T<T> R = ReflectT(wi, n);
         V3T<T> b0, b1;
@@ -852,7 +864,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
                     T invCosAtCamera = -(1.0f / DotT(camDir, dirToCamera));
                     T imagePointToCameraDist = sc.camDist * invCosAtCamera;
                     T imageToSolidAngleFactor = imagePointToCameraDist * imagePointToCameraDist * invCosAtCamera;
-                    T imageToSurfaceFactor = imageToSolidAngleFactor * Fabs(cosToCamera) / distSq;
+                    T imageToSurfaceFactor = imageToSolidAngleFactor * FabsW(cosToCamera) / distSq;  // cosToCamera's later use (surfaceToImageFactor) sees a constant
                     T wLight = MISq(imageToSurfaceFactor / sc.pixelCount) * (lps.accMISWPrev + lps.accMISWThis * MISq(bsdfRevPdf));
                     T misWeight = 1.0f / (wLight + 1.0f);
                     T surfaceToImageFactor = cosToCamera / imageToSurfaceFactor;

@@ -8,8 +8,8 @@
 
 namespace lmcd {
 
-// `sh`: 9 words of LDS (8 counters + the weight sum); the lean kernel passes its dynamic LDS so that two of its 80 KB
-// blocks still fit the CU's 160 KB
+// `sh`: 9 words of LDS (8 counters + the weight sum); the lean kernel passes its dynamic LDS (14 KB per 64-thread block) instead of
+// declaring a static array next to it
 __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned long long *counters, double *weightSum, int *sh) {
     int *sInt = sh;
     float &sW = *reinterpret_cast<float *>(sh + 8);

@@ -1,5 +1,5 @@
 // The hot launch: plain small steps (dsmall.h) of the chains on the smallPlain list.  Everything indexed at run time
-// lives in LDS (80 words per thread), the path is streamed through registers: no scratch memory.
+// lives in LDS (dsmall.h LDS_WORDS_PER_THREAD = 56 words per thread), the path is streamed through registers: no scratch memory.
 // USE_LDS_STACK = false is the fallback for scenes whose LBVH is deeper than the 32-entry LDS traversal stack.
 #include <cstdlib>
 #include <type_traits>
@@ -22,6 +22,14 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
     const LdsView L{lds + threadIdx.x, (int)blockDim.x};
     typename std::conditional<PROF, WaveProf, NoProf>::type prof;
     if constexpr (PROF) prof.Start();
+#if LMC_BVH_LDS_TOP > 0
+    uint4 *topLds = reinterpret_cast<uint4 *>(lds + blockDim.x * LDS_WORDS_PER_THREAD);  // behind the per-thread words (16 B aligned: 64 x 56 x 4)
+    const int topCount = min(S.numNodes, LMC_BVH_LDS_TOP);
+    if (USE_LDS_STACK) {
+        StageTopNodes(S, topLds, topCount);
+        __syncthreads();
+    }
+#endif
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
         Rng rng;
@@ -30,6 +38,9 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
         rng.ticks = 0;
         if (USE_LDS_STACK) {
             LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
+#if LMC_BVH_LDS_TOP > 0
+            stk.top = topLds, stk.topCount = topCount;
+#endif
             SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         } else {
             LocalStackT<GLOSSY> stk;
@@ -50,7 +61,7 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
                           const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, bool profile, hipStream_t s) {
-    size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float);
+    size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float) + (size_t)LMC_BVH_LDS_TOP * BVH_LDS_NODE_QUADS * 16;
     if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code
     const bool lds = bvhDepth <= BVH_LDS_STACK;
 #define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next)

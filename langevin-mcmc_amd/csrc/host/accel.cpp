@@ -295,12 +295,43 @@ int Collapse(const LbvhResult &bvh, int node, Bvh4Result &out, int depth, int pe
 }
 }  // namespace
 
+// The first `topCount` nodes in breadth-first order (root, its children, their children ...), the rest in their depth-first
+// order: the top of the tree is one contiguous block that a kernel can stage in LDS (dscene.h LMC_BVH_LDS_TOP) -- and that stays
+// in a handful of L1 lines when it does not.  Only node numbers change; the children keep their order inside every node, so the
+// traversal visits the same nodes in the same order.
+static void TopLevelsFirst(Bvh4Result &t, int topCount) {
+    const int n = (int)t.nodes.size();
+    if (n <= 2) return;
+    std::vector<int> order;
+    order.reserve(n);
+    std::vector<char> taken(n, 0);
+    order.push_back(0), taken[0] = 1;
+    for (size_t head = 0; head < order.size() && (int)order.size() < topCount; head++)
+        for (int k = 0; k < 4; k++) {
+            const int c = t.nodes[order[head]].child[k];
+            if (c >= 0 && c != lmcd::BVH4_EMPTY && !taken[c] && (int)order.size() < topCount) order.push_back(c), taken[c] = 1;
+        }
+    for (int i = 0; i < n; i++)
+        if (!taken[i]) order.push_back(i);
+    std::vector<int> newIndex(n);
+    for (int i = 0; i < n; i++) newIndex[order[i]] = i;
+    std::vector<lmcd::BvhNode4> nodes(n);
+    for (int i = 0; i < n; i++) {
+        lmcd::BvhNode4 nd = t.nodes[order[i]];
+        for (int k = 0; k < 4; k++)
+            if (nd.child[k] >= 0 && nd.child[k] != lmcd::BVH4_EMPTY) nd.child[k] = newIndex[nd.child[k]];
+        nodes[i] = nd;
+    }
+    t.nodes.swap(nodes);
+}
+
 Bvh4Result CollapseToBvh4(const LbvhResult &bvh) {
     Bvh4Result out;
     out.leafTris = bvh.leafTris;
     if (bvh.nodes.empty()) return out;
     Collapse(bvh, 0, out, 1, 0);
     if (out.stackNeed > lmcd::BVH_STACK) throw std::runtime_error("BVH needs a deeper traversal stack than BVH_STACK");
+    TopLevelsFirst(out, lmcd::BVH_TOP_NODES);
     return out;
 }
 

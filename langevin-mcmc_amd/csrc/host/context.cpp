@@ -125,6 +125,7 @@ struct lmc_ctx {
     int bvhDepth = 0;
     // film
     DevBuf<float> film, directFilm;
+    bool filmReduced = false;  // the device film + weightSum already hold the all-reduced sums (lmc_film_allreduce is in place)
     void *comm = nullptr;  // ncclComm_t of lmc_comm_init (multi-GPU: one process per GPU, chains sharded by id range)
     // chains
     int N = 0, numChainsTotal = 0, chainBegin = 0;
@@ -155,7 +156,7 @@ struct lmc_ctx {
     CachePushTargets pushT;
     int *hostCounts = nullptr;               // pinned mirror of cacheCounts
     bool allCachesReady = false;
-    bool seedChains = false;  // lmc_set_option("seedchains", 1): start chains in their resampled init state (not in the reference)
+    int mutationAtInit = -1;  // (mala, h2mc) the resident chain state was laid out for by lmc_chains_init; lmc_chains_step refuses any other
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
     // init results
     float normalization = 0.f;
@@ -171,7 +172,7 @@ struct lmc_ctx {
     // from a pool that is reused: a render that never asks for timings (dpt_amd) creates none.
     bool timing = false;
     std::vector<StepEvents> events, eventPool;
-    double smallMs = 0, largeMs = 0;  // accumulated by lmc_step_timing for lmc_kernel_timing
+    double smallMs = 0, largeMs = 0, largeOnlyMs = 0, genericMs = 0;  // accumulated by lmc_step_timing for lmc_kernel_timing / lmc_kernel_timing_split
     ~lmc_ctx() {
         for (auto *v : {&events, &eventPool})
             for (auto &ev : *v)
@@ -419,7 +420,6 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "mala-gn") o.malaGN = (float)v;
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
-    else if (n == "seedchains") c->seedChains = v != 0;
     else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else throw std::runtime_error("Unknown dpt option:" + n);
@@ -544,6 +544,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     c->numChainsTotal = numChainsTotal;
     c->chainBegin = chainBegin;
     c->N = chainEnd - chainBegin;
+    c->mutationAtInit = (c->scene->options.mala ? 1 : 0) | (c->scene->options.h2mc ? 2 : 0);
     const size_t NT = numChainsTotal, N = c->N;
     c->initPath.Alloc(NT * DPATH_WORDS), c->initContrib.Alloc(NT * CONTRIB_WORDS), c->initScoreSum.Alloc(NT);
     {
@@ -578,7 +579,7 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p, A.prof = c->prof.p;
     LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
-    LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, c->seedChains ? 1 : 0, c->normalization, s);
+    LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, 0, c->normalization, s);
     // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
     c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
     c->gradStride = c->stepGrid * 256;
@@ -628,14 +629,8 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     }
     c->listScratch.Alloc(N, false), c->sortBins.Alloc(((size_t)N / 2048 + 2) * 64);
     c->parity = 0;
-    if (c->seedChains) {  // chains start valid: the first step's kind is drawn like any other (mlt.cpp:96-97)
-        StepParams P;
-        P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
-        LaunchFirstKind(c->S, c->cacheDev.p, c->A, P, s);
-        NextLists first{c->lists[0][0].p, c->lists[0][1].p, c->lists[0][2].p, c->listCounts[0].p};
-        LaunchBuildLists(c->A, first, c->sortPlain, 0u, s);
-    } else
-        LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
+    // every chain begins with a forced large step (mlt.h:121: the resampled init states only feed the outlier reset)
+    LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
     HIP_CHECK(hipStreamSynchronize(s));
     return 0;
@@ -713,7 +708,11 @@ int lmc_chains_step(lmc_ctx *c, int nSteps) {
     LMC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (c->N <= 0) throw std::runtime_error("lmc_chains_step before lmc_chains_init");
+    // the chain state (H2MC Gaussian buffers, cache bookkeeping, work lists) is laid out for the mutation in force at init
+    if (c->mutationAtInit != ((c->scene->options.mala ? 1 : 0) | (c->scene->options.h2mc ? 2 : 0)))
+        throw std::runtime_error("the 'mala' / 'h2mc' options changed after lmc_chains_init: initialise the chains again before stepping");
     hipStream_t s = c->stream;
+    c->filmReduced = false;
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
     StepParams P;
     P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
@@ -795,7 +794,7 @@ int lmc_step_timing(lmc_ctx *c, double *kernelMs, long long *launches) {
     LMC_TRY
     HIP_CHECK(hipStreamSynchronize(c->stream));
     double ms = 0;
-    c->smallMs = c->largeMs = 0;
+    c->smallMs = c->largeMs = c->largeOnlyMs = c->genericMs = 0;
     for (auto &ev : c->events) {
         float t = 0;
         HIP_CHECK(hipEventElapsedTime(&t, ev.e[0], ev.e[3]));
@@ -803,9 +802,9 @@ int lmc_step_timing(lmc_ctx *c, double *kernelMs, long long *launches) {
         HIP_CHECK(hipEventElapsedTime(&t, ev.e[1], ev.e[2]));
         c->smallMs += t;
         HIP_CHECK(hipEventElapsedTime(&t, ev.e[4], ev.e[5]));
-        c->largeMs += t;
+        c->largeMs += t, c->largeOnlyMs += t;
         HIP_CHECK(hipEventElapsedTime(&t, ev.e[6], ev.e[7]));
-        c->largeMs += t;
+        c->largeMs += t, c->genericMs += t;
         c->eventPool.push_back(ev);
     }
     if (kernelMs) *kernelMs = ms;
@@ -820,6 +819,17 @@ int lmc_kernel_timing(lmc_ctx *c, double *out3) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     out3[0] = c->smallMs, out3[1] = c->largeMs;
     out3[2] = (double)c->counters.Download()[7];
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// the three step launches separately: [lean small-step ms, large-step ms, generic small-step ms (cache-filling gradient steps / all H2MC
+// small steps), cumulative chain-steps of the lean kernel]
+int lmc_kernel_timing_split(lmc_ctx *c, double *out4) {
+    LMC_TRY
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    out4[0] = c->smallMs, out4[1] = c->largeOnlyMs, out4[2] = c->genericMs;
+    out4[3] = (double)c->counters.Download()[7];
     return 0;
     LMC_CATCH(-1)
 }
@@ -914,6 +924,7 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, const void * /* ncclUniqueId by value: 128 bytes, passed in memory */, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;  // (send, recv, sendcount, type, comm, stream)
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -922,17 +933,24 @@ struct UniqueId {
 };
 Rccl &GetRccl() {
     static Rccl r;
-    if (r.h) return r;
+    static bool ready = false;  // set only after EVERY required symbol has resolved: a failed first call must not leave a half-filled table behind
+    if (ready) return r;
+    void *h = nullptr;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (r.h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
     }
-    if (!r.h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
-    r.GetUniqueId = (int (*)(void *))dlsym(r.h, "ncclGetUniqueId");
-    r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.h, "ncclAllReduce");
-    r.CommDestroy = (int (*)(void *))dlsym(r.h, "ncclCommDestroy");
-    r.GetErrorString = (const char *(*)(int))dlsym(r.h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !dlsym(r.h, "ncclCommInitRank") || !r.AllReduce) throw std::runtime_error("RCCL symbols missing");
+    if (!h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
+    Rccl t;
+    t.h = h;
+    t.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    t.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    t.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    t.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    t.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!t.GetUniqueId || !dlsym(h, "ncclCommInitRank") || !t.AllReduce || !t.AllGather || !t.CommDestroy) throw std::runtime_error("RCCL symbols missing");
+    r = t;
+    ready = true;
     return r;
 }
 // ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank): the id struct travels by value
@@ -974,6 +992,8 @@ int lmc_film_allreduce(lmc_ctx *c) {
     LMC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->comm) throw std::runtime_error("lmc_film_allreduce before lmc_comm_init");
+    if (c->filmReduced) throw std::runtime_error("lmc_film_allreduce: the film already holds the sum over ranks (a second in-place sum would count every rank's splats again); step or clear the film first");
+    c->filmReduced = true;
     // in place on the device film, on the stream the step kernels run on: ordered after the last splat, no host staging
     RcclCheck(GetRccl().AllReduce(c->film.p, c->film.p, c->film.n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->stream), "ncclAllReduce(film)");
     // the scalars that normalise the merged image: sum of splat weights (double) -- `normalization` itself is identical on
@@ -991,6 +1011,7 @@ void *lmc_film_device_ptr(lmc_ctx *c, long long *nFloats) {
 int lmc_film_clear(lmc_ctx *c) {
     LMC_TRY
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), c->stream));
+    c->filmReduced = false;
     return 0;
     LMC_CATCH(-1)
 }

@@ -153,6 +153,7 @@ struct Decoder {
     void BaselineBlock(Component &c, int16_t *blk) {
         const Huff &dc = dcTab[c.td], &ac = acTab[c.ta];
         int t = DecodeSym(dc);
+        if (t > 11) Fail("bad DC category");  // 8-bit samples: at most 11 magnitude bits (shifts below stay defined)
         int diff = t ? Extend(GetBits(t), t) : 0;
         c.dcPred += diff;
         blk[0] = (int16_t)c.dcPred;
@@ -167,12 +168,14 @@ struct Decoder {
             }
             k += r;
             if (k > 63) Fail("bad AC run");
+            if (s > 10) Fail("bad AC size");
             blk[kZigzag[k]] = (int16_t)Extend(GetBits(s), s);
             k++;
         }
     }
     void DcFirst(Component &c, int16_t *blk, int Al) {
         int t = DecodeSym(dcTab[c.td]);
+        if (t > 11) Fail("bad DC category");
         int diff = t ? Extend(GetBits(t), t) : 0;
         c.dcPred += diff;
         blk[0] = (int16_t)(c.dcPred * (1 << Al));
@@ -198,7 +201,8 @@ struct Decoder {
                 continue;
             }
             k += r;
-            if (k > 63) Fail("bad AC run");
+            if (k > Se) Fail("bad AC run");
+            if (s > 10) Fail("bad AC size");
             blk[kZigzag[k]] = (int16_t)(Extend(GetBits(s), s) * (1 << Al));
             k++;
         }
@@ -264,6 +268,14 @@ struct Decoder {
         }
         int Ss = U8(), Se = U8(), AhAl = U8(), Ah = AhAl >> 4, Al = AhAl & 15;
         if (!progressive) Ss = 0, Se = 63, Ah = Al = 0;
+        // the spectral band indexes the 64-entry zig-zag table and the coefficient block; Al is a shift count
+        if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && progressive && Se != 0)) Fail("bad spectral selection / successive approximation");
+        for (int i = 0; i < ns; i++) {  // a scan may only use Huffman tables that a DHT segment has defined (mincode / maxcode / valptr)
+            const Component &c = comp[idx[i]];
+            const bool needDc = !progressive || Ss == 0, needAc = !progressive || Ss > 0;
+            if (needDc && !(progressive && Ah != 0) && !dcTab[c.td].present) Fail("scan uses an undefined DC Huffman table");
+            if (needAc && !acTab[c.ta].present) Fail("scan uses an undefined AC Huffman table");
+        }
         ResetEntropy();
         int restartsLeft = restartInterval;
         auto block = [&](Component &c, int bx, int by) {
@@ -499,6 +511,7 @@ struct Decoder {
                     break;
                 case 0xEE: {  // Adobe
                     int len = U16();
+                    if (len < 2 || pos + (size_t)(len - 2) > n) Fail("bad segment length");
                     size_t end = pos + len - 2;
                     if (len >= 14 && pos + 12 <= n && memcmp(d + pos, "Adobe", 5) == 0) adobe = true, adobeTransform = d[pos + 11];
                     pos = end;
@@ -509,6 +522,7 @@ struct Decoder {
                     if (m == 0x01 || m == 0x00) break;
                     {
                         int len = U16();
+                        if (len < 2 || pos + (size_t)(len - 2) > n) Fail("bad segment length");
                         pos += len - 2;
                     }
             }

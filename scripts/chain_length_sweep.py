@@ -1,6 +1,6 @@
 """Chain-length sweep of the end-to-end image against the reference's shipped render.
 
-Renders scenes/torus/lmc.xml with the reference's own start-up semantics (seedchains = 0: every chain begins with a forced
+Renders scenes/torus/lmc.xml with the reference's own start-up semantics (every chain begins with a forced
 large step, mlt.h:121) at a fixed mutation budget (spp x W x H) split over different numbers of chains, and reports probe-region
 luminance ratios against tests/golden/torus_ref_images_256x192.npz (= scenes/torus/lmc_timeuse_44.689152s.exr box-downsampled).
 The reference itself runs 128 chains x 1.5 M steps.

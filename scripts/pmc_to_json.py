@@ -20,8 +20,19 @@ write_corr = GiB_KB / probe["WRITE_SIZE"]  # ... and writes 1 GiB
 k = next(v for name, v in summ.items() if name.replace(" ", "").startswith("voidk_step_small<true,false,false>"))
 fetch = k["FETCH_SIZE"] * 1024.0 * read_corr
 write = k["WRITE_SIZE"] * 1024.0 * write_corr
+# chain-steps per launch of the measured run: the bench line each pass printed (pass1.log); the wasted-traffic ratio must pair the
+# counter figure with THIS number, not with the steps of some other window
+steps_per_launch = None
+try:
+    for ln in open(os.path.join(out, "pass1.log")):
+        if ln.startswith("{") and '"roofline"' in ln:
+            steps_per_launch = json.loads(ln)["roofline"]["chain_steps_per_launch"]
+except Exception:
+    pass
 d = {
     "kernel": "k_step_small<true,false>",
+    "chain_steps_per_launch": steps_per_launch,
+    "traffic_over_algorithmic": ((fetch + write) / (bench.ALGO_BYTES_PER_STEP * steps_per_launch)) if steps_per_launch else None,
     "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-rmse --steps 32 --warmup 40`, last third of the launches)" % label,
     "fetch_bytes_per_launch": fetch,
     "write_bytes_per_launch": write,

@@ -21,11 +21,10 @@ def rel_mse(a, b):
     return float(np.mean((la - lb) ** 2 / (lb ** 2 + 1e-2)))
 
 
-def render(spp=245, chains=1 << 18, direct_spp=256, seed=0, seedchains=1, init_mult=32):
+def render(spp=245, chains=1 << 18, direct_spp=256, seed=0, init_mult=32):
     p = importlib.import_module("langevin-mcmc_amd")
     scene = os.path.join(ROOT, "scenes", "torus", "lmc.xml")
     ren = p.Renderer(scene, seed_offset=seed)
-    ren.set_option("seedchains", seedchains)
     W, H = ren.width, ren.height
     t0 = time.time()
     direct = ren.direct_lighting(direct_spp)
@@ -46,7 +45,7 @@ def render(spp=245, chains=1 << 18, direct_spp=256, seed=0, seedchains=1, init_m
 if __name__ == "__main__":
     z = np.load(os.path.join(ROOT, "tests", "golden", "torus_ref_images_256x192.npz"))
     ref_lmc, ref_h2mc = z["lmc"], z["h2mc"]
-    img, info = render(seedchains=int(os.environ.get("SEEDCHAINS", "1")), chains=int(os.environ.get("CHAINS", str(1 << 18))))
+    img, info = render(chains=int(os.environ.get("CHAINS", str(1 << 18))))
     d = down(img, 4)
     out = dict(info)
     out["relmse_gpu_vs_ref_lmc"] = rel_mse(d, ref_lmc)

@@ -179,11 +179,11 @@ def test_chain_loop_parity(use_gradient):
 def test_full_material_scene_chain_parity(use_gradient):
     """The shipped torus scene as is (Phong floor with a bitmap texture, Phong metal, rough-dielectric glass, diffuse
     donut; BASELINE.json configs[2] materials) at maxdepth 8: same checks as test_chain_loop_parity.  With gradients the
-    oracle evaluates them through the product's path program compiled for the host, so that this test isolates the
-    chain loop + BSDF code (the AD itself is checked against the reference's programs separately)."""
+    oracle evaluates them through the REFERENCE's generated derivative programs (oracle/_ref), the GPU through its own path
+    program: no self-comparison."""
     # one init stream per sample (init_threads == num_init): a Russian-roulette decision that flips on a last-bit difference
     # of a glossy BSDF value (exp(-tan^2/alpha^2) with alpha = 0.04 amplifies rounding ~600x) then stays local to its sample
-    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=use_gradient, max_depth=8, force_diffuse=0, oracle_grad="product")
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=use_gradient, max_depth=8, force_diffuse=0, oracle_grad="reference")
     assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
     assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
     assert r["init_cl_match"] > 0.97
@@ -201,9 +201,9 @@ def test_full_material_scene_chain_parity(use_gradient):
 def test_full_material_gradient_kernel_vs_reference_programs(pair_full):
     """GPU path program with Phong / rough-dielectric slots against the reference's generated programs.  logLum must
     agree everywhere (5e-3: 6-decimal constants in the generated code compound over up to 8 vertices).  The reference's
-    derivative programs are not the true gradient on glass paths (chad assigns instead of accumulating adjoints at
-    pass-through conditionals, see pathfunc.h FabsW); the product reproduces the dominant sites: >= 90 % of the states
-    must agree within 1e-2 relative L2."""
+    derivative programs are not the true gradient (chad assigns instead of accumulating adjoints at pass-through
+    conditionals, see pathfunc.h FabsW / DetachW); the product reproduces every such site: >= 99.5 % of the states must
+    agree within 1e-2 relative L2 (host twin: 859 / 859)."""
     orc, ren = pair_full
     inputs = gc.collect_grad_inputs(orc, 1024)
     ok = tot = 0
@@ -218,7 +218,7 @@ def test_full_material_gradient_kernel_vs_reference_programs(pair_full):
             assert abs(r[0] - ll[i]) < 5e-3
             tot += 1
             ok += np.linalg.norm(r[1] - g[:, i]) <= 1e-2 * max(np.linalg.norm(r[1]), 1e-2)
-    assert tot > 500 and ok >= 0.9 * tot, (ok, tot)
+    assert tot > 500 and tot - ok <= tot // 200, (ok, tot)
 
 
 @pytest.mark.parametrize("force_diffuse", [1, 0])
@@ -343,7 +343,7 @@ def test_maxdepth_12_chain_parity():
     """BASELINE.json configs[2]: the scene's own materials at max path length 12 (the reference has no depth cap in its path
     storage, path.h:38-56).  Same checks as the maxdepth-8 test; gradients exist for dim <= 12 only (mutation_mala.h:94-96), longer
     states take isotropic proposals on both sides."""
-    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=1, max_depth=12, force_diffuse=0, oracle_grad="product")
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=1, max_depth=12, force_diffuse=0, oracle_grad="reference")
     assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 4
     assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
     assert r["init_cl_match"] > 0.97
@@ -561,4 +561,70 @@ def test_bad_inputs_fail_cleanly():
         ren.init_chains(100, 4096, 4, 10)  # fewer contributions than chains (mlt.h:101-105)
     with pytest.raises(RuntimeError):
         ren.set_option("no-such-option", 1)
+    ren.close()
+
+
+@pytest.mark.parametrize("force_diffuse", [1, 0])
+def test_cfg1_twin_four_chains_thousand_mutations(force_diffuse):
+    """BASELINE.json configs[0] (torus lmc.xml, numchains = 4, film 40x25, spp = 4 => 4 chains x 1000 mutations, seedoffset 0) on
+    the GPU against the oracle, gradients from the REFERENCE's derivative programs on the oracle side.  Lambertian-forced: every
+    counter identical and the films equal to float-sum order.  Shipped materials: 1000 consecutive steps of 4 chains amplify a
+    last-bit libm difference of a glossy BSDF value into another accept decision sooner or later, so the counters are compared
+    within a few steps and the energy identity exactly."""
+    r = gc.run_pair(40, 25, 300000, 4, 8, 1000, 1000, use_gradient=1, max_depth=8, force_diffuse=force_diffuse, oracle_grad="reference")
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert r["contribs_gpu"] == r["contribs_oracle"] or abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 3
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
+    assert sg["steps"] == so["steps"] == 4000
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+    if force_diffuse:
+        assert r["init_cl_match"] == 1.0
+        for k in ("largeSteps", "accepted", "gradCalls", "resets"):
+            assert sg[k] == so[k], (k, sg[k], so[k])
+        assert r["film_rel_l2"] < 1e-3 and r["final_state_match"] == 1.0
+    else:
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 40 and abs(sg["accepted"] - so["accepted"]) <= 0.05 * so["accepted"] + 20
+
+
+@pytest.mark.parametrize("force_diffuse", [1, 0])
+def test_point_light_scene_chain_parity(force_diffuse):
+    """scenes/torus/lmc_pointlight.xml (ours: the point emitter the reference's torus file carries commented out, in place of the
+    environment map): pointlight.cpp:12-116 -- SampleDirect, Emit, the delta-light branches of the MIS weights (path.cpp:611-615,
+    1050-1060) -- executed on both sides; gradients of the oracle from the reference's derivative programs."""
+    xml = os.path.join(gc.ROOT, "scenes", "torus", "lmc_pointlight.xml")
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=1, max_depth=8, scene=xml, force_diffuse=force_diffuse, oracle_grad="reference")
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == 256 * 40 and sg["gradCalls"] > 1000
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+    if force_diffuse:
+        assert r["init_cl_match"] == 1.0
+        for k in ("largeSteps", "accepted", "gradCalls"):
+            assert sg[k] == so[k], (k, sg[k], so[k])
+        assert r["film_rel_l2"] < 1e-3 and r["final_state_match"] > 0.99
+    else:
+        assert r["init_cl_match"] > 0.97
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 3
+        assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"] + 2
+        assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * so["gradCalls"] + 2
+        assert r["film_rel_l2"] < 0.15 and r["final_state_match"] > 0.95
+
+
+def test_mutation_cannot_change_under_resident_chains():
+    """lmc_chains_init lays the chain state out for the mutation in force (H2MC: dense Gaussian buffers, no gradient cache).
+    Flipping `h2mc` / `mala` afterwards used to launch k_step_h2mc on a null buffer: now the step call fails loudly until the
+    chains are initialised again."""
+    ren = gc.pkg().Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=64, height=48, seed_offset=0, use_gradient=1)
+    ren.init_chains(4000, 64, 4, 100)
+    ren.step(2)
+    ren.set_option("h2mc", 1)
+    with pytest.raises(RuntimeError, match="initialise the chains again"):
+        ren.step(1)
+    ren.init_chains(4000, 64, 4, 100)  # H2MC state laid out now
+    ren.step(2)
+    assert ren.stats()["steps"] == 128
+    ren.set_option("h2mc", 0)
+    with pytest.raises(RuntimeError, match="initialise the chains again"):
+        ren.step(1)
     ren.close()

@@ -151,8 +151,10 @@ def test_full_material_identity_and_path_program(oracle, pathref_path):
     """Shipped torus materials (Phong incl. the checker bitmap, rough dielectric), maxdepth 8:
     (1) log(ssScore) of the oracle's scalar sampler == the reference's forward programs on the oracle's Serialize output
         (3e-3: fastpow texture gamma, 6-decimal constants, up to 8 vertices);
-    (2) the product's path program == the reference's forward programs (2e-3) and >= 90 % of the gradients agree with the
-        reference's derivative programs within 1e-2 (the remainder: chad's adjoint-overwrite defect, pathfunc.h FabsW)."""
+    (2) the product's path program == the reference's forward programs (2e-3) and the gradients agree with the reference's
+        derivative programs within 1e-2 on >= 99.5 % of the states (round 3: the pass-through sites of chad's reverse emitter --
+        fabs operands, CoordinateSystem's doubled output, the two-sided normal -- are all reproduced, pathfunc.h; measured
+        859 / 859 on this set, the slack is for ill-conditioned states only)."""
     H = _host_pathfunc()
     o = _orc.Oracle(oracle, gc.TORUS, 0, 8, 160, 120, 0, pathref_path)
     o.init(60000, 768, 8)
@@ -177,9 +179,41 @@ def test_full_material_identity_and_path_program(oracle, pathref_path):
         ok += np.linalg.norm(g - g2[:dim]) <= 1e-2 * max(np.linalg.norm(g), 1e-2)
         for k in range(c - 2):
             kinds.add(int(vert[3 + 59 * k + 48]))
-    assert n > 400 and ok >= 0.9 * n, (ok, n)
+    assert n > 400 and n - ok <= n // 200, (ok, n)
     assert kinds == {0, 1, 2}
     o.close()
+
+
+def test_golden_full_material_derivative_vectors():
+    """Committed vectors of the reference's MALA-gradient and H2MC gradient + Hessian programs on full-material states of the
+    torus AND the veach-door scene, every technique the two scenes produce up to c + l = 9 (dims 14 / 16 included)
+    (tests/golden/derv_vectors_full.npz, made by tests/golden/make_golden_derv.py from oracle/_ref): holds without
+    /root/reference.  1e-2 relative (L2 / Frobenius) for >= 99 % of the vectors, logLum 5e-3."""
+    H = _host_pathfunc()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "derv_vectors_full.npz"))
+    n = len(z["c"])
+    assert n >= 250 and {int(c) + int(l) for c, l in zip(z["c"], z["l"])} >= {4, 5, 6, 7, 8, 9}
+    bad_g, bad_h = [], []
+    for i in range(n):
+        c, l = int(z["c"][i]), int(z["l"][i])
+        dim = 2 * (c + l - 1)
+        sp = z["scenes"][int(z["scene_id"][i])].copy()
+        prim, vert = z["primary"][i].copy(), z["vert"][i].copy()
+        ll, g = np.zeros(1, np.float32), np.zeros(16, np.float32)
+        H.lmc_test_pathfunc_host(c, l, P(prim), P(sp), P(vert), P(ll), P(g))
+        assert abs(ll[0] - z["loglum"][i]) < 5e-3, (i, c, l)
+        rg = z["mala_grad"][i][:dim]
+        if np.linalg.norm(rg - g[:dim]) > 1e-2 * max(np.linalg.norm(rg), 1e-2):
+            bad_g.append((i, c, l))
+        g2, h2 = np.zeros(16, np.float32), np.zeros(256, np.float32)
+        H.lmc_test_pathfunc_hess_host(c, l, P(prim), P(sp), P(vert), P(ll), P(g2), P(h2))
+        H1, H2 = z["h2_hess"][i][: dim * dim].reshape(dim, dim), h2[: dim * dim].reshape(dim, dim)
+        eg = np.linalg.norm(z["h2_grad"][i][:dim] - g2[:dim]) / max(np.linalg.norm(z["h2_grad"][i][:dim]), 1e-2)
+        eh = np.linalg.norm(H1 - H2) / max(np.linalg.norm(H1), 1e-1)
+        if eg > 1e-2 or eh > 1e-2:
+            bad_h.append((i, c, l, float(eg), float(eh)))
+    assert len(bad_g) <= n // 100, bad_g
+    assert len(bad_h) <= n // 100, bad_h
 
 
 def test_golden_gradient_vectors(oracle):
