@@ -249,11 +249,8 @@ def main():
     total = per_gpu * world
     init_samples = args.init_samples or 8 * total
     ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, seed_offset=0, device=local, use_gradient=1)
-    t_init = time.time()
-    norm, ncontrib = ren.init_chains(init_samples, total, args.init_threads, args.samples_per_chain, 0, rank * per_gpu, (rank + 1) * per_gpu)
-    t_init = time.time() - t_init
 
-    collective = "in-library RCCL all-reduce of the device film (lmc_film_allreduce)"
+    collective = "in-library RCCL: MLTInit sharded by init stream (3 all-gathers), per-step all-gather of the cache pushes while the gradient caches fill, one all-reduce of the device film (lmc_film_allreduce)"
 
     def barrier():
         ren.sync()
@@ -282,6 +279,11 @@ def main():
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         if int(ok_t.item()) == 0 and collective.startswith("in-library"):
             collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed on another rank)"
+    # MLTInit + chain set-up AFTER the communicator exists: the ranks of the job shard the init by stream and exchange what the seeding
+    # needs (include/lmc_abi.h); without a communicator every rank runs the whole (deterministic) init for its own chain range
+    t_init = time.time()
+    norm, ncontrib = ren.init_chains(init_samples, total, args.init_threads, args.samples_per_chain, 0, rank * per_gpu, (rank + 1) * per_gpu)
+    t_init = time.time() - t_init
     ren.set_option("timing", 1)  # per-step HIP events on the launch stream (lmc_step_timing / lmc_kernel_timing)
     ren.step(args.warmup)
     ren.step_timing()  # discard warm-up launches
@@ -293,8 +295,8 @@ def main():
     if dist is not None:
         import torch
 
-        # the single data-path collective: the device films are summed in place by the library (RCCL over xGMI, on the step
-        # stream, no host staging); `normalization` is identical on all ranks (every rank runs the same MLTInit)
+        # the data-path collective at the end: the device films are summed in place by the library (RCCL over xGMI, on the step
+        # stream, no host staging); `normalization` is identical on all ranks (the sharded MLTInit ends in the same host walk everywhere)
         if collective.startswith("in-library"):
             ren.film_allreduce()
         else:

@@ -70,6 +70,25 @@ int lmc_image_write_exr(const char *path, const float *rgb, int w, int h);
  * samples_per_chain / chains_need_extra as computed at mlt.cpp:36-40. */
 int lmc_chains_init(lmc_ctx *ctx, long long num_init_samples, int n_chains_total, int init_threads, int chain_begin, int chain_end,
                     long long samples_per_chain, long long chains_need_extra);
+/* Multi-rank jobs: MLTInit is sharded by init stream (rank r runs streams [V r / R, V (r + 1) / R), V = init_threads) and the ranks
+ * exchange what the seeding needs (contribution counts, scores, the checkpoints of the seeding samples), so that normalization and
+ * every chain's init state equal the one-rank result bit for bit.  Ranks of an RCCL job (lmc_comm_init BEFORE lmc_chains_init) call
+ * lmc_chains_init collectively; the n contexts of an in-process group (one per GPU, or several on one GPU for bring-up) are driven
+ * by the two calls below (chains split into n contiguous equal ranges; their collectives are device copies). */
+int lmc_group_chains_init(lmc_ctx **ctxs, int n, long long num_init_samples, int n_chains_total, int init_threads, long long samples_per_chain,
+                          long long chains_need_extra);
+int lmc_group_chains_step(lmc_ctx **ctxs, int n, int n_steps);
+/* CPU test hooks (need no GPU): the host-side plan of the sharded MLTInit from the padded blocks the ranks all-gather.
+ * lmc_shard_layout: out5 = [first stream, end stream, first sample, end sample, samples of the largest rank] of `rank`;
+ * lmc_shard_counts_probe: rank_first[world + 1] = first contribution of every rank's block (and the total);
+ * lmc_shard_plan_probe: per chain of the job the init sample that seeds it, the seeding contribution's technique (c * 16 + l) and
+ * lsScore; owned_begin[world + 1]: rank r's samples seed the chains [owned_begin[r], owned_begin[r + 1]); normalization */
+int lmc_shard_layout(int world, int rank, int init_threads, long long num_init_samples, long long *out5);
+int lmc_shard_counts_probe(int world, int init_threads, long long num_init_samples, const unsigned char *padded_counts, long long max_local_samples,
+                           unsigned long long *rank_first);
+int lmc_shard_plan_probe(int world, int init_threads, long long num_init_samples, int n_chains_total, const unsigned char *padded_counts,
+                         long long max_local_samples, const unsigned char *padded_cl, const float *padded_ls, long long max_local_contribs,
+                         long long *seed_sample, unsigned char *seed_cl, float *seed_ls, int *owned_begin, float *normalization);
 /* normalization = avgScore (mlt.cpp:46-47), number of init contributions */
 int lmc_init_result(lmc_ctx *ctx, float *normalization, long long *num_contribs);
 /* parity probe: every contribution MLTInit collected, in stream order: index of the init sample that produced it, technique as

@@ -199,7 +199,7 @@ class Renderer:
         return d
 
     def summary(self, which=0):
-        n = self.num_chains if which == 0 else self.num_chains_total
+        n = self.num_chains  # which = 0: current states, 1: init states -- of this rank's chains
         out = np.zeros((n, 32), np.float32)
         if lib().lmc_chain_summary(self.h, which, P(out), 32) < 0:
             raise RuntimeError(_err())
@@ -244,6 +244,36 @@ class Renderer:
         if lib().lmc_occluded(self.h, len(rays), P(rays), P(occ)) != 0:
             raise RuntimeError(_err())
         return occ
+
+
+class Group:
+    """In-process ranks: the given Renderers (one per GPU, or several on one GPU for bring-up / tests) become ranks 0 .. n-1 of ONE job
+    (lmc_group_chains_init / lmc_group_chains_step): MLTInit sharded by init stream, chains split into contiguous equal ranges, the
+    global cache's pushes exchanged every step -- the same trajectories as a single rank holding all the chains."""
+
+    def __init__(self, renderers):
+        self.rens = list(renderers)
+        self._arr = (vp * len(self.rens))(*[r.h for r in self.rens])
+
+    def init_chains(self, num_init, n_chains_total, init_threads, per_chain, extra=0):
+        L = lib()
+        L.lmc_group_chains_init.argtypes = [vp, ctypes.c_int, c_ll, ctypes.c_int, ctypes.c_int, c_ll, c_ll]
+        if L.lmc_group_chains_init(self._arr, len(self.rens), num_init, n_chains_total, init_threads, per_chain, extra) != 0:
+            raise RuntimeError("lmc_group_chains_init failed: " + _err())
+        n = len(self.rens)
+        for r, ren in enumerate(self.rens):
+            b, e = n_chains_total * r // n, n_chains_total * (r + 1) // n
+            ren.num_chains, ren.num_chains_total = e - b, n_chains_total
+            nn, nc = ctypes.c_float(), c_ll()
+            L.lmc_init_result(ren.h, ctypes.byref(nn), ctypes.byref(nc))
+            ren.normalization = nn.value
+        return self.rens[0].normalization, nc.value
+
+    def step(self, n):
+        L = lib()
+        L.lmc_group_chains_step.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        if L.lmc_group_chains_step(self._arr, len(self.rens), n) != 0:
+            raise RuntimeError("lmc_group_chains_step failed: " + _err())
 
 
 def comm_unique_id():

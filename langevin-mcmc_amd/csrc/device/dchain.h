@@ -73,6 +73,24 @@ struct CachePushTargets {
     int *count;                                                                           // [CACHE_SLOTS] rows filled
 };
 
+// the stage of the multi-rank push (kernels.hip k_push_apply): one buffer of floats per rank, [16 header words: rows per slot]
+// followed, per slot, by pss | v1 | v2 (PSS_MAX_SIZE x dim each) | weight (PSS_MAX_SIZE); offsets in floats
+struct PushStageLayout {
+    int pss[CACHE_SLOTS], v1[CACHE_SLOTS], v2[CACHE_SLOTS], weight[CACHE_SLOTS];
+    int totalFloats;
+};
+LMC_HD PushStageLayout MakePushStageLayout() {
+    PushStageLayout l;
+    int off = 16;
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) {
+        const int dim = 6 + 2 * sl;
+        l.pss[sl] = off, l.v1[sl] = off + PSS_MAX_SIZE * dim, l.v2[sl] = off + 2 * PSS_MAX_SIZE * dim, l.weight[sl] = off + 3 * PSS_MAX_SIZE * dim;
+        off += PSS_MAX_SIZE * (3 * dim + 1);
+    }
+    l.totalFloats = off;
+    return l;
+}
+
 struct ChainArrays {
     int N;
     uint64_t *rngState;
@@ -94,8 +112,11 @@ struct ChainArrays {
     unsigned char *nextKind;  // N: which launch runs the chain's next step (NEXT_*), turned into id-ordered work lists by k_build_lists
     int *pushDim;        // N: dim of a pending global-cache push (0 = none)
     float *pushData;     // (3*MAXPSS+1) x N: pss, v1, v2, weight snapshot for the push
-    // init states (outlier reset, mlt.cpp:147-169)
+    // init states (outlier reset, mlt.cpp:147-169): full states of THIS rank's chains (N), and for every chain of the job (the
+    // reset walks global chain ids) the two things the loop reads of a state that is then marked invalid: lsScore and technique
     float *initPath, *initContrib, *initScoreSum;
+    const float *initLsAll;          // numChainsTotal
+    const unsigned char *initCLAll;  // numChainsTotal, c * 16 + l
     // per-launch counters: [0] steps, [1] large, [2] accepted, [3] gradCalls, [4] cacheQueries, [5] cacheHits, [6] resets
     unsigned long long *counters;
     unsigned long long *prof;  // region cycle sums of the profiling instantiation of the lean kernel (dsmall.h WaveProf), 16 words
@@ -152,6 +173,34 @@ LMC_D void ClearBuffered(const ChainArrays &A, int i, int &flags) {
         }
     }
     flags &= ~F_BUFFERED;
+}
+// REMOVE_OUTLIERS, mlt.cpp:151-158: currentState = initStates[_chainId] for the first id (walk: (_chainId + sampleIdx + cnt++) %
+// numChains, over the chains of the WHOLE job) whose lsScore is below the outlier threshold.  The state is marked invalid by the
+// caller, and of an invalid state the chain loop reads exactly one thing, spContrib.lsScore (strongReject, mlt.cpp:148; a large step
+// ignores the current state when it is invalid, mutation_large.h:87-116) -- so for a chain that lives on another rank the technique
+// and the score of the job-wide tables are copied and the path words stay as they are.
+LMC_D void ResetToInitState(const ChainArrays &A, int chainBegin, int numChainsTotal, float threshold, int i, int sampleIdx, float *curPathBuf) {
+    const size_t N = A.N;
+    int chainId = chainBegin + i, cnt = 0;
+    for (;;) {
+        if (A.initLsAll[chainId] < threshold) break;
+        chainId = (int)(((long long)chainId + sampleIdx + cnt++) % numChainsTotal);
+    }
+    const int li = chainId - chainBegin;
+    if (li >= 0 && li < A.N) {
+#pragma unroll 1
+        for (int w = 0; w < DPATH_WORDS; w++) curPathBuf[(size_t)w * N + i] = A.initPath[(size_t)w * N + li];
+#pragma unroll 1
+        for (int w = 0; w < CONTRIB_WORDS; w++) A.curContrib[(size_t)w * N + i] = A.initContrib[(size_t)w * N + li];
+        A.scoreSum[i] = A.initScoreSum[li];
+    } else {
+        const int cl = A.initCLAll[chainId];
+        A.curContrib[i] = __int_as_float(cl >> 4), A.curContrib[N + i] = __int_as_float(cl & 15);
+#pragma unroll 1
+        for (int w = 2; w < CONTRIB_WORDS; w++) A.curContrib[(size_t)w * N + i] = 0.f;
+        A.curContrib[7 * N + i] = A.initLsAll[chainId];
+        A.scoreSum[i] = 0.f;
+    }
 }
 LMC_D float *CurPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.pathBuf1 : A.curPath; }
 LMC_D float *PropPathBuf(const ChainArrays &A, int flags) { return (flags & F_SEL) ? A.curPath : A.pathBuf1; }

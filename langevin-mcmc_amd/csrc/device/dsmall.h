@@ -663,18 +663,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         A.adjacentReject[i] = rej;
         const bool strongReject = curLs > OUTLIER_RATIO_THRESHOLD * P.normalization;
         if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
-            int chainId = i + P.chainBegin, cnt = 0;
-            for (;;) {
-                const float ls = A.initContrib[7 * (size_t)P.numChains + chainId];
-                if (ls < OUTLIER_RATIO_THRESHOLD * P.normalization) break;
-                chainId = (int)(((long long)chainId + sampleIdx + cnt++) % P.numChains);
-            }
-            float *curW = sel ? A.pathBuf1 : A.curPath;
-#pragma unroll 1
-            for (int w = 0; w < DPATH_WORDS; w++) curW[(size_t)w * N + i] = A.initPath[(size_t)w * P.numChains + chainId];
-#pragma unroll 1
-            for (int w = 0; w < CONTRIB_WORDS; w++) A.curContrib[(size_t)w * N + i] = A.initContrib[(size_t)w * P.numChains + chainId];
-            A.scoreSum[i] = A.initScoreSum[chainId];
+            ResetToInitState(A, P.chainBegin, P.numChains, OUTLIER_RATIO_THRESHOLD * P.normalization, i, sampleIdx, sel ? A.pathBuf1 : A.curPath);
             A.curSplatCount[i] = 0;
             flags &= ~(F_VALID | F_GAUSS);
             ClearBuffered(A, i, flags);

@@ -348,17 +348,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         A.adjacentReject[i] = rej;
         const bool strongReject = cur.lsScore > OUTLIER_RATIO_THRESHOLD * P.normalization;
         if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
-            int chainId = P.chainBegin + i, cnt = 0;  // init states are indexed by global chain id
-            for (;;) {
-                const float ls = A.initContrib[7 * (size_t)P.numChains + chainId];
-                if (ls < OUTLIER_RATIO_THRESHOLD * P.normalization) break;
-                chainId = (int)(((long long)chainId + sampleIdx + cnt++) % P.numChains);
-            }
-            DPath ip;
-            LoadPath(A.initPath, P.numChains, chainId, ip);
-            StorePath(CurPathBuf(A, flags), A.N, i, ip);
-            StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, P.numChains, chainId));
-            A.scoreSum[i] = A.initScoreSum[chainId];
+            ResetToInitState(A, P.chainBegin, P.numChains, OUTLIER_RATIO_THRESHOLD * P.normalization, i, sampleIdx, CurPathBuf(A, flags));
             A.curSplatCount[i] = 0;
             flags &= ~(F_VALID | F_GAUSS);
             ClearBuffered(A, i, flags);

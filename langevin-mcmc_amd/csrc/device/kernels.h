@@ -14,20 +14,21 @@ void LaunchKdProbe(const lmcd::DCacheDim &C, int dim, int nq, const float *q, fl
 void LaunchGaussProbe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out, hipStream_t s);
 void LaunchGradBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, int wantGrad,
                      hipStream_t s);
-void LaunchInitPass1(const lmcd::DScene &S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
-                     uint32_t *ckTicks, unsigned char *count, hipStream_t s);
-void LaunchInitPass2(const lmcd::DScene &S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
-                     const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs, hipStream_t s);
+// MLTInit, sharded by init stream: a rank runs the streams [tBegin, tBegin + nStreams); its sample arrays start at global sample gBase
+void LaunchInitPass1(const lmcd::DScene &S, int tBegin, int nStreams, long long perThread, long long extra, long long gBase, uint32_t *tabScratch,
+                     float *contribScratch, uint64_t *ckState, uint32_t *ckTicks, unsigned char *count, hipStream_t s);
+void LaunchInitPass2(const lmcd::DScene &S, long long gBegin, long long numLocal, long long perThread, long long extra, int nSlots, uint32_t *tabScratch,
+                     float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs,
+                     hipStream_t s);
 void LaunchInitRegen(const lmcd::DScene &S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
-                     uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
+                     uint32_t *tabScratch, float *contribScratch, const uint64_t *seedCkState, const uint32_t *seedCkTicks, float *initPath, float *initContrib,
                      float *initScoreSum, hipStream_t s);
 // direct.cpp:4-54; tabScratch: 64 words per 16x16 tile
 // waveKernel: one wave per tile with speculative stream positions (kernels.hip) when maxDepth <= 2 and the BVH fits the LDS stack
 void LaunchDirect(const lmcd::DScene &S, const lmcd::Film &film, int directSpp, int minDepth, int maxDepth, int bvhDepth, bool waveKernel, uint32_t *tabScratch,
                   hipStream_t s);
 void LaunchBidirMC(const lmcd::DScene &S, const lmcd::Film &film, int nThreads, int samplesPerThread, uint32_t *tabScratch, float *contribScratch, hipStream_t s);
-void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
-                       float normalization, hipStream_t s);
+void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, long long perChain, long long chainsNeedExtra, hipStream_t s);
 void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::StepParams &P, hipStream_t s);
 // one of the three step launches (device/step_*.hip): chains of `list` (count read on the device) run one mutation and
 // append themselves to the lists of the next step
@@ -52,6 +53,8 @@ void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, i
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 // pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
 void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);
+// multi-rank push: append the gathered stages of all ranks (rank order) to the cache rows; see kernels.hip k_push_apply
+void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, const lmcd::PushStageLayout &lay, const lmcd::CachePushTargets &T, hipStream_t s);
 // measurement aid: state-layout probe (kernels.hip k_layout_probe)
 void LaunchLayoutProbe(int N, int words, int mode, int batch, const float *in, float *out, hipStream_t s);
 // groups the entries of a work list by the technique key of A.nextKind (blockHist: 64 ints per 2048 entries of the longest list)

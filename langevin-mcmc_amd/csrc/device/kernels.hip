@@ -151,23 +151,24 @@ __global__ void k_grad_batch(int c, int l, int n, const float *primarySoA, const
 // pass 1: one thread per virtual init thread (mlt.h:66-98 with NumSystemCores() := V): RNG(threadId + seedOffset),
 // samples drawn back to back; records the per-sample RNG checkpoint and the number of contributions.
 template <bool GLOSSY>
-__global__ void k_init_pass1(DScene S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
-                             uint32_t *ckTicks, unsigned char *count) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= V) return;
+__global__ void k_init_pass1(DScene S, int tBegin, int nStreams, long long perThread, long long extra, long long gBase, uint32_t *tabScratch,
+                             float *contribScratch, uint64_t *ckState, uint32_t *ckTicks, unsigned char *count) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nStreams) return;
+    const int t = tBegin + idx;  // this rank runs the init streams [tBegin, tBegin + nStreams); its arrays start at sample gBase
     Rng rng;
-    rng.tab = tabScratch + (size_t)t * 64;
+    rng.tab = tabScratch + (size_t)idx * 64;
     rng.state = PcgSeed((uint64_t)(t + S.opt.seedOffset), rng.tab);
     rng.ticks = 0;
     long long n = perThread + (t < extra ? 1 : 0);
-    long long base = (long long)t * perThread + (t < extra ? t : extra);
+    long long base = (long long)t * perThread + (t < extra ? t : extra) - gBase;
     const int minPathLength = max(S.opt.minDepth, 3);
     DPath path;
     LocalStackT<GLOSSY> stk;
     for (long long s = 0; s < n; s++) {
         ckState[base + s] = rng.state;
         ckTicks[base + s] = rng.ticks;
-        ContribSink sink{contribScratch, (size_t)V, (size_t)t, 0};
+        ContribSink sink{contribScratch, (size_t)nStreams, (size_t)idx, 0};
         GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng, stk);
         count[base + s] = (unsigned char)sink.count;
     }
@@ -188,33 +189,35 @@ LMC_D void RngFromCheckpoint(Rng &rng, uint64_t seed, uint64_t state, uint32_t t
 
 // pass 2: one grid-stride thread per sample; re-runs the sample from its checkpoint and writes (c,l,lsScore) compactly
 template <bool GLOSSY>
-__global__ void k_init_pass2(DScene S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
-                             const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs) {
+__global__ void k_init_pass2(DScene S, long long gBegin, long long numLocal, long long perThread, long long extra, int nSlots, uint32_t *tabScratch,
+                             float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL,
+                             float *outLs) {
     int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nSlots) return;
     const int minPathLength = max(S.opt.minDepth, 3);
     DPath path;
     LocalStackT<GLOSSY> stk;
-    for (long long g = slot; g < numSamples; g += nSlots) {
+    for (long long k = slot; k < numLocal; k += nSlots) {  // local sample k = global sample gBegin + k
         Rng rng;
         rng.tab = tabScratch + (size_t)slot * 64;
-        int t = InitThreadOfSample(g, perThread, extra);
-        RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
+        int t = InitThreadOfSample(gBegin + k, perThread, extra);
+        RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[k], ckTicks[k]);
         ContribSink sink{contribScratch, (size_t)nSlots, (size_t)slot, 0};
         GeneratePathBidir(S, minPathLength, S.opt.maxDepth, path, sink, rng, stk);
-        unsigned long long o = offset[g];
-        for (int k = 0; k < sink.count; k++) {
-            Contrib c = sink.Get(k);
-            outCL[o + k] = (unsigned char)(c.camDepth * 16 + c.lightDepth);
-            outLs[o + k] = c.lsScore;
+        unsigned long long o = offset[k];  // relative to this rank's first contribution
+        for (int j = 0; j < sink.count; j++) {
+            Contrib c = sink.Get(j);
+            outCL[o + j] = (unsigned char)(c.camDepth * 16 + c.lightDepth);
+            outLs[o + j] = c.lsScore;
         }
     }
 }
 
-// regenerate the selected seed paths (mlt.h:121-148) into the init-state arrays (size = total number of chains)
+// regenerate the seed paths of THIS rank's chains (mlt.h:121-148) into its init-state arrays; per chain: the init sample that seeds
+// it (global index: names the stream), the technique to pick, and the sample's RNG checkpoint (which may come from another rank)
 template <bool GLOSSY>
 __global__ void k_init_regen(DScene S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
-                             uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath,
+                             uint32_t *tabScratch, float *contribScratch, const uint64_t *seedCkState, const uint32_t *seedCkTicks, float *initPath,
                              float *initContrib, float *initScoreSum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= numChains) return;
@@ -222,7 +225,7 @@ __global__ void k_init_regen(DScene S, int numChains, long long perThread, long 
     Rng rng;
     rng.tab = tabScratch + (size_t)i * 64;
     int t = InitThreadOfSample(g, perThread, extra);
-    RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), ckState[g], ckTicks[g]);
+    RngFromCheckpoint(rng, (uint64_t)(t + S.opt.seedOffset), seedCkState[i], seedCkTicks[i]);
     DPath path;
     ContribSink sink{contribScratch, (size_t)numChains, (size_t)i, 0};
     LocalStackT<GLOSSY> stk;
@@ -381,38 +384,22 @@ __global__ void k_bidir_mc(DScene S, Film film, int nThreads, int samplesPerThre
     }
 }
 
-// chain set-up (mlt.cpp:60-90): current state = init state of the chain's GLOBAL id, everything else cleared
-// seedValid (not in the reference, which marks every init state invalid, mlt.h:121, so that each chain begins with an
-// unconditionally accepted large step): the chain starts in the state MLTInit resampled for it -- Veach's equal-spaced
-// seeding put to use -- with that state's own pending splat.  Removes the start-up bias of short chains.
-__global__ void k_setup_chains(ChainArrays A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
-                               float normalization) {
+// chain set-up (mlt.cpp:60-90): current state = the chain's init state, marked invalid (mlt.h:121: every chain begins with an
+// unconditionally accepted large step), everything else cleared.  The init arrays hold this rank's chains only.
+__global__ void k_setup_chains(ChainArrays A, int chainBegin, long long perChain, long long chainsNeedExtra) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.N) return;
     const int gid = chainBegin + i;
     DPath p;
-    LoadPath(A.initPath, numChainsTotal, gid, p);
+    LoadPath(A.initPath, A.N, i, p);
     StorePath(A.curPath, A.N, i, p);
-    StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, numChainsTotal, gid));
-    A.scoreSum[i] = A.initScoreSum[gid];
+    StoreContrib(A.curContrib, A.N, i, LoadContrib(A.initContrib, A.N, i));
+    A.scoreSum[i] = A.initScoreSum[i];
     A.flags[i] = 0;
     A.curSplatCount[i] = 0;
     A.pathWeight[i] = 0.f;
     A.lastScoreSum[i] = 1.0f;
     A.lastScore[i] = 1.0f;
-    if (seedValid) {
-        const Contrib c = LoadContrib(A.initContrib, numChainsTotal, gid);
-        if (c.lsScore > 0.f) {
-            const V3 v = c.contrib * (normalization / c.lsScore);
-            float *sp = A.curSplat + i;
-            const size_t N = A.N;
-            sp[0] = c.screenPos.x, sp[N] = c.screenPos.y, sp[2 * N] = v.x, sp[3 * N] = v.y, sp[4 * N] = v.z;
-            A.curSplatCount[i] = 1;
-            A.lastScore[i] = c.lsScore;
-            A.lastScoreSum[i] = A.initScoreSum[gid];
-            A.flags[i] = F_VALID;
-        }
-    }
     A.adjacentReject[i] = 0;
     A.sampleIdx[i] = 0;
     A.numSamples[i] = (int)(perChain + (gid < chainsNeedExtra ? 1 : 0));
@@ -625,6 +612,36 @@ __global__ void __launch_bounds__(256) k_push_finish(const unsigned long long *t
     }
 }
 
+// ---- multi-rank form of the push: every rank first writes its pushes, in its own chain order, into a STAGE with the cache's row
+// layout (k_push_count / scatter / finish above with the stage as target and a zeroed count), the ranks all-gather their stages, and
+// every rank appends the gathered rows in rank order = global chain-id order.  All ranks therefore hold the same cache at every step
+// -- the cache a single rank with all the chains would hold -- and an N-rank render follows the one-rank trajectories.
+// One block per (slot, rank); a rank's rows land behind the cache's rows and the rows of the lower ranks, cut at PSS_MAX_SIZE.
+__global__ void __launch_bounds__(256) k_push_apply(const float *gathered, size_t stageFloats, int world, PushStageLayout lay, CachePushTargets T) {
+    const int slot = blockIdx.x, r = blockIdx.y;
+    if (!T.pss[slot]) return;
+    const int dim = 6 + 2 * slot;
+    long long base = T.count[slot];
+    for (int q = 0; q < r; q++) base += reinterpret_cast<const int *>(gathered + (size_t)q * stageFloats)[slot];
+    const float *st = gathered + (size_t)r * stageFloats;
+    const int n = reinterpret_cast<const int *>(st)[slot];
+    const long long room = (long long)PSS_MAX_SIZE - base;
+    const int take = (int)(room <= 0 ? 0 : (n < room ? n : room));
+    const float *pss = st + lay.pss[slot], *v1 = st + lay.v1[slot], *v2 = st + lay.v2[slot], *w = st + lay.weight[slot];
+    for (int e = threadIdx.x; e < take * dim; e += blockDim.x) {
+        const size_t d = (size_t)base * dim + e;
+        T.pss[slot][d] = pss[e], T.v1[slot][d] = v1[e], T.v2[slot][d] = v2[e];
+    }
+    for (int e = threadIdx.x; e < take; e += blockDim.x) T.weight[slot][base + e] = w[e];
+}
+__global__ void k_push_apply_finish(const float *gathered, size_t stageFloats, int world, CachePushTargets T) {
+    const int slot = threadIdx.x;
+    if (slot >= CACHE_SLOTS) return;
+    long long n = T.count[slot];
+    for (int q = 0; q < world; q++) n += reinterpret_cast<const int *>(gathered + (size_t)q * stageFloats)[slot];
+    T.count[slot] = (int)(n < PSS_MAX_SIZE ? n : PSS_MAX_SIZE);
+}
+
 }  // namespace lmcd
 
 // ================================================================================================ launch glue
@@ -666,28 +683,30 @@ void LaunchGradBatch(int c, int l, int n, const float *primarySoA, const float *
                      hipStream_t s) {
     hipLaunchKernelGGL(k_grad_batch, dim3(GridFor(n, 128, 4096)), dim3(128), 0, s, c, l, n, primarySoA, scene, vertSoA, logLum, gradSoA, wantGrad);
 }
-void LaunchInitPass1(const DScene &S, int V, long long perThread, long long extra, uint32_t *tabScratch, float *contribScratch, uint64_t *ckState,
-                     uint32_t *ckTicks, unsigned char *count, hipStream_t s) {
-    if (S.glossy) hipLaunchKernelGGL(k_init_pass1<true>, dim3((V + 127) / 128), dim3(128), 0, s, S, V, perThread, extra, tabScratch, contribScratch, ckState, ckTicks, count);
+void LaunchInitPass1(const DScene &S, int tBegin, int nStreams, long long perThread, long long extra, long long gBase, uint32_t *tabScratch, float *contribScratch,
+                     uint64_t *ckState, uint32_t *ckTicks, unsigned char *count, hipStream_t s) {
+    if (nStreams <= 0) return;
+    if (S.glossy) hipLaunchKernelGGL(k_init_pass1<true>, dim3((nStreams + 127) / 128), dim3(128), 0, s, S, tBegin, nStreams, perThread, extra, gBase, tabScratch, contribScratch, ckState, ckTicks, count);
     else
-        hipLaunchKernelGGL(k_init_pass1<false>, dim3((V + 127) / 128), dim3(128), 0, s, S, V, perThread, extra, tabScratch, contribScratch, ckState, ckTicks, count);
+        hipLaunchKernelGGL(k_init_pass1<false>, dim3((nStreams + 127) / 128), dim3(128), 0, s, S, tBegin, nStreams, perThread, extra, gBase, tabScratch, contribScratch, ckState, ckTicks, count);
 }
-void LaunchInitPass2(const DScene &S, long long numSamples, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
+void LaunchInitPass2(const DScene &S, long long gBegin, long long numLocal, long long perThread, long long extra, int nSlots, uint32_t *tabScratch, float *contribScratch,
                      const uint64_t *ckState, const uint32_t *ckTicks, const unsigned long long *offset, unsigned char *outCL, float *outLs, hipStream_t s) {
-    if (S.glossy) hipLaunchKernelGGL(k_init_pass2<true>, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, numSamples, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
+    if (numLocal <= 0) return;
+    if (S.glossy) hipLaunchKernelGGL(k_init_pass2<true>, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, gBegin, numLocal, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
                        ckTicks, offset, outCL, outLs);
     else
-        hipLaunchKernelGGL(k_init_pass2<false>, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, numSamples, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
+        hipLaunchKernelGGL(k_init_pass2<false>, dim3((nSlots + 127) / 128), dim3(128), 0, s, S, gBegin, numLocal, perThread, extra, nSlots, tabScratch, contribScratch, ckState,
                        ckTicks, offset, outCL, outLs);
 }
 void LaunchInitRegen(const DScene &S, int numChains, long long perThread, long long extra, const long long *seedSample, const unsigned char *seedCL,
-                     uint32_t *tabScratch, float *contribScratch, const uint64_t *ckState, const uint32_t *ckTicks, float *initPath, float *initContrib,
+                     uint32_t *tabScratch, float *contribScratch, const uint64_t *seedCkState, const uint32_t *seedCkTicks, float *initPath, float *initContrib,
                      float *initScoreSum, hipStream_t s) {
     if (S.glossy) hipLaunchKernelGGL(k_init_regen<true>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
-                       contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
+                       contribScratch, seedCkState, seedCkTicks, initPath, initContrib, initScoreSum);
     else
         hipLaunchKernelGGL(k_init_regen<false>, dim3((numChains + 127) / 128), dim3(128), 0, s, S, numChains, perThread, extra, seedSample, seedCL, tabScratch,
-                       contribScratch, ckState, ckTicks, initPath, initContrib, initScoreSum);
+                       contribScratch, seedCkState, seedCkTicks, initPath, initContrib, initScoreSum);
 }
 void LaunchDirect(const DScene &S, const Film &film, int directSpp, int minDepth, int maxDepth, int bvhDepth, bool waveKernel, uint32_t *tabScratch, hipStream_t s) {
     const int nX = (S.cam.width + 15) / 16, nY = (S.cam.height + 15) / 16;
@@ -706,10 +725,8 @@ void LaunchBidirMC(const DScene &S, const Film &film, int nThreads, int samplesP
     else
         hipLaunchKernelGGL(k_bidir_mc<false>, dim3((nThreads + 127) / 128), dim3(128), 0, s, S, film, nThreads, samplesPerThread, tabScratch, contribScratch);
 }
-void LaunchSetupChains(const ChainArrays &A, int chainBegin, int numChainsTotal, long long perChain, long long chainsNeedExtra, int seedValid,
-                       float normalization, hipStream_t s) {
-    hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, seedValid,
-                       normalization);
+void LaunchSetupChains(const ChainArrays &A, int chainBegin, long long perChain, long long chainsNeedExtra, hipStream_t s) {
+    hipLaunchKernelGGL(k_setup_chains, dim3((A.N + 255) / 256), dim3(256), 0, s, A, chainBegin, perChain, chainsNeedExtra);
 }
 void LaunchFirstKind(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, hipStream_t s) {
     hipLaunchKernelGGL(k_first_kind, dim3((A.N + 255) / 256), dim3(256), 0, s, S, cache, A, P);
@@ -817,6 +834,11 @@ void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned l
     hipLaunchKernelGGL(k_push_count, dim3(nTiles), dim3(256), 0, s, A, tileCounts);
     hipLaunchKernelGGL(k_push_scatter, dim3(nTiles), dim3(256), 0, s, A, tileCounts, T);
     hipLaunchKernelGGL(k_push_finish, dim3(1), dim3(256), 0, s, tileCounts, nTiles, T);
+}
+
+void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, const PushStageLayout &lay, const CachePushTargets &T, hipStream_t s) {
+    hipLaunchKernelGGL(k_push_apply, dim3(CACHE_SLOTS, world), dim3(256), 0, s, gathered, stageFloats, world, lay, T);
+    hipLaunchKernelGGL(k_push_apply_finish, dim3(1), dim3(64), 0, s, gathered, stageFloats, world, T);
 }
 
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {

@@ -39,8 +39,15 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
 }
 
 // LDS_STACK: the BVH traversal stack in dynamic LDS ([entry][thread], BVH_LDS_STACK entries per thread) instead of private memory
+// LMC_STEP_WAVES: waves per SIMD the register allocation of these launches aims at.  Unconstrained, the glossy large-step
+// instantiation takes 256 VGPRs + 19 AGPRs = ONE wave per SIMD; with a budget of 256 (48 B more spills) two waves fit and the launch
+// is 2.9 x faster on the full-material torus (9.65 -> 3.32 ms), 1.3 x on the door scene (profiles/r03_b_ab_large_step_waves.jsonl);
+// three waves (168 VGPRs, 384 B of spills) give nothing more.
+#ifndef LMC_STEP_WAVES
+#define LMC_STEP_WAVES 2
+#endif
 template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false>
-__global__ void __launch_bounds__(256) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
+__global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
     extern __shared__ int ldsStack[];
     StepStats st;

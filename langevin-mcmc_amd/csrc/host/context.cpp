@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -18,6 +19,7 @@
 #include "../device/kernels.h"
 #include "accel.h"
 #include "scene.h"
+#include "shardplan.h"
 
 using namespace lmcd;
 
@@ -125,6 +127,8 @@ struct lmc_ctx {
     int bvhDepth = 0;
     // film
     DevBuf<float> film, directFilm;
+    int world = 1, rank = 0;          // position in the job (lmc_comm_init: RCCL ranks; lmc_group_chains_init: in-process group)
+    std::vector<lmc_ctx *> group;    // in-process group this context is a member of (empty / 1: none)
     bool filmReduced = false;  // the device film + weightSum already hold the all-reduced sums (lmc_film_allreduce is in place)
     void *comm = nullptr;  // ncclComm_t of lmc_comm_init (multi-GPU: one process per GPU, chains sharded by id range)
     // chains
@@ -133,7 +137,8 @@ struct lmc_ctx {
     DevBuf<uint64_t> rngState;
     DevBuf<uint32_t> rngTab;
     DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, gaussian1, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
-        lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum;
+        lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum, initLsAll;
+    DevBuf<unsigned char> initCLAll;
     DevBuf<unsigned char> nextKind;
     DevBuf<int> flags, curSplatCount, adjacentReject, sampleIdx, numSamples, pushDim;
     DevBuf<unsigned long long> counters, prof;
@@ -153,7 +158,10 @@ struct lmc_ctx {
     DevBuf<DCache> cacheDev;
     DevBuf<int> cacheCounts;                 // rows filled per slot (dims 6, 8, 10, 12)
     DevBuf<unsigned long long> pushTiles;    // scratch of the push launches: one word per 1024 chains
-    CachePushTargets pushT;
+    CachePushTargets pushT;                  // the cache rows themselves
+    CachePushTargets stageT;                 // ... and this rank's stage of a step's pushes (same row layout; kernels.hip k_push_apply)
+    PushStageLayout stageLayout;
+    DevBuf<float> pushStage, pushGather;     // the stage; the stages of all ranks after the exchange
     int *hostCounts = nullptr;               // pinned mirror of cacheCounts
     bool allCachesReady = false;
     int mutationAtInit = -1;  // (mala, h2mc) the resident chain state was laid out for by lmc_chains_init; lmc_chains_step refuses any other
@@ -470,94 +478,249 @@ int lmc_image_write_exr(const char *path, const float *rgb, int w, int h) {
     LMC_CATCH(-1)
 }
 
-int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, int initThreads, int chainBegin, int chainEnd, long long perChain,
-                    long long chainsNeedExtra) {
-    LMC_TRY
-    HIP_CHECK(hipSetDevice(c->device));
-    if (numChainsTotal <= 0 || chainBegin < 0 || chainEnd > numChainsTotal || chainEnd <= chainBegin) throw std::runtime_error("bad chain range");
-    const int V = std::max(1, initThreads);
-    const long long perThread = numInitSamples / V, extra = numInitSamples % V;
-    hipStream_t s = c->stream;
-    // ---- MLTInit pass 1: checkpoints + contribution counts
-    DevBuf<uint64_t> ckState;
-    DevBuf<uint32_t> ckTicks, tab1;
-    DevBuf<unsigned char> count;
-    DevBuf<float> contrib1;
-    ckState.Alloc(numInitSamples), ckTicks.Alloc(numInitSamples), count.Alloc(numInitSamples);
-    tab1.Alloc((size_t)V * 64, false), contrib1.Alloc((size_t)V * MAXCONTRIB * CONTRIB_WORDS, false);
-    LaunchInitPass1(c->S, V, perThread, extra, tab1.p, contrib1.p, ckState.p, ckTicks.p, count.p, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-    std::vector<unsigned char> hCount = count.Download();
-    std::vector<unsigned long long> hOff(numInitSamples);
-    unsigned long long total = 0;
-    for (long long g = 0; g < numInitSamples; g++) {
-        hOff[g] = total;
-        total += hCount[g];
+// ---- multi-GPU: the one data-path collective of the LMC path is a sum of the per-GPU films (SURVEY.md 8e).  RCCL is
+// bound at run time (dlopen) so that single-GPU users and the CPU-side tests do not need it.
+extern "C++" {
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, const void * /* ncclUniqueId by value: 128 bytes, passed in memory */, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;  // (send, recv, sendcount, type, comm, stream)
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct UniqueId {
+    char internal[128];
+};
+Rccl &GetRccl() {
+    static Rccl r;
+    static bool ready = false;  // set only after EVERY required symbol has resolved: a failed first call must not leave a half-filled table behind
+    if (ready) return r;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
     }
-    c->numInitContribs = (long long)total;
-    if ((long long)total < numChainsTotal)
+    if (!h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
+    Rccl t;
+    t.h = h;
+    t.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    t.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    t.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    t.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    t.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!t.GetUniqueId || !dlsym(h, "ncclCommInitRank") || !t.AllReduce || !t.AllGather || !t.CommDestroy) throw std::runtime_error("RCCL symbols missing");
+    r = t;
+    ready = true;
+    return r;
+}
+// ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank): the id struct travels by value
+typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
+void RcclCheck(int rc, const char *what) {
+    if (rc != 0) {
+        Rccl &r = GetRccl();
+        throw std::runtime_error(std::string("RCCL error in ") + what + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+static int GetRcclDestroy(void *comm) { return GetRccl().CommDestroy ? GetRccl().CommDestroy(comm) : 0; }
+
+// ================================================================================================ MLTInit + chain set-up
+// MLTInit (mlt.h:41-154), sharded over the ranks of a job BY INIT STREAM (rank r runs the streams [V r / R, V (r + 1) / R): pass 1,
+// pass 2 and the checkpoints of those streams stay on r), identical to the one-rank result bit for bit:
+//   phase 1  pass 1 on the local streams                        -> exchange: contributions per sample (1 byte each)
+//   phase 2  every rank knows every sample's offset; pass 2 on the local samples
+//                                                               -> exchange: (c,l) and lsScore of every contribution, in stream order
+//   phase 3  every rank runs the SAME sequential float sums and the same equal-spaced CDF walk (mlt.h:107-148) on the host, so
+//            normalization and the seeds agree without further communication; a rank's samples seed a contiguous range of chains
+//                                                               -> exchange: RNG checkpoints of the seeding samples
+//   phase 4  the rank regenerates the init states of ITS chains only and sets its chains up
+// What is exchanged is an all-gather of fixed-size blocks (padded to the largest rank's share): RCCL when the context has a
+// communicator (lmc_comm_init), device copies between the member contexts of an in-process group (lmc_group_*), nothing at all for a
+// single rank.  Init work and the 1.3 KB per chain of init state no longer grow with the number of ranks; what does is 5 bytes per
+// init contribution + 25 bytes per chain of the whole job on the host of every rank.
+extern "C++" {
+namespace {
+struct InitJob {
+    // job
+    long long numInitSamples = 0, perThread = 0, extra = 0, perChain = 0, chainsNeedExtra = 0;
+    int V = 1, numChainsTotal = 0, chainBegin = 0, chainEnd = 0, world = 1, rank = 0;
+    // this rank's share: streams [t0, t1), samples [g0, g1)
+    int t0 = 0, t1 = 0;
+    long long g0 = 0, g1 = 0, maxLocalSamples = 0;
+    DevBuf<uint64_t> ckState;
+    DevBuf<uint32_t> ckTicks;
+    DevBuf<unsigned char> count, gatherCount;
+    // phase 2
+    std::vector<unsigned long long> hOff;  // first contribution of every sample of the JOB (+ total at the end)
+    std::vector<unsigned long long> rankFirst;  // first contribution of every rank's block (+ total)
+    unsigned long long total = 0, o0 = 0, o1 = 0, maxLocalContribs = 0;
+    DevBuf<unsigned char> outCL, gatherCL;
+    DevBuf<float> outLs, gatherLs;
+    // phase 3
+    std::vector<long long> seedSample;  // per chain of the job
+    std::vector<unsigned char> seedCL;
+    std::vector<float> seedLs;
+    std::vector<int> ownedBegin;  // [world + 1]: rank r's samples seed the chains [ownedBegin[r], ownedBegin[r + 1])
+    int maxOwned = 0;
+    DevBuf<uint64_t> sendCk, gatherCk;  // per seeded chain: (state, ticks)
+};
+using lmc::SampleBase;
+
+// recv (on every member) = the members' `bytes` bytes at send, concatenated in rank order
+typedef void *(*BufOf)(lmc_ctx *);
+void AllGatherBlocks(const std::vector<lmc_ctx *> &g, const std::function<void *(lmc_ctx *)> &send, const std::function<void *(lmc_ctx *)> &recv, size_t bytes) {
+    if (bytes == 0) return;
+    if (g.size() == 1 && g[0]->world > 1) {  // one rank of an RCCL job
+        lmc_ctx *c = g[0];
+        HIP_CHECK(hipSetDevice(c->device));
+        RcclCheck(GetRccl().AllGather(send(c), recv(c), bytes, /*ncclUint8*/ 1, c->comm, c->stream), "ncclAllGather");
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return;
+    }
+    for (lmc_ctx *c : g) {  // in-process group (or a single rank): everything the members queued must be there before it is copied
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        for (size_t q = 0; q < g.size(); q++) HIP_CHECK(hipMemcpyAsync((char *)recv(c) + q * bytes, send(g[q]), bytes, hipMemcpyDefault, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+}
+
+void InitPhase1(lmc_ctx *c, InitJob &J) {
+    HIP_CHECK(hipSetDevice(c->device));
+    const lmc::ShardLayout lay = lmc::MakeShardLayout(J.world, J.rank, J.V, J.numInitSamples);
+    J.t0 = lay.t0, J.t1 = lay.t1, J.g0 = lay.g0, J.g1 = lay.g1, J.maxLocalSamples = lay.maxLocalSamples;
+    const size_t nLocal = (size_t)(J.g1 - J.g0), nStreams = (size_t)(J.t1 - J.t0);
+    J.ckState.Alloc(std::max<size_t>(nLocal, 1)), J.ckTicks.Alloc(std::max<size_t>(nLocal, 1));
+    J.count.Alloc((size_t)J.maxLocalSamples), J.gatherCount.Alloc((size_t)J.maxLocalSamples * J.world, false);
+    DevBuf<uint32_t> tab1;
+    DevBuf<float> contrib1;
+    tab1.Alloc(std::max<size_t>(nStreams, 1) * 64, false), contrib1.Alloc(std::max<size_t>(nStreams, 1) * MAXCONTRIB * CONTRIB_WORDS, false);
+    LaunchInitPass1(c->S, J.t0, (int)nStreams, J.perThread, J.extra, J.g0, tab1.p, contrib1.p, J.ckState.p, J.ckTicks.p, J.count.p, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+void InitPhase2(lmc_ctx *c, InitJob &J) {
+    HIP_CHECK(hipSetDevice(c->device));
+    std::vector<unsigned char> padded = J.gatherCount.Download();
+    std::vector<unsigned long long> rankFirst;
+    lmc::AssembleCounts(J.world, J.V, J.numInitSamples, padded.data(), J.maxLocalSamples, J.hOff, rankFirst);
+    const unsigned long long total = J.hOff[J.numInitSamples];
+    J.total = total;
+    J.rankFirst = rankFirst;
+    if ((long long)total < J.numChainsTotal)
         throw std::runtime_error("MLT initialization failed, consider using a larger number of initial samples or smaller number of chains");
-    // ---- pass 2: (c,l,lsScore) of every contribution, in (thread, sample, contribution) order
+    J.o0 = rankFirst[J.rank], J.o1 = rankFirst[J.rank + 1];
+    J.maxLocalContribs = 0;
+    for (int r = 0; r < J.world; r++) J.maxLocalContribs = std::max(J.maxLocalContribs, rankFirst[r + 1] - rankFirst[r]);
+    // pass 2 on the local samples: (c,l,lsScore) of every contribution, in (stream, sample, contribution) order
+    const size_t nLocal = (size_t)(J.g1 - J.g0);
+    std::vector<unsigned long long> rel(std::max<size_t>(nLocal, 1), 0);
+    for (size_t k = 0; k < nLocal; k++) rel[k] = J.hOff[J.g0 + k] - J.o0;
     DevBuf<unsigned long long> dOff;
-    dOff.Upload(hOff);
-    DevBuf<unsigned char> outCL;
-    DevBuf<float> outLs;
-    outCL.Alloc(total), outLs.Alloc(total);
-    const int nSlots = (int)std::min<long long>(numInitSamples, 1 << 18);
+    dOff.Upload(rel);
+    J.outCL.Alloc((size_t)J.maxLocalContribs), J.outLs.Alloc((size_t)J.maxLocalContribs);
+    J.gatherCL.Alloc((size_t)J.maxLocalContribs * J.world, false), J.gatherLs.Alloc((size_t)J.maxLocalContribs * J.world, false);
+    const int nSlots = (int)std::min<long long>(std::max<long long>((long long)nLocal, 1), 1 << 18);
     DevBuf<uint32_t> tab2;
     DevBuf<float> contrib2;
     tab2.Alloc((size_t)nSlots * 64, false), contrib2.Alloc((size_t)nSlots * MAXCONTRIB * CONTRIB_WORDS, false);
-    LaunchInitPass2(c->S, numInitSamples, perThread, extra, nSlots, tab2.p, contrib2.p, ckState.p, ckTicks.p, dOff.p, outCL.p, outLs.p, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-    std::vector<unsigned char> hCL = outCL.Download();
-    std::vector<float> hLs = outLs.Download();
-    c->initCL = hCL, c->initLs = hLs, c->initOffsets = hOff;
-    // ---- equal-spaced seeding (mlt.h:107-148), sequential float arithmetic on the host like the reference
-    float totalScore = 0.f;
-    for (unsigned long long i = 0; i < total; i++) totalScore += hLs[i];
-    std::vector<float> cdf(total + 1);
-    cdf[0] = 0.f;
-    for (unsigned long long i = 0; i < total; i++) cdf[i + 1] = cdf[i] + hLs[i];
-    const float interval = cdf.back() / float(numChainsTotal);
+    LaunchInitPass2(c->S, J.g0, (long long)nLocal, J.perThread, J.extra, nSlots, tab2.p, contrib2.p, J.ckState.p, J.ckTicks.p, dOff.p, J.outCL.p, J.outLs.p, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+void InitPhase3(lmc_ctx *c, InitJob &J) {
+    HIP_CHECK(hipSetDevice(c->device));
+    const unsigned long long total = J.total;
+    // the contributions of the whole job, in stream order
+    std::vector<unsigned char> hCL(total);
+    std::vector<float> hLs(total);
+    {
+        std::vector<unsigned char> pCL = J.gatherCL.Download();
+        std::vector<float> pLs = J.gatherLs.Download();
+        lmc::AssembleBlocks(J.world, J.rankFirst, pCL.data(), J.maxLocalContribs, 1, hCL.data());
+        lmc::AssembleBlocks(J.world, J.rankFirst, pLs.data(), J.maxLocalContribs, sizeof(float), hLs.data());
+    }
+    J.outCL.Free(), J.outLs.Free(), J.gatherCL.Free(), J.gatherLs.Free(), J.gatherCount.Free(), J.count.Free();
+    c->numInitContribs = (long long)total;
+    // ---- equal-spaced seeding (mlt.h:107-148) on RNG rng(mStates.size()) (mlt.h:115): the same walk on every rank
     std::vector<uint32_t> hostTab(64);
     Rng hr;
     hr.tab = hostTab.data();
-    hr.state = PcgSeed((uint64_t)total, hr.tab);  // RNG rng(mStates.size()), mlt.h:115
+    hr.state = PcgSeed((uint64_t)total, hr.tab);
     hr.ticks = 0;
-    float pos = hr.Uniform() * (interval - 0.f) + 0.f;  // uniform_real_distribution<Float>(0, interval)
-    // contribution index -> sample index
-    std::vector<long long> seedSample(numChainsTotal);
-    std::vector<unsigned char> seedCL(numChainsTotal);
-    long long cdfPos = 0, g = 0;
-    for (int i = 0; i < numChainsTotal; i++) {
-        // mlt.h:118-120; the reference's clamp inside the loop never terminates once pos > cdf[size-1]: stop at size-1
-        while (pos > cdf[cdfPos] && cdfPos < (long long)total - 1) cdfPos++;
-        long long m = std::max<long long>(cdfPos - 1, 0);
-        while (g + 1 < numInitSamples && hOff[g + 1] <= (unsigned long long)m) g++;  // monotone: sample owning contribution m
-        while (g > 0 && hOff[g] > (unsigned long long)m) g--;
-        seedSample[i] = g;
-        seedCL[i] = hCL[m];
-        pos += interval;
+    const int NT = J.numChainsTotal;
+    lmc::SeedWalk(J.numInitSamples, NT, J.hOff, hCL.data(), hLs.data(), [](void *r) { return ((Rng *)r)->Uniform(); }, &hr, J.seedSample, J.seedCL, J.seedLs, c->normalization);
+    c->initCL.swap(hCL), c->initLs.swap(hLs);
+    c->initOffsets.assign(J.hOff.begin(), J.hOff.end() - 1);
+    J.ownedBegin = lmc::OwnedRanges(J.world, J.V, J.numInitSamples, J.seedSample);
+    J.maxOwned = 0;
+    for (int r = 0; r < J.world; r++) J.maxOwned = std::max(J.maxOwned, J.ownedBegin[r + 1] - J.ownedBegin[r]);
+    // the checkpoints of the samples of MINE that seed chains, in chain order
+    const int a = J.ownedBegin[J.rank], b = J.ownedBegin[J.rank + 1];
+    std::vector<uint64_t> hState = J.ckState.Download();
+    std::vector<uint32_t> hTicks = J.ckTicks.Download();
+    std::vector<uint64_t> send((size_t)std::max(J.maxOwned, 1) * 2, 0);
+    for (int i = a; i < b; i++) {
+        const long long k = J.seedSample[i] - J.g0;
+        send[(size_t)(i - a) * 2] = hState[k], send[(size_t)(i - a) * 2 + 1] = hTicks[k];
     }
-    c->normalization = totalScore * (1.0f / float(numInitSamples));
-    // ---- regenerate the seed paths into the (global-size) init arrays
+    J.sendCk.Upload(send);
+    J.gatherCk.Alloc((size_t)std::max(J.maxOwned, 1) * 2 * J.world, false);
+    J.ckState.Free(), J.ckTicks.Free();
+}
+
+void InitPhase4(lmc_ctx *c, InitJob &J);
+}  // namespace
+}  // extern "C++"
+
+extern "C++" {
+namespace {
+void InitPhase4(lmc_ctx *c, InitJob &J) {
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int numChainsTotal = J.numChainsTotal, chainBegin = J.chainBegin, chainEnd = J.chainEnd;
+    const long long perChain = J.perChain, chainsNeedExtra = J.chainsNeedExtra;
     c->numChainsTotal = numChainsTotal;
     c->chainBegin = chainBegin;
     c->N = chainEnd - chainBegin;
     c->mutationAtInit = (c->scene->options.mala ? 1 : 0) | (c->scene->options.h2mc ? 2 : 0);
-    const size_t NT = numChainsTotal, N = c->N;
-    c->initPath.Alloc(NT * DPATH_WORDS), c->initContrib.Alloc(NT * CONTRIB_WORDS), c->initScoreSum.Alloc(NT);
+    const size_t N = c->N;
+    // ---- the init states of this rank's chains, regenerated from the checkpoints of their seeding samples (wherever those ran)
     {
+        std::vector<uint64_t> all = J.gatherCk.Download();
+        std::vector<long long> seedSample(N);
+        std::vector<unsigned char> seedCL(N);
+        std::vector<uint64_t> ckS(N);
+        std::vector<uint32_t> ckT(N);
+        int owner = 0;
+        for (size_t k = 0; k < N; k++) {
+            const int i = chainBegin + (int)k;
+            while (i >= J.ownedBegin[owner + 1]) owner++;
+            const size_t at = ((size_t)owner * std::max(J.maxOwned, 1) + (size_t)(i - J.ownedBegin[owner])) * 2;
+            seedSample[k] = J.seedSample[i], seedCL[k] = J.seedCL[i], ckS[k] = all[at], ckT[k] = (uint32_t)all[at + 1];
+        }
         DevBuf<long long> dSeedSample;
         DevBuf<unsigned char> dSeedCL;
-        DevBuf<uint32_t> tab3;
+        DevBuf<uint64_t> dCkS;
+        DevBuf<uint32_t> dCkT, tab3;
         DevBuf<float> contrib3;
-        dSeedSample.Upload(seedSample), dSeedCL.Upload(seedCL);
-        tab3.Alloc(NT * 64, false), contrib3.Alloc(NT * MAXCONTRIB * CONTRIB_WORDS, false);
-        LaunchInitRegen(c->S, numChainsTotal, perThread, extra, dSeedSample.p, dSeedCL.p, tab3.p, contrib3.p, ckState.p, ckTicks.p, c->initPath.p,
-                        c->initContrib.p, c->initScoreSum.p, s);
+        dSeedSample.Upload(seedSample), dSeedCL.Upload(seedCL), dCkS.Upload(ckS), dCkT.Upload(ckT);
+        tab3.Alloc(N * 64, false), contrib3.Alloc(N * MAXCONTRIB * CONTRIB_WORDS, false);
+        c->initPath.Alloc(N * DPATH_WORDS), c->initContrib.Alloc(N * CONTRIB_WORDS), c->initScoreSum.Alloc(N);
+        c->initLsAll.Upload(J.seedLs), c->initCLAll.Upload(J.seedCL);
+        LaunchInitRegen(c->S, (int)N, J.perThread, J.extra, dSeedSample.p, dSeedCL.p, tab3.p, contrib3.p, dCkS.p, dCkT.p, c->initPath.p, c->initContrib.p,
+                        c->initScoreSum.p, s);
         HIP_CHECK(hipStreamSynchronize(s));
     }
+    J.sendCk.Free(), J.gatherCk.Free();
     // ---- chain arrays
     c->rngState.Alloc(N), c->rngTab.Alloc(N * 64, false);
     c->curPath.Alloc(N * DPATH_WORDS), c->pathBuf1.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS), c->gaussian1.Alloc(N * GAUSS_WORDS);
@@ -576,10 +739,10 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     A.pathWeight = c->pathWeight.p, A.lastScoreSum = c->lastScoreSum.p, A.lastScore = c->lastScore.p;
     A.adjacentReject = c->adjacentReject.p, A.sampleIdx = c->sampleIdx.p, A.numSamples = c->numSamples.p;
     A.contribList = c->contribList.p, A.nextKind = c->nextKind.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
-    A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p;
+    A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p, A.initLsAll = c->initLsAll.p, A.initCLAll = c->initCLAll.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p, A.prof = c->prof.p;
     LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
-    LaunchSetupChains(A, chainBegin, numChainsTotal, perChain, chainsNeedExtra, 0, c->normalization, s);
+    LaunchSetupChains(A, chainBegin, perChain, chainsNeedExtra, s);
     // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
     c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
     c->gradStride = c->stepGrid * 256;
@@ -607,6 +770,14 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     }
     c->cacheCounts.Alloc(CACHE_SLOTS), c->pushTiles.Alloc((N + 1023) / 1024);
     if (!c->hostCounts) HIP_CHECK(hipHostMalloc((void **)&c->hostCounts, CACHE_SLOTS * sizeof(int)));
+    c->stageLayout = MakePushStageLayout();
+    c->pushStage.Alloc((size_t)c->stageLayout.totalFloats), c->pushGather.Alloc(c->world > 1 ? (size_t)c->stageLayout.totalFloats * c->world : 1);
+    memset(&c->stageT, 0, sizeof(c->stageT));
+    c->stageT.count = reinterpret_cast<int *>(c->pushStage.p);
+    for (int sl = 0; sl < CACHE_SLOTS; sl++)
+        if (c->cacheDims[6 + 2 * sl].relevant)
+            c->stageT.pss[sl] = c->pushStage.p + c->stageLayout.pss[sl], c->stageT.v1[sl] = c->pushStage.p + c->stageLayout.v1[sl],
+            c->stageT.v2[sl] = c->pushStage.p + c->stageLayout.v2[sl], c->stageT.weight[sl] = c->pushStage.p + c->stageLayout.weight[sl];
     memset(&c->pushT, 0, sizeof(c->pushT));
     c->pushT.count = c->cacheCounts.p;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) {
@@ -633,6 +804,111 @@ int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, in
     LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
     HIP_CHECK(hipStreamSynchronize(s));
+}
+
+
+// the ranks of one job run the four phases in lock step; `g` = the member contexts this process drives (one for an RCCL rank)
+void RunInit(const std::vector<lmc_ctx *> &g, long long numInitSamples, int numChainsTotal, int initThreads, const std::vector<std::pair<int, int>> &ranges,
+             long long perChain, long long chainsNeedExtra) {
+    if (numInitSamples <= 0) throw std::runtime_error("lmc_chains_init: no init samples");
+    std::vector<std::unique_ptr<InitJob>> jobs;
+    for (size_t k = 0; k < g.size(); k++) {
+        lmc_ctx *c = g[k];
+        if (numChainsTotal <= 0 || ranges[k].first < 0 || ranges[k].second > numChainsTotal || ranges[k].second <= ranges[k].first) throw std::runtime_error("bad chain range");
+        std::unique_ptr<InitJob> J(new InitJob);
+        J->V = std::max(1, initThreads);
+        J->numInitSamples = numInitSamples, J->perThread = numInitSamples / J->V, J->extra = numInitSamples % J->V;
+        J->numChainsTotal = numChainsTotal, J->chainBegin = ranges[k].first, J->chainEnd = ranges[k].second, J->perChain = perChain, J->chainsNeedExtra = chainsNeedExtra;
+        J->world = c->world, J->rank = c->rank;
+        jobs.push_back(std::move(J));
+    }
+    auto jobOf = [&](lmc_ctx *c) -> InitJob & {
+        for (size_t k = 0; k < g.size(); k++)
+            if (g[k] == c) return *jobs[k];
+        throw std::runtime_error("internal: context outside its group");
+    };
+    for (size_t k = 0; k < g.size(); k++) InitPhase1(g[k], *jobs[k]);
+    AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).count.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherCount.p; }, (size_t)jobs[0]->maxLocalSamples);
+    for (size_t k = 0; k < g.size(); k++) InitPhase2(g[k], *jobs[k]);
+    AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).outCL.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherCL.p; }, (size_t)jobs[0]->maxLocalContribs);
+    AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).outLs.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherLs.p; }, (size_t)jobs[0]->maxLocalContribs * sizeof(float));
+    for (size_t k = 0; k < g.size(); k++) InitPhase3(g[k], *jobs[k]);
+    AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).sendCk.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherCk.p; }, (size_t)std::max(jobs[0]->maxOwned, 1) * 2 * sizeof(uint64_t));
+    for (size_t k = 0; k < g.size(); k++) InitPhase4(g[k], *jobs[k]);
+}
+}  // namespace
+}  // extern "C++"
+
+int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, int initThreads, int chainBegin, int chainEnd, long long perChain,
+                    long long chainsNeedExtra) {
+    LMC_TRY
+    if (c->group.size() > 1) throw std::runtime_error("lmc_chains_init: this context is a member of an in-process group, use lmc_group_chains_init");
+    RunInit({c}, numInitSamples, numChainsTotal, initThreads, {{chainBegin, chainEnd}}, perChain, chainsNeedExtra);
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// In-process group: the n contexts (one per GPU, or several on one GPU for bring-up and tests) become the ranks 0 .. n-1 of one job; its
+// collectives are device copies between the members.  Chains are split into n contiguous, equal ranges (the last takes the rest).
+int lmc_group_chains_init(lmc_ctx **ctxs, int n, long long numInitSamples, int numChainsTotal, int initThreads, long long perChain, long long chainsNeedExtra) {
+    LMC_TRY
+    if (n < 1) throw std::runtime_error("lmc_group_chains_init: empty group");
+    std::vector<lmc_ctx *> g(ctxs, ctxs + n);
+    std::vector<std::pair<int, int>> ranges;
+    for (int r = 0; r < n; r++) {
+        if (g[r]->comm) throw std::runtime_error("lmc_group_chains_init: a member already belongs to an RCCL job");
+        g[r]->world = n, g[r]->rank = r, g[r]->group = g;
+        ranges.push_back({(int)((long long)numChainsTotal * r / n), (int)((long long)numChainsTotal * (r + 1) / n)});
+    }
+    RunInit(g, numInitSamples, numChainsTotal, initThreads, ranges, perChain, chainsNeedExtra);
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// ---- CPU test hooks (no GPU): the host-side plan of the sharded MLTInit (shardplan.h), from the very blocks the ranks exchange
+int lmc_shard_layout(int world, int rank, int initThreads, long long numInitSamples, long long *out5) {
+    LMC_TRY
+    if (world < 1 || rank < 0 || rank >= world || initThreads < 1) throw std::runtime_error("lmc_shard_layout: bad arguments");
+    const lmc::ShardLayout L = lmc::MakeShardLayout(world, rank, initThreads, numInitSamples);
+    out5[0] = L.t0, out5[1] = L.t1, out5[2] = L.g0, out5[3] = L.g1, out5[4] = L.maxLocalSamples;
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_shard_counts_probe(int world, int initThreads, long long numInitSamples, const unsigned char *paddedCounts, long long maxLocalSamples,
+                           unsigned long long *rankFirst) {
+    LMC_TRY
+    std::vector<unsigned long long> hOff, rf;
+    lmc::AssembleCounts(world, initThreads, numInitSamples, paddedCounts, maxLocalSamples, hOff, rf);
+    for (int r = 0; r <= world; r++) rankFirst[r] = rf[r];
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_shard_plan_probe(int world, int initThreads, long long numInitSamples, int numChainsTotal, const unsigned char *paddedCounts, long long maxLocalSamples,
+                         const unsigned char *paddedCL, const float *paddedLs, long long maxLocalContribs, long long *seedSample, unsigned char *seedCL,
+                         float *seedLs, int *ownedBegin, float *normalization) {
+    LMC_TRY
+    std::vector<unsigned long long> hOff, rf;
+    lmc::AssembleCounts(world, initThreads, numInitSamples, paddedCounts, maxLocalSamples, hOff, rf);
+    const unsigned long long total = rf[world];
+    if ((long long)total < numChainsTotal) throw std::runtime_error("MLT initialization failed, consider using a larger number of initial samples or smaller number of chains");
+    std::vector<unsigned char> cl(total);
+    std::vector<float> ls(total);
+    lmc::AssembleBlocks(world, rf, paddedCL, (unsigned long long)maxLocalContribs, 1, cl.data());
+    lmc::AssembleBlocks(world, rf, paddedLs, (unsigned long long)maxLocalContribs, sizeof(float), ls.data());
+    std::vector<uint32_t> hostTab(64);
+    Rng hr;
+    hr.tab = hostTab.data();
+    hr.state = PcgSeed((uint64_t)total, hr.tab);
+    hr.ticks = 0;
+    std::vector<long long> ss;
+    std::vector<unsigned char> sc;
+    std::vector<float> sl;
+    float norm = 0.f;
+    lmc::SeedWalk(numInitSamples, numChainsTotal, hOff, cl.data(), ls.data(), [](void *r) { return ((Rng *)r)->Uniform(); }, &hr, ss, sc, sl, norm);
+    const std::vector<int> ob = lmc::OwnedRanges(world, initThreads, numInitSamples, ss);
+    for (int i = 0; i < numChainsTotal; i++) seedSample[i] = ss[i], seedCL[i] = sc[i], seedLs[i] = sl[i];
+    for (int r = 0; r <= world; r++) ownedBegin[r] = ob[r];
+    *normalization = norm;
     return 0;
     LMC_CATCH(-1)
 }
@@ -664,8 +940,14 @@ static unsigned LeanDims(const lmc_ctx *c) {
         if (c->cacheDims[d].ready && !c->cacheHost.d[d].deep) m |= 1u << d;
     return m;
 }
-static void MaintainCache(lmc_ctx *c) {
-    hipStream_t s = c->stream;
+// The fill side of the global cache after a step, in three parts so that the ranks of a job can exchange their pushes in between:
+//   CachePack     the step's pushes of THIS rank's chains, in chain order, into the rank's stage (kernels.hip k_push_*)
+//   (exchange)    all-gather of the stages: RCCL, device copies inside an in-process group, nothing for a single rank
+//   CacheApply    the gathered rows appended in rank order = global chain-id order (k_push_apply), fill counts read back, the kd-tree
+//                 and the existence grid of a dim that has just reached PSS_MAX_SIZE built (global_cache.h:85-92), so that the next
+//                 step already queries it -- the lock-step contract the oracle implements too
+// Every rank applies the same rows to the same cache, so "which dims are ready" is the same on all of them without asking.
+static bool CachePending(lmc_ctx *c) {
     bool anyPending = false;
     for (int d = 6; d <= PSS_MAX_LENGTH; d += 2) anyPending = anyPending || (c->cacheDims[d].relevant && !c->cacheDims[d].ready);
     if (!anyPending) {
@@ -673,9 +955,18 @@ static void MaintainCache(lmc_ctx *c) {
         bool anyDeep = false;
         for (int d = 2; d <= PSS_MAX_LENGTH; d++) anyDeep = anyDeep || (c->cacheDims[d].ready && c->cacheHost.d[d].deep);
         c->needGeneric = anyDeep;
-        return;
     }
-    LaunchCachePush(c->A, c->pushT, c->pushTiles.p, s);
+    return anyPending;
+}
+static void CachePack(lmc_ctx *c) {
+    hipStream_t s = c->stream;
+    HIP_CHECK(hipMemsetAsync(c->pushStage.p, 0, 16 * sizeof(float), s));  // the stage's row counts
+    LaunchCachePush(c->A, c->stageT, c->pushTiles.p, s);
+}
+static void CacheApply(lmc_ctx *c) {
+    hipStream_t s = c->stream;
+    const float *gathered = c->world > 1 ? c->pushGather.p : c->pushStage.p;
+    LaunchCachePushApply(gathered, (size_t)c->stageLayout.totalFloats, c->world, c->stageLayout, c->pushT, s);
     HIP_CHECK(hipMemcpyAsync(c->hostCounts, c->cacheCounts.p, CACHE_SLOTS * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     bool changed = false;
@@ -704,80 +995,127 @@ static void MaintainCache(lmc_ctx *c) {
     if (changed) UploadCacheStruct(c);
 }
 
-int lmc_chains_step(lmc_ctx *c, int nSteps) {
-    LMC_TRY
-    HIP_CHECK(hipSetDevice(c->device));
+extern "C++" {
+namespace {
+void CheckSteppable(lmc_ctx *c) {
     if (c->N <= 0) throw std::runtime_error("lmc_chains_step before lmc_chains_init");
     // the chain state (H2MC Gaussian buffers, cache bookkeeping, work lists) is laid out for the mutation in force at init
     if (c->mutationAtInit != ((c->scene->options.mala ? 1 : 0) | (c->scene->options.h2mc ? 2 : 0)))
         throw std::runtime_error("the 'mala' / 'h2mc' options changed after lmc_chains_init: initialise the chains again before stepping");
+}
+// first half of one step: the three step launches; then, while a cache is filling, this rank's pushes into its stage.
+// Returns whether the ranks have pushes to exchange.
+bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
+    HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->filmReduced = false;
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
     StepParams P;
     P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
-    for (int it = 0; it < nSteps; it++) {
-        lmc_ctx::StepEvents ev;
-        if (c->timing) {
-            if (c->eventPool.empty()) {
-                for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
-            } else {
-                ev = c->eventPool.back();
-                c->eventPool.pop_back();
-            }
-            HIP_CHECK(hipEventRecord(ev.e[0], s));
+    if (c->timing) {
+        if (c->eventPool.empty()) {
+            for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
+        } else {
+            ev = c->eventPool.back();
+            c->eventPool.pop_back();
         }
-        const int cur = c->parity, nxt = 1 - c->parity;
-        NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
-        HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
-        const int *cnt = c->listCounts[cur].p;
-        hipStream_t sL = c->overlap ? c->sideStream[0] : s, sG = c->overlap ? c->sideStream[1] : s;
-        if (c->overlap) {
-            HIP_CHECK(hipEventRecord(c->forkEvent, s));
-            HIP_CHECK(hipStreamWaitEvent(sL, c->forkEvent, 0));
-            if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
-        }
-        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
-        LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
-        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
-        // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
-        // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
-        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
-        if (c->needGeneric && c->S.opt.h2mc)
-            LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
-        else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && c->bvhDepth <= BVH_LDS_STACK)
-            LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, sG);
-        else if (c->needGeneric)
-            LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
-        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
-        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
-        LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
-        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));
-        if (c->overlap) {
-            HIP_CHECK(hipEventRecord(c->joinEvent[0], sL));
-            HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[0], 0));
-            if (c->needGeneric) {
-                HIP_CHECK(hipEventRecord(c->joinEvent[1], sG));
-                HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[1], 0));
-            }
-        }
-        // a cache that becomes ready at the end of this step (mlt.cpp: push() flips is_ready inside the step) is seen by the
-        // list build: chains whose next step no longer needs a gradient go to the lean launch right away
-        if (!c->allCachesReady) MaintainCache(c);
-        LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c), s);
-        // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
-        // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
-        if (c->needGeneric && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
-            LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
-            std::swap(c->lists[nxt][1].p, c->listScratch.p);
-        }
-        c->parity = nxt;
-        if (c->timing) {
-            HIP_CHECK(hipEventRecord(ev.e[3], s));
-            c->events.push_back(ev);
+        HIP_CHECK(hipEventRecord(ev.e[0], s));
+    }
+    const int cur = c->parity, nxt = 1 - c->parity;
+    NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
+    HIP_CHECK(hipMemsetAsync(c->listCounts[nxt].p, 0, 4 * sizeof(int), s));
+    const int *cnt = c->listCounts[cur].p;
+    hipStream_t sL = c->overlap ? c->sideStream[0] : s, sG = c->overlap ? c->sideStream[1] : s;
+    if (c->overlap) {
+        HIP_CHECK(hipEventRecord(c->forkEvent, s));
+        HIP_CHECK(hipStreamWaitEvent(sL, c->forkEvent, 0));
+        if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
+    }
+    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
+    LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
+    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
+    // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
+    // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
+    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
+    if (c->needGeneric && c->S.opt.h2mc)
+        LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
+    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && c->bvhDepth <= BVH_LDS_STACK)
+        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, sG);
+    else if (c->needGeneric)
+        LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
+    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
+    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
+    LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
+    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));
+    if (c->overlap) {
+        HIP_CHECK(hipEventRecord(c->joinEvent[0], sL));
+        HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[0], 0));
+        if (c->needGeneric) {
+            HIP_CHECK(hipEventRecord(c->joinEvent[1], sG));
+            HIP_CHECK(hipStreamWaitEvent(s, c->joinEvent[1], 0));
         }
     }
-    HIP_CHECK(hipGetLastError());
+    const bool exchange = !c->allCachesReady && CachePending(c);
+    if (exchange) CachePack(c);
+    return exchange;
+}
+// second half: the gathered pushes applied (a cache that becomes ready at the end of this step -- mlt.cpp: push() flips is_ready
+// inside the step -- is seen by the list build: chains whose next step no longer needs a gradient go to the lean launch right
+// away), then the work lists of the next step
+void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int nxt = 1 - c->parity;
+    NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
+    if (exchanged) CacheApply(c);
+    LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c), s);
+    // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
+    // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
+    if (c->needGeneric && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
+        LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
+        std::swap(c->lists[nxt][1].p, c->listScratch.p);
+    }
+    c->parity = nxt;
+    if (c->timing) {
+        HIP_CHECK(hipEventRecord(ev.e[3], s));
+        c->events.push_back(ev);
+    }
+}
+void RunSteps(const std::vector<lmc_ctx *> &g, int nSteps) {
+    for (lmc_ctx *c : g) CheckSteppable(c);
+    std::vector<lmc_ctx::StepEvents> ev(g.size());
+    for (int it = 0; it < nSteps; it++) {
+        bool exchange = false;
+        for (size_t k = 0; k < g.size(); k++) {
+            const bool e = StepPhase1(g[k], ev[k]);
+            if (k > 0 && e != exchange) throw std::runtime_error("internal: the ranks of a job disagree on the state of the global cache");
+            exchange = e;
+        }
+        if (exchange && g[0]->world > 1)
+            AllGatherBlocks(g, [](lmc_ctx *c) { return (void *)c->pushStage.p; }, [](lmc_ctx *c) { return (void *)c->pushGather.p; }, (size_t)g[0]->stageLayout.totalFloats * sizeof(float));
+        for (size_t k = 0; k < g.size(); k++) StepPhase2(g[k], ev[k], exchange);
+    }
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipGetLastError());
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+int lmc_chains_step(lmc_ctx *c, int nSteps) {
+    LMC_TRY
+    if (c->group.size() > 1) throw std::runtime_error("lmc_chains_step: this context is a member of an in-process group, use lmc_group_chains_step");
+    RunSteps({c}, nSteps);
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_group_chains_step(lmc_ctx **ctxs, int n, int nSteps) {
+    LMC_TRY
+    std::vector<lmc_ctx *> g(ctxs, ctxs + n);
+    for (lmc_ctx *c : g)
+        if (c->group != g) throw std::runtime_error("lmc_group_chains_step: not the group lmc_group_chains_init set up");
+    RunSteps(g, nSteps);
     return 0;
     LMC_CATCH(-1)
 }
@@ -915,56 +1253,6 @@ int lmc_direct_read(lmc_ctx *c, float *rgb) {
     LMC_CATCH(-1)
 }
 
-// ---- multi-GPU: the one data-path collective of the LMC path is a sum of the per-GPU films (SURVEY.md 8e).  RCCL is
-// bound at run time (dlopen) so that single-GPU users and the CPU-side tests do not need it.
-extern "C++" {
-namespace {
-struct Rccl {
-    void *h = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, const void * /* ncclUniqueId by value: 128 bytes, passed in memory */, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;  // (send, recv, sendcount, type, comm, stream)
-    int (*CommDestroy)(void *) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-};
-struct UniqueId {
-    char internal[128];
-};
-Rccl &GetRccl() {
-    static Rccl r;
-    static bool ready = false;  // set only after EVERY required symbol has resolved: a failed first call must not leave a half-filled table behind
-    if (ready) return r;
-    void *h = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
-    }
-    if (!h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
-    Rccl t;
-    t.h = h;
-    t.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-    t.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
-    t.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
-    t.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-    t.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!t.GetUniqueId || !dlsym(h, "ncclCommInitRank") || !t.AllReduce || !t.AllGather || !t.CommDestroy) throw std::runtime_error("RCCL symbols missing");
-    r = t;
-    ready = true;
-    return r;
-}
-// ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank): the id struct travels by value
-typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
-void RcclCheck(int rc, const char *what) {
-    if (rc != 0) {
-        Rccl &r = GetRccl();
-        throw std::runtime_error(std::string("RCCL error in ") + what + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
-    }
-}
-}  // namespace
-}  // extern "C++"
-
-static int GetRcclDestroy(void *comm) { return GetRccl().CommDestroy ? GetRccl().CommDestroy(comm) : 0; }
 
 int lmc_comm_unique_id(unsigned char *out128) {
     LMC_TRY
@@ -984,6 +1272,7 @@ int lmc_comm_init(lmc_ctx *c, int nranks, int rank, const unsigned char *id128) 
     memcpy(id.internal, id128, 128);
     CommInitRankFn init = (CommInitRankFn)dlsym(GetRccl().h, "ncclCommInitRank");
     RcclCheck(init(&c->comm, nranks, id, rank), "ncclCommInitRank");
+    c->world = nranks, c->rank = rank;
     return 0;
     LMC_CATCH(-1)
 }
@@ -1033,7 +1322,7 @@ int lmc_stats(lmc_ctx *c, long long *out8, double *weightSum) {
 int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
     LMC_TRY
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    const size_t N = which == 0 ? c->N : c->numChainsTotal;
+    const size_t N = c->N;  // current states and init states of THIS rank's chains (the init arrays are per rank since round 3)
     std::vector<float> path = (which == 0 ? c->curPath : c->initPath).Download();
     std::vector<float> path1;
     if (which == 0) path1 = c->pathBuf1.Download();

@@ -154,7 +154,7 @@ def test_door_init_contributions_per_sample():
     dg, ng = dump(p.lib().lmc_init_contribs, ren.h)
     orc.close()
     ren.close()
-    assert no > 20000 and abs(no - ng) <= 0.01 * no
+    assert no > 8000 and abs(no - ng) <= 0.01 * no  # about one contribution per three init samples on this scene
     same_cl = same_all = 0
     for k in range(ninit):
         a, b = do.get(k, []), dg.get(k, [])

