@@ -161,6 +161,8 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
 int lmc_lower_bound_probe(int n, const float *cdf, int nq, const float *u, int *out);
 /* measurement aid: ms per launch of a kernel that streams `words` state words per chain in batches of `batch` loads; mode 0 = [word][chain], 1 = [tile of 64][word][lane] */
 int lmc_layout_probe(int nChains, int words, int mode, int batch, int reps, double *msPerLaunch);
+/* parity probe: the deterministic float exp (mode 0) / log (1) / pow (2) of the glossy BSDFs (device/dtrans.h) evaluated on the device */
+int lmc_trans_probe(int n, int mode, const float *x, const float *y, float *out);
 /* measurement hook (LMC_PROF=1): wave cycles per region of the lean small-step kernel since the last call: out16[0 .. LMC_PROF_REGIONS-1]
  * = cycle sums of the regions (dsmall.h PR_*), out16[LMC_PROF_REGIONS] = number of waves */
 #define LMC_PROF_REGIONS 15

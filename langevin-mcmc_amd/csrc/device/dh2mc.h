@@ -20,9 +20,9 @@ LMC_HD H2MCParam MakeH2MCParam(float sigma) {  // h2mc.h:10-16, L = pi/2
     H2MCParam p;
     p.sigma = sigma;
     p.L = float(3.14159265358979323846 / 2.0);
-    // exp / sin / cos / log of this file are evaluated in double and rounded once (dmath.h: expd, logd), so that the CPU oracle and
-    // the device agree to the bit; the reference's float libm calls are within one ulp of these
-    const float eL = expd(p.L), emL = expd(-p.L);
+    // exp / log of this file are the deterministic float routines of dtrans.h (the CPU oracle and the device agree to the bit; the
+    // reference's float libm calls are within 1-2 ulp of these); sin / cos of the one constant L in double, rounded once
+    const float eL = lexpf(p.L), emL = lexpf(-p.L);
     p.posScaleFactor = 0.5f * (eL - emL) * 0.5f * (eL - emL);
     p.posOffsetFactor = 0.5f * (eL + emL - 1.0f);
     const float sL = (float)sin((double)p.L), cL = (float)cos((double)p.L);
@@ -107,7 +107,7 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
             for (int j = 0; j < n; j++) covL[i * n + j] = (i == j) ? sigma : 0.f, invCov[i * n + j] = (i == j) ? invSigmaSq : 0.f;
         }
         logDet = 0.f;
-        for (int i = 0; i < n; i++) logDet += logd(invSigmaSq);
+        for (int i = 0; i < n; i++) logDet += llogf(invSigmaSq);
         return;
     }
     float *A = hess, *V = work, *w = work + n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
@@ -150,7 +150,7 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
         }
     }
     logDet = 0.f;
-    for (int i = 0; i < n; i++) logDet += logd(post[i]);
+    for (int i = 0; i < n; i++) logDet += llogf(post[i]);
 }
 
 // gaussian.cpp:24-36 / :38-55, dense branch

@@ -31,8 +31,17 @@ template <class In>
 #ifndef LMC_PF_ATTR
 #define LMC_PF_ATTR
 #endif
+__device__ __noinline__ LMC_PF_ATTR void PathFuncHessPassDevice(int c, int l, const float *primary, const float *scene, const In &vp, int i, int c0, float *logLum,
+                                                                float *grad, float *hess) {
+    PathFuncHessPass(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+}
+// all passes: ONE copy of the second-order program per kernel image (the single-call plugin kernel runs the passes side by side, one
+// per lane, through the same copy)
+template <class In>
 __device__ __noinline__ LMC_PF_ATTR void PathFuncHessDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
-    PathFuncHess(c, l, primary, scene, vp, logLum, grad, hess);
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    for (int i = 0; i < dim; i++)
+        for (int c0 = 0; c0 < dim; c0 += HC) PathFuncHessPassDevice(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
 }
 #endif
 

@@ -16,6 +16,8 @@
 #include <cstring>
 #include <cstddef>
 
+#include "dtrans.h"
+
 namespace lmcd {
 #if !defined(__HIPCC__)
 using std::isfinite;
@@ -123,21 +125,10 @@ LMC_HD float fastpow2(float p) {
 }
 LMC_HD float fastpow(float x, float p) { return fastpow2(p * fastlog2(x)); }
 
-// pow / exp / log of the Phong and rough-dielectric code (phong.cpp:42,109, microfacet.h:17,173): evaluated in double and
-// rounded once to float, on the device, in the CPU oracle and in the host build of the path program alike.  The
-// reference calls libm's float versions, whose last bit differs between libm builds (and from the device libm); a
-// correctly rounded value is within that spread and makes the Russian-roulette / rejection decisions downstream of a
-// glossy vertex reproducible between CPU and GPU.
-#ifdef LMC_EXP_FLOAT_TRANSCENDENTALS  // measurement aid only: what the double evaluation costs (breaks bit-parity with the oracle)
-LMC_HD float powd(float a, float e) { return powf(a, e); }
-LMC_HD float expd(float x) { return expf(x); }
-LMC_HD float logd(float x) { return logf(x); }
-#else
-LMC_HD float powd(float a, float e) { return (float)pow((double)a, (double)e); }
-LMC_HD float expd(float x) { return (float)exp((double)x); }
-LMC_HD float logd(float x) { return (float)log((double)x); }
-#endif
-
+// pow / exp / log of the Phong and rough-dielectric code (phong.cpp:42,109, microfacet.h:17,173) and of the H2MC Gaussian: the
+// deterministic float routines of dtrans.h (lpowf / lexpf / llogf), the same source on the device, in the CPU oracle and in the host
+// build of the path program -- bit-equal by construction, within 1-2 ulp of the reference's libm calls (whose last bit differs
+// between libm builds anyway).  Rounds 1-2 evaluated them in double and rounded once: 26 % of a full-material step.
 // utils.h:197-210
 LMC_HD V3 Reflect(V3 wi, V3 n) { return (2.0f * Dot(wi, n)) * n - wi; }
 LMC_HD V3 Refract(V3 wi, V3 n, float cosThetaT, float eta, float invEta) {

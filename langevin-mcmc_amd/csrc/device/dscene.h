@@ -160,7 +160,10 @@ static_assert(LMC_BVH_LDS_TOP <= BVH_TOP_NODES, "the host only guarantees breadt
 constexpr int BVH_LDS_NODE_QUADS = 9;
 
 constexpr int BVH_STACK = 64;      // host-checked bound on the LBVH depth
-constexpr int BVH_LDS_STACK = 32;  // entries of the per-thread LDS stack (the host refuses deeper trees for LDS kernels)
+// entries of the per-thread LDS stack (the host routes deeper trees to the private-memory instantiations).  40: the four-wide tree of the
+// veach-door scene needs 37 (tests/helpers/bvh_stats.cpp); with 32 that scene ran every launch on its scratch-stack fallback
+// (profiles/r03_e_door_kernel_stats.csv: large steps 11.9 ms, lean 4.5 ms, the cache-filling launch on the round-1 generic kernel)
+constexpr int BVH_LDS_STACK = 40;
 
 // Traversal stack policies.  Private arrays indexed at run time live in scratch memory, which on gfx950 is HBM-backed
 // and was the bottleneck of the first version of the step kernel (profiles/r01_a_*): the hot kernels keep the stack

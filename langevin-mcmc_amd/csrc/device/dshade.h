@@ -107,7 +107,7 @@ LMC_D float BeckmennDistributionTerm(V3 localH, float alphaU, float alphaV) {
     const float cosTheta = localH.z, mu = localH.x, mv = localH.y;
     const float cosTheta2 = square(cosTheta);
     const float beckmannExponent = (square(mu) / square(alphaU) + square(mv) / square(alphaV)) / cosTheta2;
-    return expd(-beckmannExponent) / (c_PI * alphaU * alphaV * square(cosTheta2));
+    return lexpf(-beckmannExponent) / (c_PI * alphaU * alphaV * square(cosTheta2));
 }
 LMC_D float BeckmennGeometryTerm1(float alpha, float cosTheta) {
     const float tanTheta = sqrtf(fabsf(1.0f - square(cosTheta))) / cosTheta;
@@ -136,7 +136,7 @@ LMC_D V3 SampleMicronormal(V2 rndParam, float alpha, float &pdfW) {
     const float phiM = c_TWOPI * rndParam.y;
     const float sinPhiM = lsinf(phiM), cosPhiM = lcosf(phiM);
     const float alphaSqr = square(alpha);
-    const float tanThetaMSqr = alphaSqr * (-logd(fmaxf(1.0f - rndParam.x, 1e-6f)));
+    const float tanThetaMSqr = alphaSqr * (-llogf(fmaxf(1.0f - rndParam.x, 1e-6f)));
     const float cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
     const float cosThetaMSqr = square(cosThetaM);
     pdfW = (1.0f - rndParam.x) / (c_PI * alphaSqr * cosThetaM * cosThetaMSqr);
@@ -202,7 +202,7 @@ LMC_D void PhongEvaluate(const DScene &S, const DMaterial &m, V3 wi, V3 normal, 
     if (KsWeight > 0.0f) {
         const float alpha = fmaxf(Dot(Reflect(wi, normal_), wo), 0.0f);
         const float expo = EvalTex(S, m.expOrAlpha, st).x;
-        const float weight = powd(alpha, expo) * c_INVTWOPI;
+        const float weight = lpowf(alpha, expo) * c_INVTWOPI;
         const float expoConst1 = (expo + 1.0f);
         const float expoConst2 = (expo + 2.0f);
         if (weight > 1e-10f) {
@@ -248,7 +248,7 @@ LMC_D bool PhongSample(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V2
         rndParam0 = uDiscrete / (KsWeight + 1e-10f);
     }
     const float power = 1.0f / (g + 1.0f);
-    const float cosAlpha = powd(rndParam.y, power);
+    const float cosAlpha = lpowf(rndParam.y, power);
     const float sinAlpha = sqrtf(1.0f - square(cosAlpha));
     const float phi = c_TWOPI * rndParam0;
     const V3 localDir{sinAlpha * lcosf(phi), sinAlpha * lsinf(phi), cosAlpha};
@@ -261,7 +261,7 @@ LMC_D bool PhongSample(const DScene &S, const DMaterial &m, V3 wi, V3 normal, V2
     pdf = 0.0f;
     if (KsWeight > 0.0f) {
         const float alpha = fmaxf(Dot(R, wo), 0.0f);
-        const float weight = powd(alpha, expo) * c_INVTWOPI;
+        const float weight = lpowf(alpha, expo) * c_INVTWOPI;
         const float expoConst1 = (expo + 1.0f);
         const float expoConst2 = (expo + 2.0f);
         if (weight > 1e-10f) {

@@ -29,23 +29,28 @@ namespace lmcd {
 // PSS_MAX_LENGTH always get IsotropicGaussian(malaStdDev), which needs no per-dimension storage at all.
 constexpr int MD = PSS_MAX_LENGTH;
 
-// LDS words per thread (56 = 224 B; 14 KB per wave, 11 waves per CU):
-//   [0, 32)   the BVH stack; between traversals the clipped gradient of the cache-filling launch (dim <= MD words)
-//   [32, 44)  the proposal offsets of a state with dim <= MD
-//   [44, 56)  its new primary-sample vector
-//   [32, 56)  the offsets of a state with dim > MD (up to 2 * MAXD): such a state is never looked up, it has no Q
+// LDS words per thread, S = the launch's BVH stack entries (the scene's stack need rounded up to 8, at least 32, at most
+// BVH_LDS_STACK: 32 for the torus = 56 words = 14 KB per wave, 11 waves per CU; 40 for the veach-door scene):
+//   [0, S)          the BVH stack; between traversals the staged Gaussian / moment vectors / clipped gradient (2 MD <= 32 words)
+//   [S, S + 12)     the proposal offsets of a state with dim <= MD
+//   [S + 12, S + 24) its new primary-sample vector
+//   [S, S + 24)     the offsets of a state with dim > MD (up to 2 * MAXD): such a state is never looked up, it has no Q
 // The kd-tree search frames used to live here too (80 words, 8 waves per CU).  Since the existence test (dchain.h) the search
 // runs for 0.015 % of the queries: it now keeps its frames in private memory, out of line (KdRadiusSearchRare).
-constexpr int LDS_OFF_SHORT = BVH_LDS_STACK, LDS_OFF_LONG = BVH_LDS_STACK;
-constexpr int LDS_Q_WORD = LDS_OFF_SHORT + MD;
-constexpr int LDS_WORDS_PER_THREAD = LDS_OFF_LONG + MAXPSS;  // 56
-static_assert(LDS_Q_WORD + MD <= LDS_WORDS_PER_THREAD, "short states: offsets + new pss fit the region of the long offsets");
+constexpr int LDS_MIN_STACK_WORDS = 32;
+static_assert(2 * MD <= LDS_MIN_STACK_WORDS, "the staging words live in the (idle) stack region");
+LMC_HD int LeanStackWords(int bvhStackNeed) {
+    const int w = (bvhStackNeed + 7) / 8 * 8;
+    return w < LDS_MIN_STACK_WORDS ? LDS_MIN_STACK_WORDS : w;
+}
+LMC_HD int LeanLdsWordsPerThread(int stackWords) { return stackWords + MAXPSS; }
 
 struct LdsView {
     float *base;  // &lds[threadIdx.x]
     int stride;   // blockDim.x
-    LMC_D float &U(int w) const { return base[w * stride]; }                // any word
-    LMC_D float &Q(int k) const { return base[(LDS_Q_WORD + k) * stride]; }  // new pss
+    int off;      // first word behind the BVH stack (= the launch's stack entries)
+    LMC_D float &U(int w) const { return base[w * stride]; }                  // any word
+    LMC_D float &Q(int k) const { return base[(off + MD + k) * stride]; }      // new pss
 };
 
 // word offsets inside the SoA path record (DPath layout)
@@ -341,7 +346,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     const int dim = PathDimension(c, l);
     const int camCount = max(c - 1, 0), lgtCount = max(l - 1, 0);
     const bool shortState = dim <= MD;  // may carry a stored Gaussian / be looked up in the cache
-    const int offBase = shortState ? LDS_OFF_SHORT : LDS_OFF_LONG;
+    const int offBase = L.off;
     const DCacheDim &C = cache.d[shortState ? dim : 0];
     st.steps++;
     st.lean++;

@@ -8,6 +8,10 @@
 void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s);
 void LaunchLowerBoundProbe(int n, const float *cdf, int nq, const float *u, int *out, hipStream_t s);
 void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, uint32_t *tabScratch, uint32_t *out, hipStream_t s);
+// single-call form of the plugin symbols (plugin.hip, step_small_h2mc.hip): in / out are device-visible pointers of host-mapped pinned buffers
+void LaunchPluginGrad(int c, int l, const float *in, float *out, int wantGrad, hipStream_t s);
+void LaunchPluginHess(int c, int l, const float *in, float *stage /* 655 floats of device memory */, float *out, hipStream_t s);
+void LaunchTransProbe(int n, int mode, const float *x, const float *y, float *o, hipStream_t s);
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s);
 void LaunchTrace(const lmcd::DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s);
 void LaunchKdProbe(const lmcd::DCacheDim &C, int dim, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist, hipStream_t s);
@@ -37,7 +41,8 @@ void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list,
-                             const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, hipStream_t s);
+                             const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, int bvhStackNeed,
+                             hipStream_t s);
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                           const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads,
                           bool profile, hipStream_t s);

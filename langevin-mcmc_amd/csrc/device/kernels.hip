@@ -52,6 +52,11 @@ __global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mod
 
 // ---------------------------------------------------------------------------------------------- probes
 // counter calibration: the chain state's access pattern (one dword per lane, unit stride) over a known byte count
+// parity probe of the deterministic float transcendentals (dtrans.h): mode 0 exp, 1 log, 2 pow
+__global__ void k_trans_probe(int n, int mode, const float *x, const float *y, float *o) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = mode == 0 ? lexpf(x[i]) : mode == 1 ? llogf(x[i]) : lpowf(x[i], y[i]);
+}
+
 __global__ void k_stream_probe(long long n, const float *in, float *out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = in[i] + 1.0f;
 }
@@ -841,6 +846,9 @@ void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, 
     hipLaunchKernelGGL(k_push_apply_finish, dim3(1), dim3(64), 0, s, gathered, stageFloats, world, T);
 }
 
+void LaunchTransProbe(int n, int mode, const float *x, const float *y, float *o, hipStream_t s) {
+    hipLaunchKernelGGL(k_trans_probe, dim3(GridFor(n, 256)), dim3(256), 0, s, n, mode, x, y, o);
+}
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }

@@ -143,10 +143,10 @@ LMC_HD float Fabs(float x) { return fabsf(x); }
 LMC_HD float Log(float x) { return logf(x); }
 LMC_HD float Exp(float x) { return expf(x); }
 LMC_HD float Fmax(float a, float b) { return fmaxf(a, b); }
-LMC_HD float Pow(float a, float e) { return powd(a, e); }
-LMC_HD float PowRaw(float a, float e) { return powf(a, e); }  // the derivative factor of Pow (chad.h:727 emits pow(x, e - 1))
-LMC_HD float ExpD(float x) { return expd(x); }
-LMC_HD float LogD(float x) { return logd(x); }
+LMC_HD float Pow(float a, float e) { return lpowf(a, e); }
+LMC_HD float PowRaw(float a, float e) { return lpowf(a, e); }  // the derivative factor of Pow (chad.h:727 emits pow(x, e - 1))
+LMC_HD float ExpD(float x) { return lexpf(x); }
+LMC_HD float LogD(float x) { return llogf(x); }
 LMC_DUAL_T Sqrt(const DualS<N, S> &a) { S s = Sqrt(a.v); return Chain1(a, s, S(0.5f / s)); }
 LMC_DUAL_T Sin(const DualS<N, S> &a) { return Chain1(a, S(Sin(a.v)), S(Cos(a.v))); }
 LMC_DUAL_T Cos(const DualS<N, S> &a) { return Chain1(a, S(Cos(a.v)), S(-Sin(a.v))); }
@@ -1028,24 +1028,28 @@ LMC_HD void PathFuncGrad(int c, int l, const float *primary, const float *scene,
 #define LMC_HESS_CHUNK 8
 #endif
 constexpr int HC = LMC_HESS_CHUNK;
+// one pass: row i, columns [c0, c0 + HC)
+template <class In>
+LMC_HD void PathFuncHessPass(int c, int l, const float *primary, const float *scene, const In &vp, int i, int c0, float *logLum, float *grad, float *hess) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    typedef DualS<1, Dual<HC>> T2;
+    T2 p[2 * 8 + 1];
+    p[0] = Lift<T2>::Of(primary[0]);
+    for (int k = 0; k < dim; k++) {
+        p[k + 1] = Lift<T2>::Of(primary[k + 1]);
+        if (k >= c0 && k < c0 + HC) p[k + 1].v.d[k - c0] = 1.0f;
+        if (k == i) p[k + 1].d[0].v = 1.0f;
+    }
+    T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
+    if (i == 0 && c0 == 0 && logLum) *logLum = r.v.v;
+    if (c0 == 0 && grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
+    for (int k = c0; k < dim && k < c0 + HC; k++) hess[i * dim + k] = r.d[0].d[k - c0];
+}
 template <class In>
 LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
-    typedef DualS<1, Dual<HC>> T2;
     for (int i = 0; i < dim; i++)
-        for (int c0 = 0; c0 < dim; c0 += HC) {
-            T2 p[2 * 8 + 1];
-            p[0] = Lift<T2>::Of(primary[0]);
-            for (int k = 0; k < dim; k++) {
-                p[k + 1] = Lift<T2>::Of(primary[k + 1]);
-                if (k >= c0 && k < c0 + HC) p[k + 1].v.d[k - c0] = 1.0f;
-                if (k == i) p[k + 1].d[0].v = 1.0f;
-            }
-            T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
-            if (i == 0 && c0 == 0 && logLum) *logLum = r.v.v;
-            if (c0 == 0 && grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
-            for (int k = c0; k < dim && k < c0 + HC; k++) hess[i * dim + k] = r.d[0].d[k - c0];
-        }
+        for (int c0 = 0; c0 < dim; c0 += HC) PathFuncHessPass(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
 }
 
 // The chain loop only differentiates states with dim <= PSS_MAX_LENGTH = 12 (mutation_mala.h:94-96): no Dual<16> copy of

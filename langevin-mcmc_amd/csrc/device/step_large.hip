@@ -7,7 +7,7 @@ void LaunchStepLarge(const DScene &S, const DCache *cache, const ChainArrays &A,
                      const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s) {
     if (bvhStackNeed <= BVH_LDS_STACK) {  // traversal stack in LDS; gridBlocks was sized for 256-thread blocks
         const int blocks = gridBlocks * (256 / blockThreads);
-        const size_t ldsBytes = (size_t)blockThreads * BVH_LDS_STACK * sizeof(int);
+        const size_t ldsBytes = (size_t)blockThreads * ((bvhStackNeed + 7) / 8 * 8) * sizeof(int);  // the scene's own stack need, not the cap
         if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
         else
             hipLaunchKernelGGL((k_step<true, false, false, false, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);

@@ -50,6 +50,25 @@ __global__ void __launch_bounds__(64) k_hess_batch(int c, int l, int n, const fl
 }
 
 
+// The H2MC plugin symbols, one evaluation per call (evaluate_path_bidir_<c>_<l>_static_derv; caller mutation_h2mc.h:74-79): like
+// plugin.hip, one wave, inputs / outputs in host-mapped pinned memory; lane t runs ONE pass of the second-order program (row
+// t / chunks, column chunk t % chunks): the dim x ceil(dim / 8) passes side by side.  out: [logLum | grad 16 | hess 256]
+__global__ void __launch_bounds__(64) k_plugin_hess(int c, int l, const float *in, float *stage, float *out) {
+    // the inputs are staged in device memory (the slot's own 655 floats; L1-resident for the one wave): the out-of-line program takes its
+    // accessor by reference, and an accessor over a __shared__ array would have to be a compile-time constant (unsupported address-space cast)
+    const int L = c + l - 1 > 2 ? c + l - 1 : 2, dim = 2 * L, V = 238 + 59 * (c + l - 3);
+    for (int k = threadIdx.x; k < 17 + 38 + V; k += 64) stage[k] = in[k];
+    __threadfence_block();
+    __syncthreads();
+    const int chunks = (dim + HC - 1) / HC;
+    const int t = threadIdx.x;
+    if (t < dim * chunks) {
+        const StridedIn vin{stage + 55, 1};  // the accessor type of the step kernel: the same copy of the program
+        PathFuncHessPassDevice(c, l, stage, stage + 17, vin, t / chunks, (t % chunks) * HC, out, out + 1, out + 17);
+    }
+}
+void LaunchPluginHess(int c, int l, const float *in, float *stage, float *out, hipStream_t s) { hipLaunchKernelGGL(k_plugin_hess, dim3(1), dim3(64), 0, s, c, l, in, stage, out); }
+
 void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, float *hessSoA,
                      hipStream_t s) {
     hipLaunchKernelGGL(k_hess_batch, dim3((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096), dim3(64), 0, s, c, l, n, primarySoA, scene, vertSoA, logLum, gradSoA, hessSoA);

@@ -15,12 +15,12 @@ template <bool GLOSSY>
 #define LMC_LEANGRAD_WAVES 2  // registers for two waves per SIMD: a wave of this launch then fits beside a resident wave of the hot launch
 #endif
 __global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
-                                                      const int *listCount, NextLists next, float *gradBuf, int gradStride) {
+                                                      const int *listCount, NextLists next, float *gradBuf, int gradStride, int stackWords) {
     extern __shared__ float lds[];
     StepStats st;
     const int total = *listCount;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const LdsView L{lds + threadIdx.x, (int)blockDim.x};
+    const LdsView L{lds + threadIdx.x, (int)blockDim.x, stackWords};
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
         Rng rng;
@@ -38,9 +38,10 @@ __global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DSc
 
 // gridBlocks * blockThreads must not exceed gradStride (one serialisation slot per thread)
 void LaunchStepSmallLeanGrad(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                             const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, hipStream_t s) {
-    const size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float);
-    if (glossy) hipLaunchKernelGGL((k_step_small_grad<true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+                             const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, int bvhStackNeed, hipStream_t s) {
+    const int stackWords = LeanStackWords(bvhStackNeed);
+    const size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float);
+    if (glossy) hipLaunchKernelGGL((k_step_small_grad<true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride, stackWords);
     else
-        hipLaunchKernelGGL((k_step_small_grad<false>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        hipLaunchKernelGGL((k_step_small_grad<false>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride, stackWords);
 }

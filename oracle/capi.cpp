@@ -70,6 +70,10 @@ int orc_set_option(void *h, const char *name, double v) {
     else if (n == "mala-gn") o.malaGN = (float)v;
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
+    else if (n == "uselightcoordinatesampling") {
+        o.useLightCoordinateSampling = v != 0;
+        ((MLT *)h)->scene->sceneParams[0] = v != 0 ? 1.f : 0.f;  // scene.cpp:165: the flag is the first word of the serialized scene block
+    }
     else return -1;
     return 0;
 }

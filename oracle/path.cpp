@@ -505,7 +505,19 @@ void GeneratePathBidir(const RScene *scene, const int sx, const int sy, const in
         if (camDepth + 1 >= minDepth) {
             const Light *light = GetHitLight(scene, hitSurface, surfVertex.shapeInst.obj);
             if (light != nullptr) {
-                // useLightCoordinateSampling (path.cpp:1339-1360) is off by default and out of scope
+                if (scene->options->useLightCoordinateSampling && camDepth > 1 && light->GetType() == lmc::LIGHT_AREA) {  // path.cpp:1339-1360
+                    // area light: the BSDF sampling coordinates of the previous vertex become the light's direct sampling coordinates
+                    SurfaceVertex &prevSurfVertex = path.camSurfaceVertex[path.camSurfaceVertex.size() - 2];
+                    const ShapeInst &shapeInst = surfVertex.shapeInst;
+                    prevSurfVertex.bsdfRndParam = shapeInst.obj->GetSampleParam(shapeInst.primID, camPathState.isect.position, path.time);
+                    Vector3 dirToPrev = camPathState.isect.position - raySeg.ray.org;
+                    const Float distSq = LengthSquared(dirToPrev);
+                    const Float invDistSq = inverse(distSq);
+                    const Float invDist = std::sqrt(invDistSq);
+                    dirToPrev *= invDist;
+                    camPathState.ssJacobian *= std::fabs(Dot(dirToPrev, camPathState.isect.shadingNormal) * invDistSq) *
+                                               (camPathState.lcJacobian * surfVertex.shapeInst.obj->SamplePdf());
+                }
                 HandleHitLight(camDepth, scene, light, hitSurface, raySeg.ray, path.time, path.camVertex.screenPos, camPathState, true,
                                path.envLightInst, contribs);
                 return;
@@ -666,6 +678,35 @@ static inline void Perturb(Float &value, const std::vector<Float> &offset, int &
     value = Modulo(value + offset[offsetId++], Float(1.0));
 }
 
+// path.cpp:1881-1951: the last bounce towards an area light, re-sampled in the light's own coordinates
+static bool LightCoordinateSampling(const int camDepth, const RScene *scene, const Float time, const SurfaceVertex &curSurfVertex,
+                                    const SurfaceVertex &nextSurfVertex, const bool doOcclusion, BidirPathState &pathState, Vector3 &dir, Vector3 &bsdfContrib) {
+    const ShapeInst &shapeInst = curSurfVertex.shapeInst;
+    const ShapeInst &nextShapeInst = nextSurfVertex.shapeInst;
+    const BSDF *bsdf = shapeInst.obj->bsdf;
+    const Intersection &isect = pathState.isect;
+    const Vector3 &wi = pathState.wi;
+    Vector3 nextPosition, nextNormal;
+    Float shapePdf = Float(0.0);
+    nextShapeInst.obj->Sample(curSurfVertex.bsdfRndParam, time, nextSurfVertex.shapeInst.primID, nextPosition, nextNormal, &shapePdf);
+    dir = nextPosition - isect.position;
+    Float distToLightSq = LengthSquared(dir);
+    Float distToLight = std::sqrt(distToLightSq);
+    dir *= inverse(distToLight);
+    if (doOcclusion && Occluded(scene, time, Ray{isect.position, dir}, distToLight)) return false;
+    Float cosWo, bsdfPdf, bsdfRevPdf;
+    bsdf->Evaluate(wi, isect.shadingNormal, dir, shapeInst.st, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+    if (bsdfContrib.isZero()) return false;
+    bsdfContrib *= inverse(bsdfPdf);
+    pathState.throughput = pathState.throughput.cwiseProduct(bsdfContrib);
+    pathState.ssJacobian *= std::fabs(Dot(dir, nextNormal) * inverse(distToLightSq)) * bsdfPdf;
+    pathState.accMISWThis = MIS(cosWo / bsdfPdf) * (pathState.accMISWThis * MIS(bsdfRevPdf) + pathState.accMISWPrev);
+    pathState.accMISWPrev = MIS(inverse(bsdfPdf));
+    // (camDepth == 1: lensContrib, :1926-1949 -- feeds PathFuncMode::Lens only)
+    (void)camDepth;
+    return true;
+}
+
 void PerturbPathBidir(const RScene *scene, const std::vector<Float> &offset, Path &path, std::vector<SubpathContrib> &contribs, RNG &rng) {
     // path.cpp:1953-2160
     std::normal_distribution<Float> normDist(Float(0.0), scene->options->discreteStdDev);
@@ -755,8 +796,17 @@ void PerturbPathBidir(const RScene *scene, const std::vector<Float> &offset, Pat
         }
         Perturb(surfVertex.bsdfRndParam[0], offset, offsetId);
         Perturb(surfVertex.bsdfRndParam[1], offset, offsetId);
+        bool useLightCoordinatesPerturb = false;  // path.cpp:2120-2128
+        if (scene->options->useLightCoordinateSampling) {
+            if (camDepth == int(path.camSurfaceVertex.size()) - 2 && path.lgtDepth == 0) {
+                const ShapeInst &shapeInst = path.camSurfaceVertex.back().shapeInst;
+                if (shapeInst.obj != nullptr && shapeInst.obj->areaLight != nullptr) useLightCoordinatesPerturb = true;
+            }
+        }
         Vector3 bsdfContrib;
-        {
+        if (useLightCoordinatesPerturb) {
+            if (!LightCoordinateSampling(camDepth, scene, path.time, surfVertex, path.camSurfaceVertex.back(), true, camPathState, raySeg.ray.dir, bsdfContrib)) return;
+        } else {
             BidirPathState cur = camPathState;
             if (!BSDFSampling<false, true>(scene->options->roughnessThreshold, camDepth, cur, surfVertex, camPathState, raySeg.ray.dir, bsdfContrib)) return;
         }

@@ -85,6 +85,7 @@ struct Shape {  // = TriangleMesh
     PrimID Sample(const Float u) const;
     void Sample(const Vector2 rndParam, const Float time, const PrimID primID, Vector3 &position, Vector3 &normal, Float *pdf) const;
     Float SamplePdf() const { return inverse(mesh->totalArea); }
+    Vector2 GetSampleParam(const PrimID &primID, const Vector3 &position, const Float time) const;  // trianglemesh.cpp:255-285
 };
 
 struct ShapeInst {

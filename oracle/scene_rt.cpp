@@ -4,6 +4,7 @@
 #include <stdexcept>
 
 #include "render.h"
+#include "../langevin-mcmc_amd/csrc/device/dtrans.h"
 
 namespace orc {
 
@@ -271,6 +272,29 @@ void Shape::Sample(const Vector2 rndParam, const Float /*time*/, const PrimID pr
     if (pdf) *pdf = inverse(m.totalArea);
 }
 
+// inverse of Sample on triangle primID: the sampling coordinates that produce `position` (trianglemesh.cpp:238-285; static meshes,
+// ADEpsilon<Float>() == 0)
+Vector2 Shape::GetSampleParam(const PrimID &primID, const Vector3 &position, const Float /*time*/) const {
+    const lmc::Mesh &m = *mesh;
+    uint32_t i0 = m.idx[3 * primID], i1 = m.idx[3 * primID + 1], i2 = m.idx[3 * primID + 2];
+    const Vector3 p0 = V(m.P[i0]), e1 = V(m.P[i1]) - p0, e2 = V(m.P[i2]) - p0;
+    // Barycentric, trianglemesh.cpp:238-253
+    const Vector3 e0 = position - p0;
+    const Float d11 = Dot(e1, e1);
+    const Float d12 = Dot(e1, e2);
+    const Float d22 = Dot(e2, e2);
+    const Float d01 = Dot(e0, e1);
+    const Float d02 = Dot(e0, e2);
+    const Float invDenom = inverse(d11 * d22 - d12 * d12);
+    const Float b1 = (d22 * d01 - d12 * d02) * invDenom;
+    const Float b2 = (d11 * d02 - d12 * d01) * invDenom;
+    const Float a = Float(1.0) - b1;
+    Vector2 sampleParam;
+    sampleParam[0] = (Float(1.0) + Float(0.0)) - square(a);
+    sampleParam[1] = b2 / a;
+    return sampleParam;
+}
+
 // ============================================================================================ BSDFs
 namespace {
 
@@ -332,11 +356,12 @@ struct Lambertian : BSDF {  // lambertian.cpp:15-93
     Float Roughness(const Vector2, const Float) const override { return Float(1.0); }
 };
 
-// pow / exp / log of the glossy BSDFs: double evaluation rounded once, the arithmetic contract shared with the device code
-// (device/dmath.h powd/expd/logd).  The reference calls the float libm functions here.
-static inline Float powd(Float a, Float e) { return (Float)std::pow((double)a, (double)e); }
-static inline Float expd(Float x) { return (Float)std::exp((double)x); }
-static inline Float logd(Float x) { return (Float)std::log((double)x); }
+// pow / exp / log of the glossy BSDFs: the arithmetic contract shared with the device code.  The reference calls the
+// float libm functions here.
+// the deterministic float pow / exp / log the product uses (device/dtrans.h, the same source on both sides: bit-equal by construction)
+static inline Float powd(Float a, Float e) { return lmcd::lpowf(a, e); }
+static inline Float expd(Float x) { return lmcd::lexpf(x); }
+static inline Float logd(Float x) { return lmcd::llogf(x); }
 
 // ---- microfacet helpers, microfacet.h:6-70,165-185 (scalar Float versions)
 static Float BeckmennDistributionTerm(const Vector3 &localH, Float alphaU, Float alphaV) {

@@ -178,6 +178,32 @@ def host_pathfunc_lib():
     return so
 
 
+def host_trans_lib():
+    """Test helper: device/dtrans.h compiled for the host (same flags as the oracle: no contraction)."""
+    import subprocess
+
+    so = os.path.join(ROOT, "tests", "helpers", "libdtrans_host.so")
+    src = os.path.join(ROOT, "tests", "helpers", "dtrans_host.cpp")
+    hdr = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "device", "dtrans.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], cwd=ROOT)
+    return so
+
+
+def trans_cases(seed=1, n=1 << 20):
+    """(mode, x, y) argument sets of the exp / log / pow checks: the BSDFs' ranges and the full float range"""
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    return [
+        (0, rng.uniform(-104, 89, n).astype(f), np.zeros(n, f)),
+        (0, rng.uniform(-30, 0, n).astype(f), np.zeros(n, f)),  # Beckmann exponents
+        (1, np.exp(rng.uniform(np.log(1e-38), np.log(3e38), n)).astype(f), np.zeros(n, f)),
+        (1, rng.uniform(1e-6, 1.0, n).astype(f), np.zeros(n, f)),  # -log(1 - u)
+        (2, rng.uniform(0, 1, n).astype(f), rng.choice([20.0, 100.0, 200.0, 1 / 21.0, 1 / 101.0, 1 / 201.0, 37.5], n).astype(f)),  # Phong lobes
+        (2, np.exp(rng.uniform(-20, 20, n)).astype(f), rng.uniform(-4, 4, n).astype(f)),
+    ]
+
+
 def run_pair(width, height, num_init, n_chains, init_threads, per_chain, steps, use_gradient, max_depth=6, scene=TORUS, mala=True, opts=None,
              force_diffuse=1, oracle_grad="reference"):
     """Runs the same configuration on the oracle and on the GPU; returns a dict of comparison figures.

@@ -671,3 +671,77 @@ def test_mutation_cannot_change_under_resident_chains():
     with pytest.raises(RuntimeError, match="initialise the chains again"):
         ren.step(1)
     ren.close()
+
+
+def test_deterministic_transcendentals_bit_equal_on_device():
+    """device/dtrans.h: the same source under hipcc (device) and g++ (the oracle's build flags) gives the same BITS for exp, log
+    and pow on 6 x 2^20 arguments (BSDF ranges and the whole float range) -- the contract that lets the glossy BSDFs run in float
+    on both sides (rounds 1-2 evaluated them in double)."""
+    lib = gc.pkg().lib()
+    host = ctypes.CDLL(gc.host_trans_lib())
+    for mode, x, y in gc.trans_cases():
+        a, b = np.zeros(len(x), np.float32), np.zeros(len(x), np.float32)
+        assert lib.lmc_trans_probe(len(x), mode, P(x), P(y), P(a)) == 0
+        host.lmc_test_trans_host(len(x), mode, P(x), P(y), P(b))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mode, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+
+
+def test_plugin_symbol_call_cost_and_threads(pair_full):
+    """the drop-in symbols must not cost 100-200 us per call.  Each calling thread owns a stream and two
+    host-mapped pinned buffers (context.cpp PluginSlot); a call = host memcpy of the arguments + ONE single-wave launch + one
+    stream sync.  Asserted: mean < 60 us over 1000 gradient calls on full-material states (measured ~ 35 us), the single call
+    equals the batched kernel, the H2MC symbol equals lmc_hess_batch, and four threads calling concurrently (the reference calls
+    the symbols from every worker thread, mutation_mala.h:97-110) get their own results."""
+    import threading
+    import time
+
+    orc, ren = pair_full
+    inputs = gc.collect_grad_inputs(orc, 256)
+    lib = gc.pkg().lib()
+    p = gc.pkg()
+    sp = ren.scene_params()
+    lens = np.zeros(2, np.float32)
+    (c, l), (prim, vert) = max(inputs.items(), key=lambda kv: len(kv[1][0]))
+    dim = 2 * (c + l - 1)
+    d = getattr(lib, "evaluate_path_bidir_mala_%d_%d_static_derv" % (c, l))
+    n = min(len(prim), 32)
+    pv = [np.ascontiguousarray(np.pad(prim[i], (0, 17 - len(prim[i])))) for i in range(n)]
+    vv = [np.ascontiguousarray(np.pad(vert[i], (0, 1000 - len(vert[i])))) for i in range(n)]
+    ll, gb = p.grad_batch(c, l, prim[:n].T.copy(), sp, vert[:n].T.copy())
+    g = np.zeros(16, np.float32)
+    for i in range(n):  # correctness: single call == batch
+        d(P(lens), P(pv[i]), P(sp), P(vv[i]), P(g), None)
+        assert np.allclose(g[:dim], gb[:, i], rtol=1e-5, atol=1e-6), i
+    t0 = time.perf_counter()
+    for k in range(1000):
+        d(P(lens), P(pv[k % n]), P(sp), P(vv[k % n]), P(g), None)
+    us = (time.perf_counter() - t0) * 1e6 / 1000
+    print("plugin gradient call: %.1f us mean" % us)
+    assert us < 60.0, us
+    # the H2MC symbol
+    h = getattr(lib, "evaluate_path_bidir_%d_%d_static_derv" % (c, l))
+    lib.lmc_hess_batch.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+    ps, vs = np.ascontiguousarray(prim[:n].T), np.ascontiguousarray(vert[:n].T)
+    l2, g2, h2 = np.zeros(n, np.float32), np.zeros((dim, n), np.float32), np.zeros((dim * dim, n), np.float32)
+    assert lib.lmc_hess_batch(c, l, n, P(ps), P(sp), P(vs), P(l2), P(g2), P(h2)) == 0
+    hh = np.zeros(256, np.float32)
+    for i in range(min(n, 8)):
+        h(P(lens), P(pv[i]), P(sp), P(vv[i]), P(g), P(hh))
+        assert np.allclose(g[:dim], g2[:, i], rtol=1e-5, atol=1e-6) and np.allclose(hh[: dim * dim], h2[:, i], rtol=1e-5, atol=1e-4)
+    # concurrent callers
+    errs = []
+
+    def worker(t):
+        gt = np.zeros(16, np.float32)
+        for k in range(100):
+            i = (t * 7 + k) % n
+            d(P(lens), P(pv[i]), P(sp), P(vv[i]), P(gt), None)
+            if not np.allclose(gt[:dim], gb[:, i], rtol=1e-5, atol=1e-6):
+                errs.append((t, k))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:5]

@@ -293,3 +293,43 @@ def test_bvh_builders_agree_and_stack_bound_holds(tmp_path):
     wide = rows[2]
     assert wide["tree"] == "sah_4wide" and wide["max_stack"] <= wide["stack_bound"] <= 32
     assert wide["node_visits_per_ray"] < 0.65 * rows[1]["node_visits_per_ray"]
+
+
+def test_deterministic_transcendentals_accuracy_and_conventions():
+    """device/dtrans.h (lexpf / llogf / lpowf: float-only, bit-reproducible across compilers) against float64: exp and log within
+    1 ulp over the whole float range, pow within 1.5 ulp where the result exceeds 1e-10 (the Phong lobe's own cut-off, phong.cpp:44)
+    and within 5 ulp down to the subnormal range; libm's conventions for the special arguments the BSDF code can produce."""
+    lib = ctypes.CDLL(gc.host_trans_lib())
+
+    def ulps(got, ref64):
+        ulp = np.spacing(np.abs(ref64.astype(np.float32))).astype(np.float64)
+        return np.abs(got.astype(np.float64) - ref64) / ulp
+
+    for mode, x, y in gc.trans_cases():
+        o = np.zeros(len(x), np.float32)
+        lib.lmc_test_trans_host(len(x), mode, P(x), P(y), P(o))
+        x64, y64 = x.astype(np.float64), y.astype(np.float64)
+        with np.errstate(all="ignore"):
+            ref = np.exp(x64) if mode == 0 else np.log(x64) if mode == 1 else np.power(x64, y64)
+        normal = (np.abs(ref) > 1.2e-38) & (np.abs(ref) < 3.4e38)
+        e = ulps(o[normal], ref[normal])
+        if mode < 2:
+            assert e.max() <= 1.05, (mode, e.max())  # 1.008 measured (exp, near the underflow threshold)
+        else:
+            big = np.abs(ref[normal]) > 1e-10
+            assert e[big].max() <= 1.5 and e.max() <= 5.0, (e[big].max(), e.max())
+        assert (o[normal] == ref[normal].astype(np.float32)).mean() > 0.85  # mostly correctly rounded
+    a = np.array([-2, -2, -2, 0, 0, 1, np.inf, 2, -0.9, 0.5, np.nan, 3], np.float32)
+    b = np.array([3, 2, 0.5, 2, -1, 5, 2, 0, 100, -2000, 1, np.nan], np.float32)
+    o = np.zeros(len(a), np.float32)
+    lib.lmc_test_trans_host(len(a), 2, P(a), P(b), P(o))
+    with np.errstate(all="ignore"):
+        ref = np.power(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(np.isnan(o), np.isnan(ref)) and np.allclose(o[~np.isnan(o)], ref[~np.isnan(ref)], rtol=2e-7)
+    sp = np.array([0, -1, np.inf, np.nan, 1e-45], np.float32)
+    o = np.zeros(len(sp), np.float32)
+    lib.lmc_test_trans_host(len(sp), 1, P(sp), P(sp), P(o))
+    assert o[0] == -np.inf and np.isnan(o[1]) and o[2] == np.inf and np.isnan(o[3]) and abs(o[4] - np.log(1.4e-45)) < 1e-3
+    ex = np.array([89, -104, np.nan, 0, -90], np.float32)
+    lib.lmc_test_trans_host(len(ex), 0, P(ex), P(ex), P(o))
+    assert o[0] == np.inf and o[1] == 0 and np.isnan(o[2]) and o[3] == 1 and 0 < o[4] < 1e-38
