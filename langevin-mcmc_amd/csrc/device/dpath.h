@@ -211,8 +211,10 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
 
 // path.cpp:747-900.  `in` and `out` may alias (the reference passes the same object in the camera loop);
 // every field of `in` is read before the aliased field of `out` is written.
+// lcJacobian (path.cpp:793-797,825; read by the light-coordinate branch of GeneratePathBidir only): handed out through a pointer so
+// that BPS -- live across every traversal of the hot kernel -- does not carry it
 template <bool adjoint, bool perturb, bool GLOSSY>
-LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib) {
+LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib, float *lcJacobian = nullptr) {
     const DMaterial &m = MaterialOfTri(S, v.tri);
     V2 st{v.st0, v.st1};
     float cosWo, bsdfPdf, bsdfRevPdf;
@@ -227,12 +229,16 @@ LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3
             float jacobian;
             V2 sc = ToSphericalCoord(dir, jacobian);
             v.rnd0 = sc.x, v.rnd1 = sc.y;
+            if (lcJacobian) *lcJacobian = inverse(jacobian);
             jacobian *= bsdfPdf;
             out.ssJacobian = inSsJac * jacobian;
+        } else if (lcJacobian) {
+            *lcJacobian = bsdfPdf;
         }
     } else {
         float jacobian;
         dir = SampleSphere(V2{v.rnd0, v.rnd1}, jacobian);
+        if (lcJacobian) *lcJacobian = inverse(jacobian);
         BsdfEvaluate<GLOSSY>(S, m, adjoint, wi, in.isect.shadingNormal, dir, st, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
         if (IsZero(bsdfContrib) || bsdfPdf <= 0.0f) return false;
         bsdfContrib = bsdfContrib * inverse(bsdfPdf);
@@ -429,6 +435,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
     EmitFromCamera(S, screenPos, org, dir, cps);
     float tnear, tfar;
     tnear = PrimaryMinT(S, screenPos, tfar);
+    float lcJac = 0.0f;  // camPathState.lcJacobian of the last BSDF sampling
     for (int camDepth = 0;; camDepth++) {
         if (camDepth >= MAXD) break;
         DVertex &sv = path.cam[camDepth];
@@ -442,6 +449,18 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         if (camDepth + 1 >= minDepth) {
             int light = HitLightOf(S, hitSurface, hit.tri);
             if (light >= 0) {
+                if (S.opt.useLightCoord && camDepth > 1 && S.lights[light].type == LIGHT_AREA) {  // path.cpp:1339-1360
+                    // area light: the BSDF sampling coordinates of the previous vertex become the light's direct sampling coordinates
+                    DVertex &prev = path.cam[camDepth - 1];
+                    const V2 sp = TriangleSampleParam(S, hit.tri, cps.isect.position);
+                    prev.rnd0 = sp.x, prev.rnd1 = sp.y;
+                    V3 dirToPrev = cps.isect.position - org;
+                    const float distSq = LengthSquared(dirToPrev);
+                    const float invDistSq = inverse(distSq);
+                    const float invDist = sqrtf(invDistSq);
+                    dirToPrev = dirToPrev * invDist;
+                    cps.ssJacobian *= fabsf(Dot(dirToPrev, cps.isect.shadingNormal) * invDistSq) * (lcJac * S.meshes[S.tris[hit.tri].mesh].invTotalArea);
+                }
                 Contrib c;
                 if (HandleHitLight(S, camDepth, light, hitSurface, dir, screenPos, cps, path.envPrim, c)) sink.Push(c);
                 return;
@@ -468,7 +487,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         V2 r = RndVec2(rng);
         sv.rnd0 = r.x, sv.rnd1 = r.y;
         V3 bsdfContrib;
-        if (!BSDFSampling<false, false, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
+        if (!BSDFSampling<false, false, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib, &lcJac)) break;
         if (!RussianRoulette(camDepth, bsdfContrib, sv.rrWeight, cps.throughput, rng)) break;
         org = cps.isect.position;
         tnear = c_IsectEpsilon;
@@ -506,6 +525,30 @@ LMC_D int GetPathPss(const DPath &path, float *pss) {
         pss[k++] = path.cam[d].rnd0, pss[k++] = path.cam[d].rnd1;
     }
     return k;
+}
+
+// LightCoordinateSampling, path.cpp:1881-1951: the last bounce towards an area light, re-sampled in the light's own coordinates
+// (the point the vertex's two primary samples select on the triangle the path's last vertex lies on)
+template <bool GLOSSY, class Stk>
+LMC_D bool LightCoordinateSampling(const DScene &S, const DVertex &cur, int nextTri, BPS &ps, V3 &dir, V3 &bsdfContrib, Stk &stk) {
+    const DMaterial &m = MaterialOfTri(S, cur.tri);
+    V3 nextPosition, nextNormal;
+    float shapePdf;
+    SampleTriangle(S, nextTri, V2{cur.rnd0, cur.rnd1}, nextPosition, nextNormal, shapePdf);
+    dir = nextPosition - ps.isect.position;
+    const float distToLightSq = LengthSquared(dir);
+    const float distToLight = sqrtf(distToLightSq);
+    dir = dir * inverse(distToLight);
+    if (Occluded(S, ps.isect.position, dir, distToLight, stk)) return false;
+    float cosWo, bsdfPdf, bsdfRevPdf;
+    BsdfEvaluate<GLOSSY>(S, m, false, ps.wi, ps.isect.shadingNormal, dir, V2{cur.st0, cur.st1}, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+    if (IsZero(bsdfContrib)) return false;
+    bsdfContrib = bsdfContrib * inverse(bsdfPdf);
+    ps.throughput = cmul(ps.throughput, bsdfContrib);
+    ps.ssJacobian *= fabsf(Dot(dir, nextNormal) * inverse(distToLightSq)) * bsdfPdf;
+    ps.accMISWThis = MIS(cosWo / bsdfPdf) * (ps.accMISWThis * MIS(bsdfRevPdf) + ps.accMISWPrev);
+    ps.accMISWPrev = MIS(inverse(bsdfPdf));
+    return true;
 }
 
 // PerturbPathBidir, path.cpp:1953-2160.  Returns true and fills `out` when the perturbed path carries light.
@@ -575,8 +618,16 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         }
         sv.rnd0 = Modulo1(sv.rnd0 + offset[offsetId++]);
         sv.rnd1 = Modulo1(sv.rnd1 + offset[offsetId++]);
+        bool useLightCoordinatesPerturb = false;  // path.cpp:2120-2128: the path's last vertex (as stored) lies on an area light
+        if (S.opt.useLightCoord && camDepth == path.camCount - 2 && path.lgtDepth == 0) {
+            const int lastTri = path.cam[path.camCount - 1].tri;
+            if (lastTri >= 0 && S.tris[lastTri].areaLight >= 0) useLightCoordinatesPerturb = true;
+        }
         V3 bsdfContrib;
-        if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) return false;
+        if (useLightCoordinatesPerturb) {
+            if (!LightCoordinateSampling<Stk::kGlossy>(S, sv, path.cam[path.camCount - 1].tri, cps, dir, bsdfContrib, stk)) return false;
+        } else if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib))
+            return false;
         cps.throughput = cps.throughput * sv.rrWeight;
         org = cps.isect.position;
         tnear = c_IsectEpsilon;

@@ -445,6 +445,23 @@ LMC_D void SampleTriangle(const DScene &S, int tri, V2 rnd, V3 &position, V3 &no
     pdf = S.meshes[T.mesh].invTotalArea;
 }
 
+// TriangleMesh::GetSampleParam (trianglemesh.cpp:238-285): the sampling coordinates that SampleTriangle maps to `position`
+LMC_D V2 TriangleSampleParam(const DScene &S, int tri, V3 position) {
+    const TriData &T = S.tris[tri];
+    V3 p0{T.p0[0], T.p0[1], T.p0[2]}, e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
+    const V3 e0 = position - p0;
+    const float d11 = Dot(e1, e1);
+    const float d12 = Dot(e1, e2);
+    const float d22 = Dot(e2, e2);
+    const float d01 = Dot(e0, e1);
+    const float d02 = Dot(e0, e2);
+    const float invDenom = inverse(d11 * d22 - d12 * d12);
+    const float b1 = (d22 * d01 - d12 * d02) * invDenom;
+    const float b2 = (d11 * d02 - d12 * d01) * invDenom;
+    const float a = 1.0f - b1;
+    return V2{(1.0f + 0.0f) - square(a), b2 / a};
+}
+
 // ---------------------------------------------------------------------------------------------- lights
 LMC_D V3 EnvAtLinear(const DEnv &E, int x, int y) {  // Image3::At without range check; one-past-the-end wraps (oracle AtQ)
     long idx = (long)y * E.W + x;

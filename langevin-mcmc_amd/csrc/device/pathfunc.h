@@ -612,13 +612,29 @@ LMC_PF void SampleBSDFT(bool adjoint, const In &b, int off, const V3T<T> &wi, V3
     }
 }
 
-// BSDFSampling<adjoint, fixedDiscrete=false>, path.cpp:2962-3135 (doLightCoordinateSampling branch: the
-// reference only takes it when scene[0] == 1, i.e. uselightcoordinatesampling, SURVEY.md §8f.4 -- not built)
+// BSDFSampling<adjoint, fixedDiscrete=false>, path.cpp:2962-3135.  doLightCoord: the caller's compile-time half of the reference's
+// doLightCoordinateSampling (maxLightDepth == 0 && camDepth == maxCamDepth - 3, path.cpp:3872); the branch is taken when the scene
+// block says uselightcoordinatesampling (scene[0] == 1) and the NEXT vertex's light slot is an area light (path.cpp:2979-3025): the
+// direction comes from the point the two primary samples select on the next vertex's triangle, in the light's own sampling
+// coordinates, with the area -> solid-angle Jacobian |cos| / d^2 / shapePdf
 template <bool adjoint, class T, class In>
-LMC_HD void BSDFSamplingT(const In &b, int off, const T &r0, const T &r1, float bsdfDiscrete, float useAbs, PState<T> &ps, V3T<T> &dir) {
+LMC_HD void BSDFSamplingT(const In &b, int off, const T &r0, const T &r1, float bsdfDiscrete, float useAbs, PState<T> &ps, V3T<T> &dir, bool doLightCoord = false,
+                          float useLightCoord = 0.0f) {
     V3T<T> bsdfContrib;
     T cosWo, bsdfPdf, bsdfRevPdf, jacobian;
-    if (useAbs == 0.0f) {
+    const int nextShapeOff = off + 10 + 1, nextLightOff = nextShapeOff + 46;  // behind this vertex's BSDF slot and rrWeight
+    if (doLightCoord && useLightCoord == 1.0f && b[nextLightOff] == 1.0f /* LightType::AreaLight */) {
+        V3T<T> nextPosition, nextNormal;
+        float shapePdf;
+        SampleShapeT(b, nextShapeOff, r0, r1, nextPosition, nextNormal, shapePdf);
+        dir = nextPosition - ps.position;
+        T distSq = LenSqT(dir);
+        T invDistSq = 1.0f / distSq;
+        T invDist = Sqrt(invDistSq);
+        dir = dir * invDist;
+        EvaluateBSDFT(false, b, off, ps.wi, ps.shadingNormal, dir, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
+        jacobian = Fabs(DotT(nextNormal, dir) * invDistSq) / shapePdf;
+    } else if (useAbs == 0.0f) {
         SampleBSDFT(adjoint, b, off, ps.wi, ps.shadingNormal, r0, r1, bsdfDiscrete, dir, bsdfContrib, cosWo, bsdfPdf, bsdfRevPdf);
         jacobian = Lift<T>::Of(1.0f);
     } else {
@@ -979,7 +995,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
             }
             T r0 = primary[pi++], r1 = primary[pi++];
             const float bsdfDiscrete = vp[buf++], useAbs = vp[buf++];
-            BSDFSamplingT<false>(vp, buf, r0, r1, bsdfDiscrete, useAbs, cps, dir);
+            BSDFSamplingT<false>(vp, buf, r0, r1, bsdfDiscrete, useAbs, cps, dir, maxLightDepth == 0 && camDepth == maxCamDepth - 3, sc.useLightCoord);
             buf += 10;
             const float rrWeight = vp[buf++];
             cps.throughput = cps.throughput * Lift<T>::Of(rrWeight);

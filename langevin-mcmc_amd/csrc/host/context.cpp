@@ -331,8 +331,10 @@ static void SyncOptions(lmc_ctx *c) {
     d.malaGN = o.malaGN, d.malaStepsize = o.malaStepsize, d.malaStdDev = o.malaStdDev, d.perturbStdDev = o.perturbStdDev;
     d.discreteStdDev = o.discreteStdDev, d.uniformMixingProbability = o.uniformMixingProbability, d.seedOffset = o.seedOffset;
     if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 12] on the MI355X back end");
-    if (o.largeStepMultiplexed || o.sampleFromGlobalCache || o.useLightCoordinateSampling)
-        throw std::runtime_error("largestepmultiplexed / samplecache / uselightcoordinatesampling are out of scope (SURVEY.md §8f)");
+    d.useLightCoord = o.useLightCoordinateSampling ? 1 : 0;
+    c->S.sceneParams[0] = d.useLightCoord ? 1.0f : 0.0f;  // scene.cpp:165: the flag opens the serialized scene block the path programs read
+    if (o.largeStepMultiplexed || o.sampleFromGlobalCache)
+        throw std::runtime_error("largestepmultiplexed / samplecache are out of scope (SURVEY.md §8f)");
 }
 
 static void UploadCacheStruct(lmc_ctx *c) {
@@ -430,6 +432,7 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "mala-gn") o.malaGN = (float)v;
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
+    else if (n == "uselightcoordinatesampling") o.useLightCoordinateSampling = v != 0;
     else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else throw std::runtime_error("Unknown dpt option:" + n);
@@ -939,7 +942,7 @@ int lmc_init_result(lmc_ctx *c, float *normalization, long long *numContribs) {
 // bit d: small steps of dimension d run the lean launch (MALA with that dim's cache ready and shallow enough for the LDS search)
 static unsigned LeanDims(const lmc_ctx *c) {
     unsigned m = 0;
-    if (c->S.opt.h2mc || !c->S.opt.mala) return 0;
+    if (c->S.opt.h2mc || !c->S.opt.mala || c->S.opt.useLightCoord) return 0;  // light-coordinate sampling lives in the generic small step only
     for (int d = PSS_MIN_LENGTH; d <= PSS_MAX_LENGTH; d++)
         if (c->cacheDims[d].ready && !c->cacheHost.d[d].deep) m |= 1u << d;
     return m;
@@ -958,7 +961,7 @@ static bool CachePending(lmc_ctx *c) {
         c->allCachesReady = true;
         bool anyDeep = false;
         for (int d = 2; d <= PSS_MAX_LENGTH; d++) anyDeep = anyDeep || (c->cacheDims[d].ready && c->cacheHost.d[d].deep);
-        c->needGeneric = anyDeep;
+        c->needGeneric = anyDeep || c->S.opt.useLightCoord;
     }
     return anyPending;
 }
@@ -1055,7 +1058,7 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
     if (c->needGeneric && c->S.opt.h2mc)
         LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
-    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && c->bvhDepth <= BVH_LDS_STACK)
+    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && c->bvhDepth <= BVH_LDS_STACK)
         LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
         LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);

@@ -565,6 +565,115 @@ void GeneratePathBidir(const RScene *scene, const int sx, const int sy, const in
     }
 }
 
+// GenerateSubpath, path.cpp:1451-1658 (screenPosi = (-1,-1)): ONE technique (camLength camera vertices, lgtLength light vertices), no
+// Russian roulette (rrWeight = 1); the generator of the multiplexed large step (mutation_large.h:45-57, mutation_large_cache.h:58-67).
+// NB the area-light re-parameterisation of the last bounce is unconditional here (path.cpp:1549-1571: no option test, unlike :1339).
+void GenerateSubpath(const RScene *scene, const int camLength, const int lgtLength, const bool bidirMIS, Path &path, std::vector<SubpathContrib> &contribs,
+                     RNG &rng) {
+    std::uniform_real_distribution<Float> uniDist(Float(0.0), Float(1.0));
+    const RCamera *camera = &scene->camera;
+    path.time = uniDist(rng);
+    RaySegment raySeg;
+    BidirPathState lightPathState;
+    if (lgtLength > 1) {
+        Float lightPickProb = Float(1.0);
+        EmitFromLightInit(scene, path.lgtVertex, lightPickProb, rng);
+        EmitFromLight(scene->bSphere, lightPickProb, path.time, path.lgtVertex, raySeg.ray, lightPathState);
+        raySeg.minT = c_IsectEpsilon;
+        raySeg.maxT = std::numeric_limits<Float>::infinity();
+        Vector3 prevLensContrib = Vector3::Zero();
+        for (int lgtDepth = 0;; lgtDepth++) {
+            path.lgtSurfaceVertex.push_back(SurfaceVertex());
+            bool hitSurface = Intersect(scene, path.time, raySeg, path.lgtSurfaceVertex.back().shapeInst, lightPathState.isect);
+            if (!hitSurface) return;
+            path.lgtSurfaceVertex.back().bsdfDiscrete = uniDist(rng);
+            lightPathState.wi = -raySeg.ray.dir;
+            if (bidirMIS) ConvertMIS(lgtDepth, path.lgtVertex.lightInst.light, raySeg.ray, lightPathState);
+            if (lgtDepth + 2 == lgtLength) {
+                if (camLength == 1) {
+                    ConnectToCamera(lgtDepth, scene, camera, path.time, lightPathState, path.lgtSurfaceVertex[lgtDepth], prevLensContrib, raySeg.ray.org, contribs);
+                    return;
+                }
+                break;
+            }
+            SurfaceVertex &surfVertex = path.lgtSurfaceVertex.back();
+            surfVertex.bsdfRndParam = RndVec2(uniDist, rng);
+            Vector3 bsdfContrib;
+            {
+                BidirPathState cur = lightPathState;  // the reference passes the same object as in and out
+                if (!BSDFSampling<true, false>(scene->options->roughnessThreshold, lgtDepth, cur, surfVertex, lightPathState, raySeg.ray.dir, bsdfContrib)) return;
+            }
+            surfVertex.rrWeight = Float(1.0);
+            prevLensContrib = lightPathState.lensContrib;
+            raySeg.ray.org = lightPathState.isect.position;
+        }
+    }
+    BidirPathState camPathState;
+    EmitFromCameraInit(camera, -1, -1, path.camVertex, rng);
+    EmitFromCamera(path.time, camera, path.camVertex, raySeg, camPathState);
+    for (int camDepth = 0;; camDepth++) {
+        path.camSurfaceVertex.push_back(SurfaceVertex());
+        SurfaceVertex &surfVertex = path.camSurfaceVertex.back();
+        bool hitSurface = Intersect(scene, path.time, raySeg, surfVertex.shapeInst, camPathState.isect);
+        camPathState.wi = -raySeg.ray.dir;
+        if (bidirMIS && hitSurface) ConvertMIS(camDepth, nullptr, raySeg.ray, camPathState);
+        if (camDepth + 2 >= camLength && lgtLength == 0) {
+            const Light *light = GetHitLight(scene, hitSurface, surfVertex.shapeInst.obj);
+            if (light != nullptr) {
+                if (camDepth > 1 && light->GetType() == lmc::LIGHT_AREA) {
+                    SurfaceVertex &prevSurfVertex = path.camSurfaceVertex[path.camSurfaceVertex.size() - 2];
+                    const ShapeInst &shapeInst = surfVertex.shapeInst;
+                    prevSurfVertex.bsdfRndParam = shapeInst.obj->GetSampleParam(shapeInst.primID, camPathState.isect.position, path.time);
+                    Vector3 dirToPrev = camPathState.isect.position - raySeg.ray.org;
+                    const Float distSq = LengthSquared(dirToPrev);
+                    const Float invDistSq = inverse(distSq);
+                    const Float invDist = std::sqrt(invDistSq);
+                    dirToPrev *= invDist;
+                    camPathState.ssJacobian *= std::fabs(Dot(dirToPrev, camPathState.isect.shadingNormal) * invDistSq) *
+                                               (camPathState.lcJacobian * surfVertex.shapeInst.obj->SamplePdf());
+                }
+                HandleHitLight(camDepth, scene, light, hitSurface, raySeg.ray, path.time, path.camVertex.screenPos, camPathState, bidirMIS, path.envLightInst,
+                               contribs);
+            }
+            return;
+        }
+        if (!hitSurface) return;
+        if (camDepth == 1) {
+            path.lensVertexPos = camPathState.isect.position;
+            const Float distSq = DistanceSquared(camPathState.isect.position, raySeg.ray.org);
+            if (distSq <= Float(0.0)) return;
+            camPathState.lensContrib *= inverse(distSq);
+        }
+        surfVertex.bsdfDiscrete = uniDist(rng);
+        if (camDepth + 2 == camLength) {
+            if (lgtLength == 1) {
+                Float directLightPickProb = Float(1.0);
+                {  // DirectLightingInit, path.cpp:184-193
+                    const Light *dirLight = PickLight(scene, uniDist(rng), directLightPickProb);
+                    surfVertex.directLightRndParam = RndVec2(uniDist, rng);
+                    surfVertex.directLightInst.light = dirLight;
+                    surfVertex.directLightInst.lPrimID = dirLight->SampleDiscrete(uniDist(rng));
+                }
+                DirectLighting(camDepth, scene, path.time, camPathState, path.camVertex.screenPos, directLightPickProb, surfVertex, true, bidirMIS, contribs);
+            } else {
+                ConnectVertex(camDepth, lgtLength - 2, scene, path.time, lightPathState, path.lgtSurfaceVertex.back(), camPathState, surfVertex,
+                              path.camVertex.screenPos, true, contribs);
+            }
+            return;
+        }
+        surfVertex.bsdfRndParam = RndVec2(uniDist, rng);
+        Vector3 bsdfContrib;
+        {
+            BidirPathState cur = camPathState;
+            if (!BSDFSampling<false, false>(scene->options->roughnessThreshold, camDepth, cur, surfVertex, camPathState, raySeg.ray.dir, bsdfContrib)) return;
+        }
+        surfVertex.rrWeight = Float(1.0);
+        raySeg.ray.org = camPathState.isect.position;
+        raySeg.minT = c_IsectEpsilon;
+        raySeg.maxT = std::numeric_limits<Float>::infinity();
+    }
+}
+
 // ---- unidirectional generator of the direct-lighting pre-pass: GeneratePath, path.cpp:406-527, with its own helpers
 // HandleHitLight :121-183, DirectLighting :195-294 (no shading-normal correction, power-heuristic MISWeight :23-27),
 // BSDFSampling :296-386 (perturb = false); the lens* / jacobian bookkeeping feeds nothing in this pass and is left out.

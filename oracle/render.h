@@ -199,6 +199,8 @@ void GeneratePathBidir(const RScene *scene, const int screenPosiX, const int scr
                        Path &path, std::vector<SubpathContrib> &contribs, RNG &rng);
 void GeneratePathUni(const RScene *scene, const int screenPosiX, const int screenPosiY, const int minDepth, const int maxDepth,
                      std::vector<SubpathContrib> &contribs, RNG &rng);
+void GenerateSubpath(const RScene *scene, const int camLength, const int lgtLength, const bool bidirMIS, Path &path, std::vector<SubpathContrib> &contribs,
+                     RNG &rng);  // path.cpp:1451-1658
 void ToSubpath(const int camDepth, const int lightDepth, Path &path);
 void PerturbPathBidir(const RScene *scene, const std::vector<Float> &offset, Path &path, std::vector<SubpathContrib> &contribs,
                       RNG &rng);

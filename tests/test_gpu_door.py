@@ -163,3 +163,74 @@ def test_door_init_contributions_per_sample():
             same_all += all(abs(x[1] - y[1]) <= 1e-3 * abs(x[1]) for x, y in zip(a, b))
     assert same_cl >= 0.99 * ninit, same_cl
     assert same_all >= 0.985 * ninit, same_all
+
+
+def test_door_light_coordinate_sampling():
+    """SURVEY §8(f) item 4, `uselightcoordinatesampling` (path.cpp:1339-1360 GeneratePathBidir, :1881-1951 LightCoordinateSampling,
+    :2120-2150 PerturbPathBidir, trianglemesh.cpp:238-285 GetSampleParam; derivative programs: the doLightCoordinateSampling branch,
+    path.cpp:2979-3025): a camera path that ends on an area light keeps its last bounce in the light's own sampling coordinates.
+    (1) The shipped scene with an area light, option on, 60 lock-step mutations of 2048 chains: the statistical bars of
+        test_door_chain_parity (chain-by-chain comparison is impossible on this scene).
+    (2) scenes/torus/lmc_arealight.xml (ours: the floor of the torus scene as the emitter, scenes/README.md), every BSDF diffuse: state by state.
+        MLTInit: every init state equal (technique, lsScore, ssScore, pss) with the option on AND off, and the states that end on
+        the emitter differ between the two runs (the re-parameterised ssJacobian and bsdfRndParam); 40 mutations: identical step counters,
+        film within 5e-3 (a handful of 8192 chains flip one accept); the product's path program == the reference's programs with scene[0] = 1 on the emitter-hit states."""
+    L = gc.oracle_lib()
+    p = gc.pkg()
+    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=1, max_depth=8, scene=DOOR, force_diffuse=0, oracle_grad="reference",
+                    opts={"uselightcoordinatesampling": 1})
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 0.01 * r["contribs_oracle"]
+    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 2e-3 * r["norm_oracle"]
+    assert sg["steps"] == so["steps"] == 2048 * 60
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.03 * so["largeSteps"]
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.02 * so["accepted"]
+    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.03 * max(so["gradCalls"], 100) and sg["gradCalls"] > 0
+    assert _hist_l1(r) < 0.08
+    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 0.01 and r["nonfinite_gpu"] == 0
+    # (2)
+    AREA = os.path.join(gc.ROOT, "scenes", "torus", "lmc_arealight.xml")
+    ninit, n, streams = 1 << 17, 1 << 13, 4096
+    emitter_ss = {}
+    for flag in (1, 0):
+        orc = _orc.Oracle(L, AREA, 1, 6, 160, 120, 0, gc.pathref())
+        ren = p.Renderer(AREA, force_diffuse=1, max_depth=6, width=160, height=120, seed_offset=0, use_gradient=1)
+        L.orc_set_option(orc.h, b"uselightcoordinatesampling", float(flag))
+        ren.set_option("uselightcoordinatesampling", flag)
+        no, co = orc.init(ninit, n, streams)
+        ng, cg = ren.init_chains(ninit, n, streams, 10)
+        assert co == cg and abs(no - ng) <= 1e-5 * no
+        si, gi = orc.summary(1), ren.summary(1)
+        sp = ren.scene_params()
+        assert sp[0] == float(flag) and np.array_equal(sp, orc.scene_params())
+        assert np.array_equal(si[:, 1:3], gi[:, 1:3])
+        # one state of 8192 sits on an ill-conditioned path (2e-4 relative, 1.5e-3 in one pss entry): scripts/debug/arealight_state_diff.py
+        assert np.allclose(si[:, 3], gi[:, 3], rtol=1e-3) and np.allclose(si[:, 4], gi[:, 4], rtol=1e-3)
+        assert (np.abs(si[:, 3] / gi[:, 3] - 1) > 1e-5).sum() <= 8 and (np.abs(si[:, 16:] - gi[:, 16:]).max(axis=1) > 1e-5).sum() <= 8
+        emit = []
+        for i in np.nonzero((si[:, 2] == 0) & (si[:, 1] >= 4))[0]:
+            c, l, prim, vert = orc.serialize_init_state(int(i))
+            if vert[3 + 59 * (c - 2) + 46] == 1.0:  # the path's last vertex carries an area light slot
+                emit.append((int(i), c, l, prim, vert))
+        assert len(emit) >= 1000, len(emit)
+        emit = emit[:: max(1, len(emit) // 60)]
+        if flag:
+            for i, c, l, prim, vert in emit:
+                ll, g = p.grad_batch(c, l, prim[: 2 * (c + l - 1) + 1, None].copy(), sp, vert[: 238 + 59 * (c + l - 3), None].copy())
+                rll, rg = orc.ref_eval(c, l, prim, vert)
+                assert abs(ll[0] - rll) < 2e-3 and np.linalg.norm(rg - g[:, 0]) <= 1e-2 * max(np.linalg.norm(rg), 1e-2), (i, c, l)
+        emitter_ss[flag] = {i: (float(si[i, 4]), si[i, 16:].copy()) for i, *_ in emit}
+        orc.close()
+        ren.close()
+    common = set(emitter_ss[0]) & set(emitter_ss[1])
+    assert len(common) >= 30
+    for i in common:  # the option re-parameterises exactly these states: another ssScore, another pss at the last bounce
+        assert abs(emitter_ss[1][i][0] / emitter_ss[0][i][0] - 1) > 1e-3 and np.abs(emitter_ss[1][i][1] - emitter_ss[0][i][1]).max() > 1e-4
+    r = gc.run_pair(160, 120, 1 << 17, 1 << 13, 4096, 400, 40, use_gradient=1, max_depth=6, scene=AREA, force_diffuse=1, oracle_grad="reference",
+                    opts={"uselightcoordinatesampling": 1})
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["init_cl_match"] == 1.0
+    for k in ("steps", "largeSteps"):
+        assert sg[k] == so[k], (k, sg[k], so[k])
+    assert abs(sg["accepted"] - so["accepted"]) <= 4 and abs(sg["gradCalls"] - so["gradCalls"]) <= 4
+    assert r["film_rel_l2"] < 5e-3 and r["final_state_match"] > 0.998 and abs(r["energy_gpu"] - 1.0) < 1e-4, (r["film_rel_l2"], r["final_state_match"], r["energy_gpu"])

@@ -333,3 +333,40 @@ def test_deterministic_transcendentals_accuracy_and_conventions():
     ex = np.array([89, -104, np.nan, 0, -90], np.float32)
     lib.lmc_test_trans_host(len(ex), 0, P(ex), P(ex), P(o))
     assert o[0] == np.inf and o[1] == 0 and np.isnan(o[2]) and o[3] == 1 and 0 < o[4] < 1e-38
+
+
+def test_golden_light_coordinate_vectors():
+    """`uselightcoordinatesampling`: committed vectors of the reference's programs with scene[0] = 1 on veach-door states
+    whose camera path ends on the area light (tests/golden/derv_vectors_lightcoord.npz, techniques (4..9, 0)): the product's path
+    program takes the doLightCoordinateSampling branch (pathfunc.h BSDFSamplingT; path.cpp:2979-3025) -- value 2e-3, MALA gradient
+    and H2MC gradient + Hessian 1e-2.  Also recorded there: the scalar sampler's ssScore of the same states.  The reference's scalar
+    GeneratePathBidir multiplies by SamplePdf() where its own derivative program divides (path.cpp:1359 vs :3013), so
+    logLum - log(ssScore) is not 0 but the same constant, 2 log(light area), on every state -- a quirk the oracle keeps."""
+    H = _host_pathfunc()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "derv_vectors_lightcoord.npz"))
+    n = len(z["c"])
+    assert n >= 10 and z["scene"][0] == 1.0
+    sp = z["scene"].copy()
+    off = []
+    for i in range(n):
+        c, l = int(z["c"][i]), int(z["l"][i])
+        dim = 2 * (c + l - 1)
+        prim, vert = z["primary"][i].copy(), z["vert"][i].copy()
+        ll, g = np.zeros(1, np.float32), np.zeros(16, np.float32)
+        H.lmc_test_pathfunc_host(c, l, P(prim), P(sp), P(vert), P(ll), P(g))
+        assert abs(ll[0] - z["loglum"][i]) < 2e-3, (i, c)
+        rg = z["mala_grad"][i][:dim]
+        assert np.linalg.norm(rg - g[:dim]) <= 1e-2 * max(np.linalg.norm(rg), 1e-2), (i, c)
+        g2, h2 = np.zeros(16, np.float32), np.zeros(256, np.float32)
+        H.lmc_test_pathfunc_hess_host(c, l, P(prim), P(sp), P(vert), P(ll), P(g2), P(h2))
+        H1, H2 = z["h2_hess"][i][: dim * dim].reshape(dim, dim), h2[: dim * dim].reshape(dim, dim)
+        assert np.linalg.norm(z["h2_grad"][i][:dim] - g2[:dim]) <= 1e-2 * max(np.linalg.norm(z["h2_grad"][i][:dim]), 1e-2)
+        assert np.linalg.norm(H1 - H2) <= 1e-2 * max(np.linalg.norm(H1), 1e-1), (i, c)
+        # with the flag off the same inputs take the BSDF-sampling branch: another function
+        sp0 = sp.copy()
+        sp0[0] = 0.0
+        ll0 = np.zeros(1, np.float32)
+        H.lmc_test_pathfunc_host(c, l, P(prim), P(sp0), P(vert), P(ll0), P(g))
+        assert not (abs(ll0[0] - ll[0]) < 1e-3)
+        off.append(float(z["loglum"][i] - np.log(z["scalar_ss"][i])))
+    assert max(off) - min(off) < 5e-3 and min(off) > 10.0, (min(off), max(off))  # 2 log(area of the door scene's emitter) = 18.23
