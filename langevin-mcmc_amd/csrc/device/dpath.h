@@ -495,6 +495,121 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
     }
 }
 
+// GenerateSubpath, path.cpp:1451-1658 (screenPosi = (-1,-1), bidirMIS = true): ONE technique -- camLength camera vertices, lgtLength
+// light vertices, the counts include the camera / the light itself -- and no Russian roulette (rrWeight = 1).  The generator of the
+// multiplexed large step (mutation_large.h:45-57).  Differences from GeneratePathBidir that matter: the light subpath is only
+// started for lgtLength > 1 (no random numbers drawn otherwise), ONE light state is advanced in place (its ssJacobian is carried,
+// not reset, across non-absolute vertices), and the area-light re-parameterisation of the last bounce (path.cpp:1549-1571) is
+// unconditional: this function never reads options->useLightCoordinateSampling.
+template <class Stk>
+LMC_D void GenerateSubpath(const DScene &S, int camLength, int lgtLength, DPath &path, ContribSink &sink, Rng &rng, Stk &stk) {
+    TraceOcclusion trace;
+    path.camCount = path.lgtCount = 0;
+    path.envPrim = -1;
+    path.time = rng.Uniform();
+    BPS lps;
+    V3 org, dir;
+    if (lgtLength > 1) {
+        float lightPickProb = 1.0f;
+        {  // EmitFromLightInit, path.cpp:576-586
+            V2 p = RndVec2(rng), d = RndVec2(rng);
+            path.lgtPos0 = p.x, path.lgtPos1 = p.y, path.lgtDir0 = d.x, path.lgtDir1 = d.y;
+            path.lgtLight = PickLight(S, rng.Uniform(), lightPickProb);
+            path.lgtPrim = LightSampleDiscrete(S, path.lgtLight, rng.Uniform());
+        }
+        EmitFromLight(S, lightPickProb, path, org, dir, lps);
+        for (int lgtDepth = 0;; lgtDepth++) {
+            if (lgtDepth >= MAXD) return;  // storage bound (never reached for maxDepth <= MAXD)
+            DVertex &sv = path.lgt[lgtDepth];
+            SurfHit hit;
+            if (!IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lps.isect, stk)) return;
+            path.lgtCount = lgtDepth + 1;
+            sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
+            sv.bsdfDiscrete = rng.Uniform();
+            lps.wi = -dir;
+            ConvertMIS(S, lgtDepth, path.lgtLight, org, dir, lps);
+            if (lgtDepth + 2 == lgtLength) {
+                if (camLength == 1) {
+                    Contrib c;
+                    if (ConnectToCamera(S, lgtDepth, lps, sv, c, stk, trace)) sink.Push(c);
+                    return;
+                }
+                break;
+            }
+            V2 r = RndVec2(rng);
+            sv.rnd0 = r.x, sv.rnd1 = r.y;
+            V3 bsdfContrib;
+            if (!BSDFSampling<true, false, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) return;
+            sv.rrWeight = 1.0f;
+            org = lps.isect.position;
+        }
+    }
+    BPS cps;
+    {  // EmitFromCameraInit with screenPosi = (-1,-1)
+        V2 s = RndVec2(rng);
+        path.screen0 = s.x, path.screen1 = s.y;
+    }
+    const V2 screenPos{path.screen0, path.screen1};
+    EmitFromCamera(S, screenPos, org, dir, cps);
+    float tnear, tfar;
+    tnear = PrimaryMinT(S, screenPos, tfar);
+    float lcJac = 0.0f;
+    for (int camDepth = 0;; camDepth++) {
+        if (camDepth >= MAXD) return;
+        DVertex &sv = path.cam[camDepth];
+        path.camCount = camDepth + 1;
+        SurfHit hit;
+        hit.tri = -1;
+        const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect, stk);
+        sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
+        cps.wi = -dir;
+        if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
+        if (camDepth + 2 >= camLength && lgtLength == 0) {
+            const int light = HitLightOf(S, hitSurface, hit.tri);
+            if (light >= 0) {
+                if (camDepth > 1 && S.lights[light].type == LIGHT_AREA) {
+                    DVertex &prev = path.cam[camDepth - 1];
+                    const V2 sp = TriangleSampleParam(S, hit.tri, cps.isect.position);
+                    prev.rnd0 = sp.x, prev.rnd1 = sp.y;
+                    V3 dirToPrev = cps.isect.position - org;
+                    const float distSq = LengthSquared(dirToPrev);
+                    const float invDistSq = inverse(distSq);
+                    const float invDist = sqrtf(invDistSq);
+                    dirToPrev = dirToPrev * invDist;
+                    cps.ssJacobian *= fabsf(Dot(dirToPrev, cps.isect.shadingNormal) * invDistSq) * (lcJac * S.meshes[S.tris[hit.tri].mesh].invTotalArea);
+                }
+                Contrib c;
+                if (HandleHitLight(S, camDepth, light, hitSurface, dir, screenPos, cps, path.envPrim, c)) sink.Push(c);
+            }
+            return;
+        }
+        if (!hitSurface) return;
+        sv.bsdfDiscrete = rng.Uniform();
+        if (camDepth + 2 == camLength) {
+            Contrib c;
+            if (lgtLength == 1) {
+                float directLightPickProb = 1.0f;
+                sv.dirLight = PickLight(S, rng.Uniform(), directLightPickProb);  // DirectLightingInit, path.cpp:184-193
+                V2 r = RndVec2(rng);
+                sv.dirRnd0 = r.x, sv.dirRnd1 = r.y;
+                sv.dirPrim = LightSampleDiscrete(S, sv.dirLight, rng.Uniform());
+                if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk, trace)) sink.Push(c);
+            } else {
+                if (ConnectVertex(S, camDepth, lgtLength - 2, lps, path.lgt[lgtLength - 2], cps, sv, screenPos, c, stk, trace)) sink.Push(c);
+            }
+            return;
+        }
+        V2 r = RndVec2(rng);
+        sv.rnd0 = r.x, sv.rnd1 = r.y;
+        V3 bsdfContrib;
+        if (!BSDFSampling<false, false, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib, &lcJac)) return;
+        sv.rrWeight = 1.0f;
+        org = cps.isect.position;
+        tnear = c_IsectEpsilon;
+        tfar = INFINITY;
+    }
+}
+
 LMC_D void ToSubpath(int camDepth, int lgtDepth, DPath &path) {  // path.cpp:1660-1669
     path.camCount = max(camDepth - 1, 0);
     path.lgtCount = max(lgtDepth - 1, 0);

@@ -179,7 +179,16 @@ LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A,
     A.nextKind[i] = nk;
 }
 
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, class Stk>
+// PiecewiseConstant1D::SampleDiscrete / Pmf (distribution.h:43-53) on StepParams' lengthDist
+LMC_D int LengthSampleDiscrete(const StepParams &P, float u) {
+    int pos = P.lengthCount + 1;  // std::upper_bound(cdf, cdf + count + 1, u): first element > u
+    for (int k = P.lengthCount; k >= 0; k--)
+        if (P.lengthCdf[k] > u) pos = k;
+    return Clampi(pos - 1, 0, P.lengthCount - 1);
+}
+LMC_D float LengthPmf(const StepParams &P, int length) { return P.lengthFunc[length] / (P.lengthFuncInt * float(P.lengthCount)); }
+
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool MUX = false, class Stk>
 LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
                      GradWork &gw, StepStats &st, Stk &stk) {
     const size_t N = A.N;
@@ -197,9 +206,16 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
     ContribSink sink{A.contribList, N, (size_t)i, 0};
     st.steps++;
 
-    if (WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL)) {  // LargeStep::Mutate, mutation_large.h:31-128 (largeStepMultiplexed = false)
+    if (WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL)) {  // LargeStep::Mutate, mutation_large.h:31-128; MUX = largeStepMultiplexed
         st.large++;
-        GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng, stk);
+        if constexpr (MUX) {  // mutation_large.h:45-58: a length from lengthDist, a uniform split of it, one technique
+            const int length = LengthSampleDiscrete(P, rng.Uniform());
+            const int lgtLength = Clampi(int(rng.Uniform() * float(length + 1)), 0, length);
+            const int camLength = length - lgtLength + 1;
+            GenerateSubpath(S, camLength, lgtLength, prop, sink, rng, stk);
+        } else {
+            GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng, stk);
+        }
         if (sink.count > 0) {
             float scoreSum = 0.f;
             for (int k = 0; k < sink.count; k++) scoreSum += sink.LsScore(k);  // contribCdf.back()
@@ -216,7 +232,12 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             int contribId = Clampi(pos - 1, 0, sink.count - 1);
             pc = sink.Get(contribId);
             propScoreSum = scoreSum;
-            if (curValid) {
+            if (curValid && MUX) {  // mutation_large.h:87-102
+                const int currentLength = cur.camDepth + cur.lightDepth - 1, proposalLength = pc.camDepth + pc.lightDepth - 1;
+                const float invProposalTechniquesPmf = float(proposalLength) + 1.0f, invCurrentTechniquesPmf = float(currentLength) + 1.0f;
+                a = Clampf((invProposalTechniquesPmf * pc.lsScore / LengthPmf(P, proposalLength)) / (invCurrentTechniquesPmf * cur.lsScore / LengthPmf(P, currentLength)),
+                           0.0f, 1.0f);
+            } else if (curValid) {
                 const float probProposal = pc.lsScore / scoreSum;
                 const float probLast = A.lastScore[i] / A.lastScoreSum[i];
                 a = Clampf((pc.lsScore * probLast) / (cur.lsScore * probProposal), 0.0f, 1.0f);

@@ -38,6 +38,8 @@ void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 // append themselves to the lists of the next step
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);
+void LaunchStepLargeMux(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
+                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);  // step_large_mux.hip
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list,

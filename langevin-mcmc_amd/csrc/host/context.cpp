@@ -170,6 +170,8 @@ struct lmc_ctx {
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
     // init results
     float normalization = 0.f;
+    std::vector<float> lengthFunc, lengthCdf;  // lengthDist of MLTInit (mlt.h:99), read by the multiplexed large step
+    float lengthFuncInt = 0.f;
     long long numInitContribs = 0;
     std::vector<unsigned char> initCL;            // MLTInit contributions in stream order (parity probe lmc_init_contribs)
     std::vector<float> initLs;
@@ -333,8 +335,7 @@ static void SyncOptions(lmc_ctx *c) {
     if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 12] on the MI355X back end");
     d.useLightCoord = o.useLightCoordinateSampling ? 1 : 0;
     c->S.sceneParams[0] = d.useLightCoord ? 1.0f : 0.0f;  // scene.cpp:165: the flag opens the serialized scene block the path programs read
-    if (o.largeStepMultiplexed || o.sampleFromGlobalCache)
-        throw std::runtime_error("largestepmultiplexed / samplecache are out of scope (SURVEY.md §8f)");
+    if (o.sampleFromGlobalCache) throw std::runtime_error("samplecache (LargeStepCache) is out of scope (SURVEY.md §8f)");
 }
 
 static void UploadCacheStruct(lmc_ctx *c) {
@@ -433,6 +434,7 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
     else if (n == "uselightcoordinatesampling") o.useLightCoordinateSampling = v != 0;
+    else if (n == "largestepmultiplexed") o.largeStepMultiplexed = v != 0;
     else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else throw std::runtime_error("Unknown dpt option:" + n);
@@ -663,6 +665,16 @@ void InitPhase3(lmc_ctx *c, InitJob &J) {
     hr.ticks = 0;
     const int NT = J.numChainsTotal;
     lmc::SeedWalk(J.numInitSamples, NT, J.hOff, hCL.data(), hLs.data(), [](void *r) { return ((Rng *)r)->Uniform(); }, &hr, J.seedSample, J.seedCL, J.seedLs, c->normalization);
+    {  // lengthDist, mlt.h:88-99: per-length score sums in stream order (float, like the reference's accumulation), the same on every rank
+        std::vector<float> lengthContrib;
+        for (unsigned long long k = 0; k < total; k++) {
+            const int pathLength = (hCL[k] >> 4) + (hCL[k] & 15) - 1;
+            if (pathLength >= (int)lengthContrib.size()) lengthContrib.resize(pathLength + 1, 0.f);
+            lengthContrib[pathLength] += hLs[k];
+        }
+        if ((int)lengthContrib.size() > LENGTH_DIST_MAX) throw std::runtime_error("path length beyond LENGTH_DIST_MAX");
+        lmc::BuildPiecewise1D(lengthContrib.data(), (int)lengthContrib.size(), c->lengthFunc, c->lengthCdf, c->lengthFuncInt);
+    }
     c->initCL.swap(hCL), c->initLs.swap(hLs);
     c->initOffsets.assign(J.hOff.begin(), J.hOff.end() - 1);
     J.ownedBegin = lmc::OwnedRanges(J.world, J.V, J.numInitSamples, J.seedSample);
@@ -1031,6 +1043,10 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
     StepParams P;
     P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
+    const bool mux = c->scene->options.largeStepMultiplexed;
+    P.lengthCount = mux ? (int)c->lengthFunc.size() : 0, P.lengthFuncInt = c->lengthFuncInt;
+    for (int k = 0; k < P.lengthCount; k++) P.lengthFunc[k] = c->lengthFunc[k];
+    for (int k = 0; k <= P.lengthCount; k++) P.lengthCdf[k] = c->lengthCdf[k];
     if (c->timing) {
         if (c->eventPool.empty()) {
             for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
@@ -1051,7 +1067,7 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
     }
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
-    LaunchStepLarge(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
+    (mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
     // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow

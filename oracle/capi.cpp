@@ -70,6 +70,7 @@ int orc_set_option(void *h, const char *name, double v) {
     else if (n == "mala-gn") o.malaGN = (float)v;
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
+    else if (n == "largestepmultiplexed") o.largeStepMultiplexed = v != 0;
     else if (n == "uselightcoordinatesampling") {
         o.useLightCoordinateSampling = v != 0;
         ((MLT *)h)->scene->sceneParams[0] = v != 0 ? 1.f : 0.f;  // scene.cpp:165: the flag is the first word of the serialized scene block

@@ -466,6 +466,8 @@ Float MLT::Init(int64_t numInitSamples, int numChains, int initThreads_) {  // m
         state.gaussianInitialized = false;
         pos += interval;
     }
+    // lengthDist, mlt.h:99 (PiecewiseConstant1D over the per-length score sums; the multiplexed large step samples it)
+    lmc::BuildPiecewise1D(lengthContrib.data(), (int)lengthContrib.size(), lengthFunc, lengthCdf, lengthFuncInt);
     normalization = Float(totalScore) * inverse(Float(numInitSamples));
     return normalization;
 }
@@ -502,14 +504,22 @@ void MLT::Splat(std::vector<Float> &film, const Vector2 screenPos, const Vector3
 }
 
 // ============================================================================================ mutations
-Float MLT::LargeStepMutate(ChainCtx &c) {  // mutation_large.h:31-128 (largeStepMultiplexed = false)
+Float MLT::LargeStepMutate(ChainCtx &c) {  // mutation_large.h:31-128
     std::uniform_real_distribution<Float> uniDist(Float(0.0), Float(1.0));
     const RScene *sc = scene.get();
     MarkovState &currentState = c.currentState, &proposalState = c.proposalState;
     Float a = Float(1.0);
     std::vector<SubpathContrib> spContribs;
     Clear(proposalState.path);
-    GeneratePathBidir(sc, -1, -1, std::max(sc->options->minDepth, 3), sc->options->maxDepth, proposalState.path, spContribs, c.rng);
+    const bool multiplexed = sc->options->largeStepMultiplexed;
+    if (multiplexed) {  // mutation_large.h:45-58: one technique of a length drawn from lengthDist
+        int length = lmc::SampleDiscrete1D(lengthFunc, lengthCdf, lengthFuncInt, uniDist(c.rng), nullptr);
+        int lgtLength = Clamp(int(uniDist(c.rng) * (length + 1)), 0, length);  // options->bidirectional
+        int camLength = length - lgtLength + 1;
+        GenerateSubpath(sc, camLength, lgtLength, true, proposalState.path, spContribs, c.rng);
+    } else {
+        GeneratePathBidir(sc, -1, -1, std::max(sc->options->minDepth, 3), sc->options->maxDepth, proposalState.path, spContribs, c.rng);
+    }
     proposalState.gaussianInitialized = false;
     if (spContribs.size() > 0) {
         std::vector<Float> contribCdf;
@@ -522,7 +532,15 @@ Float MLT::LargeStepMutate(ChainCtx &c) {  // mutation_large.h:31-128 (largeStep
         int64_t contribId = Clamp(int64_t(it - contribCdf.begin() - 1), int64_t(0), int64_t(spContribs.size() - 1));
         proposalState.spContrib = spContribs[contribId];
         proposalState.scoreSum = scoreSum;
-        if (currentState.valid) {
+        if (currentState.valid && multiplexed) {  // mutation_large.h:87-102
+            int currentLength = GetPathLength(currentState.spContrib.camDepth, currentState.spContrib.lightDepth);
+            int proposalLength = GetPathLength(proposalState.spContrib.camDepth, proposalState.spContrib.lightDepth);
+            Float invProposalTechniquesPmf = Float(proposalLength) + Float(1.0);
+            Float invCurrentTechniquesPmf = Float(currentLength) + Float(1.0);
+            a = Clamp((invProposalTechniquesPmf * proposalState.spContrib.lsScore / LengthPmf(proposalLength)) /
+                          (invCurrentTechniquesPmf * currentState.spContrib.lsScore / LengthPmf(currentLength)),
+                      Float(0.0), Float(1.0));
+        } else if (currentState.valid) {
             const Float probProposal = (proposalState.spContrib.lsScore / proposalState.scoreSum);
             const Float probLast = (c.lastScore / c.lastScoreSum);
             a = Clamp((proposalState.spContrib.lsScore * probLast) / (currentState.spContrib.lsScore * probProposal), Float(0.0), Float(1.0));

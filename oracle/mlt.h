@@ -143,6 +143,10 @@ struct MLT {
     PathFuncLib lib;
     std::vector<MarkovState> initStates;
     std::vector<Float> lengthContrib;
+    // lengthDist (mlt.h:99): PiecewiseConstant1D(lengthContrib), distribution.h:8-60
+    std::vector<Float> lengthFunc, lengthCdf;
+    Float lengthFuncInt = 0;
+    Float LengthPmf(int length) const { return lengthFunc[length] / (lengthFuncInt * Float(lengthFunc.size())); }  // distribution.h:51-53
     Float normalization = 0;
     GlobalCache cache;
     std::vector<ChainCtx> chains;

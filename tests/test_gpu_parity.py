@@ -745,3 +745,37 @@ def test_plugin_symbol_call_cost_and_threads(pair_full):
     for t in th:
         t.join()
     assert not errs, errs[:5]
+
+
+@pytest.mark.parametrize("scene_kind", ["lambertian", "full", "arealight"])
+def test_multiplexed_large_step_chain_parity(scene_kind):
+    """SURVEY §8(f) item 4, `largestepmultiplexed` (mutation_large.h:45-58,87-102; GenerateSubpath, path.cpp:1451-1658; lengthDist,
+    mlt.h:88-99): the large step draws a path length from the per-length score sums of MLTInit, splits it uniformly into a camera
+    and a light part, generates that ONE technique without Russian roulette and accepts with the multiplexed-MLT ratio.  Same
+    lock-step comparison as test_chain_loop_parity; the chains start invalid, so the first steps of every chain ARE large steps.
+    `arealight`: the planar-emitter scene, where GenerateSubpath's unconditional light-coordinate re-parameterisation
+    (path.cpp:1549-1571) runs -- together with uselightcoordinatesampling, as the small steps must read those coordinates back."""
+    if not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    if scene_kind == "lambertian":
+        r = gc.run_pair(160, 120, 40000, 256, 8, 400, 100, use_gradient=1, opts={"largestepmultiplexed": 1})  # the init of test_chain_loop_parity
+    elif scene_kind == "arealight":
+        r = gc.run_pair(160, 120, 1 << 17, 2048, 4096, 400, 40, use_gradient=1, max_depth=6, scene=os.path.join(gc.ROOT, "scenes", "torus", "lmc_arealight.xml"),
+                        force_diffuse=1, oracle_grad="reference", opts={"largestepmultiplexed": 1, "uselightcoordinatesampling": 1})
+    else:
+        r = gc.run_pair(160, 120, 20000, 2048, 20000, 400, 40, use_gradient=1, max_depth=8, force_diffuse=0, oracle_grad="reference", opts={"largestepmultiplexed": 1})
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == (256 * 100 if scene_kind == "lambertian" else 2048 * 40) and r["nonfinite_gpu"] == 0
+    assert abs(r["energy_gpu"] - r["energy_oracle"]) < 1e-4, (r["energy_gpu"], r["energy_oracle"])
+    assert so["largeSteps"] > 0.2 * so["steps"]  # single-technique proposals fail often: the invalid start lasts many steps
+    if scene_kind != "full":
+        assert r["contribs_gpu"] == r["contribs_oracle"] and r["init_cl_match"] > 0.999
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 2
+        assert abs(sg["accepted"] - so["accepted"]) <= 4 and abs(sg["gradCalls"] - so["gradCalls"]) <= 4
+        assert r["film_rel_l2"] < 5e-3 and r["final_state_match"] > 0.99  # 255 of 256 on the Lambertian torus
+    else:
+        assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.01 * so["largeSteps"]
+        assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
+        assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * max(so["gradCalls"], 100)
+        assert r["film_rel_l2"] < 0.15 and r["final_state_match"] > 0.95
