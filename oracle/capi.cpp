@@ -71,6 +71,7 @@ int orc_set_option(void *h, const char *name, double v) {
     else if (n == "perturbstddev") o.perturbStdDev = (float)v;
     else if (n == "mindepth") o.minDepth = (int)v;
     else if (n == "largestepmultiplexed") o.largeStepMultiplexed = v != 0;
+    else if (n == "samplecache") o.sampleFromGlobalCache = v != 0;
     else if (n == "uselightcoordinatesampling") {
         o.useLightCoordinateSampling = v != 0;
         ((MLT *)h)->scene->sceneParams[0] = v != 0 ? 1.f : 0.f;  // scene.cpp:165: the flag is the first word of the serialized scene block
@@ -95,6 +96,31 @@ long long orc_init_contribs(void *h, long long cap, long long *sample, int *cl, 
     const long long n = (long long)m->initContribCL.size();
     for (long long i = 0; i < n && i < cap; i++) sample[i] = m->initContribSample[i], cl[i] = m->initContribCL[i], ls[i] = m->initContribLs[i];
     return n;
+}
+
+// consistency probe of the two path generators: n samples of GenerateSubpath(camLength, lgtLength) on RNG(seed); sumLs / sumLsSq = sum of the
+// lsScores / of their squares, count = samples with a contribution.  In expectation sumLs / n equals what technique (camLength, lgtLength) contributes
+// per GeneratePathBidir sample (both are unbiased estimates of the technique's MIS-weighted integral; only one plays Russian roulette).
+int orc_subpath_probe(void *h, int camLength, int lgtLength, long long n, long long seed, double *sumLs, double *sumLsSq, long long *count) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    RNG rng((uint64_t)seed);
+    Path path;
+    std::vector<SubpathContrib> sp;
+    double s = 0, s2 = 0;
+    long long c = 0;
+    for (long long i = 0; i < n; i++) {
+        sp.clear();
+        Clear(path);
+        GenerateSubpath(m->scene.get(), camLength, lgtLength, true, path, sp, rng);
+        for (auto &x : sp) {
+            if (x.camDepth != camLength || x.lightDepth != lgtLength) throw std::runtime_error("GenerateSubpath returned another technique");
+            s += x.lsScore, s2 += double(x.lsScore) * x.lsScore, c++;
+        }
+    }
+    *sumLs = s, *sumLsSq = s2, *count = c;
+    return 0;
+    ORC_CATCH(-1)
 }
 
 int orc_setup_chains(void *h, long long samplesPerChain, long long chainsNeedExtra) {
@@ -376,7 +402,7 @@ double orc_bench_steps(void *h, int nsteps, int threads, long long *stepsDone) {
                     barrier();
                     if (t == 0)
                         for (int tt = 0; tt < threads; tt++)
-                            for (auto &p : pushes[tt]) m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
+                            for (auto &p : pushes[tt]) m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight, p.path, p.spContrib);
                     barrier();
                 }
             });
@@ -430,7 +456,7 @@ double orc_run_async(void *h, int threads, double maxSeconds, long long *stepsDo
                     if (!pushes.empty()) {
                         for (auto &p : pushes) {
                             std::lock_guard<std::mutex> lock(dimMutex[p.dim]);
-                            m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
+                            m->cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight, p.path, p.spContrib);
                         }
                         pushes.clear();
                     }

@@ -302,9 +302,12 @@ int KdTree::RadiusSearch(const Float *q, Float radiusSq, int knn, int *idx, Floa
 }
 
 // ============================================================================================ global cache
-bool CacheDim::push(const Float *pss_, const Float *v1_, const Float *v2_, Float weight) {  // global_cache.h:70-94
+bool CacheDim::push(const Float *pss_, const Float *v1_, const Float *v2_, Float weight, const Path &path, const SubpathContrib &spContrib) {  // global_cache.h:70-94
     if (is_ready) return false;
     if (pss.empty()) {
+        rowPath.resize(PSS_MAX_SIZE), rowContrib.resize(PSS_MAX_SIZE);
+        inv_sigma_sq = inverse(CACHE_SIG * CACHE_SIG);  // global_cache.h:57-58; exp / log: the shared float routines (dtrans.h) stand in for libm
+        factor = lmcd::lexpf(dim * (Float(0.5) * lmcd::llogf(inv_sigma_sq) - Float(0.9189385332046727)));
         pss.resize((size_t)PSS_MAX_SIZE * dim);
         v1.resize((size_t)PSS_MAX_SIZE * dim);
         v2.resize((size_t)PSS_MAX_SIZE * dim);
@@ -316,12 +319,37 @@ bool CacheDim::push(const Float *pss_, const Float *v1_, const Float *v2_, Float
         v2[(size_t)data_idx * dim + i] = v2_[i];
     }
     pathWeight[data_idx] = weight;
+    rowPath[data_idx] = path, rowContrib[data_idx] = spContrib;
+    score_sum += weight;
     data_idx += 1;
     if (data_idx >= PSS_MAX_SIZE) {
         tree.Build(pss.data(), PSS_MAX_SIZE, dim);
+        lmc::BuildPiecewise1D(pathWeight.data(), PSS_MAX_SIZE, distFunc, distCdf, distFuncInt);  // data_distrib, global_cache.h:88-89
         is_ready = true;
     }
     return true;
+}
+
+int CacheDim::sampleCache(Float u) const { return lmc::SampleDiscrete1D(distFunc, distCdf, distFuncInt, u, nullptr); }
+
+Float CacheDim::evalPdfCache(const std::vector<Float> &pss_query, const Path &path) const {  // global_cache.h:139-164
+    Float ret(0.0);
+    for (int i = 0; i < PSS_MAX_SIZE; i++) {
+        const SubpathContrib &spContrib = rowContrib[i];
+        if (spContrib.camDepth != path.camDepth || spContrib.lightDepth != path.lgtDepth) continue;
+        Float sumDistSqr = 0;
+        for (int j = 0; j < dim; j++) {
+            Float c = pss[(size_t)i * dim + j], q = pss_query[j];
+            Float d1 = std::fabs(q - c);
+            Float d2 = Float(1.0) - d1;
+            Float d = std::min(d1, d2);
+            sumDistSqr += d * d;
+        }
+        Float expo = -Float(0.5) * sumDistSqr * inv_sigma_sq;
+        Float scale = Float(double(factor * pathWeight[i]) / score_sum);  // Float * Float / double -> Float
+        ret += lmcd::lexpf(expo) * scale;
+    }
+    return ret;
 }
 
 bool CacheDim::query(const std::vector<Float> &pss_, std::vector<Float> &v1_, std::vector<Float> &v2_) const {  // global_cache.h:96-124
@@ -554,6 +582,80 @@ Float MLT::LargeStepMutate(ChainCtx &c) {  // mutation_large.h:31-128
     return a;
 }
 
+// LargeStepCache::Mutate, mutation_large_cache.h:22-141: a large step that, once the global cache of the proposed dimension is
+// built, proposes half of the time a Gaussian perturbation (sigma CACHE_SIG) of a cached path drawn by its weight, and weighs the
+// two strategies against each other (MIS over the uniform multiplexed sampler and the kernel density of the cache).
+Float MLT::LargeStepCacheMutate(ChainCtx &c) {
+    std::uniform_real_distribution<Float> uniDist(Float(0.0), Float(1.0));
+    const RScene *sc = scene.get();
+    MarkovState &currentState = c.currentState, &proposalState = c.proposalState;
+    if (!sc->options->largeStepMultiplexed) throw std::runtime_error("samplecache needs largestepmultiplexed (mutation_large_cache.h:33)");
+    Float a = Float(1.0);
+    std::vector<SubpathContrib> spContribs;
+    Clear(proposalState.path);
+    const int proposalLength = lmc::SampleDiscrete1D(lengthFunc, lengthCdf, lengthFuncInt, uniDist(c.rng), nullptr);
+    const int proposalDim = proposalLength * 2;
+    const int currentLength = GetPathLength(currentState.spContrib.camDepth, currentState.spContrib.lightDepth);
+    const int currentDim = currentLength * 2;
+    bool proposalCacheAvailable = proposalDim >= PSS_MIN_LENGTH && proposalDim <= PSS_MAX_LENGTH && cache.isReady(proposalDim);
+    bool currentCacheAvailable = currentDim >= PSS_MIN_LENGTH && currentDim <= PSS_MAX_LENGTH && cache.isReady(currentDim);
+    if (!proposalCacheAvailable || uniDist(c.rng) > CACHE_PROB) {  // uniform, as in multiplexed MLT
+        int lgtLength = Clamp(int(uniDist(c.rng) * (proposalLength + 1)), 0, proposalLength);
+        int camLength = proposalLength - lgtLength + 1;
+        GenerateSubpath(sc, camLength, lgtLength, true, proposalState.path, spContribs, c.rng);
+        if (spContribs.size() > 0) {
+            ToSubpath(spContribs[0].camDepth, spContribs[0].lightDepth, proposalState.path);
+            // GetPathPss only sizes an EMPTY vector (path.cpp:2591): the reference writes past the end of a pss left over from a
+            // shorter state here (and at :106 below); the restatement grows the vector first, which is what those writes intend
+            if ((int)proposalState.pss.size() < GetDimension(proposalState.path)) proposalState.pss.resize(GetDimension(proposalState.path));
+            GetPathPss(proposalState.path, proposalState.pss);
+        }
+    } else {  // from the global cache
+        const CacheDim &cd = cache.dims[proposalDim];
+        const int idx = cd.sampleCache(uniDist(c.rng));
+        proposalState.path = cd.rowPath[idx];
+        const SubpathContrib &rowContrib = cd.rowContrib[idx];
+        ToSubpath(rowContrib.camDepth, rowContrib.lightDepth, proposalState.path);
+        std::normal_distribution<Float> normDist(Float(0.0), CACHE_SIG);
+        proposalState.pss.resize(proposalDim);
+        std::vector<Float> offset(2 * sc->options->maxDepth, Float(0.0));
+        for (int i = 0; i < proposalDim; i++) {
+            offset[i] = normDist(c.rng);
+            proposalState.pss[i] = Modulo(cd.pss[(size_t)idx * proposalDim + i] + offset[i], Float(1.0));
+        }
+        PerturbPathBidir(sc, offset, proposalState.path, spContribs, c.rng);
+    }
+    proposalState.gaussianInitialized = false;
+    if (spContribs.size() > 0) {
+        proposalState.spContrib = spContribs[0];
+        proposalState.scoreSum = spContribs[0].lsScore;
+        if (currentState.valid) {
+            ToSubpath(currentState.spContrib.camDepth, currentState.spContrib.lightDepth, currentState.path);
+            if ((int)currentState.pss.size() < GetDimension(currentState.path)) currentState.pss.resize(GetDimension(currentState.path));
+            GetPathPss(currentState.path, currentState.pss);
+            const Float proposalJacobian = proposalState.spContrib.ssScore / proposalState.spContrib.lsScore;
+            const Float currentJacobian = currentState.spContrib.ssScore / currentState.spContrib.lsScore;
+            Float proposalTechniquePickProb = inverse(Float(proposalLength) + Float(1.0));
+            Float currentTechniquePickProb = inverse(Float(currentLength) + Float(1.0));
+            Float proposalUniformPdf = Float(1.0) * proposalTechniquePickProb * proposalJacobian;  // 1.0 * x: double in the reference, exact either way
+            Float currentUniformPdf = Float(1.0) * currentTechniquePickProb * currentJacobian;
+            Float proposalCachePdf = proposalCacheAvailable ? cache.dims[proposalDim].evalPdfCache(proposalState.pss, proposalState.path) : Float(0.0);
+            Float currentCachePdf = currentCacheAvailable ? cache.dims[currentDim].evalPdfCache(currentState.pss, currentState.path) : Float(0.0);
+            Float proposalPdf = !proposalCacheAvailable ? proposalUniformPdf : (1 - CACHE_PROB) * proposalUniformPdf + CACHE_PROB * proposalCachePdf;
+            Float currentPdf = !currentCacheAvailable ? currentUniformPdf : (1 - CACHE_PROB) * currentUniformPdf + CACHE_PROB * currentCachePdf;
+            a = Clamp(proposalState.spContrib.ssScore * currentPdf * LengthPmf(currentLength) /
+                          (currentState.spContrib.ssScore * proposalPdf * LengthPmf(proposalLength)),
+                      Float(0.0), Float(1.0));
+        }
+        proposalState.toSplat.clear();
+        for (const auto &spContrib : spContribs)
+            proposalState.toSplat.push_back(SplatSample{spContrib.screenPos, spContrib.contrib * (normalization / spContrib.lsScore)});
+    } else {
+        a = Float(0.0);
+    }
+    return a;
+}
+
 Float MLT::SmallStepMutate(ChainCtx &c) {  // mutation_small.h:16-56
     const RScene *sc = scene.get();
     MarkovState &currentState = c.currentState, &proposalState = c.proposalState;
@@ -595,6 +697,8 @@ void MLT::InitGaussianFor(ChainCtx &c, MarkovState &state, bool isProposal) {
     auto funcIt = lib.dervMap.find({cspContrib.camDepth, cspContrib.lightDepth});
     const int dim = GetDimension(state.path);
     GetPathPss(state.path, chain->pss);
+    chain->path = state.path;
+    chain->spContrib = state.spContrib;
     chain->pathWeight = state.spContrib.lsScore;
     std::vector<Float> &new_g = isProposal ? chain->prop_new_g : chain->curr_new_g;
     std::vector<Float> &new_v1 = isProposal ? chain->prop_new_v1 : chain->curr_new_v1;
@@ -785,7 +889,7 @@ void MLT::StepChain(ChainCtx &c, std::vector<PendingPush> &pushes) {  // body of
     Float lsScale = (sampleIdx > c.numSamplesThisChain * LS_RATIO) ? sc->options->largeStepProbScale : Float(1.0);
     if (!currentState.valid || uniDist(c.rng) < largeStepProb * lsScale) {
         isLargeStep = true;
-        a = LargeStepMutate(c);
+        a = (sc->options->sampleFromGlobalCache && sc->options->mala) ? LargeStepCacheMutate(c) : LargeStepMutate(c);  // mlt.cpp:71-73
         c.st->largeSteps++;
     } else {
         // mlt.cpp:74-85: H2MC takes precedence over LMC, plain isotropic steps otherwise
@@ -816,6 +920,7 @@ void MLT::StepChain(ChainCtx &c, std::vector<PendingPush> &pushes) {  // body of
                     p.v1.assign(chain.v1.begin(), chain.v1.begin() + dim);
                     p.v2.assign(chain.v2.begin(), chain.v2.begin() + dim);
                     p.weight = chain.pathWeight;
+                    p.path = chain.path, p.spContrib = chain.spContrib;
                     pushes.push_back(std::move(p));
                 }
             }
@@ -862,7 +967,7 @@ void MLT::StepAll() {
     std::vector<PendingPush> pushes;
     for (auto &c : chains)
         if (c.sampleIdx < c.numSamplesThisChain) StepChain(c, pushes);
-    for (auto &p : pushes) cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight);
+    for (auto &p : pushes) cache.dims[p.dim].push(p.pss.data(), p.v1.data(), p.v2.data(), p.weight, p.path, p.spContrib);
 }
 
 }  // namespace orc

@@ -46,6 +46,8 @@ struct MarkovState {  // mlt.h:30-39
 #define PSS_MAX_SIZE 3000
 const Float PSS_QUERY_DIST = Float(0.01);
 const Float PSS_REUSE_DIST = Float(0.10);
+const Float CACHE_SIG = Float(0.15);   // global_cache.h:13-14
+const Float CACHE_PROB = Float(0.50);
 
 // kd-tree restating nanoflann's KDTreeSingleIndexAdaptor<L2_Simple_Adaptor> build (max leaf 10) and the
 // reference-modified radiusSearch (stop after `knn` matches in traversal order, then sort by distance):
@@ -74,8 +76,18 @@ struct CacheDim {  // global_cache_t<dim>, global_cache.h:33-124 (sampleCache/ev
     bool is_ready = false;
     std::vector<Float> pss, v1, v2;  // PSS_MAX_SIZE x dim
     std::vector<Float> pathWeight;
+    // what LargeStepCache reads (global_cache.h:21-23,42-43,47,57-58,84-90): the path and contribution of every row, the running
+    // double sum of the weights, PiecewiseConstant1D over the weights once the cache is built, the Gaussian kernel's constants
+    std::vector<Path> rowPath;
+    std::vector<SubpathContrib> rowContrib;
+    double score_sum = 0;
+    std::vector<Float> distFunc, distCdf;
+    Float distFuncInt = 0;
+    Float inv_sigma_sq = 0, factor = 0;
     KdTree tree;
-    bool push(const Float *pss_, const Float *v1_, const Float *v2_, Float weight);
+    bool push(const Float *pss_, const Float *v1_, const Float *v2_, Float weight, const Path &path, const SubpathContrib &spContrib);
+    int sampleCache(Float u) const;                                             // global_cache.h:126-137: the row index
+    Float evalPdfCache(const std::vector<Float> &pss_query, const Path &path) const;  // global_cache.h:139-164
     bool query(const std::vector<Float> &pss_, std::vector<Float> &v1_, std::vector<Float> &v2_) const;
 };
 
@@ -94,6 +106,8 @@ struct Chain {  // mutation.h:28-43
     std::vector<Float> curr_new_v1, curr_new_v2, curr_new_g;
     std::vector<Float> prop_new_v1, prop_new_v2, prop_new_g;
     Float pathWeight = 0;
+    Path path;                // mutation_mala.h:90-91,185-186: the state the last Gaussian was initialised for
+    SubpathContrib spContrib;
     bool buffered = false;
     Float ss = 0;
     int chainId = 0, t = 0;
@@ -117,6 +131,8 @@ struct PendingPush {
     int dim;
     std::vector<Float> pss, v1, v2;
     Float weight;
+    Path path;
+    SubpathContrib spContrib;
 };
 
 struct alignas(128) StepStats {  // padded: one instance per worker thread in the MT baseline (no false sharing)
@@ -165,6 +181,7 @@ struct MLT {
     void StepAll();
     void StepChain(ChainCtx &c, std::vector<PendingPush> &pushes);
     Float LargeStepMutate(ChainCtx &c);
+    Float LargeStepCacheMutate(ChainCtx &c);  // mutation_large_cache.h:22-141 (`samplecache` with mala)
     Float SmallStepMutate(ChainCtx &c);
     Float MALAMutate(ChainCtx &c);
     Float H2MCMutate(ChainCtx &c);  // mutation_h2mc.h:38-128
