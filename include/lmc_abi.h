@@ -149,6 +149,11 @@ int lmc_grad_batch(int c, int l, int n, const float *primary_soa, const float *s
  * the MALA ones.  Batched form: hess_soa[(2L)^2 * n], entry (i,k) of item j at [(i*2L + k)*n + j]. */
 int lmc_hess_batch(int c, int l, int n, const float *primary_soa, const float *scene38, const float *vert_soa, float *loglum, float *grad_soa, float *hess_soa);
 
+/* Parity probe: the rows of one global-cache dim as they stand (global_cache.h:21-23 point_cloud_t).  pss: 3000 x dim, weight: 3000,
+ * extra: 3000 x 313 = every row's path words then its contribution words, only with `samplecache` (mutation_large_cache.h); any
+ * pointer may be NULL.  Returns the number of rows filled, -1 on error. */
+int lmc_cache_rows(lmc_ctx *ctx, int dim, float *pss, float *weight, float *extra);
+
 /* ---- probes used by the parity tests (tests/) ---- */
 /* rays: n x [ox,oy,oz,dx,dy,dz,tnear,tfar]; closest hit -> global triangle id (or -1) and t */
 int lmc_trace(lmc_ctx *ctx, int n, const float *rays, int *prim, float *t);

@@ -9,6 +9,7 @@ namespace lmcd {
 
 constexpr int GAUSS_WORDS = 3 * MAXPSS + 1;  // mean, covL_d, invCov_d, logDet
 constexpr int CONTRIB_WORDS = 9;
+constexpr int CACHE_ROW_EXTRA = DPATH_WORDS + CONTRIB_WORDS;  // a `samplecache` cache row beyond pss | v1 | v2 | weight: its path, its contribution
 constexpr int SPLAT_WORDS = 5;
 
 // F_SEL: which of the two path buffers holds the chain's current path (the other receives the proposal; acceptance
@@ -62,6 +63,12 @@ struct DCacheDim {
     const float *gridRows;
     int gridG, gridM;
     float rootLow[MAXPSS], rootHigh[MAXPSS];
+    // `samplecache` (LargeStepCache, global_cache.h:21-23,42-47,57-58,126-164): every row's path and contribution (CACHE_ROW_EXTRA
+    // words), its weight, PiecewiseConstant1D over the weights (cdf of PSS_MAX_SIZE + 1 entries), their double sum in row order,
+    // the Gaussian kernel's constants.  nullptr / 0 unless the option is set.
+    const float *extra, *weight, *distCdf;
+    double scoreSum;
+    float invSigmaSq, factor;
 };
 struct DCache {
     DCacheDim d[PSS_MAX_LENGTH + 1];
@@ -70,22 +77,25 @@ struct DCache {
 constexpr int CACHE_SLOTS = 4;
 struct CachePushTargets {
     float *pss[CACHE_SLOTS], *v1[CACHE_SLOTS], *v2[CACHE_SLOTS], *weight[CACHE_SLOTS];  // PSS_MAX_SIZE rows each (nullptr: dim not in use)
+    float *extra[CACHE_SLOTS];  // `samplecache`: PSS_MAX_SIZE x CACHE_ROW_EXTRA (the row's DPath, then its Contrib); nullptr otherwise
     int *count;                                                                           // [CACHE_SLOTS] rows filled
 };
 
 // the stage of the multi-rank push (kernels.hip k_push_apply): one buffer of floats per rank, [16 header words: rows per slot]
 // followed, per slot, by pss | v1 | v2 (PSS_MAX_SIZE x dim each) | weight (PSS_MAX_SIZE); offsets in floats
 struct PushStageLayout {
-    int pss[CACHE_SLOTS], v1[CACHE_SLOTS], v2[CACHE_SLOTS], weight[CACHE_SLOTS];
+    int pss[CACHE_SLOTS], v1[CACHE_SLOTS], v2[CACHE_SLOTS], weight[CACHE_SLOTS], extra[CACHE_SLOTS];
     int totalFloats;
 };
-LMC_HD PushStageLayout MakePushStageLayout() {
+LMC_HD PushStageLayout MakePushStageLayout(bool withPaths) {  // withPaths (`samplecache`): every slot also carries PSS_MAX_SIZE x CACHE_ROW_EXTRA words
     PushStageLayout l;
     int off = 16;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) {
         const int dim = 6 + 2 * sl;
         l.pss[sl] = off, l.v1[sl] = off + PSS_MAX_SIZE * dim, l.v2[sl] = off + 2 * PSS_MAX_SIZE * dim, l.weight[sl] = off + 3 * PSS_MAX_SIZE * dim;
         off += PSS_MAX_SIZE * (3 * dim + 1);
+        l.extra[sl] = off;
+        if (withPaths) off += PSS_MAX_SIZE * CACHE_ROW_EXTRA;
     }
     l.totalFloats = off;
     return l;
@@ -107,6 +117,7 @@ struct ChainArrays {
     int *curSplatCount;
     float *chV1, *chV2, *chCurrNewV2, *chPropNewV1, *chPropNewV2, *chPss, *chLastPss;  // MAXPSS x N each
     float *pathWeight, *lastScoreSum, *lastScore;
+    float *chPath, *chContrib;  // `samplecache` only (else nullptr): chain.path / chain.spContrib of mutation_mala.h:90-91,185-186, DPATH_WORDS / CONTRIB_WORDS x N
     int *adjacentReject, *sampleIdx, *numSamples;
     float *contribList;  // MAXCONTRIB*CONTRIB_WORDS x N (GeneratePathBidir scratch)
     unsigned char *nextKind;  // N: which launch runs the chain's next step (NEXT_*), turned into id-ordered work lists by k_build_lists

@@ -94,6 +94,7 @@ struct DOptions {
     float roughnessThreshold, largeStepProbability, largeStepProbScale;
     float malaGN, malaStepsize, malaStdDev, perturbStdDev, discreteStdDev, uniformMixingProbability;
     int seedOffset;
+    int sampleCache;    // samplecache with mala (LargeStepCache, mlt.cpp:71-73): every small step takes the generic launch, which keeps chain.path
     int useLightCoord;  // uselightcoordinatesampling (path.cpp:1339-1360, 1881-1951): every small step then takes the generic launch
 };
 

@@ -48,6 +48,10 @@ LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArra
     GetPathPss(path, pss);
     for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = pss[k];  // GetPathPss(path, chain->pss)
     A.pathWeight[i] = sp.lsScore;
+    if (A.chPath) {  // chain->path / chain->spContrib, mutation_mala.h:90-91,185-186 (`samplecache`)
+        StorePath(A.chPath, A.N, i, path);
+        StoreContrib(A.chContrib, A.N, i, sp);
+    }
     const bool inRange = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH;
     const bool ready = inRange && cache.d[dim].ready;
     const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth) && path.camDepth + path.lgtDepth - 1 <= P.maxDervDepth;
@@ -172,7 +176,7 @@ LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A,
         } else {
             const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
             if (S.opt.h2mc) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // every H2MC small step runs k_step_h2mc (the "generic" slot of the launch plan); key: list sort
-            else if (S.opt.useLightCoord || (S.opt.mala && NeedsGeneric(cache, P, c, l))) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // key: k_build_lists may still re-route it
+            else if (S.opt.useLightCoord || S.opt.sampleCache || (S.opt.mala && NeedsGeneric(cache, P, c, l))) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // key: k_build_lists may still re-route it
             else nk = (unsigned char)(NEXT_SMALL_PLAIN | (TechniqueKey(c, l) << 2));
         }
     }
@@ -188,7 +192,101 @@ LMC_D int LengthSampleDiscrete(const StepParams &P, float u) {
 }
 LMC_D float LengthPmf(const StepParams &P, int length) { return P.lengthFunc[length] / (P.lengthFuncInt * float(P.lengthCount)); }
 
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool MUX = false, class Stk>
+// ---- LargeStepCache (`samplecache` with mala), mutation_large_cache.h:22-141 + global_cache.h:126-164
+constexpr float CACHE_SIG = 0.15f, CACHE_PROB = 0.50f;  // global_cache.h:13-14
+
+// global_cache_t::evalPdfCache: kernel density of the cache rows of technique (camDepth, lgtDepth) at pssQuery, toroidal distance
+LMC_D float EvalPdfCache(const DCacheDim &D, int dim, const float *pssQuery, int camDepth, int lgtDepth) {
+    float ret = 0.0f;
+    for (int r = 0; r < PSS_MAX_SIZE; r++) {
+        const float *x = D.extra + (size_t)r * CACHE_ROW_EXTRA + DPATH_WORDS;  // the row's Contrib: camDepth, lightDepth first
+        if (__float_as_int(x[0]) != camDepth || __float_as_int(x[1]) != lgtDepth) continue;
+        float sumDistSqr = 0.f;
+        for (int j = 0; j < dim; j++) {
+            const float c = D.pts[(size_t)r * dim + j], q = pssQuery[j];
+            const float d1 = fabsf(q - c);
+            const float d2 = 1.0f - d1;
+            const float d = fminf(d1, d2);
+            sumDistSqr += d * d;
+        }
+        const float expo = -0.5f * sumDistSqr * D.invSigmaSq;
+        const float scale = float(double(D.factor * D.weight[r]) / D.scoreSum);
+        ret += lexpf(expo) * scale;
+    }
+    return ret;
+}
+
+// proposes into `prop` / `pc` (and the sink, for the splats), sets the acceptance a
+template <class Stk>
+LMC_D void LargeStepCacheMutate(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, int flags, bool curValid, const Contrib &cur,
+                                DPath &prop, Contrib &pc, ContribSink &sink, float &a, Rng &rng, Stk &stk) {
+    const int proposalLength = LengthSampleDiscrete(P, rng.Uniform());
+    const int proposalDim = proposalLength * 2;
+    const int currentLength = cur.camDepth + cur.lightDepth - 1;
+    const int currentDim = currentLength * 2;
+    const bool proposalCacheAvailable = proposalDim >= PSS_MIN_LENGTH && proposalDim <= PSS_MAX_LENGTH && cache.d[proposalDim].ready;
+    const bool currentCacheAvailable = currentDim >= PSS_MIN_LENGTH && currentDim <= PSS_MAX_LENGTH && cache.d[currentDim].ready;
+    float propPss[MAXPSS];
+    bool got = false;
+    if (!proposalCacheAvailable || rng.Uniform() > CACHE_PROB) {  // uniform, as in multiplexed MLT
+        const int lgtLength = Clampi(int(rng.Uniform() * float(proposalLength + 1)), 0, proposalLength);
+        const int camLength = proposalLength - lgtLength + 1;
+        GenerateSubpath(S, camLength, lgtLength, prop, sink, rng, stk);
+        if (sink.count > 0) {
+            got = true;
+            pc = sink.Get(0);
+            ToSubpath(pc.camDepth, pc.lightDepth, prop);
+            GetPathPss(prop, propPss);
+        }
+    } else {  // a cached path, drawn by its weight, perturbed by N(0, CACHE_SIG) in every primary sample
+        const DCacheDim &D = cache.d[proposalDim];
+        const float u = rng.Uniform();
+        int lo = 0, hi = PSS_MAX_SIZE + 1;  // std::upper_bound(cdf, cdf + count + 1, u)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (D.distCdf[mid] > u) hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const int idx = Clampi(lo - 1, 0, PSS_MAX_SIZE - 1);
+        const float *row = D.extra + (size_t)idx * CACHE_ROW_EXTRA;
+        float *w = reinterpret_cast<float *>(&prop);
+        for (int k = 0; k < DPATH_WORDS; k++) w[k] = row[k];
+        ToSubpath(__float_as_int(row[DPATH_WORDS]), __float_as_int(row[DPATH_WORDS + 1]), prop);
+        NormalDist nd(0.0f, CACHE_SIG);
+        float offset[MAXPSS];
+        for (int k = 0; k < MAXPSS; k++) offset[k] = 0.f;
+        for (int k = 0; k < proposalDim; k++) {
+            offset[k] = nd(rng);
+            propPss[k] = Modulo1(D.pts[(size_t)idx * proposalDim + k] + offset[k]);
+        }
+        if (PerturbPathBidir(S, offset, prop, pc, rng, stk)) {
+            got = true;
+            sink.Push(pc);
+        }
+    }
+    if (!got) {
+        a = 0.0f;
+        return;
+    }
+    a = 1.0f;
+    if (curValid) {
+        DPath curPath;
+        LoadPath(CurPathBuf(A, flags), A.N, i, curPath);  // a subpath already: ToSubpath (mutation_large_cache.h:105) changes nothing
+        float curPss[MAXPSS];
+        GetPathPss(curPath, curPss);
+        const float proposalJacobian = pc.ssScore / pc.lsScore, currentJacobian = cur.ssScore / cur.lsScore;
+        const float proposalTechniquePickProb = inverse(float(proposalLength) + 1.0f), currentTechniquePickProb = inverse(float(currentLength) + 1.0f);
+        const float proposalUniformPdf = 1.0f * proposalTechniquePickProb * proposalJacobian, currentUniformPdf = 1.0f * currentTechniquePickProb * currentJacobian;
+        const float proposalCachePdf = proposalCacheAvailable ? EvalPdfCache(cache.d[proposalDim], proposalDim, propPss, pc.camDepth, pc.lightDepth) : 0.0f;
+        const float currentCachePdf = currentCacheAvailable ? EvalPdfCache(cache.d[currentDim], currentDim, curPss, cur.camDepth, cur.lightDepth) : 0.0f;
+        const float proposalPdf = !proposalCacheAvailable ? proposalUniformPdf : (1 - CACHE_PROB) * proposalUniformPdf + CACHE_PROB * proposalCachePdf;
+        const float currentPdf = !currentCacheAvailable ? currentUniformPdf : (1 - CACHE_PROB) * currentUniformPdf + CACHE_PROB * currentCachePdf;
+        a = Clampf(pc.ssScore * currentPdf * LengthPmf(P, currentLength) / (cur.ssScore * proposalPdf * LengthPmf(P, proposalLength)), 0.0f, 1.0f);
+    }
+}
+
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, int MUX = 0, class Stk>
 LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
                      GradWork &gw, StepStats &st, Stk &stk) {
     const size_t N = A.N;
@@ -206,9 +304,12 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
     ContribSink sink{A.contribList, N, (size_t)i, 0};
     st.steps++;
 
-    if (WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL)) {  // LargeStep::Mutate, mutation_large.h:31-128; MUX = largeStepMultiplexed
+    if (WITH_LARGE && (kind == KIND_LARGE || !WITH_SMALL)) {  // LargeStep::Mutate, mutation_large.h:31-128; MUX = 1: largeStepMultiplexed, 2: LargeStepCache
         st.large++;
-        if constexpr (MUX) {  // mutation_large.h:45-58: a length from lengthDist, a uniform split of it, one technique
+        if constexpr (MUX == 2) {
+            LargeStepCacheMutate(S, cache, A, P, i, flags, curValid, cur, prop, pc, sink, a, rng, stk);
+            propScoreSum = pc.lsScore;
+        } else if constexpr (MUX == 1) {  // mutation_large.h:45-58: a length from lengthDist, a uniform split of it, one technique
             const int length = LengthSampleDiscrete(P, rng.Uniform());
             const int lgtLength = Clampi(int(rng.Uniform() * float(length + 1)), 0, length);
             const int camLength = length - lgtLength + 1;
@@ -216,7 +317,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         } else {
             GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng, stk);
         }
-        if (sink.count > 0) {
+        if (MUX != 2 && sink.count > 0) {
             float scoreSum = 0.f;
             for (int k = 0; k < sink.count; k++) scoreSum += sink.LsScore(k);  // contribCdf.back()
             const float invSc = inverse(scoreSum);
@@ -232,7 +333,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             int contribId = Clampi(pos - 1, 0, sink.count - 1);
             pc = sink.Get(contribId);
             propScoreSum = scoreSum;
-            if (curValid && MUX) {  // mutation_large.h:87-102
+            if (curValid && MUX == 1) {  // mutation_large.h:87-102
                 const int currentLength = cur.camDepth + cur.lightDepth - 1, proposalLength = pc.camDepth + pc.lightDepth - 1;
                 const float invProposalTechniquesPmf = float(proposalLength) + 1.0f, invCurrentTechniquesPmf = float(currentLength) + 1.0f;
                 a = Clampf((invProposalTechniquesPmf * pc.lsScore / LengthPmf(P, proposalLength)) / (invCurrentTechniquesPmf * cur.lsScore / LengthPmf(P, currentLength)),
@@ -242,7 +343,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
                 const float probLast = A.lastScore[i] / A.lastScoreSum[i];
                 a = Clampf((pc.lsScore * probLast) / (cur.lsScore * probProposal), 0.0f, 1.0f);
             }
-        } else {
+        } else if (MUX != 2) {
             a = 0.0f;
         }
     } else if (WITH_SMALL) {

@@ -40,6 +40,8 @@ void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);
 void LaunchStepLargeMux(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);  // step_large_mux.hip
+void LaunchStepLargeCache(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
+                     const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);  // step_large_cache.hip
 void LaunchStepSmallGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                          const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list,

@@ -591,6 +591,11 @@ __global__ void __launch_bounds__(256) k_push_scatter(ChainArrays A, const unsig
                 T.v2[slot][(size_t)row * dim + k] = A.pushData[(size_t)(2 * MAXPSS + k) * N + i];
             }
             T.weight[slot][row] = A.pushData[(size_t)(3 * MAXPSS) * N + i];
+            if (T.extra[slot]) {  // `samplecache`: chain.path, chain.spContrib (no step of this chain ran since the push was decided)
+                float *x = T.extra[slot] + (size_t)row * CACHE_ROW_EXTRA;
+                for (int k = 0; k < DPATH_WORDS; k++) x[k] = A.chPath[(size_t)k * N + i];
+                for (int k = 0; k < CONTRIB_WORDS; k++) x[DPATH_WORDS + k] = A.chContrib[(size_t)k * N + i];
+            }
         }
         A.pushDim[i] = 0;  // consumed: a chain that has run its last step must not be pushed again by the following steps
     }
@@ -638,6 +643,10 @@ __global__ void __launch_bounds__(256) k_push_apply(const float *gathered, size_
         T.pss[slot][d] = pss[e], T.v1[slot][d] = v1[e], T.v2[slot][d] = v2[e];
     }
     for (int e = threadIdx.x; e < take; e += blockDim.x) T.weight[slot][base + e] = w[e];
+    if (T.extra[slot]) {
+        const float *x = st + lay.extra[slot];
+        for (size_t e = threadIdx.x; e < (size_t)take * CACHE_ROW_EXTRA; e += blockDim.x) T.extra[slot][(size_t)base * CACHE_ROW_EXTRA + e] = x[e];
+    }
 }
 __global__ void k_push_apply_finish(const float *gathered, size_t stageFloats, int world, CachePushTargets T) {
     const int slot = threadIdx.x;

@@ -46,7 +46,7 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
 #ifndef LMC_STEP_WAVES
 #define LMC_STEP_WAVES 2
 #endif
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, bool MUX = false>
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, int MUX = 0>
 __global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
     extern __shared__ int ldsStack[];

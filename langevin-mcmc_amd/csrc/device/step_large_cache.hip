@@ -1,0 +1,20 @@
+// k_step<true, false, false, ., ., MUX = 2>: LargeStepCache (`samplecache` with mala, mutation_large_cache.h:22-141), a TU of its own like
+// step_large_mux.hip
+#include "step_kernel.h"
+
+using namespace lmcd;
+
+void LaunchStepLargeCache(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
+                     const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s) {
+    if (bvhStackNeed <= BVH_LDS_STACK) {  // traversal stack in LDS; gridBlocks was sized for 256-thread blocks
+        const int blocks = gridBlocks * (256 / blockThreads);
+        const size_t ldsBytes = (size_t)blockThreads * ((bvhStackNeed + 7) / 8 * 8) * sizeof(int);  // the scene's own stack need, not the cap
+        if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, true, 2>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        else
+            hipLaunchKernelGGL((k_step<true, false, false, false, true, 2>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        return;
+    }
+    if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, false, 2>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+    else
+        hipLaunchKernelGGL((k_step<true, false, false, false, false, 2>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+}

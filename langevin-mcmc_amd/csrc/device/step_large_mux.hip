@@ -9,12 +9,12 @@ void LaunchStepLargeMux(const DScene &S, const DCache *cache, const ChainArrays 
     if (bvhStackNeed <= BVH_LDS_STACK) {  // traversal stack in LDS; gridBlocks was sized for 256-thread blocks
         const int blocks = gridBlocks * (256 / blockThreads);
         const size_t ldsBytes = (size_t)blockThreads * ((bvhStackNeed + 7) / 8 * 8) * sizeof(int);  // the scene's own stack need, not the cap
-        if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, true, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, true, 1>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
         else
-            hipLaunchKernelGGL((k_step<true, false, false, false, true, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+            hipLaunchKernelGGL((k_step<true, false, false, false, true, 1>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
         return;
     }
-    if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, false, true>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+    if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, false, 1>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
     else
-        hipLaunchKernelGGL((k_step<true, false, false, false, false, true>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        hipLaunchKernelGGL((k_step<true, false, false, false, false, 1>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
 }

@@ -78,6 +78,7 @@ void EnsureDevice(int device) {
 
 struct CacheDimHost {
     DevBuf<float> pss, v1, v2, weight;
+    DevBuf<float> extra, distCdf;  // `samplecache`: the rows' paths + contributions (CACHE_ROW_EXTRA words each), PiecewiseConstant1D over the weights
     DevBuf<KdNode> nodes;
     DevBuf<int> gridStart, gridCursor, gridTileSums;
     DevBuf<float> gridRows;
@@ -136,7 +137,7 @@ struct lmc_ctx {
     ChainArrays A;
     DevBuf<uint64_t> rngState;
     DevBuf<uint32_t> rngTab;
-    DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, gaussian1, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, pathWeight,
+    DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, gaussian1, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, chPath, chContrib, pathWeight,
         lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum, initLsAll;
     DevBuf<unsigned char> initCLAll;
     DevBuf<unsigned char> nextKind;
@@ -335,7 +336,7 @@ static void SyncOptions(lmc_ctx *c) {
     if (o.maxDepth > MAXD || o.maxDepth < 1) throw std::runtime_error("maxdepth must be in [1, 12] on the MI355X back end");
     d.useLightCoord = o.useLightCoordinateSampling ? 1 : 0;
     c->S.sceneParams[0] = d.useLightCoord ? 1.0f : 0.0f;  // scene.cpp:165: the flag opens the serialized scene block the path programs read
-    if (o.sampleFromGlobalCache) throw std::runtime_error("samplecache (LargeStepCache) is out of scope (SURVEY.md §8f)");
+    d.sampleCache = (o.sampleFromGlobalCache && o.mala) ? 1 : 0;  // mlt.cpp:71-73: LargeStepCache only together with mala
 }
 
 static void UploadCacheStruct(lmc_ctx *c) {
@@ -435,6 +436,7 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "mindepth") o.minDepth = (int)v;
     else if (n == "uselightcoordinatesampling") o.useLightCoordinateSampling = v != 0;
     else if (n == "largestepmultiplexed") o.largeStepMultiplexed = v != 0;
+    else if (n == "samplecache") o.sampleFromGlobalCache = v != 0;
     else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else throw std::runtime_error("Unknown dpt option:" + n);
@@ -698,6 +700,11 @@ void InitPhase4(lmc_ctx *c, InitJob &J);
 }  // namespace
 }  // extern "C++"
 
+// what the resident chain state is laid out for: mala, h2mc, samplecache (chain.path copies, cache rows with paths)
+static int MutationKey(const lmc_ctx *c) {
+    const lmc::DptOptions &o = c->scene->options;
+    return (o.mala ? 1 : 0) | (o.h2mc ? 2 : 0) | ((o.sampleFromGlobalCache && o.mala) ? 4 : 0);
+}
 extern "C++" {
 namespace {
 void InitPhase4(lmc_ctx *c, InitJob &J) {
@@ -708,7 +715,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->numChainsTotal = numChainsTotal;
     c->chainBegin = chainBegin;
     c->N = chainEnd - chainBegin;
-    c->mutationAtInit = (c->scene->options.mala ? 1 : 0) | (c->scene->options.h2mc ? 2 : 0);
+    c->mutationAtInit = MutationKey(c);
     const size_t N = c->N;
     // ---- the init states of this rank's chains, regenerated from the checkpoints of their seeding samples (wherever those ran)
     {
@@ -744,6 +751,10 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->curSplat.Alloc(N * MAXCONTRIB * SPLAT_WORDS), c->curSplatCount.Alloc(N);
     c->chV1.Alloc(N * MAXPSS), c->chV2.Alloc(N * MAXPSS), c->chCurrNewV2.Alloc(N * MAXPSS), c->chPropNewV1.Alloc(N * MAXPSS),
         c->chPropNewV2.Alloc(N * MAXPSS), c->chPss.Alloc(N * MAXPSS), c->chLastPss.Alloc(N * MAXPSS);
+    const bool sampleCache = c->S.opt.sampleCache != 0;
+    if (sampleCache) c->chPath.Alloc(N * DPATH_WORDS), c->chContrib.Alloc(N * CONTRIB_WORDS);
+    else
+        c->chPath.Free(), c->chContrib.Free();
     c->pathWeight.Alloc(N), c->lastScoreSum.Alloc(N), c->lastScore.Alloc(N), c->contribList.Alloc(N * MAXCONTRIB * CONTRIB_WORDS, false);
     c->pushData.Alloc(N * GAUSS_WORDS), c->flags.Alloc(N), c->nextKind.Alloc(N + 4), c->adjacentReject.Alloc(N), c->sampleIdx.Alloc(N), c->numSamples.Alloc(N), c->pushDim.Alloc(N);
     c->counters.Alloc(8), c->weightSum.Alloc(1), c->prof.Alloc(16);
@@ -753,6 +764,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.gaussian1 = c->gaussian1.p, A.h2Gauss = nullptr, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
     A.chV1 = c->chV1.p, A.chV2 = c->chV2.p, A.chCurrNewV2 = c->chCurrNewV2.p, A.chPropNewV1 = c->chPropNewV1.p, A.chPropNewV2 = c->chPropNewV2.p,
     A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
+    A.chPath = sampleCache ? c->chPath.p : nullptr, A.chContrib = sampleCache ? c->chContrib.p : nullptr;
     A.pathWeight = c->pathWeight.p, A.lastScoreSum = c->lastScoreSum.p, A.lastScore = c->lastScore.p;
     A.adjacentReject = c->adjacentReject.p, A.sampleIdx = c->sampleIdx.p, A.numSamples = c->numSamples.p;
     A.contribList = c->contribList.p, A.nextKind = c->nextKind.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
@@ -775,6 +787,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         if (cd.relevant) {
             cd.pss.Alloc((size_t)PSS_MAX_SIZE * d), cd.v1.Alloc((size_t)PSS_MAX_SIZE * d), cd.v2.Alloc((size_t)PSS_MAX_SIZE * d);
             cd.weight.Alloc(PSS_MAX_SIZE);
+            if (sampleCache) cd.extra.Alloc((size_t)PSS_MAX_SIZE * CACHE_ROW_EXTRA), cd.distCdf.Alloc(PSS_MAX_SIZE + 1);
             // everything the "cache became ready" event needs is allocated here: hipMalloc inside the step loop costs more than
             // the kd-tree build it would sit next to
             cd.gridG = CacheGridG(d), cd.gridM = std::min(c->gridDims, d);
@@ -787,19 +800,21 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     }
     c->cacheCounts.Alloc(CACHE_SLOTS), c->pushTiles.Alloc((N + 1023) / 1024);
     if (!c->hostCounts) HIP_CHECK(hipHostMalloc((void **)&c->hostCounts, CACHE_SLOTS * sizeof(int)));
-    c->stageLayout = MakePushStageLayout();
+    c->stageLayout = MakePushStageLayout(sampleCache);
     c->pushStage.Alloc((size_t)c->stageLayout.totalFloats), c->pushGather.Alloc(c->world > 1 ? (size_t)c->stageLayout.totalFloats * c->world : 1);
     memset(&c->stageT, 0, sizeof(c->stageT));
     c->stageT.count = reinterpret_cast<int *>(c->pushStage.p);
     for (int sl = 0; sl < CACHE_SLOTS; sl++)
         if (c->cacheDims[6 + 2 * sl].relevant)
             c->stageT.pss[sl] = c->pushStage.p + c->stageLayout.pss[sl], c->stageT.v1[sl] = c->pushStage.p + c->stageLayout.v1[sl],
-            c->stageT.v2[sl] = c->pushStage.p + c->stageLayout.v2[sl], c->stageT.weight[sl] = c->pushStage.p + c->stageLayout.weight[sl];
+            c->stageT.v2[sl] = c->pushStage.p + c->stageLayout.v2[sl], c->stageT.weight[sl] = c->pushStage.p + c->stageLayout.weight[sl],
+            c->stageT.extra[sl] = sampleCache ? c->pushStage.p + c->stageLayout.extra[sl] : nullptr;
     memset(&c->pushT, 0, sizeof(c->pushT));
     c->pushT.count = c->cacheCounts.p;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) {
         CacheDimHost &cd = c->cacheDims[6 + 2 * sl];
-        if (cd.relevant) c->pushT.pss[sl] = cd.pss.p, c->pushT.v1[sl] = cd.v1.p, c->pushT.v2[sl] = cd.v2.p, c->pushT.weight[sl] = cd.weight.p;
+        if (cd.relevant)
+            c->pushT.pss[sl] = cd.pss.p, c->pushT.v1[sl] = cd.v1.p, c->pushT.v2[sl] = cd.v2.p, c->pushT.weight[sl] = cd.weight.p, c->pushT.extra[sl] = sampleCache ? cd.extra.p : nullptr;
     }
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
     UploadCacheStruct(c);
@@ -954,7 +969,7 @@ int lmc_init_result(lmc_ctx *c, float *normalization, long long *numContribs) {
 // bit d: small steps of dimension d run the lean launch (MALA with that dim's cache ready and shallow enough for the LDS search)
 static unsigned LeanDims(const lmc_ctx *c) {
     unsigned m = 0;
-    if (c->S.opt.h2mc || !c->S.opt.mala || c->S.opt.useLightCoord) return 0;  // light-coordinate sampling lives in the generic small step only
+    if (c->S.opt.h2mc || !c->S.opt.mala || c->S.opt.useLightCoord || c->S.opt.sampleCache) return 0;  // light-coordinate sampling and chain.path (samplecache) live in the generic small step only
     for (int d = PSS_MIN_LENGTH; d <= PSS_MAX_LENGTH; d++)
         if (c->cacheDims[d].ready && !c->cacheHost.d[d].deep) m |= 1u << d;
     return m;
@@ -973,7 +988,7 @@ static bool CachePending(lmc_ctx *c) {
         c->allCachesReady = true;
         bool anyDeep = false;
         for (int d = 2; d <= PSS_MAX_LENGTH; d++) anyDeep = anyDeep || (c->cacheDims[d].ready && c->cacheHost.d[d].deep);
-        c->needGeneric = anyDeep || c->S.opt.useLightCoord;
+        c->needGeneric = anyDeep || c->S.opt.useLightCoord || c->S.opt.sampleCache;
     }
     return anyPending;
 }
@@ -1020,6 +1035,19 @@ static void CacheApply(lmc_ctx *c) {
         c->anyDeepCache = c->anyDeepCache || D.deep;
         D.ready = 1, D.nodes = cd.nodes.p, D.vind = cd.vind.p, D.pts = cd.pss.p, D.v1 = cd.v1.p, D.v2 = cd.v2.p;
         for (int k = 0; k < d; k++) D.rootLow[k] = t.rootLow[k], D.rootHigh[k] = t.rootHigh[k];
+        D.extra = nullptr, D.weight = nullptr, D.distCdf = nullptr, D.scoreSum = 0, D.invSigmaSq = D.factor = 0.f;
+        if (c->S.opt.sampleCache) {  // what LargeStepCache samples and evaluates (global_cache.h:57-58,84-90): on the host like the reference, once per dim
+            std::vector<float> w = cd.weight.Download(), func, cdf;
+            float funcInt = 0.f;
+            lmc::BuildPiecewise1D(w.data(), PSS_MAX_SIZE, func, cdf, funcInt);  // data_distrib
+            double scoreSum = 0;
+            for (float x : w) scoreSum += x;  // score_sum: double, in push order
+            HIP_CHECK(hipMemcpyAsync(cd.distCdf.p, cdf.data(), cdf.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            D.extra = cd.extra.p, D.weight = cd.weight.p, D.distCdf = cd.distCdf.p, D.scoreSum = scoreSum;
+            D.invSigmaSq = 1.0f / (0.15f * 0.15f);  // inverse(CACHE_SIG * CACHE_SIG)
+            D.factor = lmcd::lexpf(d * (0.5f * lmcd::llogf(D.invSigmaSq) - 0.9189385332046727f));
+        }
         cd.ready = true;
         changed = true;
     }
@@ -1031,8 +1059,10 @@ namespace {
 void CheckSteppable(lmc_ctx *c) {
     if (c->N <= 0) throw std::runtime_error("lmc_chains_step before lmc_chains_init");
     // the chain state (H2MC Gaussian buffers, cache bookkeeping, work lists) is laid out for the mutation in force at init
-    if (c->mutationAtInit != ((c->scene->options.mala ? 1 : 0) | (c->scene->options.h2mc ? 2 : 0)))
-        throw std::runtime_error("the 'mala' / 'h2mc' options changed after lmc_chains_init: initialise the chains again before stepping");
+    if (c->mutationAtInit != MutationKey(c))
+        throw std::runtime_error("the 'mala' / 'h2mc' / 'samplecache' options changed after lmc_chains_init: initialise the chains again before stepping");
+    if (c->S.opt.sampleCache && !c->scene->options.largeStepMultiplexed)
+        throw std::runtime_error("samplecache needs largestepmultiplexed (mutation_large_cache.h:33)");
 }
 // first half of one step: the three step launches; then, while a cache is filling, this rank's pushes into its stage.
 // Returns whether the ranks have pushes to exchange.
@@ -1067,14 +1097,14 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
     }
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
-    (mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
+    (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
     // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
     if (c->needGeneric && c->S.opt.h2mc)
         LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
-    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && c->bvhDepth <= BVH_LDS_STACK)
+    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
         LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
         LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
@@ -1555,6 +1585,26 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
     HIP_CHECK(hipMemcpy(outIdx, dOutI.p, (size_t)nq * knn * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(outDist, dOutD.p, (size_t)nq * knn * 4, hipMemcpyDeviceToHost));
     return 0;
+    LMC_CATCH(-1)
+}
+// parity probe: the rows of one cache dim as they stand (pss: PSS_MAX_SIZE x dim, weight: PSS_MAX_SIZE, extra: PSS_MAX_SIZE x
+// CACHE_ROW_EXTRA = every row's DPath words followed by its Contrib words, only with `samplecache`; any pointer may be NULL).
+// Returns the number of rows filled, -1 on error.
+int lmc_cache_rows(lmc_ctx *c, int dim, float *pss, float *weight, float *extra) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (dim < 6 || dim > PSS_MAX_LENGTH || (dim & 1) || !c->cacheDims[dim].relevant) return -1;
+    CacheDimHost &cd = c->cacheDims[dim];
+    if (pss) HIP_CHECK(hipMemcpy(pss, cd.pss.p, (size_t)PSS_MAX_SIZE * dim * sizeof(float), hipMemcpyDeviceToHost));
+    if (weight) HIP_CHECK(hipMemcpy(weight, cd.weight.p, (size_t)PSS_MAX_SIZE * sizeof(float), hipMemcpyDeviceToHost));
+    if (extra) {
+        if (!cd.extra.p) return -1;
+        HIP_CHECK(hipMemcpy(extra, cd.extra.p, (size_t)PSS_MAX_SIZE * CACHE_ROW_EXTRA * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    int counts[CACHE_SLOTS];
+    HIP_CHECK(hipMemcpy(counts, c->cacheCounts.p, sizeof(counts), hipMemcpyDeviceToHost));
+    return counts[(dim - 6) / 2];
     LMC_CATCH(-1)
 }
 // checker of the device-built grid of one cache dim against the host build (accel.cpp): returns the number of cells whose row

@@ -123,6 +123,23 @@ int orc_subpath_probe(void *h, int camLength, int lgtLength, long long n, long l
     ORC_CATCH(-1)
 }
 
+// parity probe: rows of one cache dim: pss (3000 x dim), weight (3000), per row 8 words of its path / contribution:
+// camDepth, lightDepth, lsScore, ssScore, path.time, screenPos x, y, number of camera surface vertices.  Returns the rows filled.
+int orc_cache_rows(void *h, int dim, float *pss, float *weight, float *info) {
+    MLT *m = (MLT *)h;
+    const CacheDim &cd = m->cache.dims[dim];
+    for (int r = 0; r < cd.data_idx; r++) {
+        for (int k = 0; k < dim; k++) pss[(size_t)r * dim + k] = cd.pss[(size_t)r * dim + k];
+        weight[r] = cd.pathWeight[r];
+        float *o = info + (size_t)r * 8;
+        const SubpathContrib &sp = cd.rowContrib[r];
+        const Path &p = cd.rowPath[r];
+        o[0] = (float)sp.camDepth, o[1] = (float)sp.lightDepth, o[2] = sp.lsScore, o[3] = sp.ssScore, o[4] = p.time, o[5] = p.camVertex.screenPos[0],
+        o[6] = p.camVertex.screenPos[1], o[7] = (float)p.camSurfaceVertex.size();
+    }
+    return cd.data_idx;
+}
+
 int orc_setup_chains(void *h, long long samplesPerChain, long long chainsNeedExtra) {
     ORC_TRY((MLT *)h)->SetupChains(samplesPerChain, chainsNeedExtra);
     return 0;

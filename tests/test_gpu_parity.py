@@ -529,23 +529,32 @@ def test_sharded_chains_cache_phase_statistical():
     assert shard.sum() == pytest.approx(whole.sum(), rel=3 * max(abs(other.sum() / whole.sum() - 1), 2e-3))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_group_of_ranks_equals_one_rank_through_the_cache_phase(world):
+@pytest.mark.parametrize("world,sample_cache", [(2, 0), (3, 0), (2, 1)])
+def test_group_of_ranks_equals_one_rank_through_the_cache_phase(world, sample_cache):
     """a job of `world` ranks (here: contexts on one GPU, driven through lmc_group_* -- sharded MLTInit with its
     three exchanges, per-step all-gather of the cache pushes; an RCCL job runs the same phases with ncclAllGather as transport)
     against ONE rank holding all the chains, through the steps in which the gradient caches fill and become ready.
     EXACT: normalization, every chain's init state, the cache-ready mask, every counter (steps, large steps, accepted,
-    gradient calls, cache queries AND hits), every chain's final state.  Films: equal up to the order of the float atomics."""
+    gradient calls, cache queries AND hits), every chain's final state.  Films: equal up to the order of the float atomics.
+    sample_cache: with largestepmultiplexed + samplecache (LargeStepCache) the pushes also carry every row's path and contribution
+    (313 more words per row through the stage and the all-gather), and the large steps then SAMPLE those rows: any difference in
+    the rows or their order between the ranks would change trajectories."""
     p = gc.pkg()
     n, steps, ninit, streams = 1 << 15, 40, 1 << 18, 4096
     kw = dict(force_diffuse=1, max_depth=6, width=96, height=72, seed_offset=0, use_gradient=1)
+    opts = {"largestepprob": 0.3, "largestepscale": 1.0, "largestepmultiplexed": 1, "samplecache": 1} if sample_cache else {}
     one = p.Renderer(gc.TORUS, **kw)
+    for k, v in opts.items():
+        one.set_option(k, v)
     norm1, nc1 = one.init_chains(ninit, n, streams, steps, 0)
     init1 = one.summary(1)
     one.step(steps)
     st1, fin1, film1 = one.stats(), one.summary(0), one.film()
     one.close()
     rens = [p.Renderer(gc.TORUS, **kw) for _ in range(world)]
+    for r in rens:
+        for k, v in opts.items():
+            r.set_option(k, v)
     grp = p.Group(rens)
     normg, ncg = grp.init_chains(ninit, n, streams, steps, 0)
     assert normg == norm1 and ncg == nc1
@@ -779,3 +788,69 @@ def test_multiplexed_large_step_chain_parity(scene_kind):
         assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
         assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * max(so["gradCalls"], 100)
         assert r["film_rel_l2"] < 0.15 and r["final_state_match"] > 0.95
+
+
+def test_large_step_cache_parity_through_the_cache_phase():
+    """SURVEY §8(f) item 4, `samplecache` with mala and largestepmultiplexed = LargeStepCache (mutation_large_cache.h:22-141,
+    global_cache.h:126-164; mlt.cpp:71-73,123-125): once a dim's global cache is built, half of the large steps of that dimension
+    perturb a cached path drawn by its weight (sigma 0.15) and every large step weighs the two strategies by MIS over the uniform
+    multiplexed sampler and the cache's kernel density (3000 rows).  16384 chains x 50 lock-step mutations, the dim-6 cache fills
+    after ~30.  A sampled ROW INDEX is only the same on both sides while both caches hold the same rows in the same order, and one
+    chain that diverged earlier (a last-bit accept flip; about 0.5 % of the chains at any time, as in test_cache_phase_parity) pushes
+    a row the other side does not have -- so from the first cache proposal on the comparison is statistical:
+    (1) the same dim ready; large steps, acceptances, gradient calls, cache queries within 0.5 %; film within 5 % relative L2 and the
+        energy identity; technique histogram of the final states within 1 % L1;
+    (2) the cache ROWS themselves, which are written before any cache proposal: >= 97 % of the rows agree in place in pss, weight,
+        technique, scores, path time, screen position and vertex count (the row's path and contribution travel through chain.path
+        -> push stage -> cache row), >= 70 % to the last digits."""
+    if not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    p, L = gc.pkg(), gc.oracle_lib()
+    opts = {"largestepprob": 0.3, "largestepscale": 1.0, "largestepmultiplexed": 1, "samplecache": 1}
+    orc = _orc.Oracle(L, gc.TORUS, 1, 6, 128, 96, 0, gc.pathref())
+    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=128, height=96, seed_offset=0, use_gradient=1)
+    for k, v in opts.items():
+        L.orc_set_option(orc.h, k.encode(), float(v))
+        ren.set_option(k, v)
+    on, oc = orc.init(200000, 16384, 64)
+    gn, gcn = ren.init_chains(200000, 16384, 64, 120)
+    assert oc == gcn and abs(on - gn) <= 1e-5 * on
+    orc.setup_chains(120, 0)
+    orc.step(50)
+    ren.step(50)
+    so, sg = orc.stats(), ren.stats()
+    assert so["cacheReadyMask"] != 0 and sg["cacheReadyMask"] == so["cacheReadyMask"]
+    for k in ("largeSteps", "accepted", "gradCalls", "cacheQueries"):
+        assert abs(sg[k] - so[k]) <= 0.005 * so[k], (k, sg[k], so[k])
+    lo, lg = gc.lum(orc.film()), gc.lum(ren.film())
+    assert np.linalg.norm(lo - lg) <= 0.05 * np.linalg.norm(lo) and np.isfinite(lg).all()
+    assert abs(lg.sum() / (gn * sg["weightSum"]) - 1.0) < 1e-4
+    co, cg = orc.summary(0), ren.summary(0)
+    ho = np.bincount((co[:, 1] * 16 + co[:, 2]).astype(int), minlength=256) / len(co)
+    hg = np.bincount((cg[:, 1] * 16 + cg[:, 2]).astype(int), minlength=256) / len(cg)
+    assert np.abs(ho - hg).sum() < 0.01
+    # (2)
+    dim = 6
+    po, wo, io = np.zeros((3000, dim), np.float32), np.zeros(3000, np.float32), np.zeros((3000, 8), np.float32)
+    assert L.orc_cache_rows(orc.h, dim, P(po), P(wo), P(io)) == 3000
+    pg, wg, xg = np.zeros((3000, dim), np.float32), np.zeros(3000, np.float32), np.zeros((3000, 313), np.float32)
+    lib = p.lib()
+    lib.lmc_cache_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.lmc_cache_rows(ren.h, dim, P(pg), P(wg), P(xg)) == 3000
+    xi = xg.view(np.int32)
+    # the caches are filled in the same (chain-id) order.  A chain that diverged before the cache was built shows up as a row only
+    # one side has (the rows behind it are then one place off until the other side inserts one of its own), a state that drifted
+    # by float rounding (MALA steps amplify a last-bit difference of a gradient) as a row equal to ~1e-5
+    matched = same = exact = 0
+    for r in range(3000):
+        for q in range(max(r - 4, 0), min(r + 5, 3000)):
+            if np.abs(po[r] - pg[q]).max() < 2e-4:
+                matched += 1
+                exact += int(np.abs(po[r] - pg[q]).max() < 1e-6)
+                same += int(xi[q, 304] == io[r, 0] and xi[q, 305] == io[r, 1] and abs(wg[q] - wo[r]) <= 2e-3 * wo[r] and abs(xg[q, 311] - io[r, 2]) <= 2e-3 * io[r, 2]
+                            and abs(xg[q, 312] - io[r, 3]) <= 5e-3 * io[r, 3] and abs(xg[q, 0] - io[r, 4]) < 2e-4 and abs(xg[q, 1] - io[r, 5]) < 2e-4
+                            and abs(xg[q, 2] - io[r, 6]) < 2e-4 and xi[q, 10] == io[r, 0] and xi[q, 11] == io[r, 1] and xi[q, 12] == io[r, 7])
+                break
+    assert matched >= 0.97 * 3000 and same >= 0.995 * matched and exact >= 0.7 * 3000, (matched, same, exact)
+    orc.close()
+    ren.close()
