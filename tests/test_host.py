@@ -379,7 +379,7 @@ def test_oracle_subpath_generator_agrees_with_bidir_generator_in_expectation():
     torus (environment light: only l = 0 and l = 1 carry energy; the others must be empty on both sides).  Pins the restatement
     of GenerateSubpath to the generator that the reference images already validate.  (On scenes/torus/lmc_arealight.xml the two
     DISAGREE beyond length 4, by the reference's design: GeneratePathBidir ends a camera path at the first emitter it hits --
-    "Assume lights have zero reflectance", path.cpp:1374 -- GenerateSubpath only looks for the emitter at the last vertex, and that
+    "Assume lights have zero reflectance", path.cpp:1372 -- GenerateSubpath only looks for the emitter at the last vertex, and that
     scene's emitter is its floor.)"""
     import ctypes
     from tests import gpu_checks as gc, _orc
