@@ -1070,13 +1070,42 @@ LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene,
 
 // The chain loop only differentiates states with dim <= PSS_MAX_LENGTH = 12 (mutation_mala.h:94-96): no Dual<16> copy of
 // the program in the step kernel, and one non-inlined copy per kernel instead of one per call site (compile time).
+// The gradient in blocks of B components: ceil(dim / B) passes of the program in Dual<B>.  Forward-mode components never mix, so
+// the result is bit-identical to one Dual<dim> pass; the primal is recomputed per pass (dim 12, B 4: 15 units of arithmetic
+// instead of 13) in exchange for a third of the live state.
+template <int B, class In>
+LMC_HD void PathFuncGradBlocked(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    for (int b0 = 0; b0 < dim; b0 += B) {
+        Dual<B> p[2 * 8 + 1];
+        p[0] = MakeDual<B>(primary[0]);
+        for (int k = 0; k < dim; k++) {
+            p[k + 1] = MakeDual<B>(primary[k + 1]);
+            if (k >= b0 && k < b0 + B) p[k + 1].d[k - b0] = 1.0f;
+        }
+        Dual<B> r = PathProgram<Dual<B>, In>(c, l, p, scene, vp);
+        if (logLum && b0 == 0) *logLum = r.v;
+        for (int k = b0; k < dim && k < b0 + B; k++) grad[k] = r.d[k - b0];
+    }
+}
+// Inside the step kernels the blocked form with B = 2 is the default since round 3: the cache-filling launch runs beside the hot
+// launch, and what it costs there is the SIMD slots its waves hold, not its arithmetic -- one pass in Dual<12> keeps 7 KB of
+// private memory per lane alive for 2.3 ms per wave-step.  Driver window 290.5 -> 306.9 M chain-steps/s, a complete 256-step run
+// 350.5 -> 354.0 M (profiles/r03_p_ab_gradient_block.jsonl; B = 1 / 2 / 3 / 4 / 6: 305 / 307 / 299 / 300-315 / 306).
+#ifndef LMC_GRAD_BLOCK
+#define LMC_GRAD_BLOCK 2  // 0: one pass in Dual<8> / Dual<12>
+#endif
 #ifdef __HIPCC__
 template <class In>
 __device__ __noinline__ void PathFuncGradUpTo12(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad) {
+#if LMC_GRAD_BLOCK > 0
+    PathFuncGradBlocked<LMC_GRAD_BLOCK>(c, l, primary, scene, vp, logLum, grad);
+#else
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
     if (dim <= 8) PathFuncGradN<8>(c, l, primary, scene, vp, logLum, grad);
     else
         PathFuncGradN<12>(c, l, primary, scene, vp, logLum, grad);
+#endif
 }
 #endif
 
