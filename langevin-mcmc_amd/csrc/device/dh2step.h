@@ -32,8 +32,8 @@ template <class In>
 #define LMC_PF_ATTR
 #endif
 __device__ __noinline__ LMC_PF_ATTR void PathFuncHessPassDevice(int c, int l, const float *primary, const float *scene, const In &vp, int i, int c0, float *logLum,
-                                                                float *grad, float *hess) {
-    PathFuncHessPass(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+                                                                float *grad, float *hess, bool firstOfRow) {
+    PathFuncHessPass(c, l, primary, scene, vp, i, c0, logLum, grad, hess, firstOfRow);
 }
 // all passes: ONE copy of the second-order program per kernel image (the single-call plugin kernel runs the passes side by side, one
 // per lane, through the same copy)
@@ -41,7 +41,32 @@ template <class In>
 __device__ __noinline__ LMC_PF_ATTR void PathFuncHessDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
     for (int i = 0; i < dim; i++)
-        for (int c0 = 0; c0 < dim; c0 += HC) PathFuncHessPassDevice(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+        for (int c0 = 0; c0 < dim; c0 += HC) PathFuncHessPassDevice(c, l, primary, scene, vp, i, c0, logLum, grad, hess, c0 == 0);
+}
+// What the H2MC step needs of it: h2mc.cpp:78 hands the rows to Eigen as a column-major matrix and SelfAdjointEigenSolver reads its
+// lower triangle = the UPPER triangle of the rows as delivered (dh2mc.h mirrors exactly that), so row i is only evaluated from its
+// diagonal on: sum_i ceil((dim - i) / W) passes instead of dim * ceil(dim / HC) (dim 12: 24 passes of 10 floats per value with
+// W = 4, against 24 of 18).  The entries below the diagonal are read by two tests only, the all-finite test
+// (mutation_h2mc.h:80-84) and the Frobenius norm of the early-out (h2mc.cpp:84-92, `hnorm < 0.5 / sigma^2`): they are filled with
+// the mirror image of the upper triangle.  The reference's matrix is asymmetric where chad's adjoint overwrite is active
+// (DESIGN.md §2), so that norm is the norm of the symmetrised matrix here: the early-out can differ for a state whose norm sits
+// within the asymmetry of the threshold.  Leaving them ZERO instead halves the norm and costs 6 % of the chains their agreement
+// with the oracle within 30 steps (profiles/r03_r_h2mc_upper_triangle.txt).
+#ifndef LMC_HESS_ROW_CHUNK
+#define LMC_HESS_ROW_CHUNK 4
+#endif
+template <class In>
+__device__ __noinline__ LMC_PF_ATTR void PathFuncHessRowPassDevice(int c, int l, const float *primary, const float *scene, const In &vp, int i, int c0, float *logLum,
+                                                                   float *grad, float *hess) {
+    PathFuncHessRowPass<LMC_HESS_ROW_CHUNK>(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+}
+template <class In>
+__device__ __noinline__ LMC_PF_ATTR void PathFuncHessUpperDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
+    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
+    for (int i = 0; i < dim; i++) {
+        for (int k = 0; k < i; k++) hess[i * dim + k] = hess[k * dim + i];
+        for (int c0 = i; c0 < dim; c0 += LMC_HESS_ROW_CHUNK) PathFuncHessRowPassDevice(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+    }
 }
 #endif
 
@@ -77,7 +102,7 @@ LMC_D void InitGaussianH2MC(const DScene &S, const StepParams &P, const H2MCPara
             SerializePath(S, path, primary, o);
             StridedIn vin{gw.buf + gw.slot, gw.stride};
             float logLum;
-            if (!(P.expFlags & 16)) PathFuncHessDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
+            if (!(P.expFlags & 16)) PathFuncHessUpperDevice(path.camDepth, path.lgtDepth, primary, S.sceneParams, vin, &logLum, vGrad, vHess);
             st.gradCalls++;
             bool finite = true;
             for (int k = 0; k < dim; k++) finite = finite && isfinite(vGrad[k]);

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64) k_plugin_hess(int c, int l, const float *i
     const int t = threadIdx.x;
     if (t < dim * chunks) {
         const StridedIn vin{stage + 55, 1};  // the accessor type of the step kernel: the same copy of the program
-        PathFuncHessPassDevice(c, l, stage, stage + 17, vin, t / chunks, (t % chunks) * HC, out, out + 1, out + 17);
+        PathFuncHessPassDevice(c, l, stage, stage + 17, vin, t / chunks, (t % chunks) * HC, out, out + 1, out + 17, (t % chunks) == 0);
     }
 }
 void LaunchPluginHess(int c, int l, const float *in, float *stage, float *out, hipStream_t s) { hipLaunchKernelGGL(k_plugin_hess, dim3(1), dim3(64), 0, s, c, l, in, stage, out); }
