@@ -7,7 +7,10 @@
 
 using namespace lmcd;
 
-__global__ void __launch_bounds__(128) k_step_h2mc(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
+#ifndef LMC_H2MC_WAVES
+#define LMC_H2MC_WAVES 1  // waves per SIMD the register allocation aims at (A/B: profiles/r03_s_ab_h2mc_waves.txt)
+#endif
+__global__ void __launch_bounds__(128, LMC_H2MC_WAVES) k_step_h2mc(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                                   NextLists next, float *gradBuf, int gradStride) {
     StepStats st;
     const int total = *listCount;
