@@ -33,7 +33,9 @@ LMC_HD H2MCParam MakeH2MCParam(float sigma) {  // h2mc.h:10-16, L = pi/2
 
 // Symmetric eigen-decomposition by cyclic Jacobi rotations.  A (n x n, row-major, stride n) is destroyed; on return w holds
 // the eigenvalues in ascending order (Eigen's convention) and column j of V (row-major, stride n) the unit eigenvector of w[j].
-LMC_HD void JacobiEigenSym(int n, float *A, float *V, float *w) {
+// MA / MV: anything indexable as a flat n x n array (float *, MatRef): the device keeps A in LDS (dh2step.h), same arithmetic
+template <class MA, class MV>
+LMC_HD void JacobiEigenSymT(int n, MA A, MV V, float *w) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0f : 0.0f;
     for (int sweep = 0; sweep < 30; sweep++) {
@@ -83,6 +85,7 @@ LMC_HD void JacobiEigenSym(int n, float *A, float *V, float *w) {
         }
     }
 }
+LMC_HD void JacobiEigenSym(int n, float *A, float *V, float *w) { JacobiEigenSymT(n, A, V, w); }
 
 // An n x n matrix (row-major, entry (i,j) = word i*n+j) behind a stride: contiguous on the CPU, one word per chain-stride in the
 // device's SoA arrays -- the device keeps covL / invCov in HBM and never holds a dense matrix of the Gaussian in private memory.
@@ -95,8 +98,9 @@ struct MatRef {
 // Dense Gaussian of one state: mean[n], covL, invCov (n x n), logDet.
 // `hess` is the n x n matrix as the derivative program delivers it (row i at hess[i*n]); its upper triangle is mirrored IN PLACE and it is destroyed
 // by the eigen-solve; `work` needs n*n + 4*n floats.
-LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL, MatRef invCov,
-                                float &logDet, float *work) {
+template <class MA>
+LMC_HD void ComputeGaussianH2MCT(const H2MCParam &param, int n, float sc, const float *grad, MA hess, float *mean, MatRef covL, MatRef invCov,
+                                 float &logDet, float *work) {
     const float sigma = param.sigma, invSigmaSq = 1.0f / (sigma * sigma);
     float hnorm = 0.f;
     for (int i = 0; i < n * n; i++) hnorm += hess[i] * hess[i];
@@ -110,12 +114,13 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
         for (int i = 0; i < n; i++) logDet += llogf(invSigmaSq);
         return;
     }
-    float *A = hess, *V = work, *w = work + n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
+    MA A = hess;
+    float *V = work, *w = work + n * n, *eigenBuff = w + n, *offsetBuff = w + 2 * n, *post = w + 3 * n;
     // Eigen maps the row-major program output as a COLUMN-major matrix (h2mc.cpp:78) and SelfAdjointEigenSolver reads its lower
     // triangle only: entry (r, c), r >= c, of that view is hess[c * n + r], i.e. the UPPER triangle of the rows as delivered.
     for (int i = 0; i < n; i++)
         for (int j = i + 1; j < n; j++) A[j * n + i] = hess[i * n + j];
-    JacobiEigenSym(n, A, V, w);
+    JacobiEigenSymT(n, A, V, w);
     for (int i = 0; i < n; i++) eigenBuff[i] = fabsf(w[i]) > 1e-10f ? 1.0f / fabsf(w[i]) : 0.0f;
     for (int i = 0; i < n; i++) {  // offsetBuff = diag(eigenBuff) (V^T grad)
         float dot = 0.f;
@@ -151,6 +156,11 @@ LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const f
     }
     logDet = 0.f;
     for (int i = 0; i < n; i++) logDet += llogf(post[i]);
+}
+
+LMC_HD void ComputeGaussianH2MC(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL, MatRef invCov,
+                                float &logDet, float *work) {
+    ComputeGaussianH2MCT(param, n, sc, grad, hess, mean, covL, invCov, logDet, work);
 }
 
 // gaussian.cpp:24-36 / :38-55, dense branch

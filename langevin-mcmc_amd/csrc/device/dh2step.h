@@ -70,11 +70,22 @@ __device__ __noinline__ LMC_PF_ATTR void PathFuncHessUpperDevice(int c, int l, c
 }
 #endif
 
+constexpr int H2_LDS_DIM = 12;  // H2MC differentiates states of up to 16 dimensions; up to 12 (every state of the shipped scenes' depth 8 .. 6) solve in LDS
 #ifdef __HIPCC__
 // out of line: its eigen-solve work space then shares stack with the (already returned) path program instead of adding to it
 __device__ __noinline__ LMC_PF_ATTR void ComputeGaussianH2MCDevice(const H2MCParam &param, int n, float sc, const float *grad, float *hess, float *mean, MatRef covL,
                                                        MatRef invCov, float &logDet) {
     float work[H2_MAXDIM * H2_MAXDIM + 4 * H2_MAXDIM];
+    // the matrix the Jacobi rotations work on lives in LDS, [entry][thread] (H2_LDS_DIM^2 words per thread, allocated by the launch):
+    // a rotation reads and writes 4 n of its entries with run-time indices, which in private memory is a dependent round trip to
+    // HBM-backed scratch each -- the eigen-solve was 25 of the step's 80 ms (profiles/r03_u_h2mc_ablation.txt)
+    extern __shared__ float h2Lds[];
+    if (n <= H2_LDS_DIM) {
+        MatRef A{h2Lds + threadIdx.x, blockDim.x};
+        for (int k = 0; k < n * n; k++) A[k] = hess[k];
+        ComputeGaussianH2MCT(param, n, sc, grad, A, mean, covL, invCov, logDet, work);
+        return;
+    }
     ComputeGaussianH2MC(param, n, sc, grad, hess, mean, covL, invCov, logDet, work);
 }
 #endif

@@ -10,7 +10,7 @@ using namespace lmcd;
 #ifndef LMC_H2MC_WAVES
 #define LMC_H2MC_WAVES 1  // waves per SIMD the register allocation aims at (A/B: profiles/r03_s_ab_h2mc_waves.txt)
 #endif
-__global__ void __launch_bounds__(128, LMC_H2MC_WAVES) k_step_h2mc(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
+__global__ void __launch_bounds__(64, LMC_H2MC_WAVES) k_step_h2mc(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                                   NextLists next, float *gradBuf, int gradStride) {
     StepStats st;
     const int total = *listCount;
@@ -78,5 +78,7 @@ void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *
 }
 void LaunchStepSmallH2MC(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
                          const NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_step_h2mc, dim3(gridBlocks * 2), dim3(128), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+    // one wave per block; dynamic LDS: the eigen-solve's matrix, H2_LDS_DIM^2 words per thread = 36 KB per block, four blocks per CU
+    hipLaunchKernelGGL(k_step_h2mc, dim3(gridBlocks * 4), dim3(64), 64 * H2_LDS_DIM * H2_LDS_DIM * sizeof(float), s, S, cache, A, film, P, list, listCount, next, gradBuf,
+                       gradStride);
 }
