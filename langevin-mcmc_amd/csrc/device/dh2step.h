@@ -45,27 +45,34 @@ __device__ __noinline__ LMC_PF_ATTR void PathFuncHessDevice(int c, int l, const 
 }
 // What the H2MC step needs of it: h2mc.cpp:78 hands the rows to Eigen as a column-major matrix and SelfAdjointEigenSolver reads its
 // lower triangle = the UPPER triangle of the rows as delivered (dh2mc.h mirrors exactly that), so row i is only evaluated from its
-// diagonal on: sum_i ceil((dim - i) / W) passes instead of dim * ceil(dim / HC) (dim 12: 24 passes of 10 floats per value with
-// W = 4, against 24 of 18).  The entries below the diagonal are read by two tests only, the all-finite test
+// diagonal on, in blocks of R rows x W columns that cover the upper triangle (dim 12, 2 x 2: 21 passes of 9 floats per value
+// against round 2's 24 of 18).  The entries below the diagonal are read by two tests only, the all-finite test
 // (mutation_h2mc.h:80-84) and the Frobenius norm of the early-out (h2mc.cpp:84-92, `hnorm < 0.5 / sigma^2`): they are filled with
 // the mirror image of the upper triangle.  The reference's matrix is asymmetric where chad's adjoint overwrite is active
 // (DESIGN.md §2), so that norm is the norm of the symmetrised matrix here: the early-out can differ for a state whose norm sits
 // within the asymmetry of the threshold.  Leaving them ZERO instead halves the norm and costs 6 % of the chains their agreement
 // with the oracle within 30 steps (profiles/r03_r_h2mc_upper_triangle.txt).
+// Block shape of a pass, DualS<R, Dual<W>> = (1 + R)(1 + W) floats per value: 2 x 2 measured best (21 passes of 9 floats for
+// dim 12; profiles/r03_v_ab_h2mc_hessian_blocks.txt: 1x4 74.1 ms per step, 2x4 68.4, 2x3 68.0, 3x2 69.0, 4x2 68.4, 3x3 71.0, 1x2 80.1,
+// 2x2 65.3; 4x4 needs more than the ~16 KB of private memory per lane at which gfx950 faults)
 #ifndef LMC_HESS_ROW_CHUNK
-#define LMC_HESS_ROW_CHUNK 4
+#define LMC_HESS_ROW_CHUNK 2  // W: columns per pass
+#endif
+#ifndef LMC_HESS_ROW_BLOCK
+#define LMC_HESS_ROW_BLOCK 2  // R: rows per pass
 #endif
 template <class In>
-__device__ __noinline__ LMC_PF_ATTR void PathFuncHessRowPassDevice(int c, int l, const float *primary, const float *scene, const In &vp, int i, int c0, float *logLum,
+__device__ __noinline__ LMC_PF_ATTR void PathFuncHessRowPassDevice(int c, int l, const float *primary, const float *scene, const In &vp, int i0, int c0, float *logLum,
                                                                    float *grad, float *hess) {
-    PathFuncHessRowPass<LMC_HESS_ROW_CHUNK>(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+    PathFuncHessRowPass<LMC_HESS_ROW_BLOCK, LMC_HESS_ROW_CHUNK>(c, l, primary, scene, vp, i0, c0, logLum, grad, hess);
 }
 template <class In>
 __device__ __noinline__ LMC_PF_ATTR void PathFuncHessUpperDevice(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
-    for (int i = 0; i < dim; i++) {
-        for (int k = 0; k < i; k++) hess[i * dim + k] = hess[k * dim + i];
-        for (int c0 = i; c0 < dim; c0 += LMC_HESS_ROW_CHUNK) PathFuncHessRowPassDevice(c, l, primary, scene, vp, i, c0, logLum, grad, hess);
+    for (int i0 = 0; i0 < dim; i0 += LMC_HESS_ROW_BLOCK) {
+        for (int c0 = i0; c0 < dim; c0 += LMC_HESS_ROW_CHUNK) PathFuncHessRowPassDevice(c, l, primary, scene, vp, i0, c0, logLum, grad, hess);
+        for (int i = i0; i < dim && i < i0 + LMC_HESS_ROW_BLOCK; i++)  // after the block's passes: they also wrote the block's own below-diagonal entries
+            for (int k = 0; k < i; k++) hess[i * dim + k] = hess[k * dim + i];
     }
 }
 #endif

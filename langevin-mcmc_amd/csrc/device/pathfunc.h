@@ -1062,22 +1062,24 @@ LMC_HD void PathFuncHessPass(int c, int l, const float *primary, const float *sc
     if (firstOfRow && grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
     for (int k = c0; k < dim && k < c0 + HC; k++) hess[i * dim + k] = r.d[0].d[k - c0];
 }
-// The H2MC step's form of a pass (dh2step.h PathFuncHessUpperDevice): row i, columns [c0, c0 + W) with c0 >= i
-template <int W, class In>
-LMC_HD void PathFuncHessRowPass(int c, int l, const float *primary, const float *scene, const In &vp, int i, int c0, float *logLum, float *grad, float *hess) {
+// The H2MC step's form of a pass (dh2step.h PathFuncHessUpperDevice): rows [i0, i0 + R), columns [c0, c0 + W) with c0 >= i0
+template <int R, int W, class In>
+LMC_HD void PathFuncHessRowPass(int c, int l, const float *primary, const float *scene, const In &vp, int i0, int c0, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
-    typedef DualS<1, Dual<W>> T2;
+    typedef DualS<R, Dual<W>> T2;
     T2 p[2 * 8 + 1];
     p[0] = Lift<T2>::Of(primary[0]);
     for (int k = 0; k < dim; k++) {
         p[k + 1] = Lift<T2>::Of(primary[k + 1]);
         if (k >= c0 && k < c0 + W) p[k + 1].v.d[k - c0] = 1.0f;
-        if (k == i) p[k + 1].d[0].v = 1.0f;
+        if (k >= i0 && k < i0 + R) p[k + 1].d[k - i0].v = 1.0f;
     }
     T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
-    if (i == 0 && c0 == i && logLum) *logLum = r.v.v;
-    if (c0 == i) grad[i] = r.d[0].v;
-    for (int k = c0; k < dim && k < c0 + W; k++) hess[i * dim + k] = r.d[0].d[k - c0];
+    if (i0 == 0 && c0 == 0 && logLum) *logLum = r.v.v;
+    for (int q = 0; q < R && i0 + q < dim; q++) {
+        if (c0 == i0) grad[i0 + q] = r.d[q].v;
+        for (int k = c0; k < dim && k < c0 + W; k++) hess[(i0 + q) * dim + k] = r.d[q].d[k - c0];
+    }
 }
 template <class In>
 LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
