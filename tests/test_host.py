@@ -414,3 +414,34 @@ def test_oracle_subpath_generator_agrees_with_bidir_generator_in_expectation():
             checked += 1
     assert checked == 8
     orc.close()
+
+
+def test_oracle_large_step_cache_runs_and_keeps_the_image_mean():
+    """CPU side of SURVEY §8(f) item 4: the oracle's multiplexed large step and LargeStepCache (`largestepmultiplexed`, `samplecache`;
+    mutation_large.h:45-58,87-102, mutation_large_cache.h:22-141) through the cache phase on the Lambertian torus, 8192 chains x
+    100 lock-step mutations.  No reference binary can be run here, so what is asserted is what any correct Metropolis-Hastings
+    proposal must keep: the estimate of the image mean (film / splat weight) agrees with the plain large step's within 5 %, the dim-6
+    cache becomes ready, and once it is the cache-sampling run really takes other trajectories than the multiplexed one."""
+    from tests import gpu_checks as gc, _orc
+
+    L = gc.oracle_lib()
+    if not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    res = {}
+    for mode in ((0, 0), (1, 0), (1, 1)):
+        orc = _orc.Oracle(L, gc.TORUS, 1, 6, 128, 96, 0, gc.pathref())
+        for k, v in (("largestepmultiplexed", mode[0]), ("largestepprob", 0.3), ("largestepscale", 1.0), ("samplecache", mode[1])):
+            assert L.orc_set_option(orc.h, k.encode(), float(v)) == 0
+        orc.init(100000, 8192, 64)
+        orc.setup_chains(120, 0)
+        orc.step(100)
+        st = orc.stats()
+        res[mode] = (orc.film().sum() / st["weightSum"], st)
+        orc.close()
+    m0 = res[(0, 0)][0]
+    for mode in ((1, 0), (1, 1)):
+        assert abs(res[mode][0] / m0 - 1) < 0.05, (mode, res[mode][0], m0)
+        assert res[mode][1]["cacheReadyMask"] & 64
+    assert res[(1, 1)][1]["accepted"] != res[(1, 0)][1]["accepted"]
+    # single-technique proposals fail more often than the all-techniques large step: more large steps are needed to leave the invalid start
+    assert res[(1, 0)][1]["largeSteps"] > res[(0, 0)][1]["largeSteps"]
