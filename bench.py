@@ -277,8 +277,14 @@ def main():
             sys.stderr.write("bench.py rank %d: %s\n" % (rank, collective))
         ok_t = torch.tensor([1 if collective.startswith("in-library") else 0], device="cuda")
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        if int(ok_t.item()) == 0 and collective.startswith("in-library"):
-            collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed on another rank)"
+        if int(ok_t.item()) == 0:
+            if collective.startswith("in-library"):
+                collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed on another rank)"
+            # a job in which only SOME ranks hold a communicator would dead-lock in the sharded MLTInit (its all-gathers): every rank
+            # starts over with a context that has none -- each then runs the whole deterministic init for its own chain range and
+            # keeps its gradient cache to itself (the round-2 scheme)
+            ren.close()
+            ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, seed_offset=0, device=local, use_gradient=1)
     # MLTInit + chain set-up AFTER the communicator exists: the ranks of the job shard the init by stream and exchange what the seeding
     # needs (include/lmc_abi.h); without a communicator every rank runs the whole (deterministic) init for its own chain range
     t_init = time.time()
