@@ -529,7 +529,7 @@ def test_sharded_chains_cache_phase_statistical():
     assert shard.sum() == pytest.approx(whole.sum(), rel=3 * max(abs(other.sum() / whole.sum() - 1), 2e-3))
 
 
-@pytest.mark.parametrize("world,sample_cache", [(2, 0), (3, 0), (2, 1)])
+@pytest.mark.parametrize("world,sample_cache", [(2, 0), (3, 0), (8, 0), (2, 1)])
 def test_group_of_ranks_equals_one_rank_through_the_cache_phase(world, sample_cache):
     """a job of `world` ranks (here: contexts on one GPU, driven through lmc_group_* -- sharded MLTInit with its
     three exchanges, per-step all-gather of the cache pushes; an RCCL job runs the same phases with ncclAllGather as transport)
