@@ -163,6 +163,7 @@ struct lmc_ctx {
     CachePushTargets stageT;                 // ... and this rank's stage of a step's pushes (same row layout; kernels.hip k_push_apply)
     PushStageLayout stageLayout;
     DevBuf<float> pushStage, pushGather;     // the stage; the stages of all ranks after the exchange
+    DevBuf<int> warmCounts;                  // four zeros: the list lengths of the warm-up launches at the end of MLTInit
     int *hostCounts = nullptr;               // pinned mirror of cacheCounts
     int lastCounts[CACHE_SLOTS] = {0, 0, 0, 0}; // ... as last read back, and the steps run since (CacheApply)
     long long stepsSinceCounts = 0;
@@ -705,6 +706,7 @@ static int MutationKey(const lmc_ctx *c) {
     const lmc::DptOptions &o = c->scene->options;
     return (o.mala ? 1 : 0) | (o.h2mc ? 2 : 0) | ((o.sampleFromGlobalCache && o.mala) ? 4 : 0);
 }
+static void WarmStepLaunches(lmc_ctx *c);
 extern "C++" {
 namespace {
 void InitPhase4(lmc_ctx *c, InitJob &J) {
@@ -838,6 +840,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
     HIP_CHECK(hipMemsetAsync(c->film.p, 0, c->film.n * sizeof(float), s));
     HIP_CHECK(hipStreamSynchronize(s));
+    WarmStepLaunches(c);
 }
 
 
@@ -1064,6 +1067,28 @@ void CheckSteppable(lmc_ctx *c) {
     if (c->S.opt.sampleCache && !c->scene->options.largeStepMultiplexed)
         throw std::runtime_error("samplecache needs largestepmultiplexed (mutation_large_cache.h:33)");
 }
+StepParams MakeStepParams(const lmc_ctx *c) {
+    StepParams P;
+    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
+    const bool mux = c->scene->options.largeStepMultiplexed;
+    P.lengthCount = mux ? (int)c->lengthFunc.size() : 0, P.lengthFuncInt = c->lengthFuncInt;
+    for (int k = 0; k < P.lengthCount; k++) P.lengthFunc[k] = c->lengthFunc[k];
+    for (int k = 0; k <= P.lengthCount; k++) P.lengthCdf[k] = c->lengthCdf[k];
+    return P;
+}
+// which large-step / generic small-step kernel the options in force select (cnt: the three list lengths on the device)
+void LaunchLarge(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sL) {
+    const bool mux = c->scene->options.largeStepMultiplexed;
+    (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
+}
+void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sG) {
+    if (c->needGeneric && c->S.opt.h2mc)
+        LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
+    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
+        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, c->bvhDepth, sG);
+    else if (c->needGeneric)
+        LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
+}
 // first half of one step: the three step launches; then, while a cache is filling, this rank's pushes into its stage.
 // Returns whether the ranks have pushes to exchange.
 bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
@@ -1071,12 +1096,7 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     hipStream_t s = c->stream;
     c->filmReduced = false;
     Film film{c->film.p, c->S.cam.width, c->S.cam.height};
-    StepParams P;
-    P.normalization = c->normalization, P.numChains = c->numChainsTotal, P.chainBegin = c->chainBegin, P.useGradient = c->useGradient, P.maxDervDepth = c->maxDervDepth, P.expFlags = c->expFlags;
-    const bool mux = c->scene->options.largeStepMultiplexed;
-    P.lengthCount = mux ? (int)c->lengthFunc.size() : 0, P.lengthFuncInt = c->lengthFuncInt;
-    for (int k = 0; k < P.lengthCount; k++) P.lengthFunc[k] = c->lengthFunc[k];
-    for (int k = 0; k <= P.lengthCount; k++) P.lengthCdf[k] = c->lengthCdf[k];
+    const StepParams P = MakeStepParams(c);
     if (c->timing) {
         if (c->eventPool.empty()) {
             for (auto &e : ev.e) HIP_CHECK(hipEventCreate(&e));
@@ -1097,17 +1117,12 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
     }
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
-    (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
+    LaunchLarge(c, film, P, cur, cnt, next, sL);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
     // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
-    if (c->needGeneric && c->S.opt.h2mc)
-        LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
-    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
-        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, c->bvhDepth, sG);
-    else if (c->needGeneric)
-        LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
+    LaunchGeneric(c, film, P, cur, cnt, next, sG);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
     LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
@@ -1146,6 +1161,29 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
         c->events.push_back(ev);
     }
 }
+}  // namespace
+}  // extern "C++"
+// The first launch of a kernel on a stream pays one-time runtime work (code object upload, the private-memory ring of the queue:
+// between 4 ms and, on a cold box, 140 ms for the lean kernel at 2^20 chains, profiles/r03_o_step_timeline.jsonl step 0).  MLTInit
+// ends by launching the step kernels of the options in force once with EMPTY work lists, so that this is paid at set-up and not
+// inside the first mutation of a render (first step 6.5 -> 2.3 ms on a warm box; LMC_NO_WARM_LAUNCH=1 for the A/B).
+static void WarmStepLaunches(lmc_ctx *c) {
+    if (getenv("LMC_NO_WARM_LAUNCH")) return;
+    Film film{c->film.p, c->S.cam.width, c->S.cam.height};
+    const StepParams P = MakeStepParams(c);
+    c->warmCounts.Alloc(4);  // zero-filled: three empty lists
+    NextLists next{c->lists[1][0].p, c->lists[1][1].p, c->lists[1][2].p, c->listCounts[1].p};
+    hipStream_t s = c->stream, sL = c->overlap ? c->sideStream[0] : s, sG = c->overlap ? c->sideStream[1] : s;
+    const int *cnt = c->warmCounts.p;
+    LaunchLarge(c, film, P, 0, cnt, next, sL);
+    LaunchGeneric(c, film, P, 0, cnt, next, sG);
+    LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[0][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
+    HIP_CHECK(hipStreamSynchronize(sL));
+    HIP_CHECK(hipStreamSynchronize(sG));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+extern "C++" {
+namespace {
 void RunSteps(const std::vector<lmc_ctx *> &g, int nSteps) {
     for (lmc_ctx *c : g) CheckSteppable(c);
     std::vector<lmc_ctx::StepEvents> ev(g.size());
