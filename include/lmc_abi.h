@@ -153,6 +153,10 @@ int lmc_hess_batch(int c, int l, int n, const float *primary_soa, const float *s
  * extra: 3000 x 313 = every row's path words then its contribution words, only with `samplecache` (mutation_large_cache.h); any
  * pointer may be NULL.  Returns the number of rows filled, -1 on error. */
 int lmc_cache_rows(lmc_ctx *ctx, int dim, float *pss, float *weight, float *extra);
+/* Parity probe of LargeStepCache's cache-side pieces on the device (`samplecache`, dim ready): row[i] = sampleCache with the uniform
+ * u[i] (global_cache.h:126-137), pdf[i] = evalPdfCache at query[i * dim ..] for technique cl[2 i], cl[2 i + 1] (:139-164).
+ * Returns 0, -2 when the dim is not ready or the option is off, -1 on error. */
+int lmc_cache_probe(lmc_ctx *ctx, int dim, int n, const float *u, int *row, const float *query, const int *cl, float *pdf);
 
 /* ---- probes used by the parity tests (tests/) ---- */
 /* rays: n x [ox,oy,oz,dx,dy,dz,tnear,tfar]; closest hit -> global triangle id (or -1) and t */

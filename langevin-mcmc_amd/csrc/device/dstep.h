@@ -216,6 +216,18 @@ LMC_D float EvalPdfCache(const DCacheDim &D, int dim, const float *pssQuery, int
     return ret;
 }
 
+// global_cache_t::sampleCache (global_cache.h:126-137): data_distrib->SampleDiscrete(u) = clamp(upper_bound(cdf, u) - 1)
+LMC_D int CacheSampleRow(const DCacheDim &D, float u) {
+    int lo = 0, hi = PSS_MAX_SIZE + 1;  // std::upper_bound(cdf, cdf + count + 1, u)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (D.distCdf[mid] > u) hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return Clampi(lo - 1, 0, PSS_MAX_SIZE - 1);
+}
+
 // proposes into `prop` / `pc` (and the sink, for the splats), sets the acceptance a
 template <class Stk>
 LMC_D void LargeStepCacheMutate(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, int flags, bool curValid, const Contrib &cur,
@@ -240,15 +252,7 @@ LMC_D void LargeStepCacheMutate(const DScene &S, const DCache &cache, const Chai
         }
     } else {  // a cached path, drawn by its weight, perturbed by N(0, CACHE_SIG) in every primary sample
         const DCacheDim &D = cache.d[proposalDim];
-        const float u = rng.Uniform();
-        int lo = 0, hi = PSS_MAX_SIZE + 1;  // std::upper_bound(cdf, cdf + count + 1, u)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (D.distCdf[mid] > u) hi = mid;
-            else
-                lo = mid + 1;
-        }
-        const int idx = Clampi(lo - 1, 0, PSS_MAX_SIZE - 1);
+        const int idx = CacheSampleRow(D, rng.Uniform());
         const float *row = D.extra + (size_t)idx * CACHE_ROW_EXTRA;
         float *w = reinterpret_cast<float *>(&prop);
         for (int k = 0; k < DPATH_WORDS; k++) w[k] = row[k];

@@ -11,6 +11,7 @@ void LaunchRngProbe(int nSeeds, const unsigned long long *seeds, int mode, int n
 // single-call form of the plugin symbols (plugin.hip, step_small_h2mc.hip): in / out are device-visible pointers of host-mapped pinned buffers
 void LaunchPluginGrad(int c, int l, const float *in, float *out, int wantGrad, hipStream_t s);
 void LaunchPluginHess(int c, int l, const float *in, float *stage /* 655 floats of device memory */, float *out, hipStream_t s);
+void LaunchCacheProbe(const lmcd::DCache *cache, int dim, int n, const float *u, int *row, const float *query, const int *cl, float *pdf, hipStream_t s);  // step_large_cache.hip
 void LaunchTransProbe(int n, int mode, const float *x, const float *y, float *o, hipStream_t s);
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s);
 void LaunchTrace(const lmcd::DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s);

@@ -18,3 +18,18 @@ void LaunchStepLargeCache(const DScene &S, const DCache *cache, const ChainArray
     else
         hipLaunchKernelGGL((k_step<true, false, false, false, false, 2>), dim3(gridBlocks), dim3(256), 0, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
 }
+
+// parity probe of the two cache-side pieces of LargeStepCache on the cache as it stands: item i draws a row with u[i] (sampleCache)
+// and evaluates the kernel density at query[i] for technique cl[2 i], cl[2 i + 1] (evalPdfCache)
+__global__ void k_cache_probe(const DCache *cache, int dim, int n, const float *u, int *row, const float *query, const int *cl, float *pdf) {
+    const DCacheDim &D = cache->d[dim];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        row[i] = CacheSampleRow(D, u[i]);
+        float q[MAXPSS];
+        for (int k = 0; k < dim; k++) q[k] = query[(size_t)i * dim + k];
+        pdf[i] = EvalPdfCache(D, dim, q, cl[2 * i], cl[2 * i + 1]);
+    }
+}
+void LaunchCacheProbe(const DCache *cache, int dim, int n, const float *u, int *row, const float *query, const int *cl, float *pdf, hipStream_t s) {
+    hipLaunchKernelGGL(k_cache_probe, dim3((n + 63) / 64), dim3(64), 0, s, cache, dim, n, u, row, query, cl, pdf);
+}

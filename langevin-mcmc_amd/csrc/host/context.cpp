@@ -1645,6 +1645,24 @@ int lmc_cache_rows(lmc_ctx *c, int dim, float *pss, float *weight, float *extra)
     return counts[(dim - 6) / 2];
     LMC_CATCH(-1)
 }
+// parity probe of LargeStepCache's cache-side pieces on the device (`samplecache`, the dim must be ready): row[i] = sampleCache with
+// the uniform u[i] (global_cache.h:126-137), pdf[i] = evalPdfCache(query[i * dim ..], technique cl[2 i], cl[2 i + 1]) (:139-164).
+// Returns 0, -2 when the dim is not ready or the option is off, -1 on error.
+int lmc_cache_probe(lmc_ctx *c, int dim, int n, const float *u, int *row, const float *query, const int *cl, float *pdf) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (dim < 6 || dim > PSS_MAX_LENGTH || (dim & 1) || !c->cacheDims[dim].ready || !c->S.opt.sampleCache || !c->cacheDims[dim].extra.p) return -2;
+    DevBuf<float> du, dq, dp;
+    DevBuf<int> dr, dcl;
+    du.Upload(u, n), dq.Upload(query, (size_t)n * dim), dcl.Upload(cl, (size_t)2 * n), dr.Alloc(n), dp.Alloc(n);
+    LaunchCacheProbe(c->cacheDev.p, dim, n, du.p, dr.p, dq.p, dcl.p, dp.p, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpy(row, dr.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(pdf, dp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
 // checker of the device-built grid of one cache dim against the host build (accel.cpp): returns the number of cells whose row
 // sets differ (0 = identical), -1 on error, -2 when that dim's cache is not ready
 int lmc_cache_grid_check(lmc_ctx *c, int dim) {

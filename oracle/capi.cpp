@@ -140,6 +140,22 @@ int orc_cache_rows(void *h, int dim, float *pss, float *weight, float *info) {
     return cd.data_idx;
 }
 
+// parity probe: the oracle's sampleCache / evalPdfCache on its cache as it stands (same arguments as lmc_cache_probe)
+int orc_cache_probe(void *h, int dim, int n, const float *u, int *row, const float *query, const int *cl, float *pdf) {
+    MLT *m = (MLT *)h;
+    const CacheDim &cd = m->cache.dims[dim];
+    if (!cd.is_ready) return -2;
+    std::vector<Float> q(dim);
+    Path path;
+    for (int i = 0; i < n; i++) {
+        row[i] = cd.sampleCache(u[i]);
+        for (int k = 0; k < dim; k++) q[k] = query[(size_t)i * dim + k];
+        path.camDepth = cl[2 * i], path.lgtDepth = cl[2 * i + 1];
+        pdf[i] = cd.evalPdfCache(q, path);
+    }
+    return 0;
+}
+
 int orc_setup_chains(void *h, long long samplesPerChain, long long chainsNeedExtra) {
     ORC_TRY((MLT *)h)->SetupChains(samplesPerChain, chainsNeedExtra);
     return 0;

@@ -802,7 +802,9 @@ def test_large_step_cache_parity_through_the_cache_phase():
         energy identity; technique histogram of the final states within 1 % L1;
     (2) the cache ROWS themselves, which are written before any cache proposal: >= 97 % of the rows agree in place in pss, weight,
         technique, scores, path time, screen position and vertex count (the row's path and contribution travel through chain.path
-        -> push stage -> cache row), >= 70 % to the last digits."""
+        -> push stage -> cache row), >= 70 % to the last digits;
+    (3) sampleCache and evalPdfCache, device and oracle each on its own rows, against an independent numpy evaluation of those rows:
+        the same row for every u, the same density to 1e-4."""
     if not gc.pathref():
         pytest.skip("oracle/_ref not built")
     p, L = gc.pkg(), gc.oracle_lib()
@@ -852,5 +854,45 @@ def test_large_step_cache_parity_through_the_cache_phase():
                             and abs(xg[q, 2] - io[r, 6]) < 2e-4 and xi[q, 10] == io[r, 0] and xi[q, 11] == io[r, 1] and xi[q, 12] == io[r, 7])
                 break
     assert matched >= 0.97 * 3000 and same >= 0.995 * matched and exact >= 0.7 * 3000, (matched, same, exact)
+    # (3) the two cache-side pieces of the proposal, each side on ITS OWN rows against an independent numpy evaluation of the same
+    # rows: sampleCache (PiecewiseConstant1D over the weights, distribution.h:8-50: the cdf in float32 in the reference's order, then
+    # clamp(upper_bound - 1)) must give the same row for every u, evalPdfCache (global_cache.h:139-164) the same density to 1e-4
+    rng = np.random.default_rng(3)
+    nq = 1500
+    u = np.concatenate([rng.random(nq - 4), [0.0, 1e-9, 0.5, 0.99999994]]).astype(np.float32)
+    pick = rng.integers(0, 3000, nq)
+
+    def numpy_side(pts, w, cl_rows):
+        func = w.astype(np.float32)
+        cdf = np.zeros(3001, np.float32)
+        for k in range(1, 3001):
+            cdf[k] = np.float32(cdf[k - 1] + np.float32(func[k - 1] / np.float32(3000)))
+        cdf[1:] = cdf[1:] / cdf[3000]
+        rows = np.clip(np.searchsorted(cdf, u, side="right") - 1, 0, 2999)
+        q = np.mod(pts[pick] + rng2.normal(0, 0.15, (nq, dim)).astype(np.float32), 1.0).astype(np.float32)
+        clq = cl_rows[pick].astype(np.int32)
+        inv_sigma_sq = np.float32(1.0) / (np.float32(0.15) * np.float32(0.15))
+        factor = np.exp(dim * (0.5 * np.log(np.float64(inv_sigma_sq)) - 0.9189385332046727))
+        score_sum = w.astype(np.float64).sum()
+        pdf = np.zeros(nq)
+        for k in range(nq):
+            m = (cl_rows[:, 0] == clq[k, 0]) & (cl_rows[:, 1] == clq[k, 1])
+            d1 = np.abs(q[k].astype(np.float64) - pts[m].astype(np.float64))
+            d = np.minimum(d1, 1.0 - d1)
+            pdf[k] = (np.exp(-0.5 * (d * d).sum(axis=1) * np.float64(inv_sigma_sq)) * factor * w[m].astype(np.float64) / score_sum).sum()
+        return rows, q, clq, pdf
+
+    lib.lmc_cache_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    L.orc_cache_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    for fn, h, pts, w, cl_rows in ((lib.lmc_cache_probe, ren.h, pg, wg, np.stack([xi[:, 304], xi[:, 305]], axis=1)),
+                                   (L.orc_cache_probe, orc.h, po, wo, io[:, 0:2].astype(np.int32))):
+        rng2 = np.random.default_rng(4)
+        rows, q, clq, pdf = numpy_side(pts, w, cl_rows)
+        got_rows, got_pdf = np.zeros(nq, np.int32), np.zeros(nq, np.float32)
+        q = np.ascontiguousarray(q)
+        clq = np.ascontiguousarray(clq)
+        assert fn(h, dim, nq, P(u), P(got_rows), P(q), P(clq), P(got_pdf)) == 0
+        assert np.array_equal(got_rows, rows), int((got_rows != rows).sum())
+        assert pdf.min() > 0 and np.abs(got_pdf / pdf - 1).max() < 1e-4, float(np.abs(got_pdf / pdf - 1).max())
     orc.close()
     ren.close()
