@@ -462,6 +462,9 @@ int lmc_get_option(lmc_ctx *c, const char *name, double *v) {
     else if (n == "mala") *v = o.mala ? 1 : 0;
     else if (n == "h2mc") *v = o.h2mc ? 1 : 0;
     else if (n == "seedoffset") *v = o.seedOffset;
+    else if (n == "uselightcoordinatesampling") *v = o.useLightCoordinateSampling ? 1 : 0;
+    else if (n == "largestepmultiplexed") *v = o.largeStepMultiplexed ? 1 : 0;
+    else if (n == "samplecache") *v = o.sampleFromGlobalCache ? 1 : 0;
     else throw std::runtime_error("Unknown dpt option:" + n);
     return 0;
     LMC_CATCH(-1)
