@@ -17,7 +17,10 @@ constexpr int SPLAT_WORDS = 5;
 // F_GSEL: the same for the two Gaussian buffers (the lean kernel streams the proposal's Gaussian into the other buffer)
 // F_VSYNC: chain->v1 / v2 are known to equal prop_new_v1 / prop_new_v2 word for word, so the copy that follows an accepted
 // MALA step (mlt.cpp:133-142) has nothing to move.  Maintained by the lean kernel; every other kernel just clears it.
-enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64, F_VSYNC = 128 };
+enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64, F_VSYNC = 128, F_GAUSS_ISO = 256 };
+// F_GAUSS_ISO (only meaningful together with F_GAUSS): the current state's Gaussian is IsotropicGaussian(malaStdDev) -- the outcome of
+// 99.98 % of the initialisations once the caches are built (a cache query that finds nothing, mutation_mala.h:155-161) -- and is NOT
+// stored: every reader re-creates the same constants instead of streaming 3 dim + 1 words in and out per step.
 enum : int { KIND_SMALL = 0, KIND_LARGE = 1 };
 enum : unsigned char { NEXT_DONE = 0, NEXT_LARGE = 1, NEXT_SMALL_GENERIC = 2, NEXT_SMALL_PLAIN = 3 };
 

@@ -142,8 +142,12 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     vs.sum_w = 0;
     A.pathWeight[i] = lsScore;
     if (dim > MD) return;  // PSS_MAX_LENGTH: no cache, chain->pss is never read for such a state
+    // GetPathPss(path, chain->pss).  chain->pss has one reader, the cache push of an accepted large step (mlt.cpp:120-127), which only
+    // happens while the cache of this dimension is still filling: once it is ready (and it stays ready) the copy is a dead store
+    if (dim < PSS_MIN_LENGTH || !cache.d[dim].ready) {
 #pragma unroll 1
-    for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = L.Q(k);  // GetPathPss(path, chain->pss)
+        for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = L.Q(k);
+    }
     if (dim < PSS_MIN_LENGTH) return;
 #ifdef LMC_LEAN_GRAD
     if (WITH_GRAD && !cache.d[dim].ready && P.useGradient && GradAvailable(gs.c, gs.l) && gs.c + gs.l - 1 <= P.maxDervDepth) {  // mutation_mala.h:94-130
@@ -371,10 +375,11 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         // GenerateSample (gaussian.cpp:38-55) and GaussianLogPdf(offset, currentState.gaussian) (gaussian.cpp:24-36) are
         // fused into the same pass over the dimensions (the affine map draws nothing)
         float *G = CurGaussBuf(A, flags);
-        const bool stored = (flags & F_GAUSS) && shortState;
+        const bool stored = (flags & F_GAUSS) && shortState && !(flags & F_GAUSS_ISO);  // F_GAUSS_ISO: isotropic, nothing was stored (vs stays VS_ISOTROPIC below)
         VSource vs;
         vs.mode = VS_ISOTROPIC;
         float logDet = 0.f;
+        bool keepCur = false;  // the Gaussian initialised below has to be written to the chain's buffer
         if (!(flags & F_GAUSS)) {
             // GetPathPss(currentState.path) into LDS, path.cpp:2588-2632
             PssSink qs{L, shortState};
@@ -392,6 +397,8 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;  // the blend rewrote chain->v1 / v2
             flags |= F_GAUSS;
+            keepCur = shortState && vs.mode != VS_ISOTROPIC;
+            flags = keepCur ? (flags & ~F_GAUSS_ISO) : (flags | F_GAUSS_ISO);
             prof.Mark(PR_GAUSS_CUR);
         }
         NormalDist nd(0.0f, 1.0f);
@@ -425,7 +432,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 g.mean = L.Q(k), g.covL = L.U(k), g.invCov = L.U(MD + k);
             } else {
                 g = GaussianDim(S, C, A, i, dim, k, vs, curSs, L, logDet, false);
-                if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
+                if (keepCur) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
             }
             const float o = g.covL * nd(rng) + g.mean;
             L.U(offBase + k) = o;
@@ -436,7 +443,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             logDet = storedLogDet;
         } else {
             if (LogDetIsClosedForm(vs, curSs)) logDet = ClosedFormLogDet(S, vs, dim);
-            if (shortState) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
+            if (keepCur) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
         }
         py = dim * (-0.9189385332046727f);
         py += 0.5f * logDet;
@@ -595,6 +602,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 
     // ---- proposal Gaussian + acceptance probability (mutation_mala.h:174-267)
     float a = 0.0f;
+    bool keepProp = false;  // the proposal's Gaussian was written to the chain's other buffer (it is not the isotropic one)
     if (ok) {
         if (mala) {
             float *G = PropGaussBuf(A, flags);
@@ -604,16 +612,17 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;
             if (vs.mode == VS_GRAD) flags &= ~F_VSYNC;  // the moment update rewrote prop_new_v1 / v2
             if (vs.mode == VS_REUSE) StageReuseVectors(A, i, dim, L);
+            keepProp = shortState && vs.mode != VS_ISOTROPIC;
             float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)
 #pragma unroll 1
             for (int k = 0; k < dim; k++) {
                 const GaussK g = GaussianDim(S, C, A, i, dim, k, vs, pc.ssScore, L, logDet, true);
-                if (shortState) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
+                if (keepProp) G[(size_t)k * N + i] = g.mean, G[(size_t)(MAXPSS + k) * N + i] = g.covL, G[(size_t)(2 * MAXPSS + k) * N + i] = g.invCov;
                 const float d = -L.U(offBase + k) - g.mean;
                 q += d * (g.invCov * d);
             }
             if (LogDetIsClosedForm(vs, pc.ssScore)) logDet = ClosedFormLogDet(S, vs, dim);
-            if (shortState) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
+            if (keepProp) G[(size_t)(3 * MAXPSS) * N + i] = logDet;
             float px = dim * (-0.9189385332046727f);
             px += 0.5f * logDet;
             px -= 0.5f * q;
@@ -658,9 +667,14 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 }
             }
             flags |= F_BUFFERED | F_GAUSS | F_VSYNC;
-            flags ^= F_GSEL;  // the proposal's Gaussian (streamed into the other buffer above) becomes the current one
+            if (keepProp) {
+                flags ^= F_GSEL;  // the proposal's Gaussian (streamed into the other buffer above) becomes the current one
+                flags &= ~F_GAUSS_ISO;
+            } else {
+                flags |= F_GAUSS_ISO;  // isotropic: nothing was written, nothing will be read
+            }
         } else {
-            flags &= ~F_GAUSS;
+            flags &= ~(F_GAUSS | F_GAUSS_ISO);
         }
         flags |= F_VALID;
     } else {
@@ -670,7 +684,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
             ResetToInitState(A, P.chainBegin, P.numChains, OUTLIER_RATIO_THRESHOLD * P.normalization, i, sampleIdx, sel ? A.pathBuf1 : A.curPath);
             A.curSplatCount[i] = 0;
-            flags &= ~(F_VALID | F_GAUSS);
+            flags &= ~(F_VALID | F_GAUSS | F_GAUSS_ISO);
             ClearBuffered(A, i, flags);
             st.resets++;
         }

@@ -14,7 +14,11 @@ struct StepStats {  // per-thread increments, block-reduced by the kernel
 };
 
 // the chain's current Gaussian lives in the buffer F_GSEL selects (dchain.h)
-LMC_D void LoadGauss(const ChainArrays &A, int i, int dim, int flags, Gauss &g) {
+LMC_D void LoadGauss(const DScene &S, const ChainArrays &A, int i, int dim, int flags, Gauss &g) {
+    if (flags & F_GAUSS_ISO) {  // left by the lean kernel: the isotropic Gaussian is never stored (dchain.h)
+        IsotropicGaussian(dim, S.opt.malaStdDev, g);
+        return;
+    }
     const size_t N = A.N;
     const float *G = CurGaussBuf(A, flags);
     for (int k = 0; k < dim; k++) {
@@ -368,9 +372,9 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             if (!(flags & F_GAUSS)) {
                 InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, cur, false, flags, cg, gw, st);
                 StoreGauss(A, i, dim, flags, cg);
-                flags |= F_GAUSS;
+                flags = (flags | F_GAUSS) & ~F_GAUSS_ISO;
             } else {
-                LoadGauss(A, i, dim, flags, cg);
+                LoadGauss(S, A, i, dim, flags, cg);
             }
             NormalDist nd(0.0f, 1.0f);  // GenerateSample, gaussian.cpp:38-55
             for (int k = 0; k < dim; k++) offset[k] = nd(rng);
@@ -451,7 +455,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             }
             A.lastScoreSum[i] = propScoreSum;
             A.lastScore[i] = pc.lsScore;
-            flags &= ~F_GAUSS;
+            flags &= ~(F_GAUSS | F_GAUSS_ISO);
             ClearBuffered(A, i, flags);
         } else {
             float *p = A.curSplat + i;
@@ -462,10 +466,10 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
                     A.chV1[(size_t)k * N + i] = A.chPropNewV1[(size_t)k * N + i];
                     A.chV2[(size_t)k * N + i] = A.chPropNewV2[(size_t)k * N + i];
                 }
-                flags |= F_BUFFERED | F_GAUSS;
+                flags = (flags | F_BUFFERED | F_GAUSS) & ~F_GAUSS_ISO;
                 StoreGauss(A, i, PathDimension(pc.camDepth, pc.lightDepth), flags, pg);
             } else {
-                flags &= ~F_GAUSS;  // proposalState.gaussianInitialized = false, mutation_small.h:39
+                flags &= ~(F_GAUSS | F_GAUSS_ISO);  // proposalState.gaussianInitialized = false, mutation_small.h:39
             }
         }
         flags |= F_VALID;
@@ -476,7 +480,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
         if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
             ResetToInitState(A, P.chainBegin, P.numChains, OUTLIER_RATIO_THRESHOLD * P.normalization, i, sampleIdx, CurPathBuf(A, flags));
             A.curSplatCount[i] = 0;
-            flags &= ~(F_VALID | F_GAUSS);
+            flags &= ~(F_VALID | F_GAUSS | F_GAUSS_ISO);
             ClearBuffered(A, i, flags);
             st.resets++;
         }
