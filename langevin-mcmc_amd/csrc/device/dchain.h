@@ -17,7 +17,10 @@ constexpr int SPLAT_WORDS = 5;
 // F_GSEL: the same for the two Gaussian buffers (the lean kernel streams the proposal's Gaussian into the other buffer)
 // F_VSYNC: chain->v1 / v2 are known to equal prop_new_v1 / prop_new_v2 word for word, so the copy that follows an accepted
 // MALA step (mlt.cpp:133-142) has nothing to move.  Maintained by the lean kernel; every other kernel just clears it.
-enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64, F_VSYNC = 128, F_GAUSS_ISO = 256 };
+enum : int { F_VALID = 1, F_GAUSS = 2, F_BUFFERED = 4, F_QUERIED = 8, F_LAST_MALA = 16, F_SEL = 32, F_GSEL = 64, F_VSYNC = 128, F_GAUSS_ISO = 256, F_VDIRTY = 512 };
+// F_VDIRTY: one of the chain's seven MALA vectors (v1, v2, curr_new_v2, prop_new_v1 / v2, pss, last_pss) may be non-zero.  Once the
+// caches are built a chain writes none of them (no gradient moments, a cache query that finds nothing, chain->pss only feeds the
+// cache push), so ClearBuffered has nothing to zero.
 // F_GAUSS_ISO (only meaningful together with F_GAUSS): the current state's Gaussian is IsotropicGaussian(malaStdDev) -- the outcome of
 // 99.98 % of the initialisations once the caches are built (a cache query that finds nothing, mutation_mala.h:155-161) -- and is NOT
 // stored: every reader re-creates the same constants instead of streaming 3 dim + 1 words in and out per step.
@@ -176,9 +179,10 @@ LMC_D void StorePath(float *base, int N, int i, const DPath &p) {
 // chain's MALA vectors at the NEXT MALA step (mutation_mala.h:59-81); nothing reads them in between (the cache push that may
 // precede this call is the last reader), so they are zeroed here instead, where the stores of a wave are dense: inside the hot
 // small-step kernel the same zeroing ran as 168 sparsely populated store instructions in almost every wave-step and made up a
-// third of the kernel's stores.  Invariant: F_BUFFERED clear => the seven vectors are zero.
+// third of the kernel's stores.  Invariant: F_BUFFERED clear => the seven vectors are zero; F_VDIRTY clear => they are zero as well
+// (nothing was written since the last zeroing), and the 168 stores are skipped.
 LMC_D void ClearBuffered(const ChainArrays &A, int i, int &flags) {
-    if (flags & F_BUFFERED) {
+    if ((flags & F_BUFFERED) && (flags & F_VDIRTY)) {
         const size_t N = A.N;
 #pragma unroll 4
         for (int k = 0; k < MAXPSS; k++) {
@@ -186,7 +190,7 @@ LMC_D void ClearBuffered(const ChainArrays &A, int i, int &flags) {
             A.chV1[o] = A.chV2[o] = A.chCurrNewV2[o] = A.chPropNewV1[o] = A.chPropNewV2[o] = A.chPss[o] = A.chLastPss[o] = 0.f;
         }
     }
-    flags &= ~F_BUFFERED;
+    flags &= ~(F_BUFFERED | F_VDIRTY);
 }
 // REMOVE_OUTLIERS, mlt.cpp:151-158: currentState = initStates[_chainId] for the first id (walk: (_chainId + sampleIdx + cnt++) %
 // numChains, over the chains of the WHOLE job) whose lsScore is below the outlier threshold.  The state is marked invalid by the

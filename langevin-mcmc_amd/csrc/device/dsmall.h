@@ -104,6 +104,7 @@ __device__ __noinline__ int KdRadiusSearchRare(const DCacheDim &C, int dim, cons
 // Where the moment vectors (v1, v2) behind a state's Gaussian come from (mutation_mala.h:131-164 and :224-257, cache /
 // isotropic branches; chains that would evaluate a gradient run the generic kernel instead).
 struct VSource {
+    bool wrotePss;  // chain->pss was written (the cache of this dimension is still filling)
     int mode;  // 0: IsotropicGaussian(malaStdDev); 1: chain->v1 / v2 re-used; 2: inverse-distance blend of nMatches cache entries
     int nMatches;
     int idx[5];
@@ -140,6 +141,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     vs.mode = VS_ISOTROPIC;
     vs.nMatches = 0;
     vs.sum_w = 0;
+    vs.wrotePss = false;
     A.pathWeight[i] = lsScore;
     if (dim > MD) return;  // PSS_MAX_LENGTH: no cache, chain->pss is never read for such a state
     // GetPathPss(path, chain->pss).  chain->pss has one reader, the cache push of an accepted large step (mlt.cpp:120-127), which only
@@ -147,6 +149,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     if (dim < PSS_MIN_LENGTH || !cache.d[dim].ready) {
 #pragma unroll 1
         for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = L.Q(k);
+        vs.wrotePss = true;
     }
     if (dim < PSS_MIN_LENGTH) return;
 #ifdef LMC_LEAN_GRAD
@@ -396,6 +399,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             const GradState gs{cur, c, l, curSs, false, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;  // the blend rewrote chain->v1 / v2
+            if (vs.wrotePss || vs.mode == VS_BLEND || vs.mode == VS_GRAD) flags |= F_VDIRTY;
             flags |= F_GAUSS;
             keepCur = shortState && vs.mode != VS_ISOTROPIC;
             flags = keepCur ? (flags & ~F_GAUSS_ISO) : (flags | F_GAUSS_ISO);
@@ -611,6 +615,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;
             if (vs.mode == VS_GRAD) flags &= ~F_VSYNC;  // the moment update rewrote prop_new_v1 / v2
+            if (vs.wrotePss || vs.mode == VS_BLEND || vs.mode == VS_GRAD) flags |= F_VDIRTY;
             if (vs.mode == VS_REUSE) StageReuseVectors(A, i, dim, L);
             keepProp = shortState && vs.mode != VS_ISOTROPIC;
             float logDet = 0.f, q = 0.f;  // GaussianLogPdf(-offset, proposalState.gaussian)

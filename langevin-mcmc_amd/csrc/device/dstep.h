@@ -369,6 +369,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
                 flags |= F_BUFFERED;
                 flags &= ~F_QUERIED;
             }
+            flags |= F_VDIRTY;  // InitGaussianFor writes chain->pss (and the moment vectors) unconditionally
             if (!(flags & F_GAUSS)) {
                 InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, cur, false, flags, cg, gw, st);
                 StoreGauss(A, i, dim, flags, cg);
