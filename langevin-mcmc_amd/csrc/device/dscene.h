@@ -94,6 +94,9 @@ struct DOptions {
     float roughnessThreshold, largeStepProbability, largeStepProbScale;
     float malaGN, malaStepsize, malaStdDev, perturbStdDev, discreteStdDev, uniformMixingProbability;
     int seedOffset;
+    int leanLightless;  // no state of this scene can have a light sub-path (its only emitter is the environment map, whose light sub-paths carry
+                        // nothing): the lean launch runs the instantiation without the light-sub-path code; a state with l > 1, should one
+                        // ever appear, takes the generic launch (dstep.h QueueNext)
     int sampleCache;    // samplecache with mala (LargeStepCache, mlt.cpp:71-73): every small step takes the generic launch, which keeps chain.path
     int useLightCoord;  // uselightcoordinatesampling (path.cpp:1339-1360, 1881-1951): every small step then takes the generic launch
 };

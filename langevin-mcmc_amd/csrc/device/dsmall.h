@@ -339,7 +339,9 @@ struct WaveProf {
 };
 
 // One plain small step of chain i.  Returns nothing; all state changes go to HBM.
-template <bool WITH_GRAD, class Stk, class Prof>
+// LIGHTLESS: the caller guarantees l <= 1 (DOptions::leanLightless): the light-sub-path half of the walk, ConnectVertex and the
+// registers they hold are compiled out
+template <bool WITH_GRAD, bool LIGHTLESS = false, class Stk, class Prof>
 LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, Rng &rng,
                          const LdsView &L, Stk &stk, StepStats &st, Prof &prof, float *workBuf = nullptr, size_t workStride = 0, size_t workSlot = 0) {
     const size_t N = A.N;
@@ -350,6 +352,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     const bool curValid = flags & F_VALID;  // always true for a small step
     const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[N + i]);
     const float curLs = A.curContrib[7 * N + i], curSs = A.curContrib[8 * N + i];
+    if constexpr (LIGHTLESS) __builtin_assume(l <= 1);
     const int dim = PathDimension(c, l);
     const int camCount = max(c - 1, 0), lgtCount = max(l - 1, 0);
     const bool shortState = dim <= MD;  // may carry a stored Gaussian / be looked up in the cache

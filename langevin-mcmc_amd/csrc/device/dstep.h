@@ -180,7 +180,7 @@ LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A,
         } else {
             const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
             if (S.opt.h2mc) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // every H2MC small step runs k_step_h2mc (the "generic" slot of the launch plan); key: list sort
-            else if (S.opt.useLightCoord || S.opt.sampleCache || (S.opt.mala && NeedsGeneric(cache, P, c, l))) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // key: k_build_lists may still re-route it
+            else if (S.opt.useLightCoord || S.opt.sampleCache || (S.opt.leanLightless && l > 1) || (S.opt.mala && NeedsGeneric(cache, P, c, l))) nk = (unsigned char)(NEXT_SMALL_GENERIC | (TechniqueKey(c, l) << 2));  // key: k_build_lists may still re-route it
             else nk = (unsigned char)(NEXT_SMALL_PLAIN | (TechniqueKey(c, l) << 2));
         }
     }

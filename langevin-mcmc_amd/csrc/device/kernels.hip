@@ -455,7 +455,8 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
     // a generic entry whose cache became ready after the chain queued it (leanDims, context.cpp) is a plain one now; its
     // technique key gives the dimension: 2 * path length
     for (int j = 0; j < CPT; j++)
-        if ((k[j] & 3) == NEXT_SMALL_GENERIC && ((leanDims >> (2 * (3 + (k[j] >> 2) / 6))) & 1u)) k[j] = (unsigned char)(k[j] | NEXT_SMALL_PLAIN);
+        if ((k[j] & 3) == NEXT_SMALL_GENERIC && ((leanDims >> (2 * (3 + (k[j] >> 2) / 6))) & 1u) && !((leanDims >> 31) && (k[j] >> 2) % 6 > 1))  // bit 31: lean launch without light sub-paths
+            k[j] = (unsigned char)(k[j] | NEXT_SMALL_PLAIN);
     // four 16-bit counters packed into one word: [large | generic | plain A | plain B]; B = the "long path" class of sortPlain 3
     // (a STABLE two-way partition: inside a class the entries keep their chain order, so a wave's lanes stay dense)
     auto fieldOf = [&](unsigned char nk) {

@@ -9,7 +9,7 @@
 
 using namespace lmcd;
 
-template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false>
+template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = false>
 #ifndef LMC_LEAN_WAVES
 #define LMC_LEAN_WAVES 2  // waves per SIMD the register allocation aims at
 #endif
@@ -41,10 +41,10 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
 #if LMC_BVH_LDS_TOP > 0
             stk.top = topLds, stk.topCount = topCount;
 #endif
-            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
+            SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         } else {
             LocalStackT<GLOSSY> stk;
-            SmallStepLean<false>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
+            SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         }
         QueueNext(S, *cache, A, P, i, rng);
         A.rngState[i] = rng.state;
@@ -68,6 +68,10 @@ void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArray
 #define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords)
     if (profile && lds && glossy) hipLaunchKernelGGL((k_step_small<true, true, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
     else if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
+    else if (lds && !glossy && S.opt.leanLightless)
+        hipLaunchKernelGGL((k_step_small<true, false, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
+    else if (lds && glossy && S.opt.leanLightless)
+        hipLaunchKernelGGL((k_step_small<true, true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
     else if (lds && !glossy)
         LMC_LAUNCH_SMALL(true, false);
     else if (lds && glossy)

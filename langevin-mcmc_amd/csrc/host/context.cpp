@@ -170,6 +170,7 @@ struct lmc_ctx {
     bool allCachesReady = false;
     int mutationAtInit = -1;  // (mala, h2mc) the resident chain state was laid out for by lmc_chains_init; lmc_chains_step refuses any other
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
+    bool genericTokenOnly = false;  // ... but only as the fallback of the lean launch without light sub-paths: a few blocks, no list sort
     // init results
     float normalization = 0.f;
     std::vector<float> lengthFunc, lengthCdf;  // lengthDist of MLTInit (mlt.h:99), read by the multiplexed large step
@@ -338,6 +339,12 @@ static void SyncOptions(lmc_ctx *c) {
     d.useLightCoord = o.useLightCoordinateSampling ? 1 : 0;
     c->S.sceneParams[0] = d.useLightCoord ? 1.0f : 0.0f;  // scene.cpp:165: the flag opens the serialized scene block the path programs read
     d.sampleCache = (o.sampleFromGlobalCache && o.mala) ? 1 : 0;  // mlt.cpp:71-73: LargeStepCache only together with mala
+    // a scene lit by its environment map alone has no state with a light sub-path: EnvLight::Emit contributes nothing (the l >= 2
+    // techniques of such a scene are empty on the oracle and on the device alike, tests/test_host.py), so the lean launch can run
+    // without that half of the walk (LMC_LEAN_LIGHTLESS=0: A/B switch)
+    // LMC_LEAN_LIGHTLESS=2 forces it on any scene: every state with l > 1 then takes the fallback, which is how the tests exercise it
+    const int lightlessMode = getenv("LMC_LEAN_LIGHTLESS") ? atoi(getenv("LMC_LEAN_LIGHTLESS")) : 1;
+    d.leanLightless = (lightlessMode == 2 || (lightlessMode == 1 && c->S.numLights == 1 && c->S.envLight >= 0)) ? 1 : 0;
 }
 
 static void UploadCacheStruct(lmc_ctx *c) {
@@ -827,6 +834,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->stepsSinceCounts = 0;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = 0;
     c->needGeneric = true;
+    c->genericTokenOnly = false;
     c->anyDeepCache = false;
     if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
         c->allCachesReady = true;
@@ -994,7 +1002,11 @@ static bool CachePending(lmc_ctx *c) {
         c->allCachesReady = true;
         bool anyDeep = false;
         for (int d = 2; d <= PSS_MAX_LENGTH; d++) anyDeep = anyDeep || (c->cacheDims[d].ready && c->cacheHost.d[d].deep);
-        c->needGeneric = anyDeep || c->S.opt.useLightCoord || c->S.opt.sampleCache;
+        c->needGeneric = anyDeep || c->S.opt.useLightCoord || c->S.opt.sampleCache || c->S.opt.leanLightless;
+        // leanLightless: the generic launch stays as the home of a state with l > 1 (possible, never seen: an environment light's
+        // sub-paths almost never connect), but as a token launch of a few blocks -- 16384 workgroups that find an empty list still
+        // queue for SIMD slots behind the hot launch's waves and cost it 1.3 % (profiles/r03_aa_ab_lean_lightless.jsonl)
+        c->genericTokenOnly = c->S.opt.leanLightless && !(anyDeep || c->S.opt.useLightCoord || c->S.opt.sampleCache);
     }
     return anyPending;
 }
@@ -1088,7 +1100,7 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
     if (c->needGeneric && c->S.opt.h2mc)
         LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
     else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
-        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid * 4, 64, c->bvhDepth, sG);
+        LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->genericTokenOnly ? 64 : c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
         LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
 }
@@ -1151,10 +1163,10 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
     const int nxt = 1 - c->parity;
     NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
     if (exchanged) CacheApply(c);
-    LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c), s);
+    LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c) | (c->S.opt.leanLightless ? 1u << 31 : 0u), s);
     // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
     // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
-    if (c->needGeneric && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
+    if (c->needGeneric && !c->genericTokenOnly && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
         LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
         std::swap(c->lists[nxt][1].p, c->listScratch.p);
     }

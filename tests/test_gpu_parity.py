@@ -896,3 +896,35 @@ def test_large_step_cache_parity_through_the_cache_phase():
         assert pdf.min() > 0 and np.abs(got_pdf / pdf - 1).max() < 1e-4, float(np.abs(got_pdf / pdf - 1).max())
     orc.close()
     ren.close()
+
+
+def test_lean_launch_without_light_subpaths_and_its_fallback():
+    """The lean small-step launch has an instantiation without the light-sub-path half of the walk (DOptions::leanLightless), chosen
+    for scenes lit by their environment map alone -- where states with l > 1 are possible in principle and were never seen -- with the
+    generic launch as the home of any state that has one.  LMC_LEAN_LIGHTLESS=2 forces that instantiation on the point-light scene,
+    where a good part of the states DO have light sub-paths: every one of them then takes the fallback, and the run must equal the
+    general instantiation's (LMC_LEAN_LIGHTLESS=0) state by state: same counters, same final states, films equal up to the order of
+    the float atomics.  2048 chains x 60 mutations, no gradients (so that the small steps are the lean launch's from the start)."""
+    p = gc.pkg()
+    xml = os.path.join(gc.ROOT, "scenes", "torus", "lmc_pointlight.xml")
+    out = {}
+    old = os.environ.get("LMC_LEAN_LIGHTLESS")
+    try:
+        for mode in ("0", "2"):
+            os.environ["LMC_LEAN_LIGHTLESS"] = mode
+            ren = p.Renderer(xml, force_diffuse=1, max_depth=8, width=160, height=120, seed_offset=0, use_gradient=0)
+            ren.init_chains(40000, 2048, 4096, 100)
+            ren.step(60)
+            out[mode] = (ren.stats(), ren.summary(0), ren.film())
+            ren.close()
+    finally:
+        if old is None:
+            os.environ.pop("LMC_LEAN_LIGHTLESS", None)
+        else:
+            os.environ["LMC_LEAN_LIGHTLESS"] = old
+    (s0, f0, img0), (s2, f2, img2) = out["0"], out["2"]
+    assert (f0[:, 2] > 1).mean() > 0.05  # states with a light sub-path exist on this scene
+    for k in ("steps", "largeSteps", "accepted", "gradCalls", "cacheQueries", "cacheHits", "resets"):
+        assert s0[k] == s2[k], (k, s0[k], s2[k])
+    assert np.array_equal(f0, f2)
+    assert np.allclose(img0, img2, rtol=1e-4, atol=1e-6) and img0.sum() > 0
