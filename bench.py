@@ -367,7 +367,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(),
-                "kernel": "k_step_small<true>",
+                "kernel": "k_step_small<true,false,false,true> (plain small steps; the instantiation without light sub-paths: this scene is lit by its environment map alone)",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "chain_steps_per_launch": lean_steps_per_launch,
                 "algorithmic_bytes_per_step": ALGO_BYTES_PER_STEP,
