@@ -339,9 +339,11 @@ static void SyncOptions(lmc_ctx *c) {
     d.useLightCoord = o.useLightCoordinateSampling ? 1 : 0;
     c->S.sceneParams[0] = d.useLightCoord ? 1.0f : 0.0f;  // scene.cpp:165: the flag opens the serialized scene block the path programs read
     d.sampleCache = (o.sampleFromGlobalCache && o.mala) ? 1 : 0;  // mlt.cpp:71-73: LargeStepCache only together with mala
-    // a scene lit by its environment map alone has no state with a light sub-path: EnvLight::Emit contributes nothing (the l >= 2
-    // techniques of such a scene are empty on the oracle and on the device alike, tests/test_host.py), so the lean launch can run
-    // without that half of the walk (LMC_LEAN_LIGHTLESS=0: A/B switch)
+    // a scene lit by its environment map alone has, in practice, no state with a light sub-path: EnvLight::Emit (envlight.cpp:228-248)
+    // starts its rays on a disc as wide as the scene's bounding sphere, and with a ground plane in the scene the first ray misses
+    // everything the camera sees (torus: the l >= 2 techniques are empty in 4e5 init samples on the oracle and on the device alike,
+    // tests/test_host.py).  The lean launch then runs without that half of the walk; a state with l > 1, should one appear, takes the
+    // generic launch (LMC_LEAN_LIGHTLESS=0: A/B switch)
     // LMC_LEAN_LIGHTLESS=2 forces it on any scene: every state with l > 1 then takes the fallback, which is how the tests exercise it
     const int lightlessMode = getenv("LMC_LEAN_LIGHTLESS") ? atoi(getenv("LMC_LEAN_LIGHTLESS")) : 1;
     d.leanLightless = (lightlessMode == 2 || (lightlessMode == 1 && c->S.numLights == 1 && c->S.envLight >= 0)) ? 1 : 0;
