@@ -12,6 +12,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/lmc_abi.h"
@@ -1036,18 +1037,36 @@ static void CacheApply(lmc_ctx *c) {
     c->stepsSinceCounts = 0;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = c->hostCounts[sl];
     bool changed = false;
+    // the dims that became ready in this step (often two at once: at 2^20 chains dims 10 and 12 fill in the same step): the existence
+    // grids are started on the device first, the point rows are fetched, and the kd-trees are built side by side on host threads
+    // (0.5 ms each; one after the other they made that step 1 ms longer, profiles/r03_o_step_timeline.jsonl step 22)
+    int readyDims[CACHE_SLOTS], numReady = 0;
     for (int sl = 0; sl < CACHE_SLOTS; sl++) {
         const int d = 6 + 2 * sl;
+        const CacheDimHost &cd = c->cacheDims[d];
+        if (cd.relevant && !cd.ready && c->hostCounts[sl] >= PSS_MAX_SIZE) readyDims[numReady++] = d;
+    }
+    std::vector<std::vector<float>> ptsOf(numReady);
+    std::vector<lmc::KdTreeResult> treeOf(numReady);
+    for (int r = 0; r < numReady; r++) ptsOf[r] = c->cacheDims[readyDims[r]].pss.Download();
+    for (int r = 0; r < numReady; r++) {
+        CacheDimHost &cd = c->cacheDims[readyDims[r]];
+        LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, readyDims[r], cd.gridG, cd.gridM, cd.gridStart.p, cd.gridCursor.p, cd.gridRows.p, cd.gridTileSums.p, s);
+    }
+    {
+        std::vector<std::thread> workers;
+        for (int r = 1; r < numReady; r++) workers.emplace_back([&, r]() { treeOf[r] = lmc::BuildKdTree(ptsOf[r].data(), PSS_MAX_SIZE, readyDims[r]); });
+        if (numReady > 0) treeOf[0] = lmc::BuildKdTree(ptsOf[0].data(), PSS_MAX_SIZE, readyDims[0]);
+        for (auto &w : workers) w.join();
+    }
+    for (int r = 0; r < numReady; r++) {
+        const int d = readyDims[r];
         CacheDimHost &cd = c->cacheDims[d];
-        if (!cd.relevant || cd.ready || c->hostCounts[sl] < PSS_MAX_SIZE) continue;
-        std::vector<float> pts = cd.pss.Download();
-        lmc::KdTreeResult t = lmc::BuildKdTree(pts.data(), PSS_MAX_SIZE, d);
+        lmc::KdTreeResult &t = treeOf[r];
         if (t.nodes.size() > KD_MAX_NODES) throw std::runtime_error("kd-tree larger than its preallocated node buffer");
         HIP_CHECK(hipMemcpyAsync(cd.nodes.p, t.nodes.data(), t.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(cd.vind.p, t.vind.data(), t.vind.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        // the existence-test grid, on the device (no host time, nothing to upload)
-        LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, d, cd.gridG, cd.gridM, cd.gridStart.p, cd.gridCursor.p, cd.gridRows.p, cd.gridTileSums.p, s);
-        HIP_CHECK(hipStreamSynchronize(s));  // t goes out of scope below: the pageable copies above must have left the host
+        HIP_CHECK(hipStreamSynchronize(s));  // the pageable copies above must have left the host before the trees go out of scope
         DCacheDim &D = c->cacheHost.d[d];
         D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
         if (t.depth >= KD_STACK) throw std::runtime_error("kd-tree deeper than the search stack (KD_STACK)");
