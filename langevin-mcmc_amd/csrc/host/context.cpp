@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -1055,9 +1056,23 @@ static void CacheApply(lmc_ctx *c) {
     }
     {
         std::vector<std::thread> workers;
-        for (int r = 1; r < numReady; r++) workers.emplace_back([&, r]() { treeOf[r] = lmc::BuildKdTree(ptsOf[r].data(), PSS_MAX_SIZE, readyDims[r]); });
-        if (numReady > 0) treeOf[0] = lmc::BuildKdTree(ptsOf[0].data(), PSS_MAX_SIZE, readyDims[0]);
+        std::vector<std::exception_ptr> failed(numReady);  // an exception must not leave a worker thread (std::terminate): re-thrown after the join
+        for (int r = 1; r < numReady; r++)
+            workers.emplace_back([&, r]() {
+                try {
+                    treeOf[r] = lmc::BuildKdTree(ptsOf[r].data(), PSS_MAX_SIZE, readyDims[r]);
+                } catch (...) {
+                    failed[r] = std::current_exception();
+                }
+            });
+        try {
+            if (numReady > 0) treeOf[0] = lmc::BuildKdTree(ptsOf[0].data(), PSS_MAX_SIZE, readyDims[0]);
+        } catch (...) {
+            failed[0] = std::current_exception();
+        }
         for (auto &w : workers) w.join();
+        for (auto &f : failed)
+            if (f) std::rethrow_exception(f);
     }
     for (int r = 0; r < numReady; r++) {
         const int d = readyDims[r];
