@@ -118,7 +118,6 @@ struct ChainArrays {
     int *flags;        // N
     float *gaussian;   // GAUSS_WORDS x N: Gaussian buffer 0
     float *gaussian1;  // GAUSS_WORDS x N: Gaussian buffer 1 (see F_GSEL)
-    float *h2Gauss;    // H2MC renders only: dense Gaussians, 2 buffers x (16 + 2 * 256 + 1) x N (dh2step.h, F_GSEL)
     float *curSplat;   // MAXCONTRIB*SPLAT_WORDS x N
     int *curSplatCount;
     float *chV1, *chV2, *chCurrNewV2, *chPropNewV1, *chPropNewV2, *chPss, *chLastPss;  // MAXPSS x N each

@@ -1,0 +1,61 @@
+// Shared layout of the wave-cooperative H2MC pipeline (h2hess.hip, step_small_h2mc.hip, host/context.cpp).
+// An H2MC small step (H2MCSmallStep::Mutate, /root/reference/src/mutation_h2mc.h:38-128) is run as a short pipeline of launches
+// instead of one thread per chain: the lane-per-chain parts (draws, path perturbation, accept / reject) stay lane-per-chain, the
+// second-order path program runs with the lanes of a wave = the 2 x 2 Hessian blocks of ONE state (h2hess.hip k_h2_hess), the
+// eigen-solve and the dense Gaussian with 16 lanes per state (k_h2_gauss).  Hand-off between the launches, per chain (index i):
+//   rec  [i * H2_REC_WORDS ..]  the serialised state the path program reads (path.cpp:2497-2586 layout), AoS so that a wave stages
+//                               it into LDS with whole-line loads: [0,17) primary | [17] c | [18] l | [H2_REC_VP ..) vertParams
+//   hout [i * H2_OUT_WORDS ..]  what the program returns: [0,16) gradient | [16] logLum | [H2_OUT_HESS ..) Hessian rows (stride dim),
+//                               the triangle Eigen reads (h2mc.cpp:78: the UPPER triangle of the rows as delivered)
+//   gauss[buf][i * H2_GAUSS_AOS ..]  a state's proposal Gaussian (h2mc.cpp:3-142), AoS: [0,16) mean | [16] logDet | [17] kind |
+//                               [32 ..) covL (n x n, stride n) | [32 + 256 ..) invCov
+#pragma once
+#include "dmath.h"
+
+namespace lmcd {
+
+constexpr int H2_REC_WORDS = 640, H2_REC_C = 17, H2_REC_L = 18, H2_REC_VP = 20;  // vertParams: V <= 238 + 59 * 6 = 592 words
+constexpr int H2_OUT_WORDS = 288, H2_OUT_LOGLUM = 16, H2_OUT_HESS = 32;
+constexpr int H2_GAUSS_AOS = 544, H2_GAUSS_LOGDET = 16, H2_GAUSS_COVL = 32, H2_GAUSS_INVCOV = 32 + 256;
+
+// Exact technique index: the derivative programs exist for 1 <= c <= 9, 0 <= l <= 8, 3 <= c + l <= 9 (path.cpp:4030-4037): 42 of them
+constexpr int H2_NTECH = 42;
+LMC_HD int H2TechIndex(int c, int l) {  // -1: no program
+    const int s = c + l;
+    if (c < 1 || c > 9 || l < 0 || l > 8 || s < 3 || s > 9) return -1;
+    return (s - 1) * s / 2 - 3 + l;
+}
+LMC_HD void H2TechOf(int t, int &c, int &l) {
+    int s = 3, base = 0;
+    while (base + s <= t) base += s, s++;
+    l = t - base, c = s - l;
+}
+LMC_HD int H2TechDim(int t) {  // 2 * max(c + l - 1, 2)
+    int s = 3, base = 0;
+    while (base + s <= t) base += s, s++;
+    return 2 * (s - 1);
+}
+// lanes one state occupies in the Hessian launch: the 2 x 2 blocks of the upper triangle of a dim x dim matrix
+LMC_HD int H2BlocksOfDim(int dim) { return (dim / 2) * (dim / 2 + 1) / 2; }
+
+// work lists of one pipeline stage: bin t = the chains whose state of technique t needs its Gaussian, items[t * N + k]
+struct H2Bins {
+    int *items;  // H2_NTECH x N
+    int *count;  // H2_NTECH (+ padding to 64)
+};
+
+// per-step hand-off state of the H2MC pipeline (host/context.cpp allocates it for H2MC renders only)
+enum : int { H2S_H2 = 1, H2S_DENSE = 2, H2S_OK = 4 };  // `step` bits: an H2MC (not uniform-mixing) step; dim <= 16; the re-trace carries light
+enum : int { H2K_DENSE = 0, H2K_ISO_EARLYOUT = 1, H2K_ISO_NODERV = 2 };  // gauss[..][17]: which of the reference's three outcomes the record holds
+struct H2Arrays {
+    float *rec, *hout;    // AoS, H2_REC_WORDS / H2_OUT_WORDS per chain
+    float *gauss;         // AoS, 2 buffers x N x H2_GAUSS_AOS (current / proposal, selected by F_GSEL)
+    float *offset;        // MAXPSS x N (SoA): the step's normal draws z, replaced by the proposal offset
+    float *py, *px;       // N: log density of the offset under the current Gaussian / of its reverse under the proposal's
+    float *propContrib;   // 9 x N: the proposal's SubpathContrib
+    int *step;            // N: H2S_* bits
+    unsigned char *kind;  // N: 1 = k_h2_sample turns this chain's z into the offset (dense or isotropic record), 0 = k_h2_begin did
+    H2Bins bins[2];       // stage 0: current states without a Gaussian; stage 1: proposals
+};
+
+}  // namespace lmcd

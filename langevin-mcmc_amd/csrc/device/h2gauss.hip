@@ -1,0 +1,277 @@
+// k_h2_gauss, k_h2_sample: the dense proposal Gaussian of an H2MC state and the offset drawn from it, 16 lanes per state (layout: dh2coop.h).
+// Compiled with the library's arithmetic contract (no contraction, correctly rounded division / square root): these results feed the chain
+// trajectory directly, and the rotation arithmetic is the CPU oracle's element for element.
+#include "dh2coop.h"
+#include "dh2mc.h"
+#include "kernels.h"
+
+using namespace lmcd;
+
+namespace {
+__device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_h2_gauss: ComputeGaussian(H2MCParam, ...) of /root/reference/src/h2mc.cpp:3-142 for the states of a stage, 16 lanes per state
+// (four states of one technique per wave): the symmetric eigen-decomposition (the reference calls Eigen::SelfAdjointEigenSolver --
+// third party, absent: parity unpinned) is the cyclic Jacobi iteration of dh2mc.h JacobiEigenSymT with every rotation's
+// 3 n element updates spread over the lanes: same rotation sequence, same arithmetic per element, hence the same eigenvectors (sign
+// and order included) as the serial form the CPU oracle runs.  The matrices live in LDS (row stride 17: lanes k = 0..15 reading
+// [k][p] hit 16 banks).  Only the two reductions (Frobenius norm of the early-out, off-diagonal norm of the convergence test) are
+// summed in another order than the serial code.
+// Writes the state's Gaussian (AoS, dh2coop.h) into the chain's current (stage 0) or proposal (stage 1) buffer; stage 1 also
+// returns px = GaussianLogPdf(-offset, proposalGaussian) (mutation_h2mc.h:104, gaussian.cpp:24-36).
+namespace {
+constexpr int GS = 17, GW = 16 * GS;
+constexpr int G_LDS = 2 * GW + 6 * 16;  // A | V | w | eb | ob | post | grad | tmp
+__device__ __forceinline__ float GroupSum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float *__restrict__ hout, H2MCParam param, int expFlags, const int *__restrict__ chainFlags,
+                                                  int stage, float *__restrict__ gaussBuf, const float *__restrict__ offsetSoA, float *__restrict__ px) {
+    __shared__ float lds[4 * G_LDS];
+    const int lane = threadIdx.x, g = lane >> 4, k = lane & 15;
+    float *A = lds + g * G_LDS, *V = A + GW, *w = V + GW, *eb = w + 16, *ob = eb + 16, *post = ob + 16, *grad = post + 16, *tmp = grad + 16;
+    int cnt = 0;
+    if (lane < H2_NTECH) cnt = bins.count[lane];
+    const int tasks = (cnt + 3) >> 2;
+    const int incl = WaveInclusiveScan(tasks, lane);
+    const int total = __shfl(incl, 63);
+    const float sigma = param.sigma, invSigmaSq = 1.0f / (sigma * sigma);
+    for (int wk = blockIdx.x; wk < total; wk += gridDim.x) {
+        const int wr = total - 1 - wk;
+        const int t = __popcll(__ballot(incl <= wr));
+        const int j = wr - (__shfl(incl, t) - __shfl(tasks, t));
+        const int tCnt = __shfl(cnt, t);
+        const int n = H2TechDim(t);
+        const int first = 4 * j, nItems = min(4, tCnt - first);
+        const bool has = g < nItems;
+        const int item = has ? bins.items[(size_t)t * N + first + g] : 0;
+        const bool act = has && k < n;
+        const float *o = hout + (size_t)item * H2_OUT_WORDS;
+        // the triangle Eigen reads (h2mc.cpp:78: the program's rows as a column-major matrix, lower triangle = the UPPER triangle of the rows)
+        bool fin = true;
+        float sq = 0.f;
+        if (act) {
+            const float gk = o[k];
+            fin = isfinite(gk);
+            grad[k] = gk;
+            for (int c = 0; c < n; c++) {
+                const float h = c >= k ? o[H2_OUT_HESS + k * n + c] : o[H2_OUT_HESS + c * n + k];
+                fin = fin && isfinite(h);
+                A[k * GS + c] = h;
+                V[k * GS + c] = (k == c) ? 1.0f : 0.0f;
+                sq += h * h;
+            }
+        }
+        const unsigned long long finMask = __ballot(fin || !act);
+        const bool allFinite = ((finMask >> (16 * g)) & 0xffffull) == 0xffffull;  // mutation_h2mc.h:80-85: any non-finite entry zeroes gradient and Hessian
+        const float hnorm = sqrtf(GroupSum(act ? sq : 0.f));
+        const bool iso = !allFinite || (expFlags & 32) || hnorm < 0.5f / (sigma * sigma) || !(hnorm == hnorm);  // h2mc.cpp:84-92
+        bool run = has && !iso;
+        __syncthreads();
+        // ---- cyclic Jacobi, dh2mc.h JacobiEigenSymT
+        for (int sweep = 0; sweep < 30; sweep++) {
+            float offP = 0.f, diagP = 0.f;
+            if (act) {
+                diagP = A[k * GS + k] * A[k * GS + k];
+                for (int c = k + 1; c < n; c++) offP += A[k * GS + c] * A[k * GS + c];
+            }
+            const float off = GroupSum(offP), diag = GroupSum(diagP);
+            if (!(off > 1e-14f * (diag + off))) run = false;  // also leaves on NaN
+            if (!__any(run)) break;
+            for (int p = 0; p < n - 1; p++)
+                for (int q = p + 1; q < n; q++) {
+                    const float apq = A[p * GS + q];
+                    const bool rot = run && apq != 0.0f;
+                    const float app = A[p * GS + p], aqq = A[q * GS + q];
+                    const float theta = (aqq - app) / (2.0f * apq);
+                    const float tt = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                    const float cs = 1.0f / sqrtf(tt * tt + 1.0f), sn = tt * cs;
+                    const float akp = A[k * GS + p], akq = A[k * GS + q];  // A <- A J (columns p, q): lane k = row k
+                    __syncthreads();
+                    if (rot && act) {
+                        A[k * GS + p] = cs * akp - sn * akq;
+                        A[k * GS + q] = sn * akp + cs * akq;
+                    }
+                    __syncthreads();
+                    const float apk = A[p * GS + k], aqk = A[q * GS + k];  // A <- J^T A (rows p, q): lane k = column k
+                    const float vkp = V[k * GS + p], vkq = V[k * GS + q];  // V <- V J: lane k = row k
+                    __syncthreads();
+                    if (rot && act) {
+                        A[p * GS + k] = cs * apk - sn * aqk;
+                        A[q * GS + k] = sn * apk + cs * aqk;
+                        V[k * GS + p] = cs * vkp - sn * vkq;
+                        V[k * GS + q] = sn * vkp + cs * vkq;
+                    }
+                    __syncthreads();
+                }
+        }
+        float *G = gaussBuf + ((((chainFlags[item] & F_GSEL) != 0) != (stage != 0)) ? (size_t)N * H2_GAUSS_AOS : 0) + (size_t)item * H2_GAUSS_AOS;
+        float logDet = 0.f, meanK = 0.f;
+        if (iso) {
+            for (int i = 0; i < n; i++) logDet += llogf(invSigmaSq);
+            if (act) G[k] = 0.f;
+            if (has && k == 0) G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_EARLYOUT;
+        }
+        // eigenvalues in ascending order (selection sort; ties keep their order), eigenvectors = the columns of V
+        if (act) w[k] = A[k * GS + k];
+        __syncthreads();
+        for (int i = 0; i < n - 1; i++) {
+            int m = i;
+            for (int c = i + 1; c < n; c++)
+                if (w[c] < w[m]) m = c;
+            const float wi = w[i], wm = w[m];
+            const float vi = V[k * GS + i], vm = V[k * GS + m];
+            __syncthreads();
+            if (m != i && act) {
+                if (k == 0) w[i] = wm, w[m] = wi;
+                V[k * GS + i] = vm, V[k * GS + m] = vi;
+            }
+            __syncthreads();
+        }
+        if (act) {  // per eigenvalue: variance / offset remap, h2mc.cpp:100-128
+            const float wk_ = w[k];
+            float e = fabsf(wk_) > 1e-10f ? 1.0f / fabsf(wk_) : 0.0f;
+            float dot = 0.f;
+            for (int c = 0; c < n; c++) dot += V[c * GS + k] * grad[c];
+            const float ofs = e * dot;
+            float s2 = 1.0f, oo = 0.0f;
+            if (fabsf(wk_) > 1e-10f) {
+                oo = ofs;
+                if (wk_ > 0.0f) s2 = param.posScaleFactor, oo *= param.posOffsetFactor;
+                else
+                    s2 = param.negScaleFactor, oo *= param.negOffsetFactor;
+            } else {
+                s2 = param.L * param.L;
+                oo = 0.5f * ofs * param.L * param.L;
+            }
+            e *= s2;
+            e = e > 1e-10f ? 1.0f / e : 0.0f;
+            eb[k] = e, ob[k] = oo, post[k] = e + invSigmaSq;
+            tmp[k] = llogf(e + invSigmaSq);
+        }
+        __syncthreads();
+        if (!iso) {
+            for (int i = 0; i < n; i++) logDet += tmp[i];
+            if (act) {
+                float m = 0.f;
+                for (int c = 0; c < n; c++) m += V[k * GS + c] * ((eb[c] / post[c]) * ob[c]);
+                meanK = m;
+                G[k] = m;
+                const float sq1 = sqrtf(1.0f / post[k]);
+                for (int i = 0; i < n; i++) {  // lane k = column k of invCov / covL: a row of the AoS record is written by consecutive lanes
+                    float ic = 0.f;
+                    for (int c = 0; c < n; c++) ic += V[i * GS + c] * post[c] * V[k * GS + c];
+                    G[H2_GAUSS_INVCOV + i * n + k] = ic;
+                    G[H2_GAUSS_COVL + i * n + k] = V[i * GS + k] * sq1;
+                    A[i * GS + k] = ic;  // kept for px
+                }
+                if (k == 0) G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_DENSE;
+            }
+        }
+        __syncthreads();
+        if (stage != 0) {  // px = GaussianLogPdf(-offset, this Gaussian), gaussian.cpp:24-36
+            if (act) tmp[k] = -offsetSoA[(size_t)k * N + item] - meanK;
+            __syncthreads();
+            if (act) {
+                float r = 0.f;
+                if (iso) r = invSigmaSq * tmp[k];
+                else
+                    for (int c = 0; c < n; c++) r += A[k * GS + c] * tmp[c];
+                w[k] = r;
+            }
+            __syncthreads();
+            if (has && k == 0) {
+                float qf = 0.f;
+                for (int i = 0; i < n; i++) qf += tmp[i] * w[i];
+                float logPdf = n * (-0.9189385332046727f);
+                logPdf += 0.5f * logDet;
+                logPdf -= 0.5f * qf;
+                px[item] = logPdf;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// k_h2_sample: the proposal offset of an H2MC step and its density, GenerateSample / GaussianLogPdf (gaussian.cpp:24-55) with the dense
+// current Gaussian: offset = covL z + mean, py = log N(offset; mean, invCov^-1).  16 lanes per chain (lane = row), over the whole
+// small-step list; chains that take another kind of step this time (uniform mixing, isotropic Gaussian, no derivative program) were
+// given their offset by k_h2_begin and are skipped (stepKind != 1).
+__global__ void __launch_bounds__(64) k_h2_sample(const int *__restrict__ list, const int *__restrict__ listCount, int N, const int *__restrict__ chainFlags,
+                                                   const unsigned char *__restrict__ stepKind, const float *__restrict__ curContrib, const float *__restrict__ gaussBuf,
+                                                   float sigma, float *__restrict__ offsetSoA /* in: z, out: offset */, float *__restrict__ py) {
+    __shared__ float lds[4 * (2 * 256 + 48)];
+    const int lane = threadIdx.x, g = lane >> 4, k = lane & 15;
+    float *CL = lds + g * (2 * 256 + 48), *IC = CL + 256, *z = IC + 256, *x = z + 16, *mean = x + 16;
+    const int total = *listCount;
+    const float invSigmaSq = 1.0f / (sigma * sigma);
+    for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
+        const int e = base + g;
+        const int i = e < total ? list[e] : -1;
+        const bool has = i >= 0 && stepKind[i] == 1;
+        int n = 0;
+        bool iso = false;
+        const float *G = gaussBuf;
+        if (has) {
+            const int c = __float_as_int(curContrib[i]), l = __float_as_int(curContrib[(size_t)N + i]);
+            n = 2 * max(c + l - 1, 2);
+            G = gaussBuf + ((chainFlags[i] & F_GSEL) ? (size_t)N * H2_GAUSS_AOS : 0) + (size_t)i * H2_GAUSS_AOS;
+            iso = G[H2_GAUSS_LOGDET + 1] != 0.0f;  // an isotropic record (H2K_ISO_*): sigma I, mean 0, only logDet is stored
+            if (!iso)
+                for (int q = k; q < n * n; q += 16) CL[q] = G[H2_GAUSS_COVL + q], IC[q] = G[H2_GAUSS_INVCOV + q];
+            if (k < n) z[k] = offsetSoA[(size_t)k * N + i], mean[k] = iso ? 0.0f : G[k];
+        }
+        __syncthreads();
+        const bool act = has && k < n;
+        if (act) {
+            float r = 0.f;
+            if (iso) r = sigma * z[k];
+            else
+                for (int c = 0; c < n; c++) r += CL[k * n + c] * z[c];
+            const float xk = r + mean[k];
+            x[k] = xk;
+            offsetSoA[(size_t)k * N + i] = xk;
+        }
+        __syncthreads();
+        if (act) {
+            float r = 0.f;
+            if (iso) r = invSigmaSq * (x[k] - mean[k]);
+            else
+                for (int c = 0; c < n; c++) r += IC[k * n + c] * (x[c] - mean[c]);
+            z[k] = r;
+        }
+        __syncthreads();
+        if (has && k == 0) {
+            float qf = 0.f;
+            for (int c = 0; c < n; c++) qf += (x[c] - mean[c]) * z[c];
+            float logPdf = n * (-0.9189385332046727f);
+            logPdf += 0.5f * G[H2_GAUSS_LOGDET];
+            logPdf -= 0.5f * qf;
+            py[i] = logPdf;
+        }
+        __syncthreads();
+    }
+}
+
+void LaunchH2Gauss(const H2Bins &bins, int N, const float *hout, const H2MCParam &param, int expFlags, const int *chainFlags, int stage, float *gaussBuf,
+                   const float *offsetSoA, float *px, int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_h2_gauss, dim3(gridBlocks), dim3(64), 0, s, bins, N, hout, param, expFlags, chainFlags, stage, gaussBuf, offsetSoA, px);
+}
+void LaunchH2Sample(const int *list, const int *listCount, int N, const int *chainFlags, const unsigned char *stepKind, const float *curContrib, const float *gaussBuf,
+                    float sigma, float *offsetSoA, float *py, int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_h2_sample, dim3(gridBlocks), dim3(64), 0, s, list, listCount, N, chainFlags, stepKind, curContrib, gaussBuf, sigma, offsetSoA, py);
+}

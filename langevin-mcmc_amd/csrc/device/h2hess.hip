@@ -1,0 +1,114 @@
+// k_h2_hess: gradient and Hessian of log f for the H2MC proposal (the reference's evaluate_path_bidir_<c>_<l>_static_derv programs,
+// generator /root/reference/src/path.cpp:3419-3662, chad.cpp:333-544; caller mutation_h2mc.h:60-93), WAVE-COOPERATIVE:
+// the lanes of a wave are the 2 x 2 blocks of the Hessian triangle of a few states of ONE technique (c,l) -- dim 12: 21 lanes per
+// state, three states per wave -- instead of one lane walking all 21 passes of its own chain's state one after the other
+// (round 3: dh2step.h, 4 M chain-steps/s).  All lanes of a state walk the same path: same branches, the state's serialised
+// record is staged in LDS once per wave and read by broadcast, a lane holds ONE pass (values of 9 floats, seeded on the fly: no
+// indexable array of second-order values, hence no private memory for it).
+#define LMC_PF_CONTRACT  // the dual-number arithmetic of this translation unit may fuse a * b + c (pathfunc.h)
+#include "dh2coop.h"
+#include "pathfunc.h"
+#include "kernels.h"
+
+using namespace lmcd;
+
+namespace {
+
+typedef DualS<2, Dual<2>> T2;
+
+struct LdsIn {  // the state's vertParams in LDS
+    const float *p;
+    __device__ __forceinline__ float operator[](int k) const { return p[k]; }
+};
+// a lane's seeding of the float primary samples: rows [i0, i0 + 2) on the outer level, columns [c0, c0 + 2) on the inner one
+struct SeedPrim {
+    const float *p;
+    int i0, c0;
+    __device__ __forceinline__ T2 operator()(int k) const {
+        T2 r = Lift<T2>::Of(p[k]);
+        const int v = k - 1;  // primary[0] is the (inactive) time
+        r.v.d[0] = v == c0 ? 1.0f : 0.0f;
+        r.v.d[1] = v == c0 + 1 ? 1.0f : 0.0f;
+        r.d[0].v = v == i0 ? 1.0f : 0.0f;
+        r.d[1].v = v == i0 + 1 ? 1.0f : 0.0f;
+        return r;
+    }
+};
+
+__device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+}  // namespace
+
+// LDS per wave: the records of the states of one task, at most H2_HESS_LDS_WORDS floats (a task takes fewer states when they do not fit)
+constexpr int H2_HESS_LDS_WORDS = 3328;  // 13 KB: 10 states of dim 6 (314 words + pad), 3 of dim 12 (491)
+
+#ifndef LMC_H2HESS_WAVES
+#define LMC_H2HESS_WAVES 1
+#endif
+struct SceneBlock38 {  // the serialised scene block (scene.cpp:164-169) as a kernel argument: uniform, read with scalar loads
+    float v[38];
+};
+__global__ void __launch_bounds__(64, LMC_H2HESS_WAVES) k_h2_hess(const float *__restrict__ rec, H2Bins bins, int N, SceneBlock38 sceneArg, float *__restrict__ hout) {
+    const float *scene = sceneArg.v;
+    __shared__ float lds[H2_HESS_LDS_WORDS];
+    const int lane = threadIdx.x;
+    // tasks of bin t: ceil(count / states per wave); every wave derives the same table
+    int cnt = 0, nb = 1, ipw = 1, recW = 0;
+    if (lane < H2_NTECH) {
+        cnt = bins.count[lane];
+        int c, l;
+        H2TechOf(lane, c, l);
+        nb = H2BlocksOfDim(H2TechDim(lane));
+        recW = (H2_REC_VP + 238 + 59 * (c + l - 3) + 3) & ~3;
+        ipw = min(64 / nb, H2_HESS_LDS_WORDS / recW);
+    }
+    const int tasks = (cnt + ipw - 1) / ipw;
+    const int incl = WaveInclusiveScan(tasks, lane);
+    const int total = __shfl(incl, 63);
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int wr = total - 1 - w;  // longest programs first
+        const int t = __popcll(__ballot(incl <= wr));
+        const int j = wr - (__shfl(incl, t) - __shfl(tasks, t));
+        const int tIpw = __shfl(ipw, t), tNb = __shfl(nb, t), tRecW = __shfl(recW, t), tCnt = __shfl(cnt, t);
+        const int first = j * tIpw, n = min(tIpw, tCnt - first);
+        int c, l;
+        H2TechOf(t, c, l);
+        const int dim = H2TechDim(t);
+        const int *items = bins.items + (size_t)t * N + first;
+        for (int s = 0; s < n; s++) {  // stage the records: whole lines
+            const float *src = rec + (size_t)items[s] * H2_REC_WORDS;
+            for (int k = lane; k < tRecW; k += 64) lds[s * tRecW + k] = src[k];
+        }
+        __syncthreads();
+        const int slot = lane / tNb;
+        if (slot < n) {
+            int b = lane - slot * tNb, r = 0;
+            const int m = dim / 2;
+            while (b >= m - r) b -= m - r, r++;
+            const int i0 = 2 * r, c0 = 2 * (r + b);
+            const float *base = lds + slot * tRecW;
+            const SeedPrim prim{base, i0, c0};
+            const LdsIn vp{base + H2_REC_VP};
+            const T2 res = PathProgramP<T2, LdsIn, SeedPrim>(c, l, prim, scene, vp);
+            float *o = hout + (size_t)items[slot] * H2_OUT_WORDS;
+            if (i0 == 0 && c0 == 0) o[H2_OUT_LOGLUM] = res.v.v;
+            for (int q = 0; q < 2; q++) {
+                if (c0 == i0) o[i0 + q] = res.d[q].v;  // the forward directional derivative: exact (the reference's `g`)
+                for (int k = 0; k < 2; k++) o[H2_OUT_HESS + (i0 + q) * dim + c0 + k] = res.d[q].d[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void LaunchH2Hess(const float *rec, const H2Bins &bins, int N, const float *scene38 /* host */, float *hout, int gridBlocks, hipStream_t s) {
+    SceneBlock38 sc;
+    for (int k = 0; k < 38; k++) sc.v[k] = scene38[k];
+    hipLaunchKernelGGL(k_h2_hess, dim3(gridBlocks), dim3(64), 0, s, rec, bins, N, sc, hout);
+}

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include "dchain.h"
+#include "dh2coop.h"
+#include "dh2mc.h"
 #include "dstep_params.h"
 
 void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s);
@@ -51,9 +53,18 @@ void LaunchStepSmallLeanGrad(const lmcd::DScene &S, const lmcd::DCache *cache, c
 void LaunchStepSmallPlain(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                           const int *list, const int *listCount, const lmcd::NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads,
                           bool profile, hipStream_t s);
-// all small steps of an H2MC render (device/step_small_h2mc.hip)
-void LaunchStepSmallH2MC(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                         const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s);
+// all small steps of an H2MC render: the launches of the wave-cooperative pipeline (device/dh2coop.h; step_h2_phases.hip, h2hess.hip, h2gauss.hip)
+void LaunchH2Begin(const lmcd::DScene &S, const lmcd::ChainArrays &A, const lmcd::StepParams &P, const lmcd::H2Arrays &H, const int *list, const int *listCount, int gridBlocks,
+                   hipStream_t s);
+void LaunchH2Perturb(const lmcd::DScene &S, const lmcd::ChainArrays &A, const lmcd::StepParams &P, const lmcd::H2Arrays &H, const int *list, const int *listCount,
+                     int bvhStackNeed, int gridBlocks, hipStream_t s);
+void LaunchH2Finish(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const lmcd::H2Arrays &H,
+                    const int *list, const int *listCount, int gridBlocks, hipStream_t s);
+void LaunchH2Hess(const float *rec, const lmcd::H2Bins &bins, int N, const float *scene38 /* host memory: passed by value */, float *hout, int gridBlocks, hipStream_t s);
+void LaunchH2Gauss(const lmcd::H2Bins &bins, int N, const float *hout, const lmcd::H2MCParam &param, int expFlags, const int *chainFlags, int stage, float *gaussBuf,
+                   const float *offsetSoA, float *px, int gridBlocks, hipStream_t s);
+void LaunchH2Sample(const int *list, const int *listCount, int N, const int *chainFlags, const unsigned char *stepKind, const float *curContrib, const float *gaussBuf,
+                    float sigma, float *offsetSoA, float *py, int gridBlocks, hipStream_t s);
 // n gradient + Hessian evaluations of the (c,l) path program (the throughput form of the H2MC plugin symbols)
 void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, float *hessSoA,
                      hipStream_t s);

@@ -25,6 +25,13 @@
 #define LMC_PF LMC_HD
 #endif
 
+// LMC_PF_CONTRACT (h2hess.hip): a * b + c of the dual-number arithmetic may fuse.  The step's Hessian has no bit-level contract with the
+// oracle (the oracle takes its Hessians from the reference's own programs; the tests compare within 1e-2), and a second-order product
+// is 25 multiplications + 16 additions without fusing, 25 instructions with.
+#ifdef LMC_PF_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+
 namespace lmcd {
 
 struct ContigIn {
@@ -819,8 +826,11 @@ LMC_PF void EmitT(const In &b, int off, const SceneBlk &sc, const T &p0, const T
 
 // ------------------------------------------------------------------------------------------ the program
 // RegisterPathFuncBidirMALA, PathFuncMode::Static (path.cpp:3664-3911).  Returns log Luminance(contrib).
-template <class T, class In>
-LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L+1], [0] = time (inactive) */, const float *scene, const In &vp) {
+// `primary` is read through an accessor (primary(k) = the k-th primary sample as a T, [0] = time, inactive): an array of lifted values
+// for the per-lane forms below, a lane's own seeding of the float samples for the wave-cooperative Hessian (h2hess.hip), which
+// thereby never holds 17 second-order values in indexable (= private) memory.
+template <class T, class In, class Prim>
+LMC_HD T PathProgramP(int maxCamDepth, int maxLightDepth, const Prim &primary, const float *scene, const In &vp) {
     const SceneBlk sc = ReadScene(scene);
     int buf = 3;  // lensVertexPos
     int pi = 1;
@@ -832,7 +842,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
         const int lightOff = buf;
         const float lightType = vp[lightOff];
         V3T<T> org, dir;
-        T rp0 = primary[pi++], rp1 = primary[pi++], rd0 = primary[pi++], rd1 = primary[pi++];
+        T rp0 = primary(pi++), rp1 = primary(pi++), rd0 = primary(pi++), rd1 = primary(pi++);
         {  // EmitFromLight, path.cpp:2799-2841
             T cosLight, emissionPdf, directPdf;
             EmitT(vp, lightOff, sc, rp0, rp1, rd0, rd1, org, dir, lps.throughput, cosLight, emissionPdf, directPdf);
@@ -892,7 +902,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
                 buf += 10;
                 break;
             }
-            T r0 = primary[pi++], r1 = primary[pi++];
+            T r0 = primary(pi++), r1 = primary(pi++);
             BSDFSamplingT<true>(vp, buf, r0, r1, bsdfDiscrete, useAbs, lps, dir);
             buf += 10;
             const float rrWeight = vp[buf++];
@@ -901,7 +911,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
         }
     }
     if (maxCamDepth > 1) {
-        T sx = primary[pi++], sy = primary[pi++];
+        T sx = primary(pi++), sy = primary(pi++);
         V3T<T> org, dir;
         {  // EmitFromCamera, path.cpp:3138-3170
             V3T<T> cOrg, camDir;
@@ -952,7 +962,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
             }
             if (camDepth == maxCamDepth - 2) {
                 if (maxLightDepth == 1) {  // DirectLighting, path.cpp:3202-3290
-                    T r0 = primary[pi++], r1 = primary[pi++];
+                    T r0 = primary(pi++), r1 = primary(pi++);
                     const float lightType = vp[buf];
                     V3T<T> dirToLight, lightContrib;
                     T cosAtLight, directPdf, emissionPdf;
@@ -993,7 +1003,7 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
                 contrib = cps.throughput;
                 break;
             }
-            T r0 = primary[pi++], r1 = primary[pi++];
+            T r0 = primary(pi++), r1 = primary(pi++);
             const float bsdfDiscrete = vp[buf++], useAbs = vp[buf++];
             BSDFSamplingT<false>(vp, buf, r0, r1, bsdfDiscrete, useAbs, cps, dir, maxLightDepth == 0 && camDepth == maxCamDepth - 3, sc.useLightCoord);
             buf += 10;
@@ -1003,6 +1013,15 @@ LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L
         }
     }
     return Log(LumT(contrib));
+}
+template <class T>
+struct PrimArray {
+    const T *p;
+    LMC_HD const T &operator()(int k) const { return p[k]; }
+};
+template <class T, class In>
+LMC_HD T PathProgram(int maxCamDepth, int maxLightDepth, const T *primary /* [2L+1], [0] = time (inactive) */, const float *scene, const In &vp) {
+    return PathProgramP<T, In, PrimArray<T>>(maxCamDepth, maxLightDepth, PrimArray<T>{primary}, scene, vp);
 }
 
 // value only: evaluate_path_bidir_mala_<c>_<l>_static
@@ -1062,25 +1081,6 @@ LMC_HD void PathFuncHessPass(int c, int l, const float *primary, const float *sc
     if (firstOfRow && grad) grad[i] = r.d[0].v;  // the forward directional derivative: exact (the reference's `g`)
     for (int k = c0; k < dim && k < c0 + HC; k++) hess[i * dim + k] = r.d[0].d[k - c0];
 }
-// The H2MC step's form of a pass (dh2step.h PathFuncHessUpperDevice): rows [i0, i0 + R), columns [c0, c0 + W) with c0 >= i0
-template <int R, int W, class In>
-LMC_HD void PathFuncHessRowPass(int c, int l, const float *primary, const float *scene, const In &vp, int i0, int c0, float *logLum, float *grad, float *hess) {
-    const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
-    typedef DualS<R, Dual<W>> T2;
-    T2 p[2 * 8 + 1];
-    p[0] = Lift<T2>::Of(primary[0]);
-    for (int k = 0; k < dim; k++) {
-        p[k + 1] = Lift<T2>::Of(primary[k + 1]);
-        if (k >= c0 && k < c0 + W) p[k + 1].v.d[k - c0] = 1.0f;
-        if (k >= i0 && k < i0 + R) p[k + 1].d[k - i0].v = 1.0f;
-    }
-    T2 r = PathProgram<T2, In>(c, l, p, scene, vp);
-    if (i0 == 0 && c0 == 0 && logLum) *logLum = r.v.v;
-    for (int q = 0; q < R && i0 + q < dim; q++) {
-        if (c0 == i0) grad[i0 + q] = r.d[q].v;
-        for (int k = c0; k < dim && k < c0 + W; k++) hess[(i0 + q) * dim + k] = r.d[q].d[k - c0];
-    }
-}
 template <class In>
 LMC_HD void PathFuncHess(int c, int l, const float *primary, const float *scene, const In &vp, float *logLum, float *grad, float *hess) {
     const int dim = 2 * (c + l - 1 > 2 ? c + l - 1 : 2);
@@ -1130,3 +1130,6 @@ __device__ __noinline__ void PathFuncGradUpTo12(int c, int l, const float *prima
 #endif
 
 }  // namespace lmcd
+#ifdef LMC_PF_CONTRACT
+#pragma clang fp contract(off)
+#endif

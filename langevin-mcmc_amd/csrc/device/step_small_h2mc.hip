@@ -1,4 +1,6 @@
-// k_step_h2mc: every small step of an H2MC render (dh2step.h), and k_hess_batch, the batched form of the H2MC plugin symbols.
+// The per-lane forms of the H2MC library symbols (evaluate_path_bidir_<c>_<l>_static_derv with `hess`): k_hess_batch, one lane per item, and
+// k_plugin_hess, one call = one wave with a lane per pass; the FULL matrix, as the reference's programs deliver it.  (The H2MC step itself
+// needs one triangle only and evaluates it wave-cooperatively: h2hess.hip.)
 // Both call ONE out-of-line copy of the second-order path program (PathFuncHessDevice); its building blocks are outlined too
 // (LMC_PF_OUTLINE, pathfunc.h): this translation unit compiles in about two minutes instead of twenty-five.
 #define LMC_PF_OUTLINE
@@ -6,30 +8,6 @@
 #include "step_kernel.h"
 
 using namespace lmcd;
-
-#ifndef LMC_H2MC_WAVES
-#define LMC_H2MC_WAVES 1  // waves per SIMD the register allocation aims at (A/B: profiles/r03_s_ab_h2mc_waves.txt)
-#endif
-__global__ void __launch_bounds__(64, LMC_H2MC_WAVES) k_step_h2mc(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
-                                                  NextLists next, float *gradBuf, int gradStride) {
-    StepStats st;
-    const int total = *listCount;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
-        const int i = list[j];
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
-        GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
-        LocalStackT<true> stk;
-        StepChainH2MC(S, A, film, P, i, rng, gw, st, stk);
-        QueueNext(S, *cache, A, P, i, rng);
-        A.rngState[i] = rng.state;
-    }
-    __shared__ int sStats[9];
-    BlockReduceStats(st, A.counters, A.weightSum, sStats);
-}
 
 // lmc_hess_batch: value, gradient and Hessian (row i of item j at hessSoA[(i * dim + k) * n + j])
 __global__ void __launch_bounds__(64) k_hess_batch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum,
@@ -75,10 +53,4 @@ void LaunchPluginHess(int c, int l, const float *in, float *stage, float *out, h
 void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, float *hessSoA,
                      hipStream_t s) {
     hipLaunchKernelGGL(k_hess_batch, dim3((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096), dim3(64), 0, s, c, l, n, primarySoA, scene, vertSoA, logLum, gradSoA, hessSoA);
-}
-void LaunchStepSmallH2MC(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
-                         const NextLists &next, float *gradBuf, int gradStride, int gridBlocks, hipStream_t s) {
-    // one wave per block; dynamic LDS: the eigen-solve's matrix, H2_LDS_DIM^2 words per thread = 36 KB per block, four blocks per CU
-    hipLaunchKernelGGL(k_step_h2mc, dim3(gridBlocks * 4), dim3(64), 64 * H2_LDS_DIM * H2_LDS_DIM * sizeof(float), s, S, cache, A, film, P, list, listCount, next, gradBuf,
-                       gradStride);
 }

@@ -147,7 +147,13 @@ struct lmc_ctx {
     DevBuf<unsigned long long> counters, prof;
     bool profileLean = false;  // LMC_PROF=1: the lean launch runs its region-timer instantiation (lmc_prof_read)
     DevBuf<double> weightSum;
-    DevBuf<float> gradBuf, h2Gauss;
+    DevBuf<float> gradBuf;
+    // H2MC renders: hand-off state of the wave-cooperative pipeline (device/dh2coop.h)
+    DevBuf<float> h2Rec, h2Out, h2Gauss, h2Offset, h2Py, h2Px, h2PropContrib;
+    DevBuf<int> h2Step, h2Items, h2Counts;
+    DevBuf<unsigned char> h2Kind;
+    H2Arrays H2{};
+    int h2HessGrid = 0, h2GaussGrid = 0;
     int gradStride = 0, stepGrid = 0;
     // launch shape of the lean small-step kernel and the technique sort of its work list; LMC_LEAN_BLOCK / LMC_SORT_PLAIN
     // override them for A/B runs (profiles/)
@@ -408,6 +414,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_EXP_NOSTATS")) c->expFlags |= atoi(e) ? 8 : 0;
     if (const char *e = getenv("LMC_EXP_NOHESS")) c->expFlags |= atoi(e) ? 16 : 0;    // H2MC: skip the second-order path program
     if (const char *e = getenv("LMC_EXP_NOEIGEN")) c->expFlags |= atoi(e) ? 32 : 0;   // H2MC: skip the eigen-solve (isotropic Gaussian)
+    if (const char *e = getenv("LMC_EXP_NOHESSLAUNCH")) c->expFlags |= atoi(e) ? 64 : 0;  // H2MC: the stages are built but the Hessian launch is skipped (stale h2Out: timing only)
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -777,7 +784,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     ChainArrays &A = c->A;
     A.N = (int)N;
     A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.pathBuf1 = c->pathBuf1.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
-    A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.gaussian1 = c->gaussian1.p, A.h2Gauss = nullptr, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
+    A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.gaussian1 = c->gaussian1.p, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
     A.chV1 = c->chV1.p, A.chV2 = c->chV2.p, A.chCurrNewV2 = c->chCurrNewV2.p, A.chPropNewV1 = c->chPropNewV1.p, A.chPropNewV2 = c->chPropNewV2.p,
     A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
     A.chPath = sampleCache ? c->chPath.p : nullptr, A.chContrib = sampleCache ? c->chContrib.p : nullptr;
@@ -842,8 +849,19 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->anyDeepCache = false;
     if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
         c->allCachesReady = true;
-        c->h2Gauss.Alloc(2 * N * (size_t)(16 + 2 * 256 + 1), false);  // current + proposal buffer (F_GSEL)
-        c->A.h2Gauss = c->h2Gauss.p;
+        c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)H2_OUT_WORDS), c->h2Gauss.Alloc(2 * N * (size_t)H2_GAUSS_AOS, false);
+        c->h2Offset.Alloc(N * (size_t)MAXPSS), c->h2Py.Alloc(N), c->h2Px.Alloc(N), c->h2PropContrib.Alloc(N * (size_t)CONTRIB_WORDS), c->h2Step.Alloc(N), c->h2Kind.Alloc(N);
+        c->h2Items.Alloc(2 * (size_t)H2_NTECH * N, false), c->h2Counts.Alloc(2 * 64);
+        H2Arrays &H = c->H2;
+        H.rec = c->h2Rec.p, H.hout = c->h2Out.p, H.gauss = c->h2Gauss.p, H.offset = c->h2Offset.p, H.py = c->h2Py.p, H.px = c->h2Px.p, H.propContrib = c->h2PropContrib.p;
+        H.step = c->h2Step.p, H.kind = c->h2Kind.p;
+        for (int st = 0; st < 2; st++) H.bins[st] = H2Bins{c->h2Items.p + (size_t)st * H2_NTECH * N, c->h2Counts.p + 64 * st};
+        // the Hessian launch is persistent: one wave per SIMD (its waves take the whole register file), grid-stride over the tasks
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
+        c->h2HessGrid = prop.multiProcessorCount * 4;
+        if (const char *e = getenv("LMC_H2_HESS_GRID")) c->h2HessGrid = std::max(1, atoi(e));
+        c->h2GaussGrid = prop.multiProcessorCount * 16;
     }
     for (int b = 0; b < 2; b++) {
         for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
@@ -1133,9 +1151,23 @@ void LaunchLarge(lmc_ctx *c, const Film &film, const StepParams &P, int cur, con
     (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
 }
 void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sG) {
-    if (c->needGeneric && c->S.opt.h2mc)
-        LaunchStepSmallH2MC(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->stepGrid, sG);
-    else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
+    if (c->needGeneric && c->S.opt.h2mc) {  // the H2MC small step: lane-per-chain phases around the wave-cooperative Hessian / eigen-solve launches (device/dh2coop.h)
+        const int *list = c->lists[cur][1].p, *n = cnt + 1;
+        const int N = (int)c->N, laneGrid = c->stepGrid * 4;
+        const H2Arrays &H = c->H2;
+        const lmcd::H2MCParam param = lmcd::MakeH2MCParam(c->S.opt.perturbStdDev);
+        HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * 64 * sizeof(int), sG));
+        LaunchH2Begin(c->S, c->A, P, H, list, n, laneGrid, sG);
+        for (int stage = 0; stage < 2; stage++) {
+            if (!(P.expFlags & 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sG);
+            LaunchH2Gauss(H.bins[stage], N, H.hout, param, P.expFlags, c->A.flags, stage, H.gauss, H.offset, H.px, c->h2GaussGrid, sG);
+            if (stage == 0) {
+                LaunchH2Sample(list, n, N, c->A.flags, H.kind, c->A.curContrib, H.gauss, param.sigma, H.offset, H.py, laneGrid, sG);
+                LaunchH2Perturb(c->S, c->A, P, H, list, n, c->bvhDepth, laneGrid, sG);
+            }
+        }
+        LaunchH2Finish(c->S, c->cacheDev.p, c->A, film, P, H, list, n, laneGrid, sG);
+    } else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
         LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->genericTokenOnly ? 64 : c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
         LaunchStepSmallGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, sG);
