@@ -14,23 +14,30 @@ using namespace lmcd;
 
 namespace {
 
-typedef DualS<2, Dual<2>> T2;
+// A lane owns the 2 x 2 block (rows i0, i0 + 1; columns c0, c0 + 1) of one state's Hessian triangle and evaluates it in
+// (2 / LMC_H2HESS_R) x (2 / LMC_H2HESS_W) passes of the program in DualS<R, Dual<W>>: (1 + R)(1 + W) floats per value.
+#ifndef LMC_H2HESS_R
+#define LMC_H2HESS_R 1
+#endif
+#ifndef LMC_H2HESS_W
+#define LMC_H2HESS_W 2
+#endif
+constexpr int HR = LMC_H2HESS_R, HW = LMC_H2HESS_W;
+typedef DualS<HR, Dual<HW>> T2;
 
 struct LdsIn {  // the state's vertParams in LDS
     const float *p;
     __device__ __forceinline__ float operator[](int k) const { return p[k]; }
 };
-// a lane's seeding of the float primary samples: rows [i0, i0 + 2) on the outer level, columns [c0, c0 + 2) on the inner one
+// a lane's seeding of the float primary samples: rows [i0, i0 + HR) on the outer level, columns [c0, c0 + HW) on the inner one
 struct SeedPrim {
     const float *p;
     int i0, c0;
     __device__ __forceinline__ T2 operator()(int k) const {
         T2 r = Lift<T2>::Of(p[k]);
         const int v = k - 1;  // primary[0] is the (inactive) time
-        r.v.d[0] = v == c0 ? 1.0f : 0.0f;
-        r.v.d[1] = v == c0 + 1 ? 1.0f : 0.0f;
-        r.d[0].v = v == i0 ? 1.0f : 0.0f;
-        r.d[1].v = v == i0 + 1 ? 1.0f : 0.0f;
+        for (int q = 0; q < HW; q++) r.v.d[q] = v == c0 + q ? 1.0f : 0.0f;
+        for (int q = 0; q < HR; q++) r.d[q].v = v == i0 + q ? 1.0f : 0.0f;
         return r;
     }
 };
@@ -91,16 +98,32 @@ __global__ void __launch_bounds__(64, LMC_H2HESS_WAVES) k_h2_hess(const float *_
             int b = lane - slot * tNb, r = 0;
             const int m = dim / 2;
             while (b >= m - r) b -= m - r, r++;
-            const int i0 = 2 * r, c0 = 2 * (r + b);
+            const int bi0 = 2 * r, bc0 = 2 * (r + b);
             const float *base = lds + slot * tRecW;
-            const SeedPrim prim{base, i0, c0};
             const LdsIn vp{base + H2_REC_VP};
-            const T2 res = PathProgramP<T2, LdsIn, SeedPrim>(c, l, prim, scene, vp);
             float *o = hout + (size_t)items[slot] * H2_OUT_WORDS;
-            if (i0 == 0 && c0 == 0) o[H2_OUT_LOGLUM] = res.v.v;
-            for (int q = 0; q < 2; q++) {
-                if (c0 == i0) o[i0 + q] = res.d[q].v;  // the forward directional derivative: exact (the reference's `g`)
-                for (int k = 0; k < 2; k++) o[H2_OUT_HESS + (i0 + q) * dim + c0 + k] = res.d[q].d[k];
+#pragma unroll 1
+            for (int sub = 0; sub < (2 / HR) * (2 / HW); sub++) {
+                const int i0 = bi0 + (sub / (2 / HW)) * HR, c0 = bc0 + (sub % (2 / HW)) * HW;
+                if (i0 > c0 + HW - 1) continue;  // a pass of a diagonal block that lies entirely below the diagonal: nobody reads it
+                const SeedPrim prim{base, i0, c0};
+                // three copies of the program by what the technique keeps alive: only the camera state (l <= 1), only the light state (c == 1),
+                // both (the light state parked across the camera loop): the register allocation of the first two does not pay for the third
+                T2 res;
+#ifdef LMC_H2HESS_ONECLASS
+                res = PathProgramP<T2, LdsIn, SeedPrim, -1>(c, l, prim, scene, vp);
+#else
+                if (l <= 1) res = PathProgramP<T2, LdsIn, SeedPrim, 0>(c, l, prim, scene, vp);
+                else if (c == 1)
+                    res = PathProgramP<T2, LdsIn, SeedPrim, 1>(c, l, prim, scene, vp);
+                else
+                    res = PathProgramP<T2, LdsIn, SeedPrim, 2>(c, l, prim, scene, vp);
+#endif
+                if (i0 == 0 && c0 == 0) o[H2_OUT_LOGLUM] = res.v.v;
+                for (int q = 0; q < HR; q++) {
+                    if (bc0 == bi0) o[i0 + q] = res.d[q].v;  // the forward directional derivative: exact (the reference's `g`)
+                    for (int k = 0; k < HW; k++) o[H2_OUT_HESS + (i0 + q) * dim + c0 + k] = res.d[q].d[k];
+                }
             }
         }
         __syncthreads();

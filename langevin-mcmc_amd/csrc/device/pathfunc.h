@@ -829,7 +829,10 @@ LMC_PF void EmitT(const In &b, int off, const SceneBlk &sc, const T &p0, const T
 // `primary` is read through an accessor (primary(k) = the k-th primary sample as a T, [0] = time, inactive): an array of lifted values
 // for the per-lane forms below, a lane's own seeding of the float samples for the wave-cooperative Hessian (h2hess.hip), which
 // thereby never holds 17 second-order values in indexable (= private) memory.
-template <class T, class In, class Prim>
+// LCLASS: what the caller knows about the technique at compile time: -1 nothing; 0 no light sub-path (l <= 1: the light half and
+// ConnectVertex are compiled out, and with them the light state that would stay live across the camera loop); 1 no camera sub-path
+// (c == 1, light tracing: the camera half is compiled out); 2 both (c >= 2 and l >= 2)
+template <class T, class In, class Prim, int LCLASS = -1>
 LMC_HD T PathProgramP(int maxCamDepth, int maxLightDepth, const Prim &primary, const float *scene, const In &vp) {
     const SceneBlk sc = ReadScene(scene);
     int buf = 3;  // lensVertexPos
@@ -837,7 +840,7 @@ LMC_HD T PathProgramP(int maxCamDepth, int maxLightDepth, const Prim &primary, c
     int lgtBSDFOff = -1;
     PState<T> lps, cps;
     V3T<T> contrib = C3<T>(0, 0, 0);
-    if (maxLightDepth > 1) {
+    if (LCLASS != 0 && maxLightDepth > 1) {
         const float lightPickProb = vp[buf++];
         const int lightOff = buf;
         const float lightType = vp[lightOff];
@@ -910,7 +913,7 @@ LMC_HD T PathProgramP(int maxCamDepth, int maxLightDepth, const Prim &primary, c
             org = lps.position;
         }
     }
-    if (maxCamDepth > 1) {
+    if (LCLASS != 1 && maxCamDepth > 1) {
         T sx = primary(pi++), sy = primary(pi++);
         V3T<T> org, dir;
         {  // EmitFromCamera, path.cpp:3138-3170
@@ -979,7 +982,7 @@ LMC_HD T PathProgramP(int maxCamDepth, int maxLightDepth, const Prim &primary, c
                     T wCamera = MISq(emissionPdf * cosToLight / (directPdf * cosAtLight)) * (cps.accMISWPrev + cps.accMISWThis * MISq(bsdfRevPdf));
                     T misWeight = 1.0f / (wLight + 1.0f + wCamera);
                     cps.throughput = cps.throughput * misWeight;
-                } else {  // ConnectVertex, path.cpp:3292-3379
+                } else if (LCLASS != 0) {  // ConnectVertex, path.cpp:3292-3379
                     V3T<T> dirToLight = lps.position - cps.position;
                     T distSq = LenSqT(dirToLight);
                     T dist = Sqrt(distSq);

@@ -395,7 +395,12 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char *e = getenv("LMC_STREAM_PRIO");
         const int mode = e ? atoi(e) : 1;  // 1: side launches first (highest priority), 0: equal, -1: side launches last
-        for (auto &st : c->sideStream) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
+        const char *eL = getenv("LMC_STREAM_PRIO_LARGE");  // the large-step stream on its own (H2MC A/B: the small-step pipeline ahead of the large steps)
+        const int modeL = eL ? atoi(eL) : mode;
+        for (int k = 0; k < 2; k++) {
+            const int m = k == 0 ? modeL : mode;
+            HIP_CHECK(hipStreamCreateWithPriority(&c->sideStream[k], hipStreamNonBlocking, m > 0 ? hi : m < 0 ? lo : 0));
+        }
     }
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1199,14 +1204,21 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         HIP_CHECK(hipStreamWaitEvent(sL, c->forkEvent, 0));
         if (c->needGeneric) HIP_CHECK(hipStreamWaitEvent(sG, c->forkEvent, 0));
     }
-    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
-    LaunchLarge(c, film, P, cur, cnt, next, sL);
-    if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
+    // H2MC: the pipeline of the small steps goes first -- its first launch (k_h2_begin) is short and everything behind it waits for
+    // it; launched behind the large steps it sat in the queue for the whole large-step launch (r04_c kernel trace)
+    const bool genericFirst = c->S.opt.h2mc != 0;
+    auto large = [&] {
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
+        LaunchLarge(c, film, P, cur, cnt, next, sL);
+        if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
+    };
+    if (!genericFirst) large();
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
     // cache tree is too deep for the lean kernel; its list is empty once every cache is ready and shallow
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[6], sG));
     LaunchGeneric(c, film, P, cur, cnt, next, sG);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
+    if (genericFirst) large();
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
     LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));

@@ -28,22 +28,30 @@ for task in "$@"; do
     bench) timeout 900 python bench.py ${arg} 2> "$OUT/bench_$n.err" | tail -1 | tee -a "$OUT/bench.jsonl";;
     ab) mapfile -t V < "$arg"; scripts/ab_bench.sh "$OUT/ab.jsonl" -- "${V[@]}" 2> "$OUT/ab_$n.err";;
     h2mc) timeout 900 python scripts/h2mc_rates.py ${arg} 2> "$OUT/h2mc_$n.err" | tee -a "$OUT/h2mc.jsonl";;
-    h2mc_pmc)
+    h2mc_pmc)   # H2PMC=short: the two SQ groups only; LMC_LIB=<variant> is honoured
       mkdir -p "$OUT/h2mc_pmc"
+      GROUPS_=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+               "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM")
+      [ "${H2PMC:-full}" = full ] && GROUPS_+=("FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+               "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_BRANCH SQ_IFETCH SQC_ICACHE_MISSES")
       ( cd /tmp && export TMPDIR=/tmp
         i=0
-        for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-                   "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
-                   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM" \
-                   "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM SQ_INSTS_FLAT SQ_INSTS_BRANCH SQ_IFETCH SQC_ICACHE_MISSES"; do
+        for grp in "${GROUPS_[@]}"; do
           i=$((i+1))
           timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/h2mc_pmc/pass$i" -- python "$REPO/scripts/h2mc_rates.py" ${arg:-door 18} 3 3 > "$OUT/h2mc_pmc/pass$i.log" 2>&1
         done
         timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/h2mc_pmc/stats" -- python "$REPO/scripts/h2mc_rates.py" ${arg:-door 18} 3 3 > "$OUT/h2mc_pmc/stats.log" 2>&1 )
-      python scripts/pmc_summary.py "$OUT/h2mc_pmc" > "$OUT/h2mc_pmc.json"
-      find "$OUT/h2mc_pmc/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/h2mc_kernel_stats.csv" \;
-      find "$OUT/h2mc_pmc" -name "*.csv" -size +2M -delete; find "$OUT/h2mc_pmc" -name "*.db" -delete
-      head -c 3000 "$OUT/h2mc_pmc.json";;
+      python scripts/pmc_summary.py "$OUT/h2mc_pmc" > "$OUT/h2mc_pmc_$n.json"
+      find "$OUT/h2mc_pmc/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/h2mc_kernel_stats_$n.csv" \;
+      rm -rf "$OUT/h2mc_pmc"
+      python - "$OUT/h2mc_pmc_$n.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, v in d.items():
+    if "h2_" in k or "k_step" in k:
+        print(k, {a: (round(b / 1e6, 2) if b > 1e4 else round(b, 2)) for a, b in sorted(v.items())})
+PY
+      ;;
     stats)
       ( cd /tmp && export TMPDIR=/tmp
         cd "$REPO" && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$n" -- ${arg} > "$OUT/stats_$n.log" 2>&1 )
