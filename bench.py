@@ -143,7 +143,7 @@ def other_configs(args, p, gc):
         dict(name="veach-door, shipped lmc.xml (area light, textures, max path length 8), LMC (BASELINE.json configs[3], one GPU's shard)",
              xml=os.path.join(door, "lmc.xml"), kw={}, chains=args.chains, L=8, h2mc=False, warm=40, steps=40),
         dict(name="veach-door, shipped h2mc.xml, H2MC (BASELINE.json configs[4], one GPU's shard)",
-             xml=os.path.join(door, "h2mc.xml"), kw={}, chains=min(args.chains, 1 << 18), L=8, h2mc=True, warm=6, steps=12),
+             xml=os.path.join(door, "h2mc.xml"), kw={}, chains=args.chains, L=8, h2mc=True, warm=40, steps=40),
     ]
     out = []
     for c in cfgs:
@@ -170,7 +170,7 @@ def other_configs(args, p, gc):
             large_steps = s1["largeSteps"] - s0["largeSteps"]
             lean_steps = k1["lean_steps"] - k0["lean_steps"]
             ker = {"k_step_small (plain small steps)": (k1["lean_ms"], lean_steps), "k_step<large>": (k1["large_ms"], large_steps),
-                   ("k_step_h2mc (all small steps)" if c["h2mc"] else "k_step_small_grad (cache-filling small steps)"): (k1["generic_ms"], steps_total - large_steps - lean_steps)}
+                   ("H2MC small-step pipeline (k_h2_begin .. k_h2_finish: all small steps)" if c["h2mc"] else "k_step_small_grad (cache-filling small steps)"): (k1["generic_ms"], steps_total - large_steps - lean_steps)}
             dom = max(ker, key=lambda k: ker[k][0])
             ab = algorithmic_bytes(c["L"], c["h2mc"])
             dom_ms, dom_steps = ker[dom][0] / max(launches, 1), ker[dom][1] / max(launches, 1)

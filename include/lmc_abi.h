@@ -182,6 +182,15 @@ int lmc_cache_grid_check(lmc_ctx *ctx, int dim);
 int lmc_cache_filter_probe(int dim, int npts, const float *pts, int nq, const float *q, int *out);
 /* ComputeGaussian (mala.cpp:7-52) + GaussianLogPdf (gaussian.cpp:24-36): out n x (3*dim+2) */
 int lmc_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, float shk, const float *sc, const float *offset, float *out);
+/* Parity probes of the H2MC step's own launches (device/h2hess.hip, h2gauss.hip; reference: the evaluate_path_bidir_<c>_<l>_static_derv
+ * programs with `hess`, h2mc.cpp:3-142, gaussian.cpp:24-36), item-major arrays:
+ *   lmc_h2_hess_probe   n states of technique (c,l): primary n x (2L+1), vert n x V -> grad n x 16, hess n x 256 (row i at [i * dim], only
+ *                       the triangle Eigen reads -- the UPPER triangle of the rows as delivered -- is written, the rest is 0), loglum n
+ *   lmc_h2_gauss_probe  n gradients (n x 16) + Hessians (n x dim x dim, upper triangle read) -> the proposal Gaussian of each:
+ *                       gauss n x 544 = [mean 16 | logDet | kind (0 dense, 1 isotropic early-out) | .. | covL at 32 (dim x dim) | invCov at 288],
+ *                       and, with offset (n x dim) != NULL, px[n] = log N(-offset; mean, invCov^-1) */
+int lmc_h2_hess_probe(int c, int l, int n, const float *primary, const float *scene38, const float *vert, float *loglum, float *grad, float *hess);
+int lmc_h2_gauss_probe(int n, int dim, const float *grad, const float *hess, float sigma, const float *offset, float *gauss, float *px);
 /* HBM counter calibration: `reps` launches of a kernel that reads n_words floats and writes n_words floats with the
  * chain state's access pattern (4 B per lane, SoA, unit stride).  Run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
  * to obtain the bytes-per-count factors profiles/pmc_step_kernel.json applies.  Returns 0 on success. */

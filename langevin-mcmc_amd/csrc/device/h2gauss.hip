@@ -29,7 +29,7 @@ __device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
 // returns px = GaussianLogPdf(-offset, proposalGaussian) (mutation_h2mc.h:104, gaussian.cpp:24-36).
 namespace {
 constexpr int GS = 17, GW = 16 * GS;
-constexpr int G_LDS = 2 * GW + 6 * 16;  // A | V | w | eb | ob | post | grad | tmp
+constexpr int G_LDS = 2 * GW + 6 * 16 + 16;  // A | V | w | eb | ob | post | grad | tmp | pad: 656 = 16 (mod 32), so the four groups of a wave sit on disjoint LDS banks (640 put all four on the same 16: profiles/r04_f: 250 M conflict cycles per launch)
 __device__ __forceinline__ float GroupSum(float v) {
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);

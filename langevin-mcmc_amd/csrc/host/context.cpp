@@ -1818,6 +1818,70 @@ int lmc_gauss_probe(int n, int dim, const float *v1, const float *M, float ss, f
     LMC_CATCH(-1)
 }
 
+// the H2MC step's cooperative launches on caller-supplied states (tests/test_gpu_h2mc.py)
+int lmc_h2_hess_probe(int c, int l, int n, const float *primary, const float *scene38, const float *vert, float *loglum, float *grad, float *hess) {
+    LMC_TRY
+    const int t = H2TechIndex(c, l);
+    if (t < 0) throw std::runtime_error("lmc_h2_hess_probe: technique (c,l) out of range");
+    EnsureDevice(0);
+    const int L = std::max(c + l - 1, 2), V = 238 + 59 * (c + l - 3), dim = 2 * L;
+    std::vector<float> rec((size_t)n * H2_REC_WORDS, 0.f);
+    for (int i = 0; i < n; i++) {
+        float *r = rec.data() + (size_t)i * H2_REC_WORDS;
+        memcpy(r, primary + (size_t)i * (2 * L + 1), (2 * L + 1) * sizeof(float));
+        memcpy(r + H2_REC_C, &c, 4), memcpy(r + H2_REC_L, &l, 4);
+        memcpy(r + H2_REC_VP, vert + (size_t)i * V, V * sizeof(float));
+    }
+    std::vector<int> items((size_t)H2_NTECH * n, 0), counts(64, 0);
+    for (int i = 0; i < n; i++) items[(size_t)t * n + i] = i;
+    counts[t] = n;
+    DevBuf<float> dRec, dOut;
+    DevBuf<int> dItems, dCounts;
+    dRec.Upload(rec.data(), rec.size()), dItems.Upload(items.data(), items.size()), dCounts.Upload(counts.data(), counts.size()), dOut.Alloc((size_t)n * H2_OUT_WORDS);
+    LaunchH2Hess(dRec.p, H2Bins{dItems.p, dCounts.p}, n, scene38, dOut.p, 1024, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    const std::vector<float> o = dOut.Download();
+    for (int i = 0; i < n; i++) {
+        const float *r = o.data() + (size_t)i * H2_OUT_WORDS;
+        if (loglum) loglum[i] = r[H2_OUT_LOGLUM];
+        if (grad) memcpy(grad + (size_t)i * 16, r, 16 * sizeof(float));
+        if (hess) {
+            float *h = hess + (size_t)i * 256;
+            memset(h, 0, 256 * sizeof(float));
+            for (int a = 0; a < dim; a++)
+                for (int b = a; b < dim; b++) h[a * dim + b] = r[H2_OUT_HESS + a * dim + b];
+        }
+    }
+    return 0;
+    LMC_CATCH(-1)
+}
+int lmc_h2_gauss_probe(int n, int dim, const float *grad, const float *hess, float sigma, const float *offset, float *gauss, float *px) {
+    LMC_TRY
+    if (dim < 4 || dim > 16 || (dim & 1)) throw std::runtime_error("lmc_h2_gauss_probe: dim must be even, 4..16");
+    const int t = H2TechIndex(dim / 2 + 1, 0);
+    EnsureDevice(0);
+    std::vector<float> out((size_t)n * H2_OUT_WORDS, 0.f), off((size_t)MAXPSS * n, 0.f);
+    for (int i = 0; i < n; i++) {
+        memcpy(out.data() + (size_t)i * H2_OUT_WORDS, grad + (size_t)i * 16, 16 * sizeof(float));
+        memcpy(out.data() + (size_t)i * H2_OUT_WORDS + H2_OUT_HESS, hess + (size_t)i * dim * dim, (size_t)dim * dim * sizeof(float));
+        if (offset)
+            for (int k = 0; k < dim; k++) off[(size_t)k * n + i] = offset[(size_t)i * dim + k];
+    }
+    std::vector<int> items((size_t)H2_NTECH * n, 0), counts(64, 0);
+    for (int i = 0; i < n; i++) items[(size_t)t * n + i] = i;
+    counts[t] = n;
+    DevBuf<float> dOut, dOff, dGauss, dPx;
+    DevBuf<int> dItems, dCounts, dFlags;
+    dOut.Upload(out.data(), out.size()), dOff.Upload(off.data(), off.size()), dItems.Upload(items.data(), items.size()), dCounts.Upload(counts.data(), counts.size());
+    dGauss.Alloc(2 * (size_t)n * H2_GAUSS_AOS), dPx.Alloc(n), dFlags.Alloc(n);
+    LaunchH2Gauss(H2Bins{dItems.p, dCounts.p}, n, dOut.p, lmcd::MakeH2MCParam(sigma), 0, dFlags.p, 1, dGauss.p, dOff.p, dPx.p, 256, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (gauss) HIP_CHECK(hipMemcpy(gauss, dGauss.p + (size_t)n * H2_GAUSS_AOS, (size_t)n * H2_GAUSS_AOS * sizeof(float), hipMemcpyDeviceToHost));  // stage 1 with F_GSEL clear: the second buffer
+    if (px) HIP_CHECK(hipMemcpy(px, dPx.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    LMC_CATCH(-1)
+}
+
 // ---- the reference's plugin symbols (pathlibbidir_mala.so): 42 forward + 42 derivative programs.
 // A single evaluation is one (tiny) kernel launch; throughput users call lmc_grad_batch.
 // Per calling thread: a stream and two host-mapped pinned buffers, created on the first call and kept.  A call copies the caller's

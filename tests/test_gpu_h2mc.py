@@ -113,6 +113,144 @@ def test_hessian_kernel_full_materials_torus_and_door(L):
         assert max(dims) >= 14
 
 
+def _h2_hess_probe(c, l, prim, sp, vert):
+    """The H2MC STEP's Hessian launch (wave-cooperative k_h2_hess: lanes = 2 x 2 blocks of one state) on caller-supplied states."""
+    lib = gc.pkg().lib()
+    lib.lmc_h2_hess_probe.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+    n, dim = len(prim), 2 * max(c + l - 1, 2)
+    V = 238 + 59 * (c + l - 3)
+    pr, ve = np.ascontiguousarray(prim[:, : dim + 1], np.float32), np.ascontiguousarray(vert[:, :V], np.float32)
+    ll, g, h = np.zeros(n, np.float32), np.zeros((n, 16), np.float32), np.zeros((n, 256), np.float32)
+    assert lib.lmc_h2_hess_probe(c, l, n, P(pr), P(sp), P(ve), P(ll), P(g), P(h)) == 0, lib.lmc_last_error()
+    return ll, g[:, :dim].copy(), h[:, : dim * dim].reshape(n, dim, dim).copy()
+
+
+def test_step_hessian_launch_matches_reference_programs_on_golden_vectors():
+    """k_h2_hess -- the launch the H2MC step itself runs since round 4 -- against the reference's H2MC programs on the committed
+    golden vectors (full-material states of both scenes, all dims up to 16): the gradient and the triangle of the Hessian that
+    Eigen reads (h2mc.cpp:78: the UPPER triangle of the rows as delivered) within 1e-2 relative for >= 99 % of the vectors, and
+    against the per-lane batch kernel (lmc_hess_batch: the same program with unfused, correctly rounded arithmetic): >= 97 % of
+    the states within 1e-3, none beyond 5e-2 (ill-conditioned states amplify the rounding of fused multiply-adds and of the
+    approximate reciprocal the step's launch is compiled with)."""
+    z = np.load(os.path.join(gc.ROOT, "tests", "golden", "derv_vectors_full.npz"))
+    n = len(z["c"])
+    bad, vs_batch, checked, dims = [], [], 0, set()
+    for sid in (0, 1):
+        sp = z["scenes"][sid].copy()
+        for c, l in sorted({(int(a), int(b)) for a, b, s in zip(z["c"], z["l"], z["scene_id"]) if s == sid}):
+            idx = [i for i in range(n) if z["scene_id"][i] == sid and z["c"][i] == c and z["l"][i] == l]
+            dim = 2 * (c + l - 1)
+            V = 238 + 59 * (c + l - 3)
+            prim, vert = z["primary"][idx][:, : dim + 1].copy(), z["vert"][idx][:, :V].copy()
+            ll, g, h = _h2_hess_probe(c, l, prim, sp, vert)
+            ll2, g2, h2 = _hess_batch(c, l, prim, sp, vert)
+            iu = np.triu_indices(dim)
+            dims.add(dim)
+            for k, i in enumerate(idx):
+                H1 = z["h2_hess"][i][: dim * dim].reshape(dim, dim)
+                G1 = z["h2_grad"][i][:dim]
+                if not (np.isfinite(H1).all() and np.isfinite(G1).all()):
+                    continue
+                checked += 1
+                assert abs(ll[k] - z["loglum"][i]) < 5e-3
+                eg = np.linalg.norm(G1 - g[k]) / max(np.linalg.norm(G1), 1e-2)
+                eh = np.linalg.norm(H1[iu] - h[k][iu]) / max(np.linalg.norm(H1[iu]), 1e-1)
+                if max(eg, eh) > 1e-2:
+                    bad.append((sid, c, l, i, float(eg), float(eh)))
+                if np.isfinite(h2[k]).all():
+                    vs_batch.append(max(float(np.linalg.norm(h2[k][iu] - h[k][iu]) / max(np.linalg.norm(h2[k][iu]), 1e-1)),
+                                        float(np.linalg.norm(g2[k] - g[k]) / max(np.linalg.norm(g2[k]), 1e-2))))
+                assert (np.tril(h[k], -1) == 0).all()  # only the triangle Eigen reads is delivered
+    assert checked >= 250 and len(bad) <= checked // 100, bad
+    vs_batch = np.sort(np.array(vs_batch))
+    assert len(vs_batch) >= 250 and vs_batch[int(0.97 * len(vs_batch))] < 1e-3 and vs_batch[-1] < 5e-2, (vs_batch[-8:], vs_batch[int(0.97 * len(vs_batch))])
+    assert max(dims) >= 14
+
+
+def _h2_gauss_probe(grad, hess, sigma, offset):
+    lib = gc.pkg().lib()
+    lib.lmc_h2_gauss_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    n, dim = hess.shape[0], hess.shape[1]
+    g16 = np.zeros((n, 16), np.float32)
+    g16[:, :dim] = grad
+    out, px = np.zeros((n, 544), np.float32), np.zeros(n, np.float32)
+    assert lib.lmc_h2_gauss_probe(n, dim, P(g16), P(np.ascontiguousarray(hess, np.float32)), sigma, P(np.ascontiguousarray(offset, np.float32)), P(out), P(px)) == 0, lib.lmc_last_error()
+    return out, px
+
+
+@pytest.mark.parametrize("dim", [4, 6, 8, 10, 12, 14, 16])
+def test_device_h2mc_gaussian_against_numpy_eigh(dim):
+    """The DEVICE proposal Gaussian (k_h2_gauss: 16-lane Jacobi + the eigenvalue remap of h2mc.cpp:3-142) against an independent float64
+    recomputation with numpy.linalg.eigh, on 512 Hessians per dimension incl. ill-conditioned ones (condition numbers up to 1e5: beyond
+    ~1e6 single precision no longer separates the small eigenvalues' vectors, whatever the solver), rank deficient ones, negative and
+    mixed curvature, and matrices below the early-out norm: mean, invCov, covL covL^T, logDet -- the quantities that do not depend on
+    the eigenvector convention -- and px = log N(-offset; mean, invCov^-1)."""
+    rng = np.random.default_rng(100 + dim)
+    n, sigma = 512, 0.01
+    inv_s2 = 1.0 / (sigma * sigma)
+    H = np.zeros((n, dim, dim))
+    for i in range(n):
+        Q, _ = np.linalg.qr(rng.standard_normal((dim, dim)))
+        kind = i % 4
+        if kind == 0:
+            ev = rng.standard_normal(dim) * 10.0 ** rng.uniform(3, 6)
+        elif kind == 1:  # ill-conditioned: eigenvalues spread over five decades, mixed signs
+            ev = np.sign(rng.standard_normal(dim)) * 10.0 ** rng.uniform(1, 6, dim)
+        elif kind == 2:  # rank deficient with EXACT zeros (a block of zero rows / columns: the |w| <= 1e-10 branch of h2mc.cpp:100-118; zeros that
+            # only exist up to rounding would make the sign of those eigenvalues -- and with it the cosh / cos remap -- a coin toss on both sides)
+            m = max(2, dim // 2)
+            Qm, _ = np.linalg.qr(rng.standard_normal((m, m)))
+            H[i, :m, :m] = (Qm * (rng.standard_normal(m) * 1e5)) @ Qm.T
+            continue
+        else:  # below the early-out norm (hnorm < 0.5 / sigma^2 = 5000)
+            ev = rng.standard_normal(dim) * 100.0
+        H[i] = (Q * ev) @ Q.T
+    H = (H + H.transpose(0, 2, 1)) / 2
+    grad = rng.standard_normal((n, dim)) * 10.0 ** rng.uniform(0, 3, (n, 1))
+    offset = rng.standard_normal((n, dim)) * sigma
+    out, px = _h2_gauss_probe(grad.astype(np.float32), H.astype(np.float32), sigma, offset.astype(np.float32))
+    H32, g32, o32 = H.astype(np.float32).astype(np.float64), grad.astype(np.float32).astype(np.float64), offset.astype(np.float32).astype(np.float64)
+    L = np.pi / 2
+    pos_s, pos_o = np.sinh(L) ** 2, 0.5 * (np.exp(L) + np.exp(-L) - 1.0)  # h2mc.h:10-16
+    neg_s, neg_o = np.sin(L) ** 2, -(np.cos(L) - 1.0)
+    n_dense = n_iso = 0
+    for i in range(n):
+        Hs = np.triu(H32[i]) + np.triu(H32[i], 1).T  # the triangle Eigen reads
+        hnorm = np.sqrt((Hs ** 2).sum())
+        kind = out[i, 17]
+        if hnorm < 0.5 * inv_s2 * (1 - 1e-5):
+            assert kind == 1.0, (i, hnorm)
+        if kind == 1.0:  # isotropic early-out, h2mc.cpp:84-92
+            n_iso += 1
+            assert hnorm < 0.5 * inv_s2 * (1 + 1e-5)
+            assert abs(out[i, 16] - dim * np.log(inv_s2)) < 1e-3 * dim
+            ref_px = dim * (-0.9189385332046727) + 0.5 * dim * np.log(inv_s2) - 0.5 * inv_s2 * (o32[i] ** 2).sum()
+            assert abs(px[i] - ref_px) < 1e-3 * max(1.0, abs(ref_px))
+            continue
+        n_dense += 1
+        w, V = np.linalg.eigh(Hs)
+        eb = np.where(np.abs(w) > 1e-10, 1.0 / np.maximum(np.abs(w), 1e-300), 0.0)
+        ob = eb * (V.T @ g32[i])
+        s2 = np.where(np.abs(w) > 1e-10, np.where(w > 0, pos_s, neg_s), L * L)
+        oo = np.where(np.abs(w) > 1e-10, ob * np.where(w > 0, pos_o, neg_o), 0.5 * ob * L * L)
+        e2 = eb * s2
+        e2 = np.where(e2 > 1e-10, 1.0 / np.maximum(e2, 1e-300), 0.0)
+        post = e2 + inv_s2
+        mean = V @ ((e2 / post) * oo)
+        inv_cov = (V * post) @ V.T
+        cov = (V / post) @ V.T
+        log_det = np.log(post).sum()
+        d_mean, d_cl, d_ic = out[i, :dim].astype(np.float64), out[i, 32:32 + dim * dim].reshape(dim, dim).astype(np.float64), out[i, 288:288 + dim * dim].reshape(dim, dim).astype(np.float64)
+        assert np.linalg.norm(d_ic - inv_cov) <= 2e-3 * np.linalg.norm(inv_cov), (i, kind)
+        assert np.linalg.norm(d_cl @ d_cl.T - cov) <= 2e-3 * np.linalg.norm(cov), i
+        assert np.linalg.norm(d_mean - mean) <= 5e-3 * max(np.linalg.norm(mean), sigma), (i, np.linalg.norm(d_mean - mean), np.linalg.norm(mean))
+        assert abs(out[i, 16] - log_det) <= 2e-3 * dim, i
+        dd = -o32[i] - mean
+        ref_px = dim * (-0.9189385332046727) + 0.5 * log_det - 0.5 * dd @ inv_cov @ dd
+        assert abs(px[i] - ref_px) <= 5e-3 * max(1.0, abs(ref_px)), (i, px[i], ref_px)
+    assert n_dense >= 300 and n_iso >= 100, (n_dense, n_iso)
+
+
 def test_golden_derivative_vectors_through_the_c_abi():
     """tests/golden/derv_vectors_full.npz (the reference's MALA-gradient and H2MC gradient + Hessian programs on full-material
     states of both scenes, c + l up to 9) through lmc_grad_batch / lmc_hess_batch: needs neither /root/reference nor oracle/_ref."""
@@ -152,20 +290,47 @@ def test_h2mc_chain_parity_diffuse():
     assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.005 * so["largeSteps"] + 2  # the oracle's Hessians now come from the reference's programs (1e-2 agreement, not bit equality)
     assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"] + 2
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * so["gradCalls"] + 2 and sg["gradCalls"] > 256 * 10
-    assert r["film_rel_l2"] < 0.3  # 0.16 measured: a handful of the 256 chains part ways within 30 steps (see the docstring)
-    assert r["final_state_match"] > 0.85
+    assert r["film_rel_l2"] < 0.5  # 0.28 measured (round 4, fused arithmetic in the device's Hessian program; 0.16 with the strict round-3 kernel): 16 of the 256 chains part ways within 30 steps
+    assert r["final_state_match"] > 0.875  # 0.9375 measured: twice the mismatch
     assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
 def test_h2mc_chain_parity_full_materials():
+    """30 lock-step H2MC mutations of 256 chains on the full-material torus.  The two sides cannot follow each other for long: the
+    oracle's Hessians come from the reference's own programs, the device's from its own (agreement 1e-2 .. 1e-4, fused arithmetic),
+    and every accept test whose probability moves across its uniform draw sends a chain onto another trajectory for good.  Measured
+    (scripts/debug/parity_bars.py, round 4): 0.5 .. 0.8 % of the chains part per step (test_h2mc_per_step_agreement asserts THAT),
+    which compounds to final_state_match 0.79 / film 0.37 here (0.83 / 0.27 with 2048 chains).  The bars sit at the measured figures
+    + a third (a tighter bar would only test the seed); the counters carry the statistical check."""
     r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 30, use_gradient=1, max_depth=8, force_diffuse=0,
                     opts={"h2mc": 1, "largestepprob": 0.2, "perturbstddev": 0.01}, oracle_grad="reference")
     so, sg = r["stats_oracle"], r["stats_gpu"]
     assert sg["steps"] == so["steps"] == 256 * 30
-    assert abs(sg["accepted"] - so["accepted"]) <= 0.03 * so["accepted"]
-    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.03 * so["gradCalls"]
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.02 * so["accepted"]  # measured 3048 vs 3017: 1.0 %
+    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.025 * so["gradCalls"]  # 3523 vs 3480: 1.2 %
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.016 * so["largeSteps"]  # 2212 vs 2195: 0.8 %
     assert r["film_rel_l2"] < 0.5
     assert r["final_state_match"] > 0.75
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+
+
+@pytest.mark.parametrize("diffuse", [1, 0])
+def test_h2mc_per_step_agreement(diffuse):
+    """What a single H2MC mutation agrees to, before the divergence of test_h2mc_chain_parity_* compounds: 2048 chains, 6 lock-step
+    mutations from identical init states (the first is the forced large step).  Measured: 99.4 % of the chains in the same final state
+    on the Lambertian torus, 97.1 % with the full material set (99.2 % after 3 mutations); bars at twice the measured mismatch."""
+    kw = dict(use_gradient=1, opts={"h2mc": 1, "largestepprob": 0.2, "perturbstddev": 0.01}, oracle_grad="reference")
+    if diffuse:
+        r = gc.run_pair(160, 120, 40000, 2048, 8, 400, 6, **kw)
+    else:
+        r = gc.run_pair(160, 120, 40000, 2048, 40000, 400, 6, max_depth=8, force_diffuse=0, **kw)
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    assert sg["steps"] == so["steps"] == 2048 * 6
+    assert r["final_state_match"] > (0.987 if diffuse else 0.94)
+    assert abs(sg["accepted"] - so["accepted"]) <= 0.004 * so["accepted"] + 2  # 4612 vs 4619, 4433 vs 4428
+    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.005 * so["gradCalls"] + 2  # 4457 vs 4468, 4375 vs 4375
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 4
+    assert r["film_rel_l2"] < (0.3 if diffuse else 0.25)  # 0.146 / 0.121
     assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
 
 

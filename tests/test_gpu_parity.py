@@ -192,8 +192,10 @@ def test_full_material_scene_chain_parity(use_gradient):
     assert abs(sg["largeSteps"] - so["largeSteps"]) <= 3
     assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * max(so["gradCalls"], 100)
-    assert r["film_rel_l2"] < 0.15  # 256 chains x 40 steps: one diverged chain moves a few percent of the film energy
-    assert r["final_state_match"] > 0.95
+    # measured (scripts/debug/parity_bars.py, round 4): film 0.048 / 0.103 (use_gradient 0 / 1), final_state_match 0.988 / 0.984; bars at twice
+    # the measured deviation (256 chains x 40 steps: one diverged chain moves a few percent of the film energy)
+    assert r["film_rel_l2"] < (0.2 if use_gradient else 0.1)
+    assert r["final_state_match"] > (0.968 if use_gradient else 0.976)
     assert r["nonfinite_gpu"] == 0
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
@@ -351,8 +353,8 @@ def test_maxdepth_12_chain_parity():
     assert sg["steps"] == so["steps"] == 256 * 40
     assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.01 * so["largeSteps"]  # 5 of 1280 measured: longer glossy paths, more flips
     assert abs(sg["accepted"] - so["accepted"]) <= 0.015 * so["accepted"]
-    assert r["film_rel_l2"] < 0.2
-    assert r["final_state_match"] > 0.93
+    assert r["film_rel_l2"] < 0.2  # 0.108 measured (round 4): twice that
+    assert r["final_state_match"] > 0.953  # 0.977 measured: twice the mismatch
     assert r["nonfinite_gpu"] == 0
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
