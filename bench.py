@@ -3,8 +3,13 @@
 torus geometry, every BSDF diffuse, maxdepth 6, 2^20 persistent chains per GPU, sunsky environment light).
 
 One "step" = one lock-step pass of the chain loop body (mlt.cpp:91-170) over every resident chain.
-Multi-GPU: one process per GPU (torch.distributed / RCCL), chains sharded by contiguous global chain-id range
-(weak scaling: 2^20 chains per GPU), one all-reduce of the film + the normalisation scalar at the end.
+Multi-GPU, chains sharded by contiguous global chain-id range (weak scaling: 2^20 chains per GPU), one sum of the per-GPU films at
+the end.  Two launch modes, same sharding, same trajectories:
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's): one process per GPU, the exchanges
+    are RCCL collectives inside the library (WORLD_SIZE must equal --gpus);
+  * plain `python bench.py --gpus N`: ONE process drives N contexts, one per device, as an in-process job (lmc_group_*; the
+    exchanges and the film merge are peer copies -- the reference merges its per-thread films in-process too, mlt.cpp:203-207).
+Either way fewer than N visible devices is an error (exit code 2), never a silently smaller job.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects."""
 import argparse
@@ -227,11 +232,99 @@ def pmc_traffic_meta():
         return None
 
 
+def die(msg):
+    sys.stderr.write("bench.py: " + msg + "\n")
+    sys.exit(2)
+
+
+def inprocess_job(args, p, gc, name, xml, kw, devices, warm, steps):
+    """One workload on len(devices) GPUs driven from THIS process: one context per device, joined into an in-process job (sharded MLTInit,
+    contiguous chain ranges, per-step exchange of the cache pushes while the gradient caches fill, one film merge at the end).
+    Timed like the single-GPU line: `warm` untimed steps, then `steps` steps + the film merge bracketed by syncs of every context."""
+    n = len(devices)
+    per_gpu, total = args.chains, args.chains * n
+    rens = [p.Renderer(xml, seed_offset=0, device=d, use_gradient=1, **kw) for d in devices]
+    grp = p.Group(rens)
+    t0 = time.time()
+    norm, ncontrib = grp.init_chains(8 * total, total, args.init_threads, args.samples_per_chain, 0)
+    t_init = time.time() - t0
+    for r in rens:
+        r.set_option("timing", 1)
+    grp.step(warm)
+    for r in rens:
+        r.step_timing()
+        r.sync()
+    s0 = [r.stats() for r in rens]
+    t0 = time.time()
+    grp.step(steps)
+    reduce_ms = grp.film_reduce()
+    for r in rens:
+        r.sync()
+    dt = time.time() - t0
+    per_rank = []
+    for r in rens:
+        ms, launches = r.step_timing()
+        per_rank.append(ms / max(launches, 1))
+    s1 = [r.stats() for r in rens]
+    steps_total = sum(b["steps"] - a["steps"] for a, b in zip(s0, s1))
+    film_sum = float(rens[0].film().sum())
+    for r in rens:
+        r.close()
+    return {
+        "workload": name, "n_gpus": n, "devices": list(devices), "chains_per_gpu": per_gpu, "value": steps_total / dt, "unit": "chain-steps/s",
+        "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warm, "init_seconds": t_init, "normalization": norm,
+        "per_rank_step_ms": per_rank, "per_rank_step_ms_spread": (max(per_rank) - min(per_rank)) if per_rank else 0.0,
+        "film_merge_ms": reduce_ms, "film_sum": film_sum,
+        "accept_rate": sum(b["accepted"] - a["accepted"] for a, b in zip(s0, s1)) / max(steps_total, 1),
+    }
+
+
+def main_inprocess(args):
+    """`python bench.py --gpus N` without a launcher: N contexts in this process (see the module docstring)."""
+    p = importlib.import_module("langevin-mcmc_amd")
+    from tests import gpu_checks as gc
+
+    have = p.device_count()
+    devices = list(range(args.gpus))
+    oversub = False
+    if have < args.gpus:
+        if have >= 1 and os.environ.get("LMC_BENCH_OVERSUBSCRIBE"):  # bring-up / test aid ONLY: the N ranks share the visible devices; reported as such
+            devices = [k % have for k in range(args.gpus)]
+            oversub = True
+        else:
+            die("--gpus %d but only %d HIP device(s) visible to this process: refusing to measure a smaller job under that name" % (args.gpus, have))
+    door = os.path.join(ROOT, "scenes", "veachdoor", "lmc.xml")
+    head = inprocess_job(args, p, gc, "torus scene, %d persistent chains per GPU, Lambertian-only BSDF, max path length 6 (BASELINE.json configs[1])" % args.chains,
+                         gc.TORUS, dict(force_diffuse=1, max_depth=6), devices, args.warmup, args.steps)
+    out = {
+        "metric": "MALA chain-steps/sec, torus scene", "value": head["value"], "unit": "chain-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic chains on the shipped torus geometry + sunsky env map (random-seeded PCG streams)",
+        "config": {"workload": head["workload"], "chains_per_gpu": args.chains, "init_samples": 8 * args.chains * args.gpus, "samples_per_chain": args.samples_per_chain,
+                   "parallelism": "chains sharded x%d, one process, one context per device" % args.gpus,
+                   "collective": "in-process job: device-to-device copies for the sharded MLTInit, the cache pushes and the film merge (lmc_group_*)",
+                   "devices": devices, "oversubscribed": oversub},
+        "multi_gpu": {k: head[k] for k in ("per_rank_step_ms", "per_rank_step_ms_spread", "film_merge_ms", "init_seconds", "accept_rate", "film_sum")},
+    }
+    if not args.no_configs:
+        try:  # north_star names both scenes: the veach-door LMC workload as a second multi-GPU line
+            out["configs"] = [inprocess_job(args, p, gc, "veach-door, shipped lmc.xml, LMC (BASELINE.json configs[3]), chains sharded over the GPUs", door, {}, devices, 40, 40)]
+        except Exception as e:  # noqa: BLE001 -- the headline line must still come out
+            out["configs"] = [{"workload": "veach-door lmc.xml", "failed": str(e)[:300]}]
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        die("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return main_inprocess(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("LMC_BENCH_FORCE_DIST"):
+        die("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE): launch with --nproc-per-node %d, or without a launcher for the in-process job" % (args.gpus, world, args.gpus))
     dist = None
     if world > 1 or os.environ.get("LMC_BENCH_FORCE_DIST"):  # the env switch runs the multi-rank code path with one rank (launch under torch.distributed.run)
         import torch
@@ -245,6 +338,8 @@ def main():
     p = importlib.import_module("langevin-mcmc_amd")
     from tests import gpu_checks as gc
 
+    if p.device_count() <= local:
+        die("rank %d: local device %d is not visible (%d HIP device(s))" % (rank, local, p.device_count()))
     per_gpu = args.chains
     total = per_gpu * world
     init_samples = args.init_samples or 8 * total

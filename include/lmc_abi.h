@@ -46,14 +46,17 @@ const char *lmc_last_error(void);
 
 lmc_ctx *lmc_create(const lmc_scene_desc *desc);
 void lmc_destroy(lmc_ctx *ctx);
+/* number of HIP devices visible to this process (0 without a GPU): `device` of lmc_scene_desc must be below it */
+int lmc_device_count(void);
 
 /* [width, height, numTriangles, maxDepth, numBvhNodes, bvhDepth, numLights, mala] */
 int lmc_info(lmc_ctx *ctx, int *out8);
 /* the 38-float scene block of the plugin ABI (scene.cpp:160-169) */
 int lmc_scene_params(lmc_ctx *ctx, float *out38);
 /* <dpt> float options by XML name: largestepprob, largestepscale, mala, uniformmixprob, mala-stepsize, mala-gn,
- * perturbstddev, mindepth, h2mc (parsescene.cpp:538-585).  mala / h2mc select the mutation the chain state is laid out for:
- * they can only change before lmc_chains_init (afterwards the call fails; re-initialise the chains) */
+ * perturbstddev, mindepth, h2mc, uselightcoordinatesampling, largestepmultiplexed, samplecache (parsescene.cpp:538-585).  mala / h2mc /
+ * samplecache / uselightcoordinatesampling select what the resident chain state and the launch plan are laid out for: the call itself succeeds
+ * at any time, but once one of them differs from its value at lmc_chains_init, lmc_chains_step returns -1 until the chains are initialised again */
 int lmc_set_option(lmc_ctx *ctx, const char *name, double value);
 /* <dpt> options as parsed: spp, numinitsamples, numchains, directspp, mindepth, maxdepth, largestepprob, largestepscale,
  * mala, h2mc, seedoffset (dptoptions.h:7-34) */
@@ -78,6 +81,10 @@ int lmc_chains_init(lmc_ctx *ctx, long long num_init_samples, int n_chains_total
 int lmc_group_chains_init(lmc_ctx **ctxs, int n, long long num_init_samples, int n_chains_total, int init_threads, long long samples_per_chain,
                           long long chains_need_extra);
 int lmc_group_chains_step(lmc_ctx **ctxs, int n, int n_steps);
+/* The film merge of such a group (the reference merges its per-thread films in-process, mlt.cpp:203-207): every member's device film (and
+ * splat-weight sum) becomes the sum over the members, through peer copies -- lmc_film_allreduce without a communicator.  Once per stepped
+ * film, like it.  *ms (may be NULL): wall time of the merge. */
+int lmc_group_film_reduce(lmc_ctx **ctxs, int n, double *ms);
 /* CPU test hooks (need no GPU): the host-side plan of the sharded MLTInit from the padded blocks the ranks all-gather.
  * lmc_shard_layout: out5 = [first stream, end stream, first sample, end sample, samples of the largest rank] of `rank`;
  * lmc_shard_counts_probe: rank_first[world + 1] = first contribution of every rank's block (and the total);
@@ -117,7 +124,10 @@ int lmc_bidir_mc(lmc_ctx *ctx, int spp);
 int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);
 /* per-chain summary, `stride` floats each (>= 32), same layout as the oracle's orc_chain_summary:
  * [valid, camDepth, lightDepth, lsScore, ssScore, scoreSum, time, gaussianInitialized, buffered, sampleIdx,
- *  screenX, screenY, contribR, contribG, contribB, nSplats, pss[0..15]]; which = 0 current, 1 init states */
+ *  screenX, screenY, contribR, contribG, contribB, nSplats, pss[0..15]]; which = 0 current, 1 init states.
+ * Of an INVALID current state (valid == 0) only lsScore and the technique mean anything: the chain loop reads nothing else of it (mlt.cpp:148,
+ * mutation_large.h:87-116), and after an outlier reset (mlt.cpp:151-158) onto an init state that lives on another rank of the job only those
+ * are copied -- the path words (time, pss, screen) of such a row are the previous state's. */
 int lmc_chain_summary(lmc_ctx *ctx, int which, float *out, int stride);
 /* kernel time (ms, HIP events on the launch stream) and launch count of the chain-step kernel since the last call */
 int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);

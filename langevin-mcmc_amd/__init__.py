@@ -275,6 +275,20 @@ class Group:
         if L.lmc_group_chains_step(self._arr, len(self.rens), n) != 0:
             raise RuntimeError("lmc_group_chains_step failed: " + _err())
 
+    def film_reduce(self):
+        """Every member's device film becomes the sum over the members (peer copies: the in-process lmc_film_allreduce); returns its wall time in ms."""
+        L = lib()
+        L.lmc_group_film_reduce.argtypes = [vp, ctypes.c_int, vp]
+        ms = ctypes.c_double()
+        if L.lmc_group_film_reduce(self._arr, len(self.rens), ctypes.byref(ms)) != 0:
+            raise RuntimeError("lmc_group_film_reduce failed: " + _err())
+        return ms.value
+
+
+def device_count():
+    """HIP devices visible to this process (0 without a GPU)."""
+    return int(lib().lmc_device_count())
+
 
 def comm_unique_id():
     """128-byte RCCL id (rank 0 creates it, the host program broadcasts it)"""

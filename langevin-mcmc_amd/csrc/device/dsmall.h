@@ -370,13 +370,17 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         NormalDist nd(0.0f, S.opt.perturbStdDev);
 #pragma unroll 1
         for (int k = 0; k < dim; k++) L.U(offBase + k) = nd(rng);
+#ifndef LMC_PROF_FINE
         prof.Mark(PR_ISO);
+#endif
     } else {
         if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81; the vectors are zero already (dchain.h ClearBuffered)
             flags |= F_BUFFERED | F_VSYNC;  // all four vectors are zero
             flags &= ~F_QUERIED;
         }
+#ifndef LMC_PROF_FINE
         prof.Mark(PR_RESET);
+#endif
         // currentState.gaussian: stored (F_GAUSS) or initialised now from the cache / isotropic (mutation_mala.h:83-166);
         // GenerateSample (gaussian.cpp:38-55) and GaussianLogPdf(offset, currentState.gaussian) (gaussian.cpp:24-36) are
         // fused into the same pass over the dimensions (the affine map draws nothing)
@@ -530,7 +534,9 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             hit.st = V2{0.f, 0.f};
             Isect isect;
             isect.position = isect.shadingNormal = isect.geomNormal = V3{0.f, 0.f, 0.f};
+#ifndef LMC_PROF_FINE
             prof.Mark(PR_VERTEX_LOAD);
+#endif
             const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk);
             prof.Mark(PR_TRAVERSE);
             if (lightPhase) {
@@ -568,14 +574,23 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             cps.wi = -dir;
             if (hitSurface) ConvertMIS(S, depth, -1, org, dir, cps);
             if (depth == camCount - 1 && l == 0) {
+#ifdef LMC_PROF_FINE  // A/B build: isotropic_offsets = the emitter-hit terminal, vertex_load = the direct-lighting terminal, buffered_reset = PrepareGaussianLean(proposal)
+                prof.Mark(PR_SHADE);
+#endif
                 const int light = HitLightOf(S, hitSurface, hit.tri);
                 if (light >= 0) ok = HandleHitLight(S, depth, light, hitSurface, dir, screenPos, cps, envPrim, pc);
                 StoreVertex(prop, N, i, false, depth, sv);
+#ifdef LMC_PROF_FINE
+                prof.Mark(PR_ISO);
+#endif
                 break;
             }
             if (!hitSurface) break;
             sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
             if (depth == camCount - 1) {
+#ifdef LMC_PROF_FINE
+                prof.Mark(PR_SHADE);
+#endif
                 if (l == 1) {
                     const float directLightPickProb = PickLightProb(S, sv.dirLight);
                     sv.dirRnd0 = Modulo1(sv.dirRnd0 + off.Pop());
@@ -586,6 +601,9 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                     ok = ConnectVertex(S, depth, lgtCount - 1, lps, lastLgt, cps, sv, screenPos, pc, stk, occ);
                 }
                 StoreVertex(prop, N, i, false, depth, sv);
+#ifdef LMC_PROF_FINE
+                prof.Mark(PR_VERTEX_LOAD);
+#endif
                 break;
             }
             sv.rnd0 = Modulo1(sv.rnd0 + off.Pop());
@@ -616,6 +634,9 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             VSource vs;
             const GradState gs{prop, c, l, pc.ssScore, true, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
+#ifdef LMC_PROF_FINE
+            prof.Mark(PR_RESET);
+#endif
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;
             if (vs.mode == VS_GRAD) flags &= ~F_VSYNC;  // the moment update rewrote prop_new_v1 / v2
             if (vs.wrotePss || vs.mode == VS_BLEND || vs.mode == VS_GRAD) flags |= F_VDIRTY;

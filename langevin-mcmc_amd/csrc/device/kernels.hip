@@ -859,6 +859,13 @@ void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, 
 void LaunchTransProbe(int n, int mode, const float *x, const float *y, float *o, hipStream_t s) {
     hipLaunchKernelGGL(k_trans_probe, dim3(GridFor(n, 256)), dim3(256), 0, s, n, mode, x, y, o);
 }
+// dst += src (the film merge of an in-process group of contexts, host/context.cpp lmc_group_film_reduce)
+template <class T>
+__global__ void k_add_into(T *dst, const T *src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+void LaunchAddInto(float *dst, const float *src, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_into<float>, dim3(GridFor((long long)n, 256)), dim3(256), 0, s, dst, src, n); }
+void LaunchAddIntoF64(double *dst, const double *src, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_into<double>, dim3(GridFor((long long)n, 256)), dim3(256), 0, s, dst, src, n); }
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>  // declarations only (types, enum values, signatures): librccl is dlopen'ed, never linked
 
 #include "../../../include/lmc_abi.h"
 #include "../device/drng.h"
@@ -197,6 +200,11 @@ struct lmc_ctx {
     std::vector<StepEvents> events, eventPool;
     double smallMs = 0, largeMs = 0, largeOnlyMs = 0, genericMs = 0;  // accumulated by lmc_step_timing for lmc_kernel_timing / lmc_kernel_timing_split
     ~lmc_ctx() {
+        for (lmc_ctx *peer : group)  // the other members of an in-process group hold raw pointers to this context
+            if (peer != this) {
+                peer->group.clear();
+                peer->world = 1, peer->rank = 0;
+            }
         for (auto *v : {&events, &eventPool})
             for (auto &ev : *v)
                 for (auto e : ev.e) (void)hipEventDestroy(e);
@@ -430,6 +438,16 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
 
 void lmc_destroy(lmc_ctx *ctx) { delete ctx; }
 
+// HIP devices this process can use; 0 without a GPU / driver (never an error: callers use it to refuse a job they cannot place)
+int lmc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 int lmc_info(lmc_ctx *c, int *out) {
     out[0] = c->S.cam.width, out[1] = c->S.cam.height, out[2] = c->S.numTris, out[3] = c->S.opt.maxDepth, out[4] = c->S.numNodes, out[5] = c->bvhDepth;
     out[6] = c->S.numLights, out[7] = c->S.opt.mala;
@@ -518,18 +536,18 @@ int lmc_image_write_exr(const char *path, const float *rgb, int w, int h) {
 // bound at run time (dlopen) so that single-GPU users and the CPU-side tests do not need it.
 extern "C++" {
 namespace {
+// Signatures, ncclUniqueId and the enum values come from rccl.h at BUILD time (decltype of the declarations: a mismatch with the
+// installed header is a compile error, not a silent ABI bug); the library itself is still bound at run time.
 struct Rccl {
     void *h = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, const void * /* ncclUniqueId by value: 128 bytes, passed in memory */, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;  // (send, recv, sendcount, type, comm, stream)
-    int (*CommDestroy)(void *) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
-struct UniqueId {
-    char internal[128];
-};
+static_assert(sizeof(ncclUniqueId) == 128, "lmc_comm_unique_id hands out 128 bytes (include/lmc_abi.h)");
 Rccl &GetRccl() {
     static Rccl r;
     static bool ready = false;  // set only after EVERY required symbol has resolved: a failed first call must not leave a half-filled table behind
@@ -542,20 +560,19 @@ Rccl &GetRccl() {
     if (!h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
     Rccl t;
     t.h = h;
-    t.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-    t.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
-    t.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
-    t.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-    t.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!t.GetUniqueId || !dlsym(h, "ncclCommInitRank") || !t.AllReduce || !t.AllGather || !t.CommDestroy) throw std::runtime_error("RCCL symbols missing");
+    t.GetUniqueId = (decltype(t.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    t.CommInitRank = (decltype(t.CommInitRank))dlsym(h, "ncclCommInitRank");
+    t.AllReduce = (decltype(t.AllReduce))dlsym(h, "ncclAllReduce");
+    t.AllGather = (decltype(t.AllGather))dlsym(h, "ncclAllGather");
+    t.CommDestroy = (decltype(t.CommDestroy))dlsym(h, "ncclCommDestroy");
+    t.GetErrorString = (decltype(t.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!t.GetUniqueId || !t.CommInitRank || !t.AllReduce || !t.AllGather || !t.CommDestroy) throw std::runtime_error("RCCL symbols missing");
     r = t;
     ready = true;
     return r;
 }
-// ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank): the id struct travels by value
-typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
-void RcclCheck(int rc, const char *what) {
-    if (rc != 0) {
+void RcclCheck(ncclResult_t rc, const char *what) {
+    if (rc != ncclSuccess) {
         Rccl &r = GetRccl();
         throw std::runtime_error(std::string("RCCL error in ") + what + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
     }
@@ -563,7 +580,7 @@ void RcclCheck(int rc, const char *what) {
 }  // namespace
 }  // extern "C++"
 
-static int GetRcclDestroy(void *comm) { return GetRccl().CommDestroy ? GetRccl().CommDestroy(comm) : 0; }
+static int GetRcclDestroy(void *comm) { return GetRccl().CommDestroy ? (int)GetRccl().CommDestroy((ncclComm_t)comm) : 0; }
 
 // ================================================================================================ MLTInit + chain set-up
 // MLTInit (mlt.h:41-154), sharded over the ranks of a job BY INIT STREAM (rank r runs the streams [V r / R, V (r + 1) / R): pass 1,
@@ -614,7 +631,7 @@ void AllGatherBlocks(const std::vector<lmc_ctx *> &g, const std::function<void *
     if (g.size() == 1 && g[0]->world > 1) {  // one rank of an RCCL job
         lmc_ctx *c = g[0];
         HIP_CHECK(hipSetDevice(c->device));
-        RcclCheck(GetRccl().AllGather(send(c), recv(c), bytes, /*ncclUint8*/ 1, c->comm, c->stream), "ncclAllGather");
+        RcclCheck(GetRccl().AllGather(send(c), recv(c), bytes, ncclUint8, (ncclComm_t)c->comm, c->stream), "ncclAllGather");
         HIP_CHECK(hipStreamSynchronize(c->stream));
         return;
     }
@@ -730,7 +747,9 @@ void InitPhase4(lmc_ctx *c, InitJob &J);
 // what the resident chain state is laid out for: mala, h2mc, samplecache (chain.path copies, cache rows with paths)
 static int MutationKey(const lmc_ctx *c) {
     const lmc::DptOptions &o = c->scene->options;
-    return (o.mala ? 1 : 0) | (o.h2mc ? 2 : 0) | ((o.sampleFromGlobalCache && o.mala) ? 4 : 0);
+    // uselightcoordinatesampling: which launch runs a chain's small steps is decided when its step is queued and the launch plan is fixed when
+    // the caches become ready -- switching it under resident chains would leave them on a list no launch serves
+    return (o.mala ? 1 : 0) | (o.h2mc ? 2 : 0) | ((o.sampleFromGlobalCache && o.mala) ? 4 : 0) | (o.useLightCoordinateSampling ? 8 : 0);
 }
 static void WarmStepLaunches(lmc_ctx *c);
 extern "C++" {
@@ -852,6 +871,11 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->needGeneric = true;
     c->genericTokenOnly = false;
     c->anyDeepCache = false;
+    if (!c->S.opt.mala && !c->S.opt.h2mc) {  // plain MLT never pushes to the cache (mlt.cpp:120-127 sits behind the MALA step): nothing to pack, exchange or read back
+        c->allCachesReady = true;
+        c->needGeneric = c->S.opt.useLightCoord || c->S.opt.leanLightless;
+        c->genericTokenOnly = c->S.opt.leanLightless && !c->S.opt.useLightCoord;
+    }
     if (c->S.opt.h2mc) {  // no gradient cache on the H2MC path: nothing to maintain, every small step takes the "generic" launch
         c->allCachesReady = true;
         c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)H2_OUT_WORDS), c->h2Gauss.Alloc(2 * N * (size_t)H2_GAUSS_AOS, false);
@@ -930,12 +954,20 @@ int lmc_group_chains_init(lmc_ctx **ctxs, int n, long long numInitSamples, int n
     if (n < 1) throw std::runtime_error("lmc_group_chains_init: empty group");
     std::vector<lmc_ctx *> g(ctxs, ctxs + n);
     std::vector<std::pair<int, int>> ranges;
-    for (int r = 0; r < n; r++) {
+    for (int r = 0; r < n; r++)
         if (g[r]->comm) throw std::runtime_error("lmc_group_chains_init: a member already belongs to an RCCL job");
+    for (int r = 0; r < n; r++) {
+        for (lmc_ctx *peer : g[r]->group)  // leaving an earlier group: its other members must not keep a pointer to this context as a peer
+            if (peer != g[r]) peer->group.clear(), peer->world = 1, peer->rank = 0;
         g[r]->world = n, g[r]->rank = r, g[r]->group = g;
         ranges.push_back({(int)((long long)numChainsTotal * r / n), (int)((long long)numChainsTotal * (r + 1) / n)});
     }
-    RunInit(g, numInitSamples, numChainsTotal, initThreads, ranges, perChain, chainsNeedExtra);
+    try {
+        RunInit(g, numInitSamples, numChainsTotal, initThreads, ranges, perChain, chainsNeedExtra);
+    } catch (...) {  // a failed init (too few contributions, a bad range) must not leave the contexts marked as ranks of an n-rank job
+        for (lmc_ctx *c : g) c->group.clear(), c->world = 1, c->rank = 0, c->N = 0;
+        throw;
+    }
     return 0;
     LMC_CATCH(-1)
 }
@@ -1137,7 +1169,7 @@ void CheckSteppable(lmc_ctx *c) {
     if (c->N <= 0) throw std::runtime_error("lmc_chains_step before lmc_chains_init");
     // the chain state (H2MC Gaussian buffers, cache bookkeeping, work lists) is laid out for the mutation in force at init
     if (c->mutationAtInit != MutationKey(c))
-        throw std::runtime_error("the 'mala' / 'h2mc' / 'samplecache' options changed after lmc_chains_init: initialise the chains again before stepping");
+        throw std::runtime_error("the 'mala' / 'h2mc' / 'samplecache' / 'uselightcoordinatesampling' options changed after lmc_chains_init: initialise the chains again before stepping");
     if (c->S.opt.sampleCache && !c->scene->options.largeStepMultiplexed)
         throw std::runtime_error("samplecache needs largestepmultiplexed (mutation_large_cache.h:33)");
 }
@@ -1384,6 +1416,45 @@ int lmc_prof_read(lmc_ctx *c, unsigned long long *out16) {
     LMC_CATCH(-1)
 }
 
+// The film merge of an in-process job (mlt.cpp:203-207 MergeBuffer over the per-thread films; here: over the per-GPU films of the group's
+// members): member 0 pulls every other member's film over xGMI into a staging buffer on its device and adds it, then the sum is copied
+// back to every member -- the in-process counterpart of lmc_film_allreduce (same semantics: in place, once per stepped film).
+// out_ms (may be NULL): wall time of the merge, for bench.py's scaling line.
+int lmc_group_film_reduce(lmc_ctx **ctxs, int n, double *out_ms) {
+    LMC_TRY
+    std::vector<lmc_ctx *> g(ctxs, ctxs + n);
+    for (lmc_ctx *c : g) {
+        if (c->group != g) throw std::runtime_error("lmc_group_film_reduce: not the group lmc_group_chains_init set up");
+        if (c->filmReduced) throw std::runtime_error("lmc_group_film_reduce: the films already hold the sum over the members; step or clear them first");
+        if (c->film.n != g[0]->film.n) throw std::runtime_error("lmc_group_film_reduce: the members' films differ in size");
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    lmc_ctx *r = g[0];
+    HIP_CHECK(hipSetDevice(r->device));
+    DevBuf<float> stage;
+    DevBuf<double> wstage;
+    if (n > 1) stage.Alloc(r->film.n, false), wstage.Alloc(1, false);
+    for (int k = 1; k < n; k++) {
+        HIP_CHECK(hipMemcpyPeerAsync(stage.p, r->device, g[k]->film.p, g[k]->device, r->film.n * sizeof(float), r->stream));
+        LaunchAddInto(r->film.p, stage.p, r->film.n, r->stream);
+        HIP_CHECK(hipMemcpyPeerAsync(wstage.p, r->device, g[k]->weightSum.p, g[k]->device, sizeof(double), r->stream));
+        LaunchAddIntoF64(r->weightSum.p, wstage.p, 1, r->stream);
+    }
+    HIP_CHECK(hipStreamSynchronize(r->stream));
+    for (int k = 1; k < n; k++) {
+        HIP_CHECK(hipSetDevice(g[k]->device));
+        HIP_CHECK(hipMemcpyPeerAsync(g[k]->film.p, g[k]->device, r->film.p, r->device, r->film.n * sizeof(float), g[k]->stream));
+        HIP_CHECK(hipMemcpyPeerAsync(g[k]->weightSum.p, g[k]->device, r->weightSum.p, r->device, sizeof(double), g[k]->stream));
+        HIP_CHECK(hipStreamSynchronize(g[k]->stream));
+    }
+    for (lmc_ctx *c : g) c->filmReduced = true;
+    if (out_ms) *out_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+    LMC_CATCH(-1)
+}
+
 int lmc_film_read(lmc_ctx *c, float *rgb) {
     LMC_TRY
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1454,10 +1525,10 @@ int lmc_direct_read(lmc_ctx *c, float *rgb) {
 
 int lmc_comm_unique_id(unsigned char *out128) {
     LMC_TRY
-    UniqueId id;
+    ncclUniqueId id;
     memset(&id, 0, sizeof(id));
     RcclCheck(GetRccl().GetUniqueId(&id), "ncclGetUniqueId");
-    memcpy(out128, id.internal, 128);
+    memcpy(out128, &id, 128);
     return 0;
     LMC_CATCH(-1)
 }
@@ -1466,10 +1537,18 @@ int lmc_comm_init(lmc_ctx *c, int nranks, int rank, const unsigned char *id128) 
     LMC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (c->comm) throw std::runtime_error("lmc_comm_init: communicator already initialised");
-    UniqueId id;
-    memcpy(id.internal, id128, 128);
-    CommInitRankFn init = (CommInitRankFn)dlsym(GetRccl().h, "ncclCommInitRank");
-    RcclCheck(init(&c->comm, nranks, id, rank), "ncclCommInitRank");
+    // the chain state is laid out for the job's rank count at lmc_chains_init (sharded MLTInit, the gather buffer of the cache pushes:
+    // world x stage): a communicator that appears afterwards would make the next cache-filling step gather world stages into a
+    // one-stage buffer
+    // (a one-rank communicator changes nothing about the layout and is accepted at any time)
+    if (c->N > 0 && nranks != 1) throw std::runtime_error("lmc_comm_init after lmc_chains_init: create the communicator first, then initialise the chains");
+    if (c->group.size() > 1) throw std::runtime_error("lmc_comm_init: this context is a member of an in-process group");
+    if (nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("lmc_comm_init: rank out of range");
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm = nullptr;
+    RcclCheck(GetRccl().CommInitRank(&comm, nranks, id, rank), "ncclCommInitRank");
+    c->comm = comm;
     c->world = nranks, c->rank = rank;
     return 0;
     LMC_CATCH(-1)
@@ -1482,10 +1561,10 @@ int lmc_film_allreduce(lmc_ctx *c) {
     if (c->filmReduced) throw std::runtime_error("lmc_film_allreduce: the film already holds the sum over ranks (a second in-place sum would count every rank's splats again); step or clear the film first");
     c->filmReduced = true;
     // in place on the device film, on the stream the step kernels run on: ordered after the last splat, no host staging
-    RcclCheck(GetRccl().AllReduce(c->film.p, c->film.p, c->film.n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->stream), "ncclAllReduce(film)");
+    RcclCheck(GetRccl().AllReduce(c->film.p, c->film.p, c->film.n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream), "ncclAllReduce(film)");
     // the scalars that normalise the merged image: sum of splat weights (double) -- `normalization` itself is identical on
     // every rank (each runs the same MLTInit), so it is not reduced
-    RcclCheck(GetRccl().AllReduce(c->weightSum.p, c->weightSum.p, 1, /*ncclFloat64*/ 8, 0, c->comm, c->stream), "ncclAllReduce(weightSum)");
+    RcclCheck(GetRccl().AllReduce(c->weightSum.p, c->weightSum.p, 1, ncclFloat64, ncclSum, (ncclComm_t)c->comm, c->stream), "ncclAllReduce(weightSum)");
     return 0;
     LMC_CATCH(-1)
 }

@@ -331,7 +331,9 @@ def test_h2mc_per_step_agreement(diffuse):
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.005 * so["gradCalls"] + 2  # 4457 vs 4468, 4375 vs 4375
     assert abs(sg["largeSteps"] - so["largeSteps"]) <= 4
     assert r["film_rel_l2"] < (0.3 if diffuse else 0.25)  # 0.146 / 0.121
-    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+    # energy identity: film luminance == normalization x splatted weight, up to the splats Splat() drops as non-finite (image.h:66-77: glossy
+    # states now and then, 1.2e-3 of the weight of this run) -- which the oracle drops as well
+    assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < (1e-4 if diffuse else 5e-3) and abs(r["energy_gpu"] - r["energy_oracle"]) < 1e-3
 
 
 def test_h2mc_door_render_matches_reference_image():

