@@ -260,9 +260,9 @@ class Group:
         L.lmc_group_chains_init.argtypes = [vp, ctypes.c_int, c_ll, ctypes.c_int, ctypes.c_int, c_ll, c_ll]
         if L.lmc_group_chains_init(self._arr, len(self.rens), num_init, n_chains_total, init_threads, per_chain, extra) != 0:
             raise RuntimeError("lmc_group_chains_init failed: " + _err())
-        n = len(self.rens)
-        for r, ren in enumerate(self.rens):
-            b, e = n_chains_total * r // n, n_chains_total * (r + 1) // n
+        from . import sharding
+
+        for ren, (b, e) in zip(self.rens, sharding.group_ranges(n_chains_total, len(self.rens))):
             ren.num_chains, ren.num_chains_total = e - b, n_chains_total
             nn, nc = ctypes.c_float(), c_ll()
             L.lmc_init_result(ren.h, ctypes.byref(nn), ctypes.byref(nc))

@@ -118,6 +118,7 @@ struct lmc_ctx {
     // LMC_OVERLAP=0 serialises them on the main stream (A/B).
     hipStream_t sideStream[2] = {nullptr, nullptr};
     hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
+    hipEvent_t packedEvent = nullptr, copiedEvent = nullptr;  // in-process group: this member's stage is complete / this member has copied every stage (ExchangeStagesAsync)
     bool overlap = true;
     // scene buffers
     DevBuf<BvhNode4> nodes;
@@ -215,7 +216,7 @@ struct lmc_ctx {
             }
         }
         if (hostCounts) (void)hipHostFree(hostCounts);
-        for (auto e : {forkEvent, joinEvent[0], joinEvent[1]})
+        for (auto e : {forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent})
             if (e) (void)hipEventDestroy(e);
         for (auto st : sideStream)
             if (st) (void)hipStreamDestroy(st);
@@ -412,6 +413,8 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     }
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->packedEvent, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->copiedEvent, hipEventDisableTiming));
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
     if (const char *e = getenv("LMC_LARGE_LDS")) c->largeLdsStack = atoi(e) != 0;
@@ -643,6 +646,39 @@ void AllGatherBlocks(const std::vector<lmc_ctx *> &g, const std::function<void *
         HIP_CHECK(hipSetDevice(c->device));
         for (size_t q = 0; q < g.size(); q++) HIP_CHECK(hipMemcpyAsync((char *)recv(c) + q * bytes, send(g[q]), bytes, hipMemcpyDefault, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+}
+
+// The per-step exchange of the cache pushes, STREAM-ORDERED: nothing here makes the host wait (the init-time AllGatherBlocks above
+// synchronises after every collective because the host reads the result next; in the step loop the consumer is the next kernel on the
+// same stream).  RCCL rank: ncclAllGather on the step stream.  In-process group: every member's stream waits for every member's stage
+// (packedEvent), copies the stages device to device, and before any member may overwrite its stage again waits for every member's
+// copies (copiedEvent) -- a barrier among the streams, not among the host threads: the host runs ahead and queues the next step.
+void ExchangeStagesAsync(const std::vector<lmc_ctx *> &g, size_t bytes) {
+    if (bytes == 0) return;
+    if (g.size() == 1) {
+        lmc_ctx *c = g[0];
+        if (c->world <= 1) return;
+        HIP_CHECK(hipSetDevice(c->device));
+        RcclCheck(GetRccl().AllGather(c->pushStage.p, c->pushGather.p, bytes, ncclUint8, (ncclComm_t)c->comm, c->stream), "ncclAllGather(cache pushes)");
+        return;
+    }
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipEventRecord(c->packedEvent, c->stream));
+    }
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        for (size_t q = 0; q < g.size(); q++) {
+            if (g[q] != c) HIP_CHECK(hipStreamWaitEvent(c->stream, g[q]->packedEvent, 0));
+            HIP_CHECK(hipMemcpyAsync((char *)c->pushGather.p + q * bytes, g[q]->pushStage.p, bytes, hipMemcpyDefault, c->stream));
+        }
+        HIP_CHECK(hipEventRecord(c->copiedEvent, c->stream));
+    }
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        for (lmc_ctx *peer : g)
+            if (peer != c) HIP_CHECK(hipStreamWaitEvent(c->stream, peer->copiedEvent, 0));
     }
 }
 
@@ -1321,8 +1357,7 @@ void RunSteps(const std::vector<lmc_ctx *> &g, int nSteps) {
             if (k > 0 && e != exchange) throw std::runtime_error("internal: the ranks of a job disagree on the state of the global cache");
             exchange = e;
         }
-        if (exchange && g[0]->world > 1)
-            AllGatherBlocks(g, [](lmc_ctx *c) { return (void *)c->pushStage.p; }, [](lmc_ctx *c) { return (void *)c->pushGather.p; }, (size_t)g[0]->stageLayout.totalFloats * sizeof(float));
+        if (exchange && g[0]->world > 1) ExchangeStagesAsync(g, (size_t)g[0]->stageLayout.totalFloats * sizeof(float));
         for (size_t k = 0; k < g.size(); k++) StepPhase2(g[k], ev[k], exchange);
     }
     for (lmc_ctx *c : g) {

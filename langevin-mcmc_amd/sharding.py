@@ -21,6 +21,12 @@ def split_total(total_chains, world):
     return out
 
 
+def group_ranges(total_chains, world):
+    """The partition lmc_group_chains_init (and a job of RCCL ranks that follows the same rule) gives a fixed total: rank r holds the
+    global chain ids [total r / world, total (r + 1) / world) -- host/context.cpp lmc_group_chains_init."""
+    return [(total_chains * r // world, total_chains * (r + 1) // world) for r in range(world)]
+
+
 def allreduce_film(film, normalization, dist, device=None):
     """Sums the per-rank indirect film buffers (the only data-path collective) and checks that every rank used
     the same normalisation scalar.  `dist` is torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU)."""

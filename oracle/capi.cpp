@@ -203,6 +203,57 @@ int orc_direct(void *h, int directSpp, float *out) {
     ORC_CATCH(-1)
 }
 
+// Plain Monte Carlo estimators of the image, the oracle side of lmc_path_trace / lmc_bidir_mc (the product's cross-check estimators, which
+// bench.py's equal-time RMSE and the option tests use as ground truth: pinned here so that a biased "truth" cannot hide):
+//   orc_path_trace  GeneratePath (path.cpp:406-527; the "mc" integrator's generator, pathtrace.cpp) over the depth range [minDepth, maxDepth],
+//                   tile / stream structure of DirectLighting (direct.cpp:4-54); out = un-normalised W*H*3
+//   orc_bidir_mc    GeneratePathBidir (path.cpp:1237-1449) samples of nThreads streams RNG(t + seedOffset), samplesPerThread each, every
+//                   contribution splatted as is (they carry their MIS weights); out = un-normalised sum
+int orc_path_trace(void *h, int spp, int minDepth, int maxDepth, float *out) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    const RScene *scene = m->scene.get();
+    const int W = scene->camera.pixelWidth, H = scene->camera.pixelHeight;
+    std::vector<Float> buf((size_t)W * H * 3, 0.f);
+    const int tileSize = 16, nX = (W + tileSize - 1) / tileSize, nY = (H + tileSize - 1) / tileSize;
+    for (int ty = 0; ty < nY; ty++)
+        for (int tx = 0; tx < nX; tx++) {
+            RNG rng(ty * nX + tx + scene->options->seedOffset);
+            const int x0 = tx * tileSize, x1 = std::min(x0 + tileSize, W), y0 = ty * tileSize, y1 = std::min(y0 + tileSize, H);
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++)
+                    for (int s = 0; s < spp; s++) {
+                        std::vector<SubpathContrib> sp;
+                        GeneratePathUni(scene, x, y, minDepth, maxDepth, sp, rng);
+                        for (const auto &c : sp) m->Splat(buf, c.screenPos, c.contrib);
+                    }
+        }
+    memcpy(out, buf.data(), buf.size() * sizeof(float));
+    return 0;
+    ORC_CATCH(-1)
+}
+int orc_bidir_mc(void *h, int nThreads, int samplesPerThread, float *out) {
+    ORC_TRY
+    MLT *m = (MLT *)h;
+    const RScene *scene = m->scene.get();
+    const int W = scene->camera.pixelWidth, H = scene->camera.pixelHeight;
+    std::vector<Float> buf((size_t)W * H * 3, 0.f);
+    std::vector<SubpathContrib> sp;
+    Path path;
+    for (int t = 0; t < nThreads; t++) {
+        RNG rng((uint64_t)(t + scene->options->seedOffset));
+        for (int s = 0; s < samplesPerThread; s++) {
+            sp.clear();
+            Clear(path);
+            GeneratePathBidir(scene, -1, -1, std::max(scene->options->minDepth, 3), scene->options->maxDepth, path, sp, rng);
+            for (const auto &c : sp) m->Splat(buf, c.screenPos, c.contrib);
+        }
+    }
+    memcpy(out, buf.data(), buf.size() * sizeof(float));
+    return 0;
+    ORC_CATCH(-1)
+}
+
 void orc_film(void *h, float *out) {
     MLT *m = (MLT *)h;
     memcpy(out, m->film.data(), m->film.size() * sizeof(float));
@@ -470,7 +521,13 @@ double orc_run_async(void *h, int threads, double maxSeconds, long long *stepsDo
     threads = std::max(1, std::min(threads, std::max(1, n)));
     const long long before = m->stats.steps;
     std::vector<std::vector<Float>> films(threads);
-    std::vector<StepStats> st(threads);
+    // one cache line (and its prefetched neighbour) per worker: the counters are bumped at every mutation, and packed 56 bytes apart they
+    // made the workers fight over lines -- on the GPU box's 256-thread host the whole pool ran no faster than 32 threads (5.5 M steps/s at
+    // 32, 64 and 128 threads, 3.9 M at 256: scripts/cpu_baseline_scaling.py, round 4)
+    struct alignas(128) PaddedStats {
+        StepStats s;
+    };
+    std::vector<PaddedStats> stPad(threads);
     std::mutex dimMutex[17];
     std::atomic<int> next{0};
     auto t0 = std::chrono::steady_clock::now();
@@ -483,7 +540,7 @@ double orc_run_async(void *h, int threads, double maxSeconds, long long *stepsDo
                 const int i = next.fetch_add(1);
                 if (i >= n) break;
                 ChainCtx &c = m->chains[i];
-                c.film = &films[t], c.st = &st[t];
+                c.film = &films[t], c.st = &stPad[t].s;
                 while (c.sampleIdx < c.numSamplesThisChain) {
                     m->StepChain(c, pushes);
                     if (!pushes.empty()) {
@@ -505,10 +562,11 @@ double orc_run_async(void *h, int threads, double maxSeconds, long long *stepsDo
     for (int t = 0; t < threads; t++) {
         if (films[t].size() == m->film.size())
             for (size_t i = 0; i < m->film.size(); i++) m->film[i] += films[t][i];
-        m->stats.steps += st[t].steps, m->stats.largeSteps += st[t].largeSteps, m->stats.accepted += st[t].accepted;
-        m->stats.gradCalls += st[t].gradCalls, m->stats.cacheQueries += st[t].cacheQueries, m->stats.cacheHits += st[t].cacheHits;
-        m->stats.resets += st[t].resets;
-        m->stats.weightSum += st[t].weightSum;
+        const StepStats &x = stPad[t].s;
+        m->stats.steps += x.steps, m->stats.largeSteps += x.largeSteps, m->stats.accepted += x.accepted;
+        m->stats.gradCalls += x.gradCalls, m->stats.cacheQueries += x.cacheQueries, m->stats.cacheHits += x.cacheHits;
+        m->stats.resets += x.resets;
+        m->stats.weightSum += x.weightSum;
     }
     for (auto &c : m->chains) c.film = &m->film, c.st = &m->stats;
     const double sec = std::chrono::duration<double>(t1 - t0).count();

@@ -971,3 +971,52 @@ def test_multiplexed_render_converges_to_plain_monte_carlo():
     bright = bg >= 0.5 * gt.mean()  # the dim corner blocks carry little energy and converge last (1.15 / 1.08 here, 1.05 at 48000 mutations)
     assert bright.sum() >= 8 and r[bright].min() > 0.92 and r[bright].max() < 1.08, (np.round(r, 3), np.round(bg / gt.mean(), 2))
     assert r.min() > 0.8 and r.max() < 1.2, np.round(r, 3)
+
+
+def test_plain_monte_carlo_estimators_are_pinned_to_the_oracle():
+    """lmc_bidir_mc and lmc_path_trace are the product's ground-truth estimators (bench.py's equal-time RMSE, the option tests): before
+    anything is measured against them they are pinned themselves --
+      (1) lmc_bidir_mc against the oracle's plain Monte Carlo over GeneratePathBidir samples of the SAME PCG streams (thread t seeded
+          t + seedOffset): the same image up to float-add order;
+      (2) lmc_path_trace against the oracle's GeneratePath estimator on the same tile streams;
+      (3) the two estimators, which share no sampling code (unidirectional + next-event estimation vs bidirectional with MIS), against each
+          other on path lengths >= 3: global mean within 1 %, every block of a 4 x 4 grid within 3 sigma of their difference."""
+    L = gc.oracle_lib()
+    p = gc.pkg()
+    W, H = 64, 48
+    for fn in ("orc_path_trace", "orc_bidir_mc"):
+        getattr(L, fn).restype = ctypes.c_int
+    L.orc_path_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.orc_bidir_mc.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    orc = _orc.Oracle(L, gc.TORUS, 1, 6, W, H, 0, "")
+    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=W, height=H, seed_offset=0, use_gradient=0)
+    for o in (orc, ren):
+        (L.orc_set_option(o.h, b"mindepth", 3.0) if o is orc else o.set_option("mindepth", 3))
+    lum = lambda x: x @ np.array([0.212671, 0.715160, 0.072169])
+    # (1) bidirectional: lmc_bidir_mc runs 65536 streams x ceil(spp W H / 65536) samples and scales to radiance
+    spp = 64
+    per = (spp * W * H + 65535) // 65536
+    g_b = ren.bidir_mc(spp)
+    o_b = np.zeros((H, W, 3), np.float32)
+    assert L.orc_bidir_mc(orc.h, 65536, per, P(o_b)) == 0
+    o_b = o_b * (W * H / (per * 65536.0))
+    assert o_b.sum() > 0 and np.isfinite(g_b).all()
+    assert np.linalg.norm(g_b - o_b) <= 1e-3 * np.linalg.norm(o_b), np.linalg.norm(g_b - o_b) / np.linalg.norm(o_b)
+    # (2) unidirectional, path lengths 3 .. 6 like the bidirectional samples
+    spp_u = 32
+    g_u = ren.path_trace(spp_u) / spp_u
+    o_u = np.zeros((H, W, 3), np.float32)
+    assert L.orc_path_trace(orc.h, spp_u, 3, 6, P(o_u)) == 0
+    o_u = o_u / spp_u
+    assert np.linalg.norm(g_u - o_u) <= 1e-3 * np.linalg.norm(o_u), np.linalg.norm(g_u - o_u) / np.linalg.norm(o_u)
+    # (3) the two estimators against each other, at a sample count where the block means are tight
+    g_b2, g_u2 = lum(ren.bidir_mc(1024)), lum(ren.path_trace(1024) / 1024)
+    assert abs(g_b2.mean() / g_u2.mean() - 1) < 0.01, g_b2.mean() / g_u2.mean()
+    for gy in range(4):
+        for gx in range(4):
+            a, b = g_b2[gy * 12:(gy + 1) * 12, gx * 16:(gx + 1) * 16], g_u2[gy * 12:(gy + 1) * 12, gx * 16:(gx + 1) * 16]
+            # per-pixel spread of each block's estimates as the noise scale of its mean (192 pixels per block)
+            sigma = np.sqrt((a.var() + b.var()) / a.size)
+            assert abs(a.mean() - b.mean()) < 3 * sigma + 0.01 * b.mean(), (gy, gx, a.mean(), b.mean(), sigma)
+    orc.close()
+    ren.close()
