@@ -250,6 +250,10 @@ def other_configs(args, p, gc):
             _, launches = ren.step_timing()
             k1 = ren.kernel_timing_split()
             s1 = ren.stats()
+            # path length of the resident states (the stream a step moves scales with it): mean over the valid chains
+            summ = ren.summary(0)
+            valid = summ[:, 0] > 0
+            mean_L = float((summ[valid, 1] + summ[valid, 2] - 1).mean()) if valid.any() else float(c["L"])
             ren.close()
             steps_total = s1["steps"] - s0["steps"]
             large_steps = s1["largeSteps"] - s0["largeSteps"]
@@ -258,6 +262,7 @@ def other_configs(args, p, gc):
                    ("H2MC small-step pipeline (k_h2_begin .. k_h2_finish: all small steps)" if c["h2mc"] else "k_step_small_grad (cache-filling small steps)"): (k1["generic_ms"], steps_total - large_steps - lean_steps)}
             dom = max(ker, key=lambda k: ker[k][0])
             ab = algorithmic_bytes(c["L"], c["h2mc"])
+            ab_mean = algorithmic_bytes(mean_L, c["h2mc"])  # at the step-weighted mean path length instead of the workload's maximum
             dom_ms, dom_steps = ker[dom][0] / max(launches, 1), ker[dom][1] / max(launches, 1)
             ach = ab * dom_steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             out.append({
@@ -266,6 +271,7 @@ def other_configs(args, p, gc):
                 "kernel_ms_per_step": {k: v[0] / max(launches, 1) for k, v in ker.items()},
                 "roofline": {"bound": "hbm", "kernel": dom, "avg_launch_ms": dom_ms, "chain_steps_per_launch": dom_steps, "algorithmic_bytes_per_step": ab,
                              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "mean_path_length": mean_L, "algorithmic_bytes_per_step_at_mean_length": ab_mean, "frac_at_mean_length": ach / HBM_PEAK_GBS * ab_mean / ab,
                              "concurrent_launches": "the three step launches share the GPU inside each bracket"},
                 "accept_rate": (s1["accepted"] - s0["accepted"]) / max(steps_total, 1), "large_step_frac": large_steps / max(steps_total, 1),
             })

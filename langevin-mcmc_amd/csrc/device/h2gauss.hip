@@ -1,6 +1,7 @@
 // k_h2_gauss, k_h2_sample: the dense proposal Gaussian of an H2MC state and the offset drawn from it, 16 lanes per state (layout: dh2coop.h).
-// Compiled with the library's arithmetic contract (no contraction, correctly rounded division / square root): these results feed the chain
-// trajectory directly, and the rotation arithmetic is the CPU oracle's element for element.
+// No contraction (a * b + c stays two roundings, like everywhere outside the Hessian program); division and square root are the hardware's
+// approximate reciprocal / rsqrt sequences (H2GAUSS_FLAGS in the Makefile) -- the rotation SEQUENCE and every convention (ascending
+// eigenvalues, the order of every sum) are the CPU oracle's serial solver's, so both sides produce the same eigenvectors up to rounding.
 #include "dh2coop.h"
 #include "dh2mc.h"
 #include "kernels.h"

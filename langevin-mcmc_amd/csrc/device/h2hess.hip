@@ -6,6 +6,9 @@
 // record is staged in LDS once per wave and read by broadcast, a lane holds ONE pass (values of 9 floats, seeded on the fly: no
 // indexable array of second-order values, hence no private memory for it).
 #define LMC_PF_CONTRACT  // the dual-number arithmetic of this translation unit may fuse a * b + c (pathfunc.h)
+#ifndef LMC_H2HESS_EXACT_MATH
+#define LMC_PF_FASTMATH  // ... and sin / cos / exp / log / pow are the hardware's approximate instructions
+#endif
 #include "dh2coop.h"
 #include "pathfunc.h"
 #include "kernels.h"

@@ -141,19 +141,45 @@ template <int N, class S> LMC_HD DualS<N, S> Detach(const DualS<N, S> &x) { retu
 template <class T> LMC_HD T FabsW(T &x);
 template <class T> LMC_HD T FmaxW(T &x, float b);
 
+// LMC_PF_FASTMATH (h2hess.hip, together with LMC_PF_CONTRACT): sin / cos / exp / log / pow through the hardware's approximate instructions
+// (v_sin_f32, v_cos_f32, v_exp_f32, v_log_f32: ~1e-6 absolute on the arguments that occur here -- angles within a few turns, BSDF
+// exponents) instead of the correctly rounded device libm / the float-float routines of dtrans.h.  Only the step's Hessian launch
+// is built this way: it has no bit-level contract (see LMC_PF_CONTRACT), and a second-order value evaluates each of them three times.
+#if defined(LMC_PF_FASTMATH) && defined(__HIP_DEVICE_COMPILE__)
+#define LMC_PF_FAST 1
+#else
+#define LMC_PF_FAST 0
+#endif
 LMC_HD float Sqrt(float x) { return sqrtf(x); }
+#if LMC_PF_FAST
+LMC_HD float Sin(float x) { return __sinf(x); }
+LMC_HD float Cos(float x) { return __cosf(x); }
+#else
 LMC_HD float Sin(float x) { return sinf(x); }
 LMC_HD float Cos(float x) { return cosf(x); }
+#endif
 LMC_HD float Acos(float x) { return acosf(x); }
 LMC_HD float Atan2(float y, float x) { return atan2f(y, x); }
 LMC_HD float Fabs(float x) { return fabsf(x); }
+#if LMC_PF_FAST
+LMC_HD float Log(float x) { return __logf(x); }
+LMC_HD float Exp(float x) { return __expf(x); }
+#else
 LMC_HD float Log(float x) { return logf(x); }
 LMC_HD float Exp(float x) { return expf(x); }
+#endif
 LMC_HD float Fmax(float a, float b) { return fmaxf(a, b); }
+#if LMC_PF_FAST
+LMC_HD float Pow(float a, float e) { return a > 0.0f ? __expf(e * __logf(a)) : lpowf(a, e); }  // the corner cases (zero / negative base) stay with the exact routine
+LMC_HD float PowRaw(float a, float e) { return a > 0.0f ? __expf(e * __logf(a)) : lpowf(a, e); }
+LMC_HD float ExpD(float x) { return __expf(x); }
+LMC_HD float LogD(float x) { return x > 0.0f ? __logf(x) : llogf(x); }
+#else
 LMC_HD float Pow(float a, float e) { return lpowf(a, e); }
 LMC_HD float PowRaw(float a, float e) { return lpowf(a, e); }  // the derivative factor of Pow (chad.h:727 emits pow(x, e - 1))
 LMC_HD float ExpD(float x) { return lexpf(x); }
 LMC_HD float LogD(float x) { return llogf(x); }
+#endif
 LMC_DUAL_T Sqrt(const DualS<N, S> &a) { S s = Sqrt(a.v); return Chain1(a, s, S(0.5f / s)); }
 LMC_DUAL_T Sin(const DualS<N, S> &a) { return Chain1(a, S(Sin(a.v)), S(Cos(a.v))); }
 LMC_DUAL_T Cos(const DualS<N, S> &a) { return Chain1(a, S(Cos(a.v)), S(-Sin(a.v))); }

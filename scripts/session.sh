@@ -6,7 +6,8 @@
 #   bench[=bench.py args]      one bench line                                          -> bench.jsonl (appended)
 #   ab=<file of variants>      scripts/ab_bench.sh with one variant per line           -> ab.jsonl
 #   h2mc[=scene lg steps warm] scripts/h2mc_rates.py                                   -> h2mc.jsonl (appended)
-#   h2mc_pmc[=scene lg]        rocprofv3 --pmc passes + kernel stats over h2mc_rates   -> h2mc_pmc/ + h2mc_pmc.json
+#   h2mc_pmc[=scene lg]        rocprofv3 --pmc passes + kernel stats over h2mc_rates   -> pmc_<n>.json, kernel_stats_<n>.csv
+#   pmc_cmd=<python command>   the same over any command (e.g. python scripts/run_one_config.py door)
 #   stats=<python command>     rocprofv3 --kernel-trace --stats of any command         -> stats_<n>/
 #   pmc=<bench.py args>        scripts/pmc_passes.sh                                   -> pmc/
 #   final                      scripts/final_measure.sh                                -> final/
@@ -28,8 +29,9 @@ for task in "$@"; do
     bench) timeout 900 python bench.py ${arg} 2> "$OUT/bench_$n.err" | tail -1 | tee -a "$OUT/bench.jsonl";;
     ab) mapfile -t V < "$arg"; scripts/ab_bench.sh "$OUT/ab.jsonl" -- "${V[@]}" 2> "$OUT/ab_$n.err";;
     h2mc) timeout 900 python scripts/h2mc_rates.py ${arg} 2> "$OUT/h2mc_$n.err" | tee -a "$OUT/h2mc.jsonl";;
-    h2mc_pmc)   # H2PMC=short: the two SQ groups only; LMC_LIB=<variant> is honoured
-      mkdir -p "$OUT/h2mc_pmc"
+    h2mc_pmc|pmc_cmd)   # PMC passes + kernel stats over a command (h2mc_pmc=<scene lg>: scripts/h2mc_rates.py; pmc_cmd=<python command>); H2PMC=short: the two SQ groups only; LMC_LIB honoured
+      if [ "$name" = h2mc_pmc ]; then CMD="python $REPO/scripts/h2mc_rates.py ${arg:-door 18} 3 3"; else CMD="${arg}"; fi
+      mkdir -p "$OUT/pmc_tmp"
       GROUPS_=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
                "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM")
       [ "${H2PMC:-full}" = full ] && GROUPS_+=("FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
@@ -38,13 +40,13 @@ for task in "$@"; do
         i=0
         for grp in "${GROUPS_[@]}"; do
           i=$((i+1))
-          timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/h2mc_pmc/pass$i" -- python "$REPO/scripts/h2mc_rates.py" ${arg:-door 18} 3 3 > "$OUT/h2mc_pmc/pass$i.log" 2>&1
+          ( cd "$REPO" && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_tmp/pass$i" -- $CMD > "$OUT/pmc_tmp/pass$i.log" 2>&1 )
         done
-        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/h2mc_pmc/stats" -- python "$REPO/scripts/h2mc_rates.py" ${arg:-door 18} 3 3 > "$OUT/h2mc_pmc/stats.log" 2>&1 )
-      python scripts/pmc_summary.py "$OUT/h2mc_pmc" > "$OUT/h2mc_pmc_$n.json"
-      find "$OUT/h2mc_pmc/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/h2mc_kernel_stats_$n.csv" \;
-      rm -rf "$OUT/h2mc_pmc"
-      python - "$OUT/h2mc_pmc_$n.json" <<'PY'
+        ( cd "$REPO" && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pmc_tmp/stats" -- $CMD > "$OUT/pmc_tmp/stats.log" 2>&1 ) )
+      python scripts/pmc_summary.py "$OUT/pmc_tmp" > "$OUT/pmc_$n.json"
+      find "$OUT/pmc_tmp/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$n.csv" \;
+      rm -rf "$OUT/pmc_tmp"
+      python - "$OUT/pmc_$n.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 for k, v in d.items():
