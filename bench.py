@@ -281,13 +281,21 @@ def other_configs(args, p, gc):
 
 
 def kernel_source_sha():
-    """Fingerprint of the sources the dominant kernel is compiled from (device headers + its translation unit)."""
-    import glob, hashlib
+    """Fingerprint of the sources the dominant kernel is compiled from: its translation unit and every header it includes, followed
+    recursively (so that a change to a header only another kernel includes -- the H2MC launches', say -- leaves it alone)."""
+    import hashlib, re
 
     dev = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "device")
+    seen, todo = [], ["step_small_plain.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(os.path.join(dev, f)):
+            continue
+        seen.append(f)
+        todo += re.findall(r'^\s*#\s*include\s+"([^"/]+)"', open(os.path.join(dev, f)).read(), flags=re.M)
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(dev, "*.h"))) + [os.path.join(dev, "step_small_plain.hip")]:
-        h.update(open(f, "rb").read())
+    for f in sorted(seen):
+        h.update(open(os.path.join(dev, f), "rb").read())
     return h.hexdigest()[:16]
 
 
