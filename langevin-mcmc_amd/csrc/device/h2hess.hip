@@ -17,33 +17,58 @@ using namespace lmcd;
 
 namespace {
 
-// A lane owns the 2 x 2 block (rows i0, i0 + 1; columns c0, c0 + 1) of one state's Hessian triangle and evaluates it in
-// (2 / LMC_H2HESS_R) x (2 / LMC_H2HESS_W) passes of the program in DualS<R, Dual<W>>: (1 + R)(1 + W) floats per value.
+// A lane owns the 2 x 2 block (rows bi0, bi0 + 1; columns bc0, bc0 + 1) of one state's Hessian triangle and evaluates it in
+// (2 / R) x (2 / W) passes of the program in DualS<R, Dual<W>>: (1 + R)(1 + W) floats per value.  The shape is chosen per copy of the
+// program (below): 1 x 2 where one sub-path's state is alive (6 floats per value: the fastest shape measured, profiles/r04_d_*, r04_s_*),
+// 1 x 1 for the techniques that keep BOTH sub-paths' states alive across the camera loop -- with 6-float values that copy spills most
+// and the launch waits for private memory half of the time on the area-lit scene (profiles/r04_final_h2mc_pmc_door.json).
 #ifndef LMC_H2HESS_R
 #define LMC_H2HESS_R 1
 #endif
 #ifndef LMC_H2HESS_W
 #define LMC_H2HESS_W 2
 #endif
-constexpr int HR = LMC_H2HESS_R, HW = LMC_H2HESS_W;
-typedef DualS<HR, Dual<HW>> T2;
+#ifndef LMC_H2HESS_W_BOTH
+#define LMC_H2HESS_W_BOTH 1  // columns per pass of the copy with both sub-paths
+#endif
 
 struct LdsIn {  // the state's vertParams in LDS
     const float *p;
     __device__ __forceinline__ float operator[](int k) const { return p[k]; }
 };
-// a lane's seeding of the float primary samples: rows [i0, i0 + HR) on the outer level, columns [c0, c0 + HW) on the inner one
+// a lane's seeding of the float primary samples: rows [i0, i0 + R) on the outer level, columns [c0, c0 + W) on the inner one
+template <int R, int W>
 struct SeedPrim {
+    typedef DualS<R, Dual<W>> T2;
     const float *p;
     int i0, c0;
     __device__ __forceinline__ T2 operator()(int k) const {
         T2 r = Lift<T2>::Of(p[k]);
         const int v = k - 1;  // primary[0] is the (inactive) time
-        for (int q = 0; q < HW; q++) r.v.d[q] = v == c0 + q ? 1.0f : 0.0f;
-        for (int q = 0; q < HR; q++) r.d[q].v = v == i0 + q ? 1.0f : 0.0f;
+        for (int q = 0; q < W; q++) r.v.d[q] = v == c0 + q ? 1.0f : 0.0f;
+        for (int q = 0; q < R; q++) r.d[q].v = v == i0 + q ? 1.0f : 0.0f;
         return r;
     }
 };
+
+// one lane's block: LCLASS selects the copy of the program (pathfunc.h PathProgramP)
+template <int R, int W, int LCLASS>
+__device__ __forceinline__ void HessBlock(int c, int l, int dim, int bi0, int bc0, const float *base, const float *scene, float *o) {
+    typedef DualS<R, Dual<W>> T2;
+    const LdsIn vp{base + H2_REC_VP};
+#pragma unroll 1
+    for (int sub = 0; sub < (2 / R) * (2 / W); sub++) {
+        const int i0 = bi0 + (sub / (2 / W)) * R, c0 = bc0 + (sub % (2 / W)) * W;
+        if (i0 > c0 + W - 1) continue;  // a pass of a diagonal block that lies entirely below the diagonal: nobody reads it
+        const SeedPrim<R, W> prim{base, i0, c0};
+        const T2 res = PathProgramP<T2, LdsIn, SeedPrim<R, W>, LCLASS>(c, l, prim, scene, vp);
+        if (i0 == 0 && c0 == 0) o[H2_OUT_LOGLUM] = res.v.v;
+        for (int q = 0; q < R; q++) {
+            if (bc0 == bi0) o[i0 + q] = res.d[q].v;  // the forward directional derivative: exact (the reference's `g`)
+            for (int k = 0; k < W; k++) o[H2_OUT_HESS + (i0 + q) * dim + c0 + k] = res.d[q].d[k];
+        }
+    }
+}
 
 __device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
     for (int off = 1; off < 64; off <<= 1) {
@@ -103,31 +128,18 @@ __global__ void __launch_bounds__(64, LMC_H2HESS_WAVES) k_h2_hess(const float *_
             while (b >= m - r) b -= m - r, r++;
             const int bi0 = 2 * r, bc0 = 2 * (r + b);
             const float *base = lds + slot * tRecW;
-            const LdsIn vp{base + H2_REC_VP};
             float *o = hout + (size_t)items[slot] * H2_OUT_WORDS;
-#pragma unroll 1
-            for (int sub = 0; sub < (2 / HR) * (2 / HW); sub++) {
-                const int i0 = bi0 + (sub / (2 / HW)) * HR, c0 = bc0 + (sub % (2 / HW)) * HW;
-                if (i0 > c0 + HW - 1) continue;  // a pass of a diagonal block that lies entirely below the diagonal: nobody reads it
-                const SeedPrim prim{base, i0, c0};
-                // three copies of the program by what the technique keeps alive: only the camera state (l <= 1), only the light state (c == 1),
-                // both (the light state parked across the camera loop): the register allocation of the first two does not pay for the third
-                T2 res;
+            // three copies of the program by what the technique keeps alive: only the camera state (l <= 1), only the light state (c == 1),
+            // both (the light state parked across the camera loop): the register allocation of the first two does not pay for the third
 #ifdef LMC_H2HESS_ONECLASS
-                res = PathProgramP<T2, LdsIn, SeedPrim, -1>(c, l, prim, scene, vp);
+            HessBlock<LMC_H2HESS_R, LMC_H2HESS_W, -1>(c, l, dim, bi0, bc0, base, scene, o);
 #else
-                if (l <= 1) res = PathProgramP<T2, LdsIn, SeedPrim, 0>(c, l, prim, scene, vp);
-                else if (c == 1)
-                    res = PathProgramP<T2, LdsIn, SeedPrim, 1>(c, l, prim, scene, vp);
-                else
-                    res = PathProgramP<T2, LdsIn, SeedPrim, 2>(c, l, prim, scene, vp);
+            if (l <= 1) HessBlock<LMC_H2HESS_R, LMC_H2HESS_W, 0>(c, l, dim, bi0, bc0, base, scene, o);
+            else if (c == 1)
+                HessBlock<LMC_H2HESS_R, LMC_H2HESS_W, 1>(c, l, dim, bi0, bc0, base, scene, o);
+            else
+                HessBlock<LMC_H2HESS_R, LMC_H2HESS_W_BOTH, 2>(c, l, dim, bi0, bc0, base, scene, o);
 #endif
-                if (i0 == 0 && c0 == 0) o[H2_OUT_LOGLUM] = res.v.v;
-                for (int q = 0; q < HR; q++) {
-                    if (bc0 == bi0) o[i0 + q] = res.d[q].v;  // the forward directional derivative: exact (the reference's `g`)
-                    for (int k = 0; k < HW; k++) o[H2_OUT_HESS + (i0 + q) * dim + c0 + k] = res.d[q].d[k];
-                }
-            }
         }
         __syncthreads();
     }

