@@ -21,7 +21,7 @@ __device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // k_h2_gauss: ComputeGaussian(H2MCParam, ...) of /root/reference/src/h2mc.cpp:3-142 for the states of a stage, 16 lanes per state
 // (four states of one technique per wave): the symmetric eigen-decomposition (the reference calls Eigen::SelfAdjointEigenSolver --
-// third party, absent: parity unpinned) is the cyclic Jacobi iteration of dh2mc.h JacobiEigenSymT with every rotation's
+// third party, absent: parity unpinned) is the cyclic Jacobi iteration (the oracle's serial form: oracle/h2mc_serial.h JacobiEigenSymT) with every rotation's
 // 3 n element updates spread over the lanes: same rotation sequence, same arithmetic per element, hence the same eigenvectors (sign
 // and order included) as the serial form the CPU oracle runs.  The matrices live in LDS (row stride 17: lanes k = 0..15 reading
 // [k][p] hit 16 banks).  Only the two reductions (Frobenius norm of the early-out, off-diagonal norm of the convergence test) are
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
         const bool iso = !allFinite || (expFlags & 32) || hnorm < 0.5f / (sigma * sigma) || !(hnorm == hnorm);  // h2mc.cpp:84-92
         bool run = has && !iso;
         __syncthreads();
-        // ---- cyclic Jacobi, dh2mc.h JacobiEigenSymT
+        // ---- cyclic Jacobi: the rotation sequence of oracle/h2mc_serial.h JacobiEigenSymT
         for (int sweep = 0; sweep < 30; sweep++) {
             float offP = 0.f, diagP = 0.f;
             if (act) {

@@ -3,9 +3,13 @@
 #include <hip/hip_runtime.h>
 
 #include "dchain.h"
-#include "dh2coop.h"
-#include "dh2mc.h"
 #include "dstep_params.h"
+
+namespace lmcd {  // the H2MC launches' types (dh2coop.h, dh2mc.h): only named here, so that the LMC kernels do not depend on those headers
+struct H2Arrays;
+struct H2Bins;
+struct H2MCParam;
+}  // namespace lmcd
 
 void LaunchSeedRng(int n, long long firstSeed, uint64_t *state, uint32_t *tab, hipStream_t s);
 void LaunchLowerBoundProbe(int n, const float *cdf, int nq, const float *u, int *out, hipStream_t s);

@@ -20,7 +20,7 @@ __device__ __forceinline__ bool H2HaveDerv(const StepParams &P, int c, int l, in
 }
 // IsotropicGaussian(dim, sigma), gaussian.cpp:4-22: what a state without a derivative program gets (mutation_h2mc.h:62,92)
 __device__ __forceinline__ float H2IsoLogDetNoDerv(int dim, float sigma) { return dim * fastlog(1.0f / (sigma * sigma)); }
-// the isotropic outcome of ComputeGaussian (h2mc.cpp:84-92) as dh2mc.h spells it: n additions of log(1 / sigma^2)
+// the isotropic outcome of ComputeGaussian (h2mc.cpp:84-92) as k_h2_gauss and the oracle spell it: n additions of log(1 / sigma^2)
 __device__ __forceinline__ float H2IsoLogDetEarlyOut(int n, float sigma) {
     const float invSigmaSq = 1.0f / (sigma * sigma);
     float logDet = 0.f;

@@ -22,6 +22,8 @@
 #include "../../../include/lmc_abi.h"
 #include "../device/drng.h"
 #include "../device/kernels.h"
+#include "../device/dh2coop.h"
+#include "../device/dh2mc.h"
 #include "accel.h"
 #include "scene.h"
 #include "shardplan.h"

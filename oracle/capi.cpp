@@ -9,7 +9,7 @@
 #include <thread>
 
 #include "mlt.h"
-#include "../langevin-mcmc_amd/csrc/device/dh2mc.h"
+#include "h2mc_serial.h"
 
 using namespace orc;
 
@@ -429,7 +429,7 @@ int orc_cache_points(void *h, int dim, float *out, int cap) {
     return n;
 }
 
-// H2MC Gaussian of one state (h2mc.cpp:70-142 through the shared header device/dh2mc.h): out = mean[dim], covL[dim*dim],
+// H2MC Gaussian of one state (h2mc.cpp:70-142 through oracle/h2mc_serial.h): out = mean[dim], covL[dim*dim],
 // invCov[dim*dim], logDet
 void orc_h2mc_gaussian(int dim, float sigma, float sc, const float *grad, const float *hess, float *out) {
     lmcd::H2MCParam p = lmcd::MakeH2MCParam(sigma);

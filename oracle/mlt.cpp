@@ -8,7 +8,7 @@
 // cache pushes of a step after the step, in chain-id order -- one legal interleaving of the reference,
 // made deterministic; it is the contract the HIP back end is compared against.
 #include "mlt.h"
-#include "../langevin-mcmc_amd/csrc/device/dh2mc.h"  // H2MC Gaussian + Jacobi eigen-solver, shared with the device (see the header)
+#include "h2mc_serial.h"  // the oracle's serial H2MC Gaussian (Jacobi eigen-solver); the device has its own 16-lane one
 
 #include <dlfcn.h>
 
