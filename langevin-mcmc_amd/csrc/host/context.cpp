@@ -112,7 +112,7 @@ struct lmc_ctx {
     bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
     bool sortH2mc = true;
     bool sortGeneric = true;   // LMC_SORT_GENERIC=0: A/B switch for the technique sort of the cache-filling launch
-    DevBuf<int> listScratch, sortBins;
+    DevBuf<int> listScratch, listScratch2, sortBins, sortBins2;
     int expFlags = 0;      // LMC_EXP_NOSPLAT / LMC_EXP_NOQUERY: measurement aids (dstep_params.h)
     hipStream_t stream = nullptr;
     // The three step launches of one iteration touch disjoint chains, so they run concurrently: large steps and the generic
@@ -861,7 +861,13 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->stepGrid = (int)std::min<size_t>((N + 255) / 256, 4096);
     c->gradStride = c->stepGrid * 256;
     if (const char *e = getenv("LMC_LEAN_BLOCK")) c->leanBlock = std::max(64, std::min(256, atoi(e) / 64 * 64));
-    if (const char *e = getenv("LMC_SORT_PLAIN")) c->sortPlain = atoi(e);  // 0 | 1 (1024-chain tiles) | 2 (256-chain tiles)
+    // Technique sort of the lean launch's work list.  On a Lambertian-only scene the lean kernel waits for its streamed chain state and scattered
+    // lanes cost more than divergence saves (sorted: -10 %, r02 / r03 A/Bs); the glossy instantiations run with 15-17 % of their lanes active and the
+    // vector ALU issuing a third of the time (profiles/r04_p_*): there grouping the WHOLE list by technique pays (full-material torus at maxdepth 12:
+    // 144 -> 153 M inside 1024-chain tiles -> 163 M over the whole list; veach-door 139 -> 144 M either way; profiles/r04_u_ab_sort_glossy.jsonl).
+    // LMC_SORT_PLAIN overrides: 0 | 1 (1024-chain tiles) | 2 (256-chain tiles) | 3 (two classes) | 4 (whole list)
+    c->sortPlain = c->S.glossy ? 4 : 0;
+    if (const char *e = getenv("LMC_SORT_PLAIN")) c->sortPlain = atoi(e);
     c->leanGrid = (int)std::min<size_t>((N + c->leanBlock - 1) / c->leanBlock, (size_t)4096 * 256 / c->leanBlock);
     c->gradBuf.Alloc(c->useGradient ? (size_t)c->gradStride * 640 : 1, false);  // V <= 238 + 59*6 = 592 words for c+l <= 9
     // global cache: dims 2L for L in [3, maxDepth], capped by PSS_MAX_LENGTH
@@ -935,6 +941,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         c->listCounts[b].Alloc(4);
     }
     c->listScratch.Alloc(N, false), c->sortBins.Alloc(((size_t)N / 2048 + 2) * 64);
+    if (c->sortPlain == 4) c->listScratch2.Alloc(N, false), c->sortBins2.Alloc(((size_t)N / 2048 + 2) * 64);
     c->parity = 0;
     // every chain begins with a forced large step (mlt.h:121: the resampled init states only feed the outlier reset)
     LaunchInitLists((int)N, c->lists[0][0].p, c->listCounts[0].p, s);
@@ -1313,7 +1320,11 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
     const int nxt = 1 - c->parity;
     NextLists next{c->lists[nxt][0].p, c->lists[nxt][1].p, c->lists[nxt][2].p, c->listCounts[nxt].p};
     if (exchanged) CacheApply(c);
-    LaunchBuildLists(c->A, next, c->sortPlain, LeanDims(c) | (c->S.opt.leanLightless ? 1u << 31 : 0u), s);
+    LaunchBuildLists(c->A, next, c->sortPlain == 4 ? 0 : c->sortPlain, LeanDims(c) | (c->S.opt.leanLightless ? 1u << 31 : 0u), s);
+    if (c->sortPlain == 4) {  // A/B: the lean list grouped by technique over the WHOLE list (a wave then retraces one technique; its lanes' state lines are anywhere)
+        LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][2].p, c->listScratch2.p, c->listCounts[nxt].p + 2, c->sortBins2.p, (int)c->N, s);
+        std::swap(c->lists[nxt][2].p, c->listScratch2.p);
+    }
     // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
     // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
     if (c->needGeneric && !c->genericTokenOnly && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
