@@ -38,11 +38,61 @@ LMC_HD int H2TechDim(int t) {  // 2 * max(c + l - 1, 2)
 // lanes one state occupies in the Hessian launch: the 2 x 2 blocks of the upper triangle of a dim x dim matrix
 LMC_HD int H2BlocksOfDim(int dim) { return (dim / 2) * (dim / 2 + 1) / 2; }
 
-// work lists of one pipeline stage: bin t = the chains whose state of technique t needs its Gaussian, items[t * N + k]
+// Work lists of one pipeline stage: a bin holds the chains whose state of ONE technique needs its Gaussian, items[bin * N + k].  A technique has
+// H2_NSIG bins, chosen by a signature of the state's materials (the BSDF type and the sampling mode of every surface vertex, hashed to three
+// bits): the three to ten states that share a wave of the Hessian launch then take the same BSDF branches as well as the same path structure
+// (lanes active per issued instruction 0.74-0.77 with one bin per technique: profiles/r04_final_h2mc_pmc_*.json).
+constexpr int H2_NSIG = 8, H2_NBINS = H2_NTECH * H2_NSIG;
 struct H2Bins {
-    int *items;  // H2_NTECH x N
-    int *count;  // H2_NTECH (+ padding to 64)
+    int *items;  // H2_NBINS x N
+    int *count;  // H2_NBINS (+ padding to a multiple of 64)
 };
+constexpr int H2_COUNT_WORDS = (H2_NBINS + 63) / 64 * 64;
+LMC_HD int H2BinIndex(int tech, unsigned sigHash) { return tech * H2_NSIG + (int)((sigHash ^ (sigHash >> 3) ^ (sigHash >> 6) ^ (sigHash >> 9) ^ (sigHash >> 12)) & (unsigned)(H2_NSIG - 1)); }
+
+#if defined(__HIPCC__)
+// The task table of a stage, built by every block for itself: a task = up to ipw(technique) consecutive items of one bin.  incl (LDS, H2_NBINS
+// words) receives the inclusive prefix of the bins' task counts; returns the total.  One wave; lane k handles the bins 6 k .. 6 k + 5.
+template <class IpwOfTech>
+__device__ __forceinline__ int H2BuildTaskTable(const int *count, int *incl, IpwOfTech ipwOfTech) {
+    constexpr int PER = (H2_NBINS + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    int tasks[PER], sum = 0;
+    for (int k = 0; k < PER; k++) {
+        const int b = lane * PER + k;
+        tasks[k] = 0;
+        if (b < H2_NBINS) {
+            const int ipw = ipwOfTech(b / H2_NSIG);
+            tasks[k] = (count[b] + ipw - 1) / ipw;
+        }
+        sum += tasks[k];
+    }
+    int inclLane = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inclLane, off);
+        if (lane >= off) inclLane += o;
+    }
+    int run = inclLane - sum;
+    for (int k = 0; k < PER; k++) {
+        const int b = lane * PER + k;
+        run += tasks[k];
+        if (b < H2_NBINS) incl[b] = run;
+    }
+    __syncthreads();
+    return __shfl(inclLane, 63);
+}
+// the bin of task w: the first bin whose inclusive prefix exceeds w (all lanes read the same words: LDS broadcasts)
+__device__ __forceinline__ int H2BinOfTask(const int *incl, int w) {
+    int lo = 0, hi = H2_NBINS - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (incl[mid] > w) hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+#endif
 
 // per-step hand-off state of the H2MC pipeline (host/context.cpp allocates it for H2MC renders only)
 enum : int { H2S_H2 = 1, H2S_DENSE = 2, H2S_OK = 4 };  // `step` bits: an H2MC (not uniform-mixing) step; dim <= 16; the re-trace carries light

@@ -8,16 +8,6 @@
 
 using namespace lmcd;
 
-namespace {
-__device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-}  // namespace
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // k_h2_gauss: ComputeGaussian(H2MCParam, ...) of /root/reference/src/h2mc.cpp:3-142 for the states of a stage, 16 lanes per state
 // (four states of one technique per wave): the symmetric eigen-decomposition (the reference calls Eigen::SelfAdjointEigenSolver --
@@ -45,21 +35,19 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
     __shared__ float lds[4 * G_LDS];
     const int lane = threadIdx.x, g = lane >> 4, k = lane & 15;
     float *A = lds + g * G_LDS, *V = A + GW, *w = V + GW, *eb = w + 16, *ob = eb + 16, *post = ob + 16, *grad = post + 16, *tmp = grad + 16;
-    int cnt = 0;
-    if (lane < H2_NTECH) cnt = bins.count[lane];
-    const int tasks = (cnt + 3) >> 2;
-    const int incl = WaveInclusiveScan(tasks, lane);
-    const int total = __shfl(incl, 63);
+    __shared__ int taskIncl[H2_NBINS];
+    const int total = H2BuildTaskTable(bins.count, taskIncl, [](int) { return 4; });
     const float sigma = param.sigma, invSigmaSq = 1.0f / (sigma * sigma);
     for (int wk = blockIdx.x; wk < total; wk += gridDim.x) {
         const int wr = total - 1 - wk;
-        const int t = __popcll(__ballot(incl <= wr));
-        const int j = wr - (__shfl(incl, t) - __shfl(tasks, t));
-        const int tCnt = __shfl(cnt, t);
+        const int bin = H2BinOfTask(taskIncl, wr);
+        const int t = bin / H2_NSIG;
+        const int j = wr - (bin ? taskIncl[bin - 1] : 0);
+        const int tCnt = bins.count[bin];
         const int n = H2TechDim(t);
         const int first = 4 * j, nItems = min(4, tCnt - first);
         const bool has = g < nItems;
-        const int item = has ? bins.items[(size_t)t * N + first + g] : 0;
+        const int item = has ? bins.items[(size_t)bin * N + first + g] : 0;
         const bool act = has && k < n;
         const float *o = hout + (size_t)item * H2_OUT_WORDS;
         // the triangle Eigen reads (h2mc.cpp:78: the program's rows as a column-major matrix, lower triangle = the UPPER triangle of the rows)

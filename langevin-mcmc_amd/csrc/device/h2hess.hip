@@ -70,14 +70,6 @@ __device__ __forceinline__ void HessBlock(int c, int l, int dim, int bi0, int bc
     }
 }
 
-__device__ __forceinline__ int WaveInclusiveScan(int v, int lane) {
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-
 }  // namespace
 
 // LDS per wave: the records of the states of one task, at most H2_HESS_LDS_WORDS floats (a task takes fewer states when they do not fit)
@@ -93,29 +85,27 @@ __global__ void __launch_bounds__(64, LMC_H2HESS_WAVES) k_h2_hess(const float *_
     const float *scene = sceneArg.v;
     __shared__ float lds[H2_HESS_LDS_WORDS];
     const int lane = threadIdx.x;
-    // tasks of bin t: ceil(count / states per wave); every wave derives the same table
-    int cnt = 0, nb = 1, ipw = 1, recW = 0;
-    if (lane < H2_NTECH) {
-        cnt = bins.count[lane];
+    // tasks of a bin: ceil(count / states per wave); every wave derives the same table (dh2coop.h)
+    __shared__ int taskIncl[H2_NBINS];
+    auto recWordsOf = [](int t) {
         int c, l;
-        H2TechOf(lane, c, l);
-        nb = H2BlocksOfDim(H2TechDim(lane));
-        recW = (H2_REC_VP + 238 + 59 * (c + l - 3) + 3) & ~3;
-        ipw = min(64 / nb, H2_HESS_LDS_WORDS / recW);
-    }
-    const int tasks = (cnt + ipw - 1) / ipw;
-    const int incl = WaveInclusiveScan(tasks, lane);
-    const int total = __shfl(incl, 63);
+        H2TechOf(t, c, l);
+        return (H2_REC_VP + 238 + 59 * (c + l - 3) + 3) & ~3;
+    };
+    auto ipwOf = [&](int t) { return min(64 / H2BlocksOfDim(H2TechDim(t)), H2_HESS_LDS_WORDS / recWordsOf(t)); };
+    const int total = H2BuildTaskTable(bins.count, taskIncl, ipwOf);
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int wr = total - 1 - w;  // longest programs first
-        const int t = __popcll(__ballot(incl <= wr));
-        const int j = wr - (__shfl(incl, t) - __shfl(tasks, t));
-        const int tIpw = __shfl(ipw, t), tNb = __shfl(nb, t), tRecW = __shfl(recW, t), tCnt = __shfl(cnt, t);
+        const int bin = H2BinOfTask(taskIncl, wr);
+        const int t = bin / H2_NSIG;
+        const int j = wr - (bin ? taskIncl[bin - 1] : 0);
+        const int tIpw = ipwOf(t), tRecW = recWordsOf(t), tCnt = bins.count[bin];
+        const int dim = H2TechDim(t);
+        const int tNb = H2BlocksOfDim(dim);
         const int first = j * tIpw, n = min(tIpw, tCnt - first);
         int c, l;
         H2TechOf(t, c, l);
-        const int dim = H2TechDim(t);
-        const int *items = bins.items + (size_t)t * N + first;
+        const int *items = bins.items + (size_t)bin * N + first;
         for (int s = 0; s < n; s++) {  // stage the records: whole lines
             const float *src = rec + (size_t)items[s] * H2_REC_WORDS;
             for (int k = lane; k < tRecW; k += 64) lds[s * tRecW + k] = src[k];

@@ -29,7 +29,7 @@ __device__ __forceinline__ float H2IsoLogDetEarlyOut(int n, float sigma) {
 }
 __device__ __forceinline__ float *H2GaussRec(const H2Arrays &H, int N, int i, bool second) { return H.gauss + (second ? (size_t)N * H2_GAUSS_AOS : 0) + (size_t)i * H2_GAUSS_AOS; }
 
-// one entry of a stage's work list: wave-aggregated (the chains of a wave are grouped by technique, so one atomic per wave is the rule)
+// one entry of a stage's work list (t = its bin): wave-aggregated (the chains of a wave are grouped by technique, so a few atomics per wave are the rule)
 __device__ __forceinline__ void H2Enqueue(const H2Bins &bins, int N, bool want, int t, int i) {
     unsigned long long todo = __ballot(want);
     const int lane = threadIdx.x & 63;
@@ -43,6 +43,18 @@ __device__ __forceinline__ void H2Enqueue(const H2Bins &bins, int N, bool want, 
         if (want && t == tl) bins.items[(size_t)tl * N + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
         todo &= ~mask;
     }
+}
+
+// what decides the BSDF branches the second-order program takes on this state: every surface vertex's material type and sampling mode
+__device__ __forceinline__ unsigned H2MaterialSignature(const DScene &S, const DPath &path) {
+#ifdef LMC_H2_NOSIG  // A/B build: one bin per technique
+    return 0;
+#endif
+    unsigned h = 0;
+    for (int d = 0; d < path.lgtCount; d++) h = h * 7u + (unsigned)MaterialOfTri(S, path.lgt[d].tri).type + (path.lgt[d].useAbs != 0.0f ? 3u : 0u) + 1u;
+    for (int d = 0; d < path.camCount; d++)
+        if (path.cam[d].tri >= 0) h = h * 7u + (unsigned)MaterialOfTri(S, path.cam[d].tri).type + (path.cam[d].useAbs != 0.0f ? 3u : 0u) + 1u;
+    return h;
 }
 
 // Serialize(scene, path, ss) (path.cpp:2497-2586) into the chain's record
@@ -95,7 +107,7 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
                         DPath path;
                         LoadPath(CurPathBuf(A, flags), N, i, path);
                         H2Serialize(S, path, H.rec + (size_t)i * H2_REC_WORDS);
-                        want = true, t = H2TechIndex(c, l);
+                        want = true, t = H2BinIndex(H2TechIndex(c, l), H2MaterialSignature(S, path));
                     } else {  // zero gradient and Hessian: the early-out of ComputeGaussian
                         G[H2_GAUSS_LOGDET] = H2IsoLogDetEarlyOut(dim, sigma), G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_EARLYOUT;
                     }
@@ -165,7 +177,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
                         if (pc.ssScore > 1e-15f) st.gradCalls++;
                         if (pc.ssScore > 1e-15f && !(P.expFlags & 16)) {
                             H2Serialize(S, prop, H.rec + (size_t)i * H2_REC_WORDS);
-                            want = true, t = H2TechIndex(prop.camDepth, prop.lgtDepth), iso = false;
+                            want = true, t = H2BinIndex(H2TechIndex(prop.camDepth, prop.lgtDepth), H2MaterialSignature(S, prop)), iso = false;
                         } else {
                             logDet = H2IsoLogDetEarlyOut(dim, sigma);
                             G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_EARLYOUT;

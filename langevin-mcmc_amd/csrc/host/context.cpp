@@ -924,11 +924,11 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         c->allCachesReady = true;
         c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)H2_OUT_WORDS), c->h2Gauss.Alloc(2 * N * (size_t)H2_GAUSS_AOS, false);
         c->h2Offset.Alloc(N * (size_t)MAXPSS), c->h2Py.Alloc(N), c->h2Px.Alloc(N), c->h2PropContrib.Alloc(N * (size_t)CONTRIB_WORDS), c->h2Step.Alloc(N), c->h2Kind.Alloc(N);
-        c->h2Items.Alloc(2 * (size_t)H2_NTECH * N, false), c->h2Counts.Alloc(2 * 64);
+        c->h2Items.Alloc(2 * (size_t)H2_NBINS * N, false), c->h2Counts.Alloc(2 * H2_COUNT_WORDS);  // 336 bins x N chain ids per stage: sized for "every chain in one bin" (2.8 GB at 2^20 chains), never compacted
         H2Arrays &H = c->H2;
         H.rec = c->h2Rec.p, H.hout = c->h2Out.p, H.gauss = c->h2Gauss.p, H.offset = c->h2Offset.p, H.py = c->h2Py.p, H.px = c->h2Px.p, H.propContrib = c->h2PropContrib.p;
         H.step = c->h2Step.p, H.kind = c->h2Kind.p;
-        for (int st = 0; st < 2; st++) H.bins[st] = H2Bins{c->h2Items.p + (size_t)st * H2_NTECH * N, c->h2Counts.p + 64 * st};
+        for (int st = 0; st < 2; st++) H.bins[st] = H2Bins{c->h2Items.p + (size_t)st * H2_NBINS * N, c->h2Counts.p + H2_COUNT_WORDS * st};
         // the Hessian launch is persistent: one wave per SIMD (its waves take the whole register file), grid-stride over the tasks
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
@@ -1238,7 +1238,7 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         const int N = (int)c->N, laneGrid = c->stepGrid * 4;
         const H2Arrays &H = c->H2;
         const lmcd::H2MCParam param = lmcd::MakeH2MCParam(c->S.opt.perturbStdDev);
-        HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * 64 * sizeof(int), sG));
+        HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * H2_COUNT_WORDS * sizeof(int), sG));
         LaunchH2Begin(c->S, c->A, P, H, list, n, laneGrid, sG);
         for (int stage = 0; stage < 2; stage++) {
             if (!(P.expFlags & 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sG);
@@ -1959,9 +1959,10 @@ int lmc_h2_hess_probe(int c, int l, int n, const float *primary, const float *sc
         memcpy(r + H2_REC_C, &c, 4), memcpy(r + H2_REC_L, &l, 4);
         memcpy(r + H2_REC_VP, vert + (size_t)i * V, V * sizeof(float));
     }
-    std::vector<int> items((size_t)H2_NTECH * n, 0), counts(64, 0);
-    for (int i = 0; i < n; i++) items[(size_t)t * n + i] = i;
-    counts[t] = n;
+    std::vector<int> items((size_t)H2_NBINS * n, 0), counts(H2_COUNT_WORDS, 0);
+    const int bin = t * H2_NSIG;
+    for (int i = 0; i < n; i++) items[(size_t)bin * n + i] = i;
+    counts[bin] = n;
     DevBuf<float> dRec, dOut;
     DevBuf<int> dItems, dCounts;
     dRec.Upload(rec.data(), rec.size()), dItems.Upload(items.data(), items.size()), dCounts.Upload(counts.data(), counts.size()), dOut.Alloc((size_t)n * H2_OUT_WORDS);
@@ -1994,9 +1995,10 @@ int lmc_h2_gauss_probe(int n, int dim, const float *grad, const float *hess, flo
         if (offset)
             for (int k = 0; k < dim; k++) off[(size_t)k * n + i] = offset[(size_t)i * dim + k];
     }
-    std::vector<int> items((size_t)H2_NTECH * n, 0), counts(64, 0);
-    for (int i = 0; i < n; i++) items[(size_t)t * n + i] = i;
-    counts[t] = n;
+    std::vector<int> items((size_t)H2_NBINS * n, 0), counts(H2_COUNT_WORDS, 0);
+    const int bin = t * H2_NSIG;
+    for (int i = 0; i < n; i++) items[(size_t)bin * n + i] = i;
+    counts[bin] = n;
     DevBuf<float> dOut, dOff, dGauss, dPx;
     DevBuf<int> dItems, dCounts, dFlags;
     dOut.Upload(out.data(), out.size()), dOff.Upload(off.data(), off.size()), dItems.Upload(items.data(), items.size()), dCounts.Upload(counts.data(), counts.size());

@@ -9,4 +9,5 @@ mkdir -p $D
 cp -u langevin-mcmc_amd/csrc/_build/*.o langevin-mcmc_amd/csrc/_build/*.d $D/
 rm -f $D/$TU.o
 make -s -f langevin-mcmc_amd/csrc/Makefile OBJ=$D OUT=$D/liblmc_hip.so CLI=$D/dpt_amd EXTRA_$TU="$FLAGS" $D/liblmc_hip.so
+rm -f $D/*.o $D/*.d   # the snapshot that travels to the GPU box is capped at 512 MiB: only the library stays
 ls -la $D/liblmc_hip.so
