@@ -1,4 +1,4 @@
-// Shared layout of the wave-cooperative H2MC pipeline (h2hess.hip, step_small_h2mc.hip, host/context.cpp).
+// Shared layout of the wave-cooperative H2MC pipeline (h2hess.hip, h2gauss.hip, step_h2_phases.hip, host/context.cpp).
 // An H2MC small step (H2MCSmallStep::Mutate, /root/reference/src/mutation_h2mc.h:38-128) is run as a short pipeline of launches
 // instead of one thread per chain: the lane-per-chain parts (draws, path perturbation, accept / reject) stay lane-per-chain, the
 // second-order path program runs with the lanes of a wave = the 2 x 2 Hessian blocks of ONE state (h2hess.hip k_h2_hess), the

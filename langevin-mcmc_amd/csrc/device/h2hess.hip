@@ -2,9 +2,10 @@
 // generator /root/reference/src/path.cpp:3419-3662, chad.cpp:333-544; caller mutation_h2mc.h:60-93), WAVE-COOPERATIVE:
 // the lanes of a wave are the 2 x 2 blocks of the Hessian triangle of a few states of ONE technique (c,l) -- dim 12: 21 lanes per
 // state, three states per wave -- instead of one lane walking all 21 passes of its own chain's state one after the other
-// (round 3: dh2step.h, 4 M chain-steps/s).  All lanes of a state walk the same path: same branches, the state's serialised
-// record is staged in LDS once per wave and read by broadcast, a lane holds ONE pass (values of 9 floats, seeded on the fly: no
-// indexable array of second-order values, hence no private memory for it).
+// (round 3: one lane per chain, 4 M chain-steps/s).  All lanes of a state walk the same path: same branches, the state's serialised
+// record is staged in LDS once per wave and read by broadcast; a lane evaluates its block in two passes of 6-float values (four of
+// 4-float values for the techniques with both sub-paths), seeded on the fly: no indexable array of second-order values, hence no private
+// memory for it.  A wave's states also share a material signature (the stage's bins, dh2coop.h), so they take the same BSDF branches.
 #define LMC_PF_CONTRACT  // the dual-number arithmetic of this translation unit may fuse a * b + c (pathfunc.h)
 #ifndef LMC_H2HESS_EXACT_MATH
 #define LMC_PF_FASTMATH  // ... and sin / cos / exp / log / pow are the hardware's approximate instructions
