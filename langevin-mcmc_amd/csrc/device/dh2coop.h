@@ -108,4 +108,17 @@ struct H2Arrays {
     H2Bins bins[2];       // stage 0: current states without a Gaussian; stage 1: proposals
 };
 
+// ---- the same pipeline shape for the gradient steps of the LMC cache-fill phase (step_mala_phases.hip, gradcoop.hip): MALASmallStep::Mutate
+// (mutation_mala.h:38-290) cut at its two gradient evaluations; records, bins and task table as above, per chain a gradient instead of a Hessian
+constexpr int MG_OUT_WORDS = 32, MG_OUT_LOGLUM = 16;  // gout [i * MG_OUT_WORDS ..]: [0,16) gradient | [16] logLum
+enum : int { MS_MALA = 1, MS_OK = 2, MS_GRAD_CUR = 4, MS_GRAD_PROP = 8 };  // `step` bits: a MALA (not uniform-mixing) step; the re-trace carries light; a stage evaluated the state's gradient
+struct MalaPipe {
+    float *rec, *gout;   // AoS, H2_REC_WORDS / MG_OUT_WORDS per chain
+    float *offset;       // MAXPSS x N (SoA): the step's normal draws z, replaced by the proposal offset
+    float *py;           // N: log density of the offset under the current Gaussian
+    float *propContrib;  // 9 x N: the proposal's SubpathContrib
+    int *step;           // N: MS_* bits
+    H2Bins bins[2];      // stage 0: current states without a Gaussian; stage 1: proposals
+};
+
 }  // namespace lmcd

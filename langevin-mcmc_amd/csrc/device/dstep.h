@@ -40,11 +40,12 @@ LMC_D void StoreGauss(const ChainArrays &A, int i, int dim, int flags, const Gau
 }
 
 // The twin blocks of MALASmallStep::Mutate (mutation_mala.h:83-166 current, :174-260 proposal).
+// gradIn: the state's gradient where the step is run as a pipeline of launches (step_mala_phases.hip), else it is evaluated here.
 // Persistent Chain vectors (mutation.h:28-43) live in HBM: v1, v2, curr_new_v2, prop_new_v1, prop_new_v2, pss,
 // last_pss (g / curr_new_v1 / curr_new_g / prop_new_g / M are write-only or recomputed in the reference).
 template <bool WITH_GRAD>
 LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, const DPath &path,
-                           const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st) {
+                           const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st, const float *gradIn = nullptr) {
     const size_t N = A.N;
     const int dim = PathDimension(path.camDepth, path.lgtDepth);
     float pss[MAXPSS];
@@ -67,7 +68,9 @@ LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArra
         if (sp.ssScore > 1e-10f) {
             // chains are only dispatched to a launch without the gradient code once the cache of their dim is
             // ready (NeedsGradient below), so this branch is unreachable there; NaN -> zeroed keeps it defined
-            if (WITH_GRAD && !(P.expFlags & 4)) ComputeGradient(S, path, sp, vGrad, gw);
+            if (gradIn) {  // evaluated by the launch in front of this one (step_mala_phases.hip, gradcoop.hip)
+                for (int k = 0; k < dim; k++) vGrad[k] = gradIn[k];
+            } else if (WITH_GRAD && !(P.expFlags & 4)) ComputeGradient(S, path, sp, vGrad, gw);
             else
                 for (int k = 0; k < dim; k++) vGrad[k] = NAN;
             st.gradCalls++;

@@ -160,6 +160,9 @@ struct lmc_ctx {
     DevBuf<unsigned char> h2Kind;
     H2Arrays H2{};
     int h2HessGrid = 0, h2GaussGrid = 0;
+    // LMC renders with gradients: the cache-filling small steps as a pipeline (dh2coop.h MalaPipe; the buffers above, sized for it); LMC_MALA_PIPE=0: one launch
+    bool malaPipe = true;
+    MalaPipe MP{};
     int gradStride = 0, stepGrid = 0;
     // launch shape of the lean small-step kernel and the technique sort of its work list; LMC_LEAN_BLOCK / LMC_SORT_PLAIN
     // override them for A/B runs (profiles/)
@@ -423,6 +426,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_LARGE_BLOCK")) c->largeBlock = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
+    if (const char *e = getenv("LMC_MALA_PIPE")) c->malaPipe = atoi(e) != 0;
     if (const char *e = getenv("LMC_SORT_H2MC")) c->sortH2mc = atoi(e) != 0;
     if (const char *e = getenv("LMC_SORT_GENERIC")) c->sortGeneric = atoi(e) != 0;
     if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
@@ -936,6 +940,20 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         if (const char *e = getenv("LMC_H2_HESS_GRID")) c->h2HessGrid = std::max(1, atoi(e));
         c->h2GaussGrid = prop.multiProcessorCount * 16;
     }
+    if (c->S.opt.mala && !c->S.opt.h2mc && c->useGradient && c->malaPipe && !c->S.opt.sampleCache) {
+        c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)MG_OUT_WORDS);
+        c->h2Offset.Alloc(N * (size_t)MAXPSS), c->h2Py.Alloc(N), c->h2PropContrib.Alloc(N * (size_t)CONTRIB_WORDS), c->h2Step.Alloc(N);
+        c->h2Items.Alloc(2 * (size_t)H2_NBINS * N, false), c->h2Counts.Alloc(2 * H2_COUNT_WORDS);
+        MalaPipe &M = c->MP;
+        M.rec = c->h2Rec.p, M.gout = c->h2Out.p, M.offset = c->h2Offset.p, M.py = c->h2Py.p, M.propContrib = c->h2PropContrib.p, M.step = c->h2Step.p;
+        for (int st = 0; st < 2; st++) M.bins[st] = H2Bins{c->h2Items.p + (size_t)st * H2_NBINS * N, c->h2Counts.p + H2_COUNT_WORDS * st};
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
+        c->h2HessGrid = prop.multiProcessorCount * 4;  // persistent, grid-stride over the tasks
+        if (const char *e = getenv("LMC_MALA_GRAD_GRID")) c->h2HessGrid = std::max(1, atoi(e));
+    } else {
+        c->MP = MalaPipe{};
+    }
     for (int b = 0; b < 2; b++) {
         for (int k = 0; k < 3; k++) c->lists[b][k].Alloc(N, false);
         c->listCounts[b].Alloc(4);
@@ -1249,6 +1267,18 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
             }
         }
         LaunchH2Finish(c->S, c->cacheDev.p, c->A, film, P, H, list, n, laneGrid, sG);
+    } else if (c->needGeneric && c->MP.rec && !c->allCachesReady && !c->S.opt.useLightCoord) {
+        // while a cache fills: the gradient steps as a pipeline, the path program wave-cooperative between lane-per-chain phases
+        const int *list = c->lists[cur][1].p, *n = cnt + 1;
+        static const int laneGridEnv = getenv("LMC_MALA_LANE_GRID") ? atoi(getenv("LMC_MALA_LANE_GRID")) : 0;
+        const int N = (int)c->N, laneGrid = laneGridEnv > 0 ? std::min(laneGridEnv, c->stepGrid * 4) : c->stepGrid * 4;
+        const MalaPipe &M = c->MP;
+        HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * H2_COUNT_WORDS * sizeof(int), sG));
+        LaunchMalaBegin(c->S, c->cacheDev.p, c->A, P, M, list, n, laneGrid, sG);
+        LaunchMalaGrad(M.rec, M.bins[0], N, c->S.sceneParams, M.gout, c->h2HessGrid, sG);
+        LaunchMalaMid(c->S, c->cacheDev.p, c->A, P, M, list, n, c->bvhDepth, c->S.glossy != 0, laneGrid, sG);
+        LaunchMalaGrad(M.rec, M.bins[1], N, c->S.sceneParams, M.gout, c->h2HessGrid, sG);
+        LaunchMalaFinish(c->S, c->cacheDev.p, c->A, film, P, M, list, n, laneGrid, sG);
     } else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
         LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->genericTokenOnly ? 64 : c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
