@@ -938,6 +938,37 @@ def test_lean_launch_without_light_subpaths_and_its_fallback():
     assert np.allclose(img0, img2, rtol=1e-4, atol=1e-6) and img0.sum() > 0
 
 
+def test_cache_fill_pipeline_equals_the_single_launch_form():
+    """While a dimension's cache fills, the gradient small steps run as a pipeline of launches (step_mala_phases.hip) with the path
+    program evaluated wave-cooperatively in between (gradcoop.hip, lanes = the Dual<2> passes of a state).  LMC_MALA_PIPE=0 keeps the
+    former form -- one launch, one lane per chain, the program in a non-inlined function (step_small_leangrad.hip) -- whose arithmetic
+    is the same (forward-mode components never mix; strict rounding on both sides): the two runs must agree state by state through the
+    whole fill phase and beyond it: same counters, same final states, films equal up to the order of the float atomics.  Full materials
+    (Phong + rough dielectric) and maxdepth 8, 65536 chains x 48 mutations: the caches of the short dims fill inside the run."""
+    p = gc.pkg()
+    out = {}
+    old = os.environ.get("LMC_MALA_PIPE")
+    try:
+        for mode in ("0", "1"):
+            os.environ["LMC_MALA_PIPE"] = mode
+            ren = p.Renderer(gc.TORUS, force_diffuse=0, max_depth=8, width=160, height=120, seed_offset=0, use_gradient=1)
+            ren.init_chains(1 << 19, 1 << 16, 16384, 48)
+            ren.step(48)
+            out[mode] = (ren.stats(), ren.summary(0), ren.film())
+            ren.close()
+    finally:
+        if old is None:
+            os.environ.pop("LMC_MALA_PIPE", None)
+        else:
+            os.environ["LMC_MALA_PIPE"] = old
+    (s0, f0, img0), (s1, f1, img1) = out["0"], out["1"]
+    assert s0["gradCalls"] > 20000 and s0["cacheHits"] > 0  # both phases were run: gradients, then cache look-ups
+    for k in ("steps", "largeSteps", "accepted", "gradCalls", "cacheQueries", "cacheHits", "resets"):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+    assert np.array_equal(f0, f1)
+    assert np.allclose(img0, img1, rtol=1e-4, atol=1e-6) and img0.sum() > 0
+
+
 def test_multiplexed_render_converges_to_plain_monte_carlo():
     """No reference binary can run here, so the multiplexed large step (`largestepmultiplexed`) is also checked against something
     that does not share its code: the plain Monte Carlo bidirectional estimate of the same image (lmc_bidir_mc, path length >= 3).
