@@ -88,9 +88,10 @@ void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *
 void LaunchBuildLists(const lmcd::ChainArrays &A, const lmcd::NextLists &next, int sortPlain, unsigned leanDims, hipStream_t s);
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s);
 // pending global-cache pushes of the step just run, all dims in one pass, chain-id order; tileCounts: one word per 1024 chains
-void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s);
+void LaunchCachePush(const lmcd::ChainArrays &A, const lmcd::CachePushTargets &T, unsigned long long *tileCounts, int *stageCounts /* zeroed first */, hipStream_t s);
 // multi-rank push: append the gathered stages of all ranks (rank order) to the cache rows; see kernels.hip k_push_apply
-void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, const lmcd::PushStageLayout &lay, const lmcd::CachePushTargets &T, hipStream_t s);
+void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, const lmcd::PushStageLayout &lay, const lmcd::CachePushTargets &T,
+                          int *hostCounts /* pinned; nullptr: the fill counts stay on the device */, hipStream_t s);
 // measurement aid: state-layout probe (kernels.hip k_layout_probe)
 void LaunchLayoutProbe(int N, int words, int mode, int batch, const float *in, float *out, hipStream_t s);
 // groups the entries of a work list by the technique key of A.nextKind (blockHist: 64 ints per 2048 entries of the longest list)

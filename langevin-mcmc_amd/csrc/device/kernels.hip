@@ -526,57 +526,51 @@ __global__ void k_init_lists(int n, int *large, int *counts) {
 // Counts of the four slots travel packed 4 x 16 bit (a tile holds 1024 chains, so a field never overflows).
 LMC_D unsigned long long PushKey(int dim) { return (dim >= 6 && dim <= PSS_MAX_LENGTH && !(dim & 1)) ? 1ull << (16 * ((dim - 6) >> 1)) : 0ull; }
 
-__global__ void __launch_bounds__(256) k_push_count(ChainArrays A, unsigned long long *tileCounts) {
-    __shared__ unsigned long long sTotal;
-    if (threadIdx.x == 0) sTotal = 0;
-    __syncthreads();
-    const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
+// One WAVE per tile (64 threads x 16 chains): the pack runs beside the small-step launches, whose waves hold every SIMD's registers -- a
+// one-wave block takes the first slot that frees up, a four-wave block waited for four at once, i.e. for the tail of the hot launch
+// (0.9 ms for k_push_count, profiles/r04_r_*).  Block 0 also zeroes the stage's row counts (no separate fill launch, same reason).
+constexpr int PUSH_PER = 16;  // chains per thread: a tile = 64 * PUSH_PER = 1024 chains
+__global__ void __launch_bounds__(64) k_push_count(ChainArrays A, unsigned long long *tileCounts, int *stageCounts) {
+    if (stageCounts && blockIdx.x == 0 && threadIdx.x < 16) stageCounts[threadIdx.x] = 0;
+    const int first = (blockIdx.x * 64 + threadIdx.x) * PUSH_PER;
     unsigned long long mine = 0;
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < PUSH_PER; j++)
         if (first + j < A.N) mine += PushKey(A.pushDim[first + j]);
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sTotal, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) tileCounts[blockIdx.x] = sTotal;
+    if (threadIdx.x == 0) tileCounts[blockIdx.x] = mine;
 }
 
-__global__ void __launch_bounds__(256) k_push_scatter(ChainArrays A, const unsigned long long *tileCounts, CachePushTargets T) {
-    __shared__ unsigned long long sWave[4];
+__global__ void __launch_bounds__(64) k_push_scatter(ChainArrays A, const unsigned long long *tileCounts, CachePushTargets T) {
     if (tileCounts[blockIdx.x] == 0) return;  // nothing to push in this tile (the common case once the caches fill up)
     // pushes of all lower tiles; a lower tile's field can exceed 16 bits only in the sum, so widen while adding
     unsigned long long lo = 0, hi = 0;  // slots 0,1 (32 bit each) | slots 2,3
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) {
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) {
         const unsigned long long v = tileCounts[b];
         lo += (v & 0xffffull) | (((v >> 16) & 0xffffull) << 32);
         hi += ((v >> 32) & 0xffffull) | (((v >> 48) & 0xffffull) << 32);
     }
     for (int off = 32; off > 0; off >>= 1) lo += __shfl_down(lo, off), hi += __shfl_down(hi, off);
-    __shared__ unsigned long long sLo, sHi;
-    if (threadIdx.x == 0) sLo = 0, sHi = 0;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sLo, lo), atomicAdd(&sHi, hi);
-    const int first = (blockIdx.x * 256 + threadIdx.x) * 4;
-    int dims[4] = {0, 0, 0, 0};
+    const unsigned long long sLo = __shfl(lo, 0), sHi = __shfl(hi, 0);
+    const int first = (blockIdx.x * 64 + threadIdx.x) * PUSH_PER;
+    int dims[PUSH_PER];
     unsigned long long mine = 0;
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < PUSH_PER; j++) {
+        dims[j] = 0;
         if (first + j < A.N) {
             dims[j] = A.pushDim[first + j];
             if (!PushKey(dims[j])) dims[j] = 0;
             mine += PushKey(dims[j]);
         }
+    }
     unsigned long long incl = mine;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned long long o = __shfl_up(incl, off);
         if (lane >= off) incl += o;
     }
-    if (lane == 63) sWave[wave] = incl;
-    __syncthreads();
-    unsigned long long before = 0;
-    for (int w = 0; w < wave; w++) before += sWave[w];
-    const unsigned long long excl = before + incl - mine;
+    const unsigned long long excl = incl - mine;
     const size_t N = A.N;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < PUSH_PER; j++) {
         const int dim = dims[j];
         if (!dim) continue;
         const int slot = (dim - 6) >> 1;
@@ -602,19 +596,15 @@ __global__ void __launch_bounds__(256) k_push_scatter(ChainArrays A, const unsig
     }
 }
 
-__global__ void __launch_bounds__(256) k_push_finish(const unsigned long long *tileCounts, int nTiles, CachePushTargets T) {
-    __shared__ unsigned long long sLo, sHi;
-    if (threadIdx.x == 0) sLo = 0, sHi = 0;
-    __syncthreads();
+__global__ void __launch_bounds__(64) k_push_finish(const unsigned long long *tileCounts, int nTiles, CachePushTargets T) {
     unsigned long long lo = 0, hi = 0;
-    for (int b = threadIdx.x; b < nTiles; b += 256) {
+    for (int b = threadIdx.x; b < nTiles; b += 64) {
         const unsigned long long v = tileCounts[b];
         lo += (v & 0xffffull) | (((v >> 16) & 0xffffull) << 32);
         hi += ((v >> 32) & 0xffffull) | (((v >> 48) & 0xffffull) << 32);
     }
     for (int off = 32; off > 0; off >>= 1) lo += __shfl_down(lo, off), hi += __shfl_down(hi, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sLo, lo), atomicAdd(&sHi, hi);
-    __syncthreads();
+    const unsigned long long sLo = __shfl(lo, 0), sHi = __shfl(hi, 0);
     if (threadIdx.x < CACHE_SLOTS) {
         const int slot = threadIdx.x;
         const long long add = slot == 0 ? (long long)(sLo & 0xffffffffull) : slot == 1 ? (long long)(sLo >> 32) : slot == 2 ? (long long)(sHi & 0xffffffffull) : (long long)(sHi >> 32);
@@ -628,7 +618,7 @@ __global__ void __launch_bounds__(256) k_push_finish(const unsigned long long *t
 // every rank appends the gathered rows in rank order = global chain-id order.  All ranks therefore hold the same cache at every step
 // -- the cache a single rank with all the chains would hold -- and an N-rank render follows the one-rank trajectories.
 // One block per (slot, rank); a rank's rows land behind the cache's rows and the rows of the lower ranks, cut at PSS_MAX_SIZE.
-__global__ void __launch_bounds__(256) k_push_apply(const float *gathered, size_t stageFloats, int world, PushStageLayout lay, CachePushTargets T) {
+__global__ void __launch_bounds__(64) k_push_apply(const float *gathered, size_t stageFloats, int world, PushStageLayout lay, CachePushTargets T) {
     const int slot = blockIdx.x, r = blockIdx.y;
     if (!T.pss[slot]) return;
     const int dim = 6 + 2 * slot;
@@ -649,12 +639,18 @@ __global__ void __launch_bounds__(256) k_push_apply(const float *gathered, size_
         for (size_t e = threadIdx.x; e < (size_t)take * CACHE_ROW_EXTRA; e += blockDim.x) T.extra[slot][(size_t)base * CACHE_ROW_EXTRA + e] = x[e];
     }
 }
-__global__ void k_push_apply_finish(const float *gathered, size_t stageFloats, int world, CachePushTargets T) {
+// hostCounts: the pinned mirror of the fill counts, written from here (no copy launch behind this one; visible to the host once the
+// event recorded behind the launch has completed)
+__global__ void k_push_apply_finish(const float *gathered, size_t stageFloats, int world, CachePushTargets T, int *hostCounts) {
     const int slot = threadIdx.x;
     if (slot >= CACHE_SLOTS) return;
     long long n = T.count[slot];
     for (int q = 0; q < world; q++) n += reinterpret_cast<const int *>(gathered + (size_t)q * stageFloats)[slot];
     T.count[slot] = (int)(n < PSS_MAX_SIZE ? n : PSS_MAX_SIZE);
+    if (hostCounts) {
+        hostCounts[slot] = T.count[slot];
+        __threadfence_system();
+    }
 }
 
 }  // namespace lmcd
@@ -844,16 +840,16 @@ void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *s
     hipLaunchKernelGGL(k_grid_scatter, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, start, cursor, rows);
 }
 
-void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned long long *tileCounts, hipStream_t s) {
+void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned long long *tileCounts, int *stageCounts, hipStream_t s) {
     const int nTiles = (A.N + 1023) / 1024;
-    hipLaunchKernelGGL(k_push_count, dim3(nTiles), dim3(256), 0, s, A, tileCounts);
-    hipLaunchKernelGGL(k_push_scatter, dim3(nTiles), dim3(256), 0, s, A, tileCounts, T);
-    hipLaunchKernelGGL(k_push_finish, dim3(1), dim3(256), 0, s, tileCounts, nTiles, T);
+    hipLaunchKernelGGL(k_push_count, dim3(nTiles), dim3(64), 0, s, A, tileCounts, stageCounts);
+    hipLaunchKernelGGL(k_push_scatter, dim3(nTiles), dim3(64), 0, s, A, tileCounts, T);
+    hipLaunchKernelGGL(k_push_finish, dim3(1), dim3(64), 0, s, tileCounts, nTiles, T);
 }
 
-void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, const PushStageLayout &lay, const CachePushTargets &T, hipStream_t s) {
-    hipLaunchKernelGGL(k_push_apply, dim3(CACHE_SLOTS, world), dim3(256), 0, s, gathered, stageFloats, world, lay, T);
-    hipLaunchKernelGGL(k_push_apply_finish, dim3(1), dim3(64), 0, s, gathered, stageFloats, world, T);
+void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, const PushStageLayout &lay, const CachePushTargets &T, int *hostCounts, hipStream_t s) {
+    hipLaunchKernelGGL(k_push_apply, dim3(CACHE_SLOTS, world), dim3(64), 0, s, gathered, stageFloats, world, lay, T);
+    hipLaunchKernelGGL(k_push_apply_finish, dim3(1), dim3(64), 0, s, gathered, stageFloats, world, T, hostCounts);
 }
 
 void LaunchTransProbe(int n, int mode, const float *x, const float *y, float *o, hipStream_t s) {
