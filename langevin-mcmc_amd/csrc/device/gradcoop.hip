@@ -40,7 +40,7 @@ __device__ __forceinline__ void GradPass(int c, int l, int b0, const float *base
 
 // 17 KB of records per wave: 13 states of dim 6 (314 words + pad), 8 of dim 12 (491).  Not more: with the task table a block stays under
 // 20 KB, so two of its waves fit a SIMD -- and one fits BESIDE a resident wave of the hot launch (256 registers, 14 KB); compiled for one wave
-// per SIMD (406 registers) the launch waited for a SIMD to drain, i.e. for the end of the hot launch (profiles/r04_l_*)
+// per SIMD (406 registers) the launch waited for a SIMD to drain, i.e. for the end of the hot launch (profiles/r04_fill_l_*)
 constexpr int MG_LDS_WORDS = 4352;
 
 struct SceneBlock38G {  // the serialised scene block (scene.cpp:164-169) as a kernel argument: uniform, read with scalar loads

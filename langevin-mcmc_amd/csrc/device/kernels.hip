@@ -528,7 +528,7 @@ LMC_D unsigned long long PushKey(int dim) { return (dim >= 6 && dim <= PSS_MAX_L
 
 // One WAVE per tile (64 threads x 16 chains): the pack runs beside the small-step launches, whose waves hold every SIMD's registers -- a
 // one-wave block takes the first slot that frees up, a four-wave block waited for four at once, i.e. for the tail of the hot launch
-// (0.9 ms for k_push_count, profiles/r04_r_*).  Block 0 also zeroes the stage's row counts (no separate fill launch, same reason).
+// (0.9 ms for k_push_count, profiles/r04_fill_r_*).  Block 0 also zeroes the stage's row counts (no separate fill launch, same reason).
 constexpr int PUSH_PER = 16;  // chains per thread: a tile = 64 * PUSH_PER = 1024 chains
 __global__ void __launch_bounds__(64) k_push_count(ChainArrays A, unsigned long long *tileCounts, int *stageCounts) {
     if (stageCounts && blockIdx.x == 0 && threadIdx.x < 16) stageCounts[threadIdx.x] = 0;

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cach
         A.rngState[i] = rng.state;
     }
     // the stages' bin counts are zero again for the next step (both stages have been consumed: this launch is queued behind them).  No fill
-    // launch in front of k_mala_begin: queued beside the hot launch, that small launch waited 0.25 ms for a slot (profiles/r04_s_*)
+    // launch in front of k_mala_begin: queued beside the hot launch, that small launch waited 0.25 ms for a slot (profiles/r04_fill_s_*)
     if (blockIdx.x == 0)
         for (int k = threadIdx.x; k < H2_COUNT_WORDS; k += blockDim.x) M.bins[0].count[k] = 0, M.bins[1].count[k] = 0;
     __shared__ int sStats[9];

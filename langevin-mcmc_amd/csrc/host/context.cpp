@@ -1146,7 +1146,7 @@ static void CachePack(lmc_ctx *c, hipStream_t s) {
 // The device half of the apply, on stream s: the rows appended, and -- only when a pending dim can have reached PSS_MAX_SIZE -- the fill
 // counts on their way to the host (countsEvent).  A single rank queues it behind its pack on the large-step stream: the rows of a dim that is
 // not ready have no reader among the step's kernels, and the host then learns the counts long before the hot launch ends -- in all the steps
-// in which no dim became ready it never waits for the step (0.15 ms per step of the fill phase at 2^20 chains, profiles/r04_o_*).
+// in which no dim became ready it never waits for the step (0.15 ms per step of the fill phase at 2^20 chains, profiles/r04_fill_o_*).
 static void CacheApplyLaunch(lmc_ctx *c, hipStream_t s) {
     const float *gathered = c->world > 1 ? c->pushGather.p : c->pushStage.p;
     // The fill counts are sent to the host (which has to know at the end of the step whether a dim became ready) only when a pending dim can
@@ -1415,7 +1415,7 @@ static void WarmStepLaunches(lmc_ctx *c) {
     const int *cnt = c->warmCounts.p;
     LaunchLarge(c, film, P, 0, cnt, next, sL);
     LaunchGeneric(c, film, P, 0, cnt, next, sG);
-    if (c->MP.rec && !c->allCachesReady) {  // ... and the launch that takes the generic slot once the caches are ready (first launched in the step after the fill phase: 1.2 ms, profiles/r04_s_*)
+    if (c->MP.rec && !c->allCachesReady) {  // ... and the launch that takes the generic slot once the caches are ready (first launched in the step after the fill phase: 1.2 ms, profiles/r04_fill_s_*)
         c->allCachesReady = true;
         LaunchGeneric(c, film, P, 0, cnt, next, sG);
         c->allCachesReady = false;

@@ -20,6 +20,10 @@ timeout 1500 bash scripts/pmc_passes.sh "$OUT/pmc" --no-rmse --no-configs > "$OU
 rm -rf "$OUT"/pmc/pass*/ "$OUT"/pmc/calib_*/   # keep the summaries, drop the raw csv trees
 LMC_PROF=1 timeout 300 python scripts/lean_region_profile.py > "$OUT/lean_regions.json" 2>/dev/null
 timeout 300 python scripts/step_trace.py 30 > "$OUT/step_trace.jsonl" 2>/dev/null
+# the fill phase launch by launch: per-step durations of the first 30 steps of the headline workload and the timeline of step 12
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kfill && cd "$ROOT" && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/kfill -- python scripts/run_one_config.py torus6 2 > /dev/null 2>&1
+  python scripts/step_durations.py /tmp/kfill 1 30 > "$OUT/step_durations_fill_phase.txt" 2>&1
+  python scripts/kernel_trace_summary.py /tmp/kfill 8 12 | grep -A30 ^step >> "$OUT/step_durations_fill_phase.txt" 2>&1 )
 # H2MC (BASELINE.json configs[4]): rates, per-kernel counters and the step's timeline on both shipped scenes at 2^20 chains
 timeout 600 python scripts/h2mc_rates.py both 20 16 40 > "$OUT/h2mc_rates.jsonl" 2>/dev/null
 for sc in door torus; do
