@@ -129,6 +129,11 @@ int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);
  * mutation_large.h:87-116), and after an outlier reset (mlt.cpp:151-158) onto an init state that lives on another rank of the job only those
  * are copied -- the path words (time, pss, screen) of such a row are the previous state's. */
 int lmc_chain_summary(lmc_ctx *ctx, int which, float *out, int stride);
+/* chain relocation (device/relocate.hip; no counterpart in the reference, whose chains are objects a thread walks, mlt.cpp:60-196): once every
+ * gradient cache is ready the resident chains are kept physically grouped by technique (c,l).  Invisible in every result except the order of
+ * the film's atomics; lmc_chain_summary reports rows in chain order regardless.
+ * out4 = [relocations run, chains moved by the last one, adjacent slot pairs whose chains differ in technique key, slots]; -1 when off */
+int lmc_relocation_stats(lmc_ctx *ctx, long long *out4);
 /* kernel time (ms, HIP events on the launch stream) and launch count of the chain-step kernel since the last call */
 int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);
 /* split of the interval the last lmc_step_timing call covered: out3[0] = ms inside the lean small-step kernel

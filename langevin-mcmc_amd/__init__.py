@@ -57,6 +57,7 @@ def lib():
         L.lmc_stats.argtypes = [vp, vp, vp]
         L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.lmc_step_timing.argtypes = [vp, vp, vp]
+        L.lmc_relocation_stats.argtypes = [vp, vp]
         L.lmc_kernel_timing.argtypes = [vp, vp]
         L.lmc_kernel_timing_split.argtypes = [vp, vp]
         L.lmc_get_option.argtypes = [vp, ctypes.c_char_p, vp]
@@ -197,6 +198,16 @@ class Renderer:
         d = dict(zip(keys, list(s)))
         d["weightSum"] = w.value
         return d
+
+    def relocation_stats(self):
+        """None when chain relocation is off; else relocations run, chains moved by the last one, technique breaks between adjacent slots, slots"""
+        o = (c_ll * 4)()
+        r = lib().lmc_relocation_stats(self.h, o)
+        if r == -1:
+            return None
+        if r != 0:
+            raise RuntimeError(_err())
+        return dict(relocations=o[0], moved=o[1], breaks=o[2], slots=o[3])
 
     def summary(self, which=0):
         n = self.num_chains  # which = 0: current states, 1: init states -- of this rank's chains

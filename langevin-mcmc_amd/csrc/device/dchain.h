@@ -125,6 +125,9 @@ struct ChainArrays {
     float *chPath, *chContrib;  // `samplecache` only (else nullptr): chain.path / chain.spContrib of mutation_mala.h:90-91,185-186, DPATH_WORDS / CONTRIB_WORDS x N
     int *adjacentReject, *sampleIdx, *numSamples;
     float *contribList;  // MAXCONTRIB*CONTRIB_WORDS x N (GeneratePathBidir scratch)
+    int *slotOf;         // N, or nullptr = the identity: the inverse of chainId (the cache pushes are packed in chain order, kernels.hip k_push_*)
+    int *chainId;        // N, or nullptr = the identity: the (rank-local) id of the chain that lives in a slot, once chains are relocated (relocate.hip)
+    unsigned char *stepKind;  // N, or nullptr: the launch (NEXT_*) that runs the chain's CURRENT step, recorded by k_build_lists for the relocation
     unsigned char *nextKind;  // N: which launch runs the chain's next step (NEXT_*), turned into id-ordered work lists by k_build_lists
     int *pushDim;        // N: dim of a pending global-cache push (0 = none)
     float *pushData;     // (3*MAXPSS+1) x N: pss, v1, v2, weight snapshot for the push
@@ -139,6 +142,13 @@ struct ChainArrays {
     double *weightSum;
 };
 
+// Technique key of a state (c,l), 6 bits: path length first, then the light-subpath length.  Work lists (dstep.h QueueNext, kernels.hip)
+// and the relocation of chains (relocate.hip) group by it.
+LMC_HD unsigned char TechniqueKey(int c, int l) {
+    const int L = c + l - 1 > 3 ? c + l - 1 : 3;
+    const int k = (L - 3) * 6 + (l < 5 ? l : 5);
+    return (unsigned char)(k < 63 ? k : 63);
+}
 LMC_D void LoadWords(const float *base, int N, int i, float *dst, int n) {
     for (int w = 0; w < n; w++) dst[w] = base[(size_t)w * N + i];
 }
@@ -198,7 +208,7 @@ LMC_D void ClearBuffered(const ChainArrays &A, int i, int &flags) {
 // and the score of the job-wide tables are copied and the path words stay as they are.
 LMC_D void ResetToInitState(const ChainArrays &A, int chainBegin, int numChainsTotal, float threshold, int i, int sampleIdx, float *curPathBuf) {
     const size_t N = A.N;
-    int chainId = chainBegin + i, cnt = 0;
+    int chainId = chainBegin + (A.chainId ? A.chainId[i] : i), cnt = 0;  // i is the slot; the walk starts at the chain's own id
     for (;;) {
         if (A.initLsAll[chainId] < threshold) break;
         chainId = (int)(((long long)chainId + sampleIdx + cnt++) % numChainsTotal);

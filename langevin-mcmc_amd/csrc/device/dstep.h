@@ -168,11 +168,7 @@ LMC_D bool NeedsGeneric(const DCache &cache, const StepParams &P, int camDepth, 
 // k_build_lists groups the plain entries of every 1024-chain tile by this key so that the 64 chains of a wave retrace the
 // same technique (c,l): same number of rays, same terminal strategy, same code path.  Path length first, then the
 // light-subpath length.
-LMC_D unsigned char TechniqueKey(int c, int l) {
-    const int L = max(c + l - 1, 3);
-    const int k = (L - 3) * 6 + min(l, 5);
-    return (unsigned char)min(k, 63);
-}
+// (TechniqueKey itself: dchain.h)
 // End of a step: decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between, so the RNG order is the
 // reference's) and publish it for k_build_lists.
 LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, Rng &rng) {

@@ -96,5 +96,20 @@ void LaunchCachePushApply(const float *gathered, size_t stageFloats, int world, 
 void LaunchLayoutProbe(int N, int words, int mode, int batch, const float *in, float *out, hipStream_t s);
 // groups the entries of a work list by the technique key of A.nextKind (blockHist: 64 ints per 2048 entries of the longest list)
 void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *out, const int *count, int *blockHist, int maxEntries, hipStream_t s);
+// inclusive scan of v[0, n) in place; tileSums: n / 2048 + 1 ints
+void LaunchInclusiveScan(int *v, int n, int *tileSums, hipStream_t s);
+// chain relocation (relocate.hip): the chains of the step's large-step launch whose technique changed since they were placed are sorted by technique into the slots they occupy
+struct RelocBuffers {
+    unsigned char *placedKey;   // N: the key a slot's chain was placed under (0xff: never placed)
+    int *tileCount, *tileHist;  // RelocTiles(N), 64 x RelocTiles(N): members per 1024-slot tile / per (tile, key); then their exclusive prefixes
+    int *members;               // N: the slots that take part, ascending
+    int *sorted;                // N: member indices by key
+    int *count;                 // 1: number of members
+    float *staging;             // RelocRecordWords(maxDepth) floats per member (capacity: see host/context.cpp)
+};
+size_t RelocTiles(int N);
+size_t RelocRecordWords(int maxDepth);
+void LaunchRelocIota(int n, int *v, hipStream_t s);
+void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
 void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s);

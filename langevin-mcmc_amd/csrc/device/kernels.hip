@@ -457,6 +457,9 @@ __global__ void __launch_bounds__(256) k_build_lists(ChainArrays A, NextLists ne
     for (int j = 0; j < CPT; j++)
         if ((k[j] & 3) == NEXT_SMALL_GENERIC && ((leanDims >> (2 * (3 + (k[j] >> 2) / 6))) & 1u) && !((leanDims >> 31) && (k[j] >> 2) % 6 > 1))  // bit 31: lean launch without light sub-paths
             k[j] = (unsigned char)(k[j] | NEXT_SMALL_PLAIN);
+    if (A.stepKind)  // relocate.hip: which launch runs the slot's chain in the step these lists are for
+        for (int j = 0; j < CPT; j++)
+            if (first + j < A.N) A.stepKind[first + j] = k[j] & 3;
     // four 16-bit counters packed into one word: [large | generic | plain A | plain B]; B = the "long path" class of sortPlain 3
     // (a STABLE two-way partition: inside a class the entries keep their chain order, so a wave's lanes stay dense)
     auto fieldOf = [&](unsigned char nk) {
@@ -532,10 +535,10 @@ LMC_D unsigned long long PushKey(int dim) { return (dim >= 6 && dim <= PSS_MAX_L
 constexpr int PUSH_PER = 16;  // chains per thread: a tile = 64 * PUSH_PER = 1024 chains
 __global__ void __launch_bounds__(64) k_push_count(ChainArrays A, unsigned long long *tileCounts, int *stageCounts) {
     if (stageCounts && blockIdx.x == 0 && threadIdx.x < 16) stageCounts[threadIdx.x] = 0;
-    const int first = (blockIdx.x * 64 + threadIdx.x) * PUSH_PER;
+    const int first = (blockIdx.x * 64 + threadIdx.x) * PUSH_PER;  // chain ids; their slots: A.slotOf once chains are relocated (relocate.hip)
     unsigned long long mine = 0;
     for (int j = 0; j < PUSH_PER; j++)
-        if (first + j < A.N) mine += PushKey(A.pushDim[first + j]);
+        if (first + j < A.N) mine += PushKey(A.pushDim[A.slotOf ? A.slotOf[first + j] : first + j]);
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
     if (threadIdx.x == 0) tileCounts[blockIdx.x] = mine;
 }
@@ -557,7 +560,7 @@ __global__ void __launch_bounds__(64) k_push_scatter(ChainArrays A, const unsign
     for (int j = 0; j < PUSH_PER; j++) {
         dims[j] = 0;
         if (first + j < A.N) {
-            dims[j] = A.pushDim[first + j];
+            dims[j] = A.pushDim[A.slotOf ? A.slotOf[first + j] : first + j];
             if (!PushKey(dims[j])) dims[j] = 0;
             mine += PushKey(dims[j]);
         }
@@ -578,7 +581,7 @@ __global__ void __launch_bounds__(64) k_push_scatter(ChainArrays A, const unsign
         int rank = (int)((excl >> (16 * slot)) & 0xffffull);
         for (int jj = 0; jj < j; jj++) rank += dims[jj] == dim ? 1 : 0;
         const long long row = (long long)T.count[slot] + lower + rank;
-        const int i = first + j;
+        const int i = A.slotOf ? A.slotOf[first + j] : first + j;
         if (row < PSS_MAX_SIZE) {
             for (int k = 0; k < dim; k++) {
                 T.pss[slot][(size_t)row * dim + k] = A.pushData[(size_t)k * N + i];
@@ -815,6 +818,12 @@ __global__ void __launch_bounds__(256) k_scan_carry(int *v, int n, const int *ti
     const int carry = tileSums[blockIdx.x - 1], base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     for (int k = 0; k < SCAN_ITEMS; k++)
         if (base + k < n) v[base + k] += carry;
+}
+void LaunchInclusiveScan(int *v, int n, int *tileSums, hipStream_t s) {
+    const int nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nTiles), dim3(256), 0, s, v, n, tileSums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, tileSums, nTiles);
+    hipLaunchKernelGGL(k_scan_carry, dim3(nTiles), dim3(256), 0, s, v, n, tileSums);
 }
 __global__ void __launch_bounds__(256) k_grid_scatter(GridShape g, const float *pts, const int *start, int *cursor, float *rows) {
     const int t = blockIdx.x * 256 + threadIdx.x;

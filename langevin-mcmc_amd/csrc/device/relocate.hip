@@ -1,0 +1,262 @@
+// Chain relocation: the resident chains kept PHYSICALLY grouped by technique (c,l), so that the 64 consecutive chains of a wave
+// retrace the same technique -- same number of path segments, same terminal strategy -- while their state accesses stay coalesced.
+//
+// Why: the lanes of the lean small-step kernel (dsmall.h) idle while the longest path of their wave finishes.  Grouping the WORK LIST by
+// technique removes that (-24 % vector instructions on the Lambertian torus) but was measured slower there three times (rounds 2-4):
+// the chain state is SoA [word][chain], and the lanes of a sorted wave touch one cache line each per state word instead of two lines per
+// wave (L2 misses x 2.5, profiles/r03_a_ab_sorted_lists_instruction_counts.jsonl).  Moving the STATE instead costs little, because a
+// chain's technique only changes when it accepts a large step (mlt.cpp:113-132: small steps perturb a path of fixed (c,l),
+// path.cpp:1953-2160) or is reset to an init state (mlt.cpp:147-169) -- about a tenth of the chains per step -- and because what is
+// alive of a chain right after either event is small: its new path, contribution and splats, its RNG, a dozen scalars (the MALA vectors
+// are zero and no Gaussian is stored: dchain.h ClearBuffered).
+//
+// One relocation (after the step's launches, before the next step's work lists are built):
+//   members = slots whose chain's technique key differs from the key the slot was placed under, in ascending slot order
+//   the members' chains are sorted by key; the p-th chain of that order moves into the p-th member slot
+// so every mover lands at the slot quantile of its key quantile.  In the stationary regime the chains that leave a technique and the
+// chains that enter it balance, so the movers of a key land in the slots that movers of that key region vacated: the array stays sorted
+// by key without any region bookkeeping.  The very first relocation finds every slot unplaced and is a full sort.
+// The state travels slot -> staging record (AoS, one record per member) -> slot, two launches, because the moves form cycles.
+// Nothing that a chain computes depends on the slot it lives in: the RNG stream moves with it, and the one use of the chain's id
+// (the outlier reset, dchain.h ResetToInitState) reads it from A.chainId.  The film differs by the order of its atomics only.
+#include "dstep.h"
+#include "kernels.h"
+
+namespace lmcd {
+namespace {
+
+enum : int { RW_FLAGS = 0, RW_SAMPLEIDX, RW_NUMSAMPLES, RW_ADJREJECT, RW_SPLATCOUNT, RW_CHAINID, RW_SCORESUM, RW_LASTSCORESUM, RW_LASTSCORE, RW_PATHWEIGHT, RW_NEXTKIND, RW_RNG_LO, RW_RNG_HI, RW_KEY, RW_SCALARS = 16 };
+constexpr int RW_TAB = RW_SCALARS, RW_HEAD = RW_TAB + 64, RW_VERT = RW_HEAD + DPATH_HEAD_WORDS;
+
+struct RecordLayout {
+    int nV, nS;  // vertex records kept per sub-path, splats kept
+    LMC_HD int Contrib() const { return RW_VERT + 2 * nV * DVERTEX_WORDS; }
+    LMC_HD int Splats() const { return Contrib() + CONTRIB_WORDS; }
+    LMC_HD int Vectors() const { return Splats() + nS * SPLAT_WORDS; }
+    LMC_HD int Gauss() const { return Vectors() + 7 * MAXPSS; }
+    LMC_HD int Words() const { return Gauss() + GAUSS_WORDS; }
+};
+
+LMC_D int SlotKey(const ChainArrays &A, int i) {
+    return TechniqueKey(__float_as_int(A.curContrib[i]), __float_as_int(A.curContrib[(size_t)A.N + i]));
+}
+LMC_D bool VectorsMayBeNonZero(int flags) { return (flags & F_BUFFERED) && (flags & F_VDIRTY); }  // dchain.h: the invariant of the seven MALA vectors
+LMC_D bool HasStoredGaussian(int flags) { return (flags & F_GAUSS) && !(flags & F_GAUSS_ISO); }
+
+// ---- who moves, and where.  A tile = 1024 consecutive slots (one block, four slots per thread).
+// Members: the slots whose chain ran a LARGE step in the step just launched (A.stepKind, written by k_build_lists) and now has another
+// technique key than the one the slot was placed under.  Only those: the relocation runs on the large-step launch's stream right behind
+// it, BESIDE the small-step launches, whose chains it must not touch (a small step changes (c,l) only through the outlier reset; such a
+// chain is picked up at its next large step).
+constexpr int RELOC_TILE = 1024;
+LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i) {  // -1: not a member
+    if (i >= A.N || A.stepKind[i] != NEXT_LARGE) return -1;
+    const int key = SlotKey(A, i);
+    return key != placedKey[i] ? key : -1;
+}
+// All three launches are ONE-WAVE blocks: they run beside the small-step launches, whose waves hold every SIMD's registers -- a one-wave block
+// takes the first slot that frees up, a four-wave block waits for four at once (k_reloc_count as 256-thread blocks: 1.0 ms in the queue,
+// profiles/r04_reloc_b_*; the same lesson as kernels.hip k_push_count).  Lane l of a tile's wave looks at slots base + 64 j + l, j = 0 .. 15.
+// tileCount[t] = members of tile t; tileHist[t][k] = ... with key k
+__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned char *placedKey, int *tileCount, int *tileHist) {
+    __shared__ int h[64];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
+    int total = 0;
+    for (int j = 0; j < RELOC_TILE / 64; j++) {
+        const int key = MemberKey(A, placedKey, base + 64 * j);
+        if (key >= 0) atomicAdd(&h[key], 1), total++;
+    }
+    __syncthreads();
+    tileHist[blockIdx.x * 64 + threadIdx.x] = h[threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (threadIdx.x == 0) tileCount[blockIdx.x] = total;
+}
+// one wave: tileCount -> first member index of every tile; tileHist -> first sorted position of every (tile, key) group; *count
+__global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount, int *tileHist, int *count) {
+    const int key = threadIdx.x;
+    int total = 0;
+#pragma unroll 8
+    for (int t = 0; t < nTiles; t++) total += tileHist[t * 64 + key];
+    int incl = total;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (key >= off) incl += o;
+    }
+    if (key == 63) *count = incl;
+    int run = incl - total;
+#pragma unroll 8
+    for (int t = 0; t < nTiles; t++) {
+        const int c = tileHist[t * 64 + key];
+        tileHist[t * 64 + key] = run;
+        run += c;
+    }
+    int carry = 0;
+    for (int b = 0; b < nTiles; b += 64) {
+        const int t = b + threadIdx.x, v = t < nTiles ? tileCount[t] : 0;
+        int in = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(in, off);
+            if (key >= off) in += o;
+        }
+        if (t < nTiles) tileCount[t] = carry + in - v;
+        carry += __shfl(in, 63);
+    }
+}
+// members[m] = slot (ascending); sorted[p] = m for the p-th chain by key (inside a (tile, key) group the order is the LDS atomics')
+__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned char *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted) {
+    __shared__ int cursor[64];
+    cursor[threadIdx.x] = groupStart[blockIdx.x * 64 + threadIdx.x];
+    __syncthreads();
+    const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
+    int m0 = tileStart[blockIdx.x];
+    for (int j = 0; j < RELOC_TILE / 64; j++) {
+        const int key = MemberKey(A, placedKey, base + 64 * j);
+        const unsigned long long mask = __ballot(key >= 0);
+        if (key >= 0) {
+            const int m = m0 + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+            members[m] = base + 64 * j;
+            sorted[atomicAdd(&cursor[key], 1)] = m;
+        }
+        m0 += __popcll(mask);
+    }
+}
+
+LMC_D float *VectorBase(const ChainArrays &A, int v) {
+    float *const b[7] = {A.chV1, A.chV2, A.chCurrNewV2, A.chPropNewV1, A.chPropNewV2, A.chPss, A.chLastPss};
+    return b[v];
+}
+
+// member m's chain -> staging record m
+__global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, float *staging) {
+    const int M = *count;
+    const size_t N = A.N;
+    for (int m = blockIdx.x * 64 + threadIdx.x; m < M; m += gridDim.x * 64) {
+        const int i = members[m];
+        float *r = staging + (size_t)m * R.Words();
+        const int flags = A.flags[i];
+        const uint64_t rs = A.rngState[i];
+        const int nSplat = min(A.curSplatCount[i], R.nS);
+        r[RW_FLAGS] = __int_as_float(flags), r[RW_SAMPLEIDX] = __int_as_float(A.sampleIdx[i]), r[RW_NUMSAMPLES] = __int_as_float(A.numSamples[i]);
+        r[RW_ADJREJECT] = __int_as_float(A.adjacentReject[i]), r[RW_SPLATCOUNT] = __int_as_float(nSplat), r[RW_CHAINID] = __int_as_float(A.chainId[i]);
+        r[RW_SCORESUM] = A.scoreSum[i], r[RW_LASTSCORESUM] = A.lastScoreSum[i], r[RW_LASTSCORE] = A.lastScore[i], r[RW_PATHWEIGHT] = A.pathWeight[i];
+        r[RW_NEXTKIND] = __int_as_float((int)A.nextKind[i]), r[RW_RNG_LO] = __int_as_float((int)(uint32_t)rs), r[RW_RNG_HI] = __int_as_float((int)(uint32_t)(rs >> 32));
+        r[RW_KEY] = __int_as_float(SlotKey(A, i));
+        const uint4 *tab = reinterpret_cast<const uint4 *>(A.rngTab + (size_t)i * 64);
+        uint4 *rt = reinterpret_cast<uint4 *>(r + RW_TAB);
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) rt[k] = tab[k];
+        const float *path = CurPathBuf(A, flags);
+#pragma unroll 4
+        for (int k = 0; k < DPATH_HEAD_WORDS; k++) r[RW_HEAD + k] = path[(size_t)k * N + i];
+        const int camCount = min(max(__float_as_int(r[RW_HEAD + 12]), 0), R.nV), lgtCount = min(max(__float_as_int(r[RW_HEAD + 13]), 0), R.nV);  // DPath: camCount, lgtCount
+        for (int v = 0; v < camCount; v++)
+#pragma unroll
+            for (int k = 0; k < DVERTEX_WORDS; k++) r[RW_VERT + v * DVERTEX_WORDS + k] = path[(size_t)(DPATH_HEAD_WORDS + v * DVERTEX_WORDS + k) * N + i];
+        for (int v = 0; v < lgtCount; v++)
+#pragma unroll
+            for (int k = 0; k < DVERTEX_WORDS; k++) r[RW_VERT + (R.nV + v) * DVERTEX_WORDS + k] = path[(size_t)(DPATH_HEAD_WORDS + (MAXD + v) * DVERTEX_WORDS + k) * N + i];
+#pragma unroll
+        for (int k = 0; k < CONTRIB_WORDS; k++) r[R.Contrib() + k] = A.curContrib[(size_t)k * N + i];
+        for (int k = 0; k < nSplat * SPLAT_WORDS; k++) r[R.Splats() + k] = A.curSplat[(size_t)k * N + i];
+        if (VectorsMayBeNonZero(flags))
+            for (int v = 0; v < 7; v++) {
+                const float *src = VectorBase(A, v);
+#pragma unroll 4
+                for (int k = 0; k < MAXPSS; k++) r[R.Vectors() + v * MAXPSS + k] = src[(size_t)k * N + i];
+            }
+        if (HasStoredGaussian(flags)) {
+            const float *G = CurGaussBuf(A, flags);
+#pragma unroll 4
+            for (int k = 0; k < GAUSS_WORDS; k++) r[R.Gauss() + k] = G[(size_t)k * N + i];
+        }
+    }
+}
+
+// staging record sorted[d] -> member slot d.  Record d still holds what the slot contained: its flags say whether the slot's MALA
+// vectors have to be zeroed for an incoming chain whose vectors are zero by the invariant.
+__global__ void __launch_bounds__(64) k_reloc_scatter(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, const float *staging,
+                                                       unsigned char *placedKey) {
+    const int M = *count;
+    const size_t N = A.N;
+    for (int d = blockIdx.x * 64 + threadIdx.x; d < M; d += gridDim.x * 64) {
+        const int i = members[d], m = sorted[d];
+        const float *r = staging + (size_t)m * R.Words();
+        placedKey[i] = (unsigned char)__float_as_int(r[RW_KEY]);
+        if (m == d) continue;  // the chain stays where it is
+        const int flags = __float_as_int(r[RW_FLAGS]), oldFlags = __float_as_int(staging[(size_t)d * R.Words() + RW_FLAGS]);
+        const int nSplat = __float_as_int(r[RW_SPLATCOUNT]);
+        A.flags[i] = flags, A.sampleIdx[i] = __float_as_int(r[RW_SAMPLEIDX]), A.numSamples[i] = __float_as_int(r[RW_NUMSAMPLES]);
+        A.adjacentReject[i] = __float_as_int(r[RW_ADJREJECT]), A.curSplatCount[i] = nSplat, A.chainId[i] = __float_as_int(r[RW_CHAINID]), A.slotOf[__float_as_int(r[RW_CHAINID])] = i;
+        A.scoreSum[i] = r[RW_SCORESUM], A.lastScoreSum[i] = r[RW_LASTSCORESUM], A.lastScore[i] = r[RW_LASTSCORE], A.pathWeight[i] = r[RW_PATHWEIGHT];
+        A.nextKind[i] = (unsigned char)__float_as_int(r[RW_NEXTKIND]);
+        A.rngState[i] = (uint64_t)(uint32_t)__float_as_int(r[RW_RNG_LO]) | ((uint64_t)(uint32_t)__float_as_int(r[RW_RNG_HI]) << 32);
+        uint4 *tab = reinterpret_cast<uint4 *>(A.rngTab + (size_t)i * 64);
+        const uint4 *rt = reinterpret_cast<const uint4 *>(r + RW_TAB);
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) tab[k] = rt[k];
+        float *path = CurPathBuf(A, flags);
+#pragma unroll 4
+        for (int k = 0; k < DPATH_HEAD_WORDS; k++) path[(size_t)k * N + i] = r[RW_HEAD + k];
+        const int camCount = min(max(__float_as_int(r[RW_HEAD + 12]), 0), R.nV), lgtCount = min(max(__float_as_int(r[RW_HEAD + 13]), 0), R.nV);
+        for (int v = 0; v < camCount; v++)
+#pragma unroll
+            for (int k = 0; k < DVERTEX_WORDS; k++) path[(size_t)(DPATH_HEAD_WORDS + v * DVERTEX_WORDS + k) * N + i] = r[RW_VERT + v * DVERTEX_WORDS + k];
+        for (int v = 0; v < lgtCount; v++)
+#pragma unroll
+            for (int k = 0; k < DVERTEX_WORDS; k++) path[(size_t)(DPATH_HEAD_WORDS + (MAXD + v) * DVERTEX_WORDS + k) * N + i] = r[RW_VERT + (R.nV + v) * DVERTEX_WORDS + k];
+#pragma unroll
+        for (int k = 0; k < CONTRIB_WORDS; k++) A.curContrib[(size_t)k * N + i] = r[R.Contrib() + k];
+        for (int k = 0; k < nSplat * SPLAT_WORDS; k++) A.curSplat[(size_t)k * N + i] = r[R.Splats() + k];
+        if (VectorsMayBeNonZero(flags)) {
+            for (int v = 0; v < 7; v++) {
+                float *dst = VectorBase(A, v);
+#pragma unroll 4
+                for (int k = 0; k < MAXPSS; k++) dst[(size_t)k * N + i] = r[R.Vectors() + v * MAXPSS + k];
+            }
+        } else if (VectorsMayBeNonZero(oldFlags)) {
+            for (int v = 0; v < 7; v++) {
+                float *dst = VectorBase(A, v);
+#pragma unroll 4
+                for (int k = 0; k < MAXPSS; k++) dst[(size_t)k * N + i] = 0.f;
+            }
+        }
+        if (HasStoredGaussian(flags)) {
+            float *G = CurGaussBuf(A, flags);
+#pragma unroll 4
+            for (int k = 0; k < GAUSS_WORDS; k++) G[(size_t)k * N + i] = r[R.Gauss() + k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reloc_iota(int n, int *v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+}  // namespace
+}  // namespace lmcd
+
+using namespace lmcd;
+
+static RecordLayout MakeRecordLayout(int maxDepth) {
+    RecordLayout R;
+    R.nV = std::min(MAXD, std::max(maxDepth, 1));
+    R.nS = std::min(MAXCONTRIB, (maxDepth + 1) * (maxDepth + 2) / 2);
+    return R;
+}
+size_t RelocRecordWords(int maxDepth) { return (size_t)MakeRecordLayout(maxDepth).Words(); }
+void LaunchRelocIota(int n, int *v, hipStream_t s) { hipLaunchKernelGGL(k_reloc_iota, dim3((n + 255) / 256), dim3(256), 0, s, n, v); }
+size_t RelocTiles(int N) { return (size_t)(N + RELOC_TILE - 1) / RELOC_TILE; }
+
+void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s) {
+    const RecordLayout R = MakeRecordLayout(maxDepth);
+    const int N = A.N, nTiles = (N + RELOC_TILE - 1) / RELOC_TILE;
+    hipLaunchKernelGGL(k_reloc_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist);
+    hipLaunchKernelGGL(k_reloc_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.tileHist, B.count);
+    hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted);
+    const int moveBlocks = std::min((N + 63) / 64, 4096);
+    hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging);
+    hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey);
+}

@@ -65,8 +65,11 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
     }
 }
 
+#ifndef LMC_MALA_MID_WAVES
+#define LMC_MALA_MID_WAVES 2  // waves per SIMD the register allocation aims at (A/B: profiles/r04_fill_w_*)
+#endif
 template <bool LDS_STACK, bool GLOSSY>
-__global__ void __launch_bounds__(64, 2) k_mala_mid(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+__global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
     extern __shared__ int ldsStack[];
     const DCache &cache = *cachePtr;
     StepStats st;

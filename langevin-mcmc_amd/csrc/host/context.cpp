@@ -167,6 +167,13 @@ struct lmc_ctx {
     // launch shape of the lean small-step kernel and the technique sort of its work list; LMC_LEAN_BLOCK / LMC_SORT_PLAIN
     // override them for A/B runs (profiles/)
     int leanBlock = 64, leanGrid = 0, sortPlain = 0;
+    // chain relocation (device/relocate.hip): the chains kept physically grouped by technique once every cache is ready; LMC_RELOCATE overrides
+    bool relocate = false;
+    DevBuf<int> chainId, slotOf, relocTileCount, relocTileHist, relocMembers, relocSorted, relocCount;
+    DevBuf<unsigned char> relocPlacedKey, stepKind;
+    DevBuf<float> relocStaging;
+    RelocBuffers RB{};
+    long long relocations = 0;
     // work lists (double buffered): [parity][large | smallGrad | smallPlain]
     DevBuf<int> lists[2][3], listCounts[2];
     int parity = 0;
@@ -864,6 +871,25 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     A.contribList = c->contribList.p, A.nextKind = c->nextKind.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p, A.initLsAll = c->initLsAll.p, A.initCLAll = c->initCLAll.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p, A.prof = c->prof.p;
+    // Relocation: off for H2MC (the pipeline's Gaussians are indexed by slot) and `samplecache` (chain.path is not moved)
+    c->relocate = true;
+    if (const char *e = getenv("LMC_RELOCATE")) c->relocate = atoi(e) != 0;
+    if (c->S.opt.h2mc || sampleCache) c->relocate = false;
+    c->relocations = 0;
+    if (c->relocate) {
+        c->chainId.Alloc(N, false), c->slotOf.Alloc(N, false), c->relocTileCount.Alloc(RelocTiles((int)N) + 1, false), c->relocTileHist.Alloc(RelocTiles((int)N) * 64, false), c->relocMembers.Alloc(N, false);
+        c->relocSorted.Alloc(N, false), c->relocCount.Alloc(1), c->relocPlacedKey.Alloc(N, false), c->stepKind.Alloc(N + 4, false);
+        c->relocStaging.Alloc(N * RelocRecordWords(c->S.opt.maxDepth), false);  // the first step is a large step of every chain
+        HIP_CHECK(hipMemsetAsync(c->relocPlacedKey.p, 0xff, N, s));
+        HIP_CHECK(hipMemsetAsync(c->stepKind.p, NEXT_LARGE, N, s));  // k_init_lists: every chain starts with a large step
+        LaunchRelocIota((int)N, c->chainId.p, s), LaunchRelocIota((int)N, c->slotOf.p, s);
+        c->RB = RelocBuffers{c->relocPlacedKey.p, c->relocTileCount.p, c->relocTileHist.p, c->relocMembers.p, c->relocSorted.p, c->relocCount.p, c->relocStaging.p};
+        A.chainId = c->chainId.p, A.slotOf = c->slotOf.p, A.stepKind = c->stepKind.p;
+    } else {
+        A.chainId = nullptr, A.slotOf = nullptr, A.stepKind = nullptr;
+        for (auto *b : {&c->chainId, &c->slotOf, &c->relocTileCount, &c->relocTileHist, &c->relocMembers, &c->relocSorted, &c->relocCount}) b->Free();
+        c->relocPlacedKey.Free(), c->stepKind.Free(), c->relocStaging.Free();
+    }
     LaunchSeedRng((int)N, (long long)chainBegin + c->S.opt.seedOffset, c->rngState.p, c->rngTab.p, s);  // RNG rng(chainId + seedOffset), mlt.cpp:61-62
     LaunchSetupChains(A, chainBegin, perChain, chainsNeedExtra, s);
     // step launch geometry: one thread per chain up to a persistent cap; gradient work buffer per launched thread
@@ -1349,6 +1375,9 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
             CachePack(c, sL);
             if (c->world == 1 && c->earlyApply) CacheApplyLaunch(c, sL), c->appliedEarly = true;
         }
+        // the chains this launch gave a new technique move to the slots of their technique (relocate.hip) -- on this stream, beside the small-step
+        // launches, whose chains it does not touch, and behind the pack, which reads the pushes of these very chains (in chain order: A.slotOf)
+        if (c->relocate) LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, sL), c->relocations++;
     };
     if (!genericFirst) large();
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
@@ -1382,8 +1411,9 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
         if (!c->appliedEarly) CacheApplyLaunch(c, s);
         CacheApplyFinish(c);
     }
-    LaunchBuildLists(c->A, next, c->sortPlain == 4 ? 0 : c->sortPlain, LeanDims(c) | (c->S.opt.leanLightless ? 1u << 31 : 0u), s);
-    if (c->sortPlain == 4) {  // A/B: the lean list grouped by technique over the WHOLE list (a wave then retraces one technique; its lanes' state lines are anywhere)
+    const int sortPlain = c->relocate ? 0 : c->sortPlain;  // relocated chains are grouped already, and in place
+    LaunchBuildLists(c->A, next, sortPlain == 4 ? 0 : sortPlain, LeanDims(c) | (c->S.opt.leanLightless ? 1u << 31 : 0u), s);
+    if (sortPlain == 4) {  // A/B: the lean list grouped by technique over the WHOLE list (a wave then retraces one technique; its lanes' state lines are anywhere)
         LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][2].p, c->listScratch2.p, c->listCounts[nxt].p + 2, c->sortBins2.p, (int)c->N, s);
         std::swap(c->lists[nxt][2].p, c->listScratch2.p);
     }
@@ -1711,6 +1741,27 @@ int lmc_stats(lmc_ctx *c, long long *out8, double *weightSum) {
     LMC_CATCH(-1)
 }
 
+int lmc_relocation_stats(lmc_ctx *c, long long *out4) {
+    LMC_TRY
+    if (!c->relocate || c->N <= 0) return -1;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    const size_t N = c->N;
+    std::vector<float> con(2 * N);
+    HIP_CHECK(hipMemcpy(con.data(), c->curContrib.p, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
+    long long breaks = 0;
+    int prev = -1;
+    for (size_t i = 0; i < N; i++) {
+        int cc, ll;
+        memcpy(&cc, &con[i], 4), memcpy(&ll, &con[N + i], 4);
+        const int key = TechniqueKey(cc, ll);
+        if (i && key != prev) breaks++;
+        prev = key;
+    }
+    out4[0] = c->relocations, out4[1] = c->relocations ? c->relocCount.Download()[0] : 0, out4[2] = breaks, out4[3] = (long long)N;
+    return 0;
+    LMC_CATCH(-2)
+}
+
 int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
     LMC_TRY
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1722,8 +1773,10 @@ int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
     std::vector<float> ss = (which == 0 ? c->scoreSum : c->initScoreSum).Download();
     std::vector<int> fl, sidx, nspl;
     if (which == 0) fl = c->flags.Download(), sidx = c->sampleIdx.Download(), nspl = c->curSplatCount.Download();
+    std::vector<int> idOf;  // relocation: slot -> chain; the rows go out in chain order
+    if (which == 0 && c->relocate) idOf = c->chainId.Download();
     for (size_t i = 0; i < N; i++) {
-        float *o = out + i * stride;
+        float *o = out + (idOf.empty() ? i : (size_t)idOf[i]) * stride;
         memset(o, 0, stride * sizeof(float));
         DPath p;
         float *w = reinterpret_cast<float *>(&p);
@@ -1737,7 +1790,7 @@ int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
         o[10] = con[2 * N + i], o[11] = con[3 * N + i], o[12] = con[4 * N + i], o[13] = con[5 * N + i], o[14] = con[6 * N + i];
         // GetPathPss on the host copy (same ordering as device/dpath.h)
         int k = 0;
-        float *pss = o + 16;
+        float pss[2 * MAXPSS + 16];  // a long state has more primary samples than a row has room for: the row keeps the first stride - 16
         if (p.lgtDepth > 1) {
             pss[k++] = p.lgtPos0, pss[k++] = p.lgtPos1, pss[k++] = p.lgtDir0, pss[k++] = p.lgtDir1;
             for (int d = 0; d < p.lgtCount - 1; d++) pss[k++] = p.lgt[d].rnd0, pss[k++] = p.lgt[d].rnd1;
@@ -1752,6 +1805,7 @@ int lmc_chain_summary(lmc_ctx *c, int which, float *out, int stride) {
                 pss[k++] = p.cam[d].rnd0, pss[k++] = p.cam[d].rnd1;
             }
         }
+        for (int q = 0; q < k && 16 + q < stride; q++) o[16 + q] = pss[q];
     }
     return (int)N;
     LMC_CATCH(-1)

@@ -1,0 +1,78 @@
+"""Chain relocation (langevin-mcmc_amd/csrc/device/relocate.hip): the chains are kept physically grouped by technique so that a wave
+of the step kernels retraces one (c,l).  The reference has no counterpart (its chains are objects a thread walks, mlt.cpp:60-196), so
+the contract checked here is transparency: with relocation on, EVERY chain follows the trajectory it follows with relocation off --
+same RNG stream, same states, same counters -- and the film differs by the order of its float atomics only."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import gpu_checks as gc
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(relocate, mala, n_chains, steps, opts, checkpoints=(), max_depth=6):
+    os.environ["LMC_RELOCATE"] = "1" if relocate else "0"
+    try:
+        p = gc.pkg()
+        ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=max_depth, width=128, height=96, seed_offset=0, use_gradient=1 if gc.pathref() else 0)
+        for k, v in opts.items():
+            ren.set_option(k, v)
+        if not mala:
+            ren.set_option("mala", 0)
+        ren.init_chains(200000, n_chains, 64, 10 ** 6)
+    finally:
+        del os.environ["LMC_RELOCATE"]
+    out = []
+    done = 0
+    for upto in list(checkpoints) + [steps]:
+        ren.step(upto - done)
+        done = upto
+        out.append((ren.summary(0).copy(), ren.stats(), ren.relocation_stats()))
+    film = ren.film().copy()
+    ren.close()
+    return out, film
+
+
+def _same_states(a, b):
+    # rows are reported in chain order whatever slot a chain lives in.  Of an invalid state only technique and lsScore mean anything
+    valid = a[:, 0] == 1
+    assert (a[:, 0] == b[:, 0]).all()
+    assert np.array_equal(a[valid], b[valid])
+    assert np.array_equal(a[~valid][:, 1:4], b[~valid][:, 1:4])
+    assert np.array_equal(a[:, 9], b[:, 9])  # sampleIdx
+
+
+def test_relocation_is_transparent_plain_mlt():
+    """Plain MLT (mala = 0): no gradient cache, relocation runs from the first step on.  4096 chains x 40 steps, states compared at three points."""
+    opts = {"largestepprob": 0.3, "largestepscale": 1.0}
+    off, film0 = _run(False, False, 4096, 40, opts, checkpoints=(1, 7))
+    on, film1 = _run(True, False, 4096, 40, opts, checkpoints=(1, 7))
+    for (s0, st0, r0), (s1, st1, r1) in zip(off, on):
+        assert r0 is None and r1 is not None and r1["relocations"] > 0
+        _same_states(s0, s1)
+        for k in ("steps", "largeSteps", "accepted", "resets"):
+            assert st0[k] == st1[k], k
+        assert st1["weightSum"] == pytest.approx(st0["weightSum"], rel=1e-6)
+    l0, l1 = gc.lum(film0), gc.lum(film1)
+    assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
+    # and the chains ARE grouped: at most a few technique changes along the slots per technique, instead of one at most slot boundaries
+    r = on[-1][2]
+    assert r["breaks"] < 0.35 * r["slots"], r  # ~30 % of the chains changed technique in the step just run and have not been placed yet
+
+
+def test_relocation_is_transparent_once_the_caches_are_ready():
+    """MALA with the gradient cache (the set-up of test_cache_phase_parity): relocation starts when every cache is ready; the chains then carry
+    stored Gaussians, moment vectors and cache look-ups -- all of which must travel with them."""
+    opts = {"largestepprob": 0.5, "largestepscale": 1.0}  # maxdepth 4: two cache dims (6, 8), both full after ~25 steps of 16384 chains
+    off, film0 = _run(False, True, 16384, 72, opts, checkpoints=(8, 40), max_depth=4)
+    on, film1 = _run(True, True, 16384, 72, opts, checkpoints=(8, 40), max_depth=4)
+    assert off[-1][1]["cacheReadyMask"] != 0, "test set-up: the cache never filled"
+    assert on[-1][2]["relocations"] > 0, "test set-up: relocation never started"
+    for (s0, st0, r0), (s1, st1, r1) in zip(off, on):
+        _same_states(s0, s1)
+        for k in ("steps", "largeSteps", "accepted", "resets", "cacheQueries", "cacheHits", "gradCalls", "cacheReadyMask"):
+            assert st0[k] == st1[k], k
+    l0, l1 = gc.lum(film0), gc.lum(film1)
+    assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
