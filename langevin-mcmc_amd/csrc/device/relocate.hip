@@ -37,8 +37,15 @@ struct RecordLayout {
     LMC_HD int Words() const { return Gauss() + GAUSS_WORDS; }
 };
 
+// Order of the groups along the slots: LONGEST paths first (LMC_RELOC_ORDER=1, the default).  The work lists follow the slot order, a launch
+// hands out its blocks in list order, and a wave of long paths runs several times as long as a wave of short ones: started last they are
+// the tail of the launch, started first the short waves fill in behind them.
+#ifndef LMC_RELOC_ORDER
+#define LMC_RELOC_ORDER 1
+#endif
 LMC_D int SlotKey(const ChainArrays &A, int i) {
-    return TechniqueKey(__float_as_int(A.curContrib[i]), __float_as_int(A.curContrib[(size_t)A.N + i]));
+    const int key = TechniqueKey(__float_as_int(A.curContrib[i]), __float_as_int(A.curContrib[(size_t)A.N + i]));
+    return LMC_RELOC_ORDER ? 63 - key : key;
 }
 LMC_D bool VectorsMayBeNonZero(int flags) { return (flags & F_BUFFERED) && (flags & F_VDIRTY); }  // dchain.h: the invariant of the seven MALA vectors
 LMC_D bool HasStoredGaussian(int flags) { return (flags & F_GAUSS) && !(flags & F_GAUSS_ISO); }
