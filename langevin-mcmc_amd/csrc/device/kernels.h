@@ -110,6 +110,7 @@ struct RelocBuffers {
 size_t RelocTiles(int N);
 size_t RelocRecordWords(int maxDepth);
 void LaunchRelocIota(int n, int *v, hipStream_t s);
-void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s);
+// withoutGaussianOnly (H2MC renders): chains that hold a stored Gaussian stay where they are (the pipeline's Gaussian buffers are per slot)
+void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
 void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s);

@@ -56,23 +56,28 @@ LMC_D bool HasStoredGaussian(int flags) { return (flags & F_GAUSS) && !(flags & 
 // it, BESIDE the small-step launches, whose chains it must not touch (a small step changes (c,l) only through the outlier reset; such a
 // chain is picked up at its next large step).
 constexpr int RELOC_TILE = 1024;
-LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i) {  // -1: not a member
+// H2MC renders (placedKey's top bit of the launch argument `mode`): a chain that holds a stored Gaussian stays -- the dense Gaussian lives in the
+// pipeline's own per-slot buffers (dh2coop.h H2Arrays::gauss), which are not moved; an accepted large step, the event that changes the
+// technique, has just dropped it (dstep.h), so only chains kept by a REJECTED large step wait for their next one.
+LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i, bool withoutGaussianOnly) {  // -1: not a member
     if (i >= A.N || A.stepKind[i] != NEXT_LARGE) return -1;
     const int key = SlotKey(A, i);
-    return key != placedKey[i] ? key : -1;
+    if (key == placedKey[i]) return -1;
+    if (withoutGaussianOnly && (A.flags[i] & F_GAUSS)) return -1;
+    return key;
 }
 // All three launches are ONE-WAVE blocks: they run beside the small-step launches, whose waves hold every SIMD's registers -- a one-wave block
 // takes the first slot that frees up, a four-wave block waits for four at once (k_reloc_count as 256-thread blocks: 1.0 ms in the queue,
 // profiles/r04_reloc_b_*; the same lesson as kernels.hip k_push_count).  Lane l of a tile's wave looks at slots base + 64 j + l, j = 0 .. 15.
 // tileCount[t] = members of tile t; tileHist[t][k] = ... with key k
-__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned char *placedKey, int *tileCount, int *tileHist) {
+__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned char *placedKey, int *tileCount, int *tileHist, bool noGauss) {
     __shared__ int h[64];
     h[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
     int total = 0;
     for (int j = 0; j < RELOC_TILE / 64; j++) {
-        const int key = MemberKey(A, placedKey, base + 64 * j);
+        const int key = MemberKey(A, placedKey, base + 64 * j, noGauss);
         if (key >= 0) atomicAdd(&h[key], 1), total++;
     }
     __syncthreads();
@@ -112,14 +117,14 @@ __global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount
     }
 }
 // members[m] = slot (ascending); sorted[p] = m for the p-th chain by key (inside a (tile, key) group the order is the LDS atomics')
-__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned char *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted) {
+__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned char *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted, bool noGauss) {
     __shared__ int cursor[64];
     cursor[threadIdx.x] = groupStart[blockIdx.x * 64 + threadIdx.x];
     __syncthreads();
     const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
     int m0 = tileStart[blockIdx.x];
     for (int j = 0; j < RELOC_TILE / 64; j++) {
-        const int key = MemberKey(A, placedKey, base + 64 * j);
+        const int key = MemberKey(A, placedKey, base + 64 * j, noGauss);
         const unsigned long long mask = __ballot(key >= 0);
         if (key >= 0) {
             const int m = m0 + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
@@ -257,12 +262,12 @@ size_t RelocRecordWords(int maxDepth) { return (size_t)MakeRecordLayout(maxDepth
 void LaunchRelocIota(int n, int *v, hipStream_t s) { hipLaunchKernelGGL(k_reloc_iota, dim3((n + 255) / 256), dim3(256), 0, s, n, v); }
 size_t RelocTiles(int N) { return (size_t)(N + RELOC_TILE - 1) / RELOC_TILE; }
 
-void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s) {
+void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s) {
     const RecordLayout R = MakeRecordLayout(maxDepth);
     const int N = A.N, nTiles = (N + RELOC_TILE - 1) / RELOC_TILE;
-    hipLaunchKernelGGL(k_reloc_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist);
+    hipLaunchKernelGGL(k_reloc_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, withoutGaussianOnly);
     hipLaunchKernelGGL(k_reloc_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.tileHist, B.count);
-    hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted);
+    hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted, withoutGaussianOnly);
     const int moveBlocks = std::min((N + 63) / 64, 4096);
     hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging);
     hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey);

@@ -871,10 +871,10 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     A.contribList = c->contribList.p, A.nextKind = c->nextKind.p, A.pushDim = c->pushDim.p, A.pushData = c->pushData.p;
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p, A.initLsAll = c->initLsAll.p, A.initCLAll = c->initCLAll.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p, A.prof = c->prof.p;
-    // Relocation: off for H2MC (the pipeline's Gaussians are indexed by slot) and `samplecache` (chain.path is not moved)
+    // Relocation: off for `samplecache` (chain.path is not moved); H2MC renders move only chains without a stored Gaussian (relocate.hip)
     c->relocate = true;
     if (const char *e = getenv("LMC_RELOCATE")) c->relocate = atoi(e) != 0;
-    if (c->S.opt.h2mc || sampleCache) c->relocate = false;
+    if (sampleCache) c->relocate = false;
     c->relocations = 0;
     if (c->relocate) {
         c->chainId.Alloc(N, false), c->slotOf.Alloc(N, false), c->relocTileCount.Alloc(RelocTiles((int)N) + 1, false), c->relocTileHist.Alloc(RelocTiles((int)N) * 64, false), c->relocMembers.Alloc(N, false);
@@ -1377,7 +1377,7 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         }
         // the chains this launch gave a new technique move to the slots of their technique (relocate.hip) -- on this stream, beside the small-step
         // launches, whose chains it does not touch, and behind the pack, which reads the pushes of these very chains (in chain order: A.slotOf)
-        if (c->relocate) LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, sL), c->relocations++;
+        if (c->relocate) LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, c->S.opt.h2mc != 0, sL), c->relocations++;
     };
     if (!genericFirst) large();
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose

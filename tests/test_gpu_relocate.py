@@ -76,3 +76,17 @@ def test_relocation_is_transparent_once_the_caches_are_ready():
             assert st0[k] == st1[k], k
     l0, l1 = gc.lum(film0), gc.lum(film1)
     assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
+
+
+def test_relocation_is_transparent_h2mc():
+    """H2MC renders: only chains without a stored Gaussian move (the dense Gaussian lives in the pipeline's per-slot buffers)."""
+    opts = {"h2mc": 1, "largestepprob": 0.2, "perturbstddev": 0.01}
+    off, film0 = _run(False, True, 4096, 30, opts, checkpoints=(2, 9))
+    on, film1 = _run(True, True, 4096, 30, opts, checkpoints=(2, 9))
+    assert on[-1][2]["relocations"] > 0 and on[-1][2]["moved"] > 0
+    for (s0, st0, r0), (s1, st1, r1) in zip(off, on):
+        _same_states(s0, s1)
+        for k in ("steps", "largeSteps", "accepted", "resets"):
+            assert st0[k] == st1[k], k
+    l0, l1 = gc.lum(film0), gc.lum(film1)
+    assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
