@@ -27,6 +27,24 @@ struct alignas(16) BvhNode4 {
     int pad[4];
 };
 static_assert(sizeof(BvhNode4) == 128, "one node = two cache lines of 64 B");
+// The same node in 64 B (build option LMC_BVH_QUANT=1; off by default): the children's boxes as 8-bit offsets inside the node's own box,
+//   child k, axis a:  [org[a] + qmin[a][k] * scale[a],  org[a] + qmax[a][k] * scale[a]]  contains  [bmin[k][a], bmax[k][a]]
+// with one quantisation step of margin wherever the offset is not already at the node's face (host/accel.cpp QuantizeBvh4 checks every
+// bound in double precision).  Why it was built: once the chains are grouped by technique (relocate.hip) the closest-hit traversal is 41 % of
+// the lean kernel (profiles/r04_reloc_g_*), and what a node visit costs is the vector L1's work for 64 lanes x 128 B from 64 different lines
+// -- seven 16-byte loads per lane; this node takes four, from one 64 B half line.  Boxes only cull: a larger box means a visit more, never
+// another hit, so every intersection result stays what the exact boxes give.  Measured (profiles/r04_quant_a_*): torus +2.5 % (headline) /
+// +6 % (full materials, maxdepth 12), veach-door -9 % (LMC) / -5 % (H2MC): its tree mixes room-sized and small boxes in one node, and a
+// step of 1/255 of the node inflates the small ones.  Scene dependent, hence not the default.
+struct alignas(16) BvhNode4Q {
+    float org[3], scale[3];
+    unsigned char qmin[3][4], qmax[3][4];  // [axis][child]
+    int child[4];
+};
+static_assert(sizeof(BvhNode4Q) == 64, "one node = one 64 B half line");
+#ifndef LMC_BVH_QUANT
+#define LMC_BVH_QUANT 0
+#endif
 // triangle in BVH leaf order, 48 B: Moeller-Trumbore operands + global triangle id
 struct alignas(16) LeafTri {
     float p0[3];
@@ -103,6 +121,7 @@ struct DOptions {
 
 struct DScene {
     const BvhNode4 *nodes;
+    const BvhNode4Q *qnodes;  // the same tree, quantised boxes
     const LeafTri *leafTris;
     const TriData *tris;
     const DMesh *meshes;
@@ -153,16 +172,9 @@ LMC_D bool SlabTest(const float *bmin, const float *bmax, V3 org, V3 invd, float
 }
 
 // The host numbers the top of the four-wide tree breadth first (accel.cpp TopLevelsFirst): nodes [0, BVH_TOP_NODES) are the root,
-// its children and grandchildren ... (1 + 4 + 16 + 64 = 85 when every node is full).
+// its children and grandchildren ... (1 + 4 + 16 + 64 = 85 when every node is full), so that the top of the tree sits in a handful of
+// cache lines.  (Round 3 staged those nodes in LDS: no gain, profiles/r03_b_ab_bvh_lds_top_rejected.jsonl; the code is gone.)
 constexpr int BVH_TOP_NODES = 85;
-// LMC_BVH_LDS_TOP = K > 0 (build experiment, profiles/r03_*_ab_bvh_lds_top.jsonl): the lean kernel stages nodes [0, K) in LDS at
-// launch and the traversal reads them from there.  Node stride in LDS: 9 x 16 B (144 B) instead of 128 B, so that lanes reading
-// the same word of different nodes fall on different banks (128 B = one full turn of the 32 banks: every node would start on bank 0).
-#ifndef LMC_BVH_LDS_TOP
-#define LMC_BVH_LDS_TOP 0
-#endif
-static_assert(LMC_BVH_LDS_TOP <= BVH_TOP_NODES, "the host only guarantees breadth-first numbering for BVH_TOP_NODES nodes");
-constexpr int BVH_LDS_NODE_QUADS = 9;
 
 constexpr int BVH_STACK = 64;      // host-checked bound on the LBVH depth
 // entries of the per-thread LDS stack (the host routes deeper trees to the private-memory instantiations).  40: the four-wide tree of the
@@ -181,8 +193,6 @@ struct LocalStackT {
     static constexpr bool kGlossy = GLOSSY;
     int s[BVH_STACK];
     int sp = 0;
-    LMC_D const uint4 *Top() const { return nullptr; }
-    LMC_D int TopCount() const { return 0; }
     LMC_D void Reset() { sp = 0; }
     LMC_D bool Empty() const { return sp == 0; }
     LMC_D void Push(int v) {
@@ -196,10 +206,6 @@ struct LdsStackT {
     int *base;   // &lds[threadIdx.x]
     int stride;  // blockDim.x
     int sp;
-    const uint4 *top = nullptr;  // LMC_BVH_LDS_TOP: the staged top of the tree, topCount nodes of BVH_LDS_NODE_QUADS x 16 B
-    int topCount = 0;
-    LMC_D const uint4 *Top() const { return top; }
-    LMC_D int TopCount() const { return topCount; }
     LMC_D void Reset() { sp = 0; }
     LMC_D bool Empty() const { return sp == 0; }
     LMC_D void Push(int v) {
@@ -255,27 +261,66 @@ LMC_D int VisitNode4(const BvhNode4 &nd, V3 org, V3 invd, float tnear, float tfa
     return ck[0];
 }
 
-// one node: from the LDS copy of the top of the tree when the kernel staged one (LMC_BVH_LDS_TOP), from memory otherwise
-template <class Stk>
-LMC_D BvhNode4 FetchNode4(const DScene &S, int cur, const Stk &stk) {
-#if LMC_BVH_LDS_TOP > 0
-    if (cur < stk.TopCount()) {
-        union {
-            BvhNode4 nd;
-            uint4 q[8];
-        } u;
-        const uint4 *p = stk.Top() + cur * BVH_LDS_NODE_QUADS;
+// one inner-node visit on the quantised node: the slab distances straight from the 8-bit offsets,
+//   t = ((org_n - o) * invd) + q * (scale * invd)      (one convert + one fused multiply-add per bound, as many instructions as the exact form)
+// The rounding of the three products / sums is covered by the quantisation margin where the node's extent dominates (error <= 1e-6 steps)
+// and by the widened comparison where the distance dominates.  A zero direction component gives inf / NaN slab distances, which fminf /
+// fmaxf drop: the axis then culls nothing.
+template <bool ORDERED, class Stk>
+LMC_D int VisitNode4Q(const BvhNode4Q &nd, V3 org, V3 invd, float tnear, float tfar, Stk &stk) {
+    const float A[3] = {(nd.org[0] - org.x) * invd.x, (nd.org[1] - org.y) * invd.y, (nd.org[2] - org.z) * invd.z};
+    const float B[3] = {nd.scale[0] * invd.x, nd.scale[1] * invd.y, nd.scale[2] * invd.z};
+    float t[4];
+    bool h[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) u.q[k] = p[k];
-        return u.nd;
+    for (int k = 0; k < 4; k++) {
+        const float ax = __builtin_fmaf((float)nd.qmin[0][k], B[0], A[0]), bx = __builtin_fmaf((float)nd.qmax[0][k], B[0], A[0]);
+        const float ay = __builtin_fmaf((float)nd.qmin[1][k], B[1], A[1]), by = __builtin_fmaf((float)nd.qmax[1][k], B[1], A[1]);
+        const float az = __builtin_fmaf((float)nd.qmin[2][k], B[2], A[2]), bz = __builtin_fmaf((float)nd.qmax[2][k], B[2], A[2]);
+        const float t0 = fmaxf(fmaxf(tnear, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+        const float t1 = fminf(fminf(tfar, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+        t[k] = t0;
+        h[k] = nd.child[k] != BVH4_EMPTY && t0 * 0.9999992f <= t1 * 1.0000008f;
     }
-#endif
-    return S.nodes[cur];
+    int next = BVH4_EMPTY;
+    if (!ORDERED) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (h[k]) {
+                if (next == BVH4_EMPTY) next = nd.child[k];
+                else
+                    stk.Push(nd.child[k]);
+            }
+        return next;
+    }
+    float tk[4];
+    int ck[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tk[k] = h[k] ? t[k] : INFINITY, ck[k] = h[k] ? nd.child[k] : BVH4_EMPTY;
+    auto cswap = [&](int a, int b) {
+        if (tk[b] < tk[a]) {
+            const float tt = tk[a];
+            tk[a] = tk[b], tk[b] = tt;
+            const int cc = ck[a];
+            ck[a] = ck[b], ck[b] = cc;
+        }
+    };
+    cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+    if (ck[3] != BVH4_EMPTY) stk.Push(ck[3]);
+    if (ck[2] != BVH4_EMPTY) stk.Push(ck[2]);
+    if (ck[1] != BVH4_EMPTY) stk.Push(ck[1]);
+    return ck[0];
 }
-// cooperative copy of the top of the tree into LDS (all threads of the block; the caller synchronises)
-LMC_D void StageTopNodes(const DScene &S, uint4 *dst, int count) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(S.nodes);
-    for (int k = threadIdx.x; k < count * 8; k += blockDim.x) dst[(k >> 3) * BVH_LDS_NODE_QUADS + (k & 7)] = src[k];
+// one visit of inner node `cur`: the nearest hit child (or BVH4_EMPTY), the others pushed
+template <bool ORDERED, class Stk>
+LMC_D int VisitInner(const DScene &S, int cur, V3 org, V3 invd, float tnear, float tfar, Stk &stk) {
+#if LMC_BVH_QUANT
+    const BvhNode4Q nd = S.qnodes[cur];
+    return VisitNode4Q<ORDERED>(nd, org, invd, tnear, tfar, stk);
+#else
+    const BvhNode4 nd = S.nodes[cur];
+    return VisitNode4<ORDERED>(nd, org, invd, tnear, tfar, stk);
+#endif
 }
 
 // closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer).
@@ -293,8 +338,7 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     int cur = 0;  // root is an inner node
     for (;;) {
         while (cur >= 0) {
-            const BvhNode4 nd = FetchNode4(S, cur, stk);
-            cur = VisitNode4<true>(nd, org, invd, tnear, bestT, stk);
+            cur = VisitInner<true>(S, cur, org, invd, tnear, bestT, stk);
             if (cur == BVH4_EMPTY) {
                 if (stk.Empty()) {
                     tHit = bestT;
@@ -335,8 +379,7 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     int cur = 0;
     for (;;) {
         while (cur >= 0) {
-            const BvhNode4 nd = FetchNode4(S, cur, stk);
-            cur = VisitNode4<false>(nd, org, invd, tnear, tfar, stk);
+            cur = VisitInner<false>(S, cur, org, invd, tnear, tfar, stk);
             if (cur == BVH4_EMPTY) {
                 if (stk.Empty()) return false;
                 cur = stk.Pop();

@@ -22,14 +22,6 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
     const LdsView L{lds + threadIdx.x, (int)blockDim.x, stackWords};
     typename std::conditional<PROF, WaveProf, NoProf>::type prof;
     if constexpr (PROF) prof.Start();
-#if LMC_BVH_LDS_TOP > 0
-    uint4 *topLds = reinterpret_cast<uint4 *>(lds + blockDim.x * LeanLdsWordsPerThread(stackWords));  // behind the per-thread words (16 B aligned: 64 x 56 x 4)
-    const int topCount = min(S.numNodes, LMC_BVH_LDS_TOP);
-    if (USE_LDS_STACK) {
-        StageTopNodes(S, topLds, topCount);
-        __syncthreads();
-    }
-#endif
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
         Rng rng;
@@ -38,9 +30,6 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
         rng.ticks = 0;
         if (USE_LDS_STACK) {
             LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
-#if LMC_BVH_LDS_TOP > 0
-            stk.top = topLds, stk.topCount = topCount;
-#endif
             SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         } else {
             LocalStackT<GLOSSY> stk;
@@ -62,7 +51,7 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
                           const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, bool profile, hipStream_t s) {
     const int stackWords = LeanStackWords(bvhDepth);  // bvhDepth: the tree's stack need (host/accel.cpp)
-    size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float) + (size_t)LMC_BVH_LDS_TOP * BVH_LDS_NODE_QUADS * 16;
+    size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float);
     if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code
     const bool lds = bvhDepth <= BVH_LDS_STACK;
 #define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords)

@@ -296,7 +296,7 @@ int Collapse(const LbvhResult &bvh, int node, Bvh4Result &out, int depth, int pe
 }  // namespace
 
 // The first `topCount` nodes in breadth-first order (root, its children, their children ...), the rest in their depth-first
-// order: the top of the tree is one contiguous block that a kernel can stage in LDS (dscene.h LMC_BVH_LDS_TOP) -- and that stays
+// order: the top of the tree is one contiguous block -- and that stays
 // in a handful of L1 lines when it does not.  Only node numbers change; the children keep their order inside every node, so the
 // traversal visits the same nodes in the same order.
 static void TopLevelsFirst(Bvh4Result &t, int topCount) {
@@ -325,6 +325,42 @@ static void TopLevelsFirst(Bvh4Result &t, int topCount) {
     t.nodes.swap(nodes);
 }
 
+// dscene.h BvhNode4Q: child boxes as 8-bit offsets inside the node's box, rounded outwards plus one step of margin (none at the node's own
+// faces, where the offset is exact), every bound checked in double precision
+static void QuantizeBvh4(Bvh4Result &t) {
+    t.qnodes.resize(t.nodes.size());
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        const lmcd::BvhNode4 &nd = t.nodes[i];
+        lmcd::BvhNode4Q q;
+        memset(&q, 0, sizeof(q));
+        for (int a = 0; a < 3; a++) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int k = 0; k < 4; k++)
+                if (nd.child[k] != lmcd::BVH4_EMPTY) lo = std::min(lo, nd.bmin[k][a]), hi = std::max(hi, nd.bmax[k][a]);
+            if (!(lo <= hi)) lo = hi = 0.f;  // no child
+            float scale = (float)(((double)hi - (double)lo) / 255.0);
+            while ((double)lo + 255.0 * (double)scale < (double)hi) scale = std::nextafter(scale, INFINITY);
+            q.org[a] = lo, q.scale[a] = scale;
+            for (int k = 0; k < 4; k++) {
+                if (nd.child[k] == lmcd::BVH4_EMPTY) continue;
+                int a0 = 0, a1 = 255;
+                if (scale > 0.f) {
+                    a0 = (int)std::floor(((double)nd.bmin[k][a] - (double)lo) / (double)scale) - 1;
+                    a1 = (int)std::ceil(((double)nd.bmax[k][a] - (double)lo) / (double)scale) + 1;
+                    a0 = std::max(0, std::min(255, a0)), a1 = std::max(0, std::min(255, a1));
+                    while (a0 > 0 && (double)lo + a0 * (double)scale > (double)nd.bmin[k][a]) a0--;
+                    while (a1 < 255 && (double)lo + a1 * (double)scale < (double)nd.bmax[k][a]) a1++;
+                }
+                if ((double)lo + a0 * (double)scale > (double)nd.bmin[k][a] || (double)lo + a1 * (double)scale < (double)nd.bmax[k][a])
+                    throw std::runtime_error("internal: a quantised BVH box does not contain its exact box");
+                q.qmin[a][k] = (unsigned char)a0, q.qmax[a][k] = (unsigned char)a1;
+            }
+        }
+        for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
+        t.qnodes[i] = q;
+    }
+}
+
 Bvh4Result CollapseToBvh4(const LbvhResult &bvh) {
     Bvh4Result out;
     out.leafTris = bvh.leafTris;
@@ -332,6 +368,7 @@ Bvh4Result CollapseToBvh4(const LbvhResult &bvh) {
     Collapse(bvh, 0, out, 1, 0);
     if (out.stackNeed > lmcd::BVH_STACK) throw std::runtime_error("BVH needs a deeper traversal stack than BVH_STACK");
     TopLevelsFirst(out, lmcd::BVH_TOP_NODES);
+    QuantizeBvh4(out);
     return out;
 }
 

@@ -27,6 +27,7 @@ LbvhResult BuildSceneBvh(const std::vector<lmcd::TriData> &tris);
 // stackNeed = the largest number of entries the depth-first traversal can have pending.
 struct Bvh4Result {
     std::vector<lmcd::BvhNode4> nodes;
+    std::vector<lmcd::BvhNode4Q> qnodes;  // the same nodes with quantised child boxes (dscene.h BvhNode4Q), each verified to contain the exact box
     std::vector<lmcd::LeafTri> leafTris;
     int depth = 0, stackNeed = 0;
 };
