@@ -325,8 +325,9 @@ static void TopLevelsFirst(Bvh4Result &t, int topCount) {
     t.nodes.swap(nodes);
 }
 
-// dscene.h BvhNode4Q: child boxes as 8-bit offsets inside the node's box, rounded outwards plus one step of margin (none at the node's own
+// dscene.h BvhNode4Q: child boxes as 8-bit offsets inside the node's box, rounded outwards with a minimum margin (none at the node's own
 // faces, where the offset is exact), every bound checked in double precision
+static constexpr double QUANT_SLACK = 1.0 / 64;
 static void QuantizeBvh4(Bvh4Result &t) {
     t.qnodes.resize(t.nodes.size());
     for (size_t i = 0; i < t.nodes.size(); i++) {
@@ -345,8 +346,10 @@ static void QuantizeBvh4(Bvh4Result &t) {
                 if (nd.child[k] == lmcd::BVH4_EMPTY) continue;
                 int a0 = 0, a1 = 255;
                 if (scale > 0.f) {
-                    a0 = (int)std::floor(((double)nd.bmin[k][a] - (double)lo) / (double)scale) - 1;
-                    a1 = (int)std::ceil(((double)nd.bmax[k][a] - (double)lo) / (double)scale) + 1;
+                    // outwards, with at least QUANT_SLACK of a step between the offset and the exact bound (the device's slab distances carry
+                    // rounding errors of ~1e-4 step at most); none at the node's own faces, where the offset is exact
+                    const double x0 = ((double)nd.bmin[k][a] - (double)lo) / (double)scale, x1 = ((double)nd.bmax[k][a] - (double)lo) / (double)scale;
+                    a0 = (int)std::floor(x0 - QUANT_SLACK), a1 = (int)std::ceil(x1 + QUANT_SLACK);
                     a0 = std::max(0, std::min(255, a0)), a1 = std::max(0, std::min(255, a1));
                     while (a0 > 0 && (double)lo + a0 * (double)scale > (double)nd.bmin[k][a]) a0--;
                     while (a1 < 255 && (double)lo + a1 * (double)scale < (double)nd.bmax[k][a]) a1++;

@@ -8,7 +8,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 f = src if src.endswith(".csv") else sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-short = lambda k: k.split("(")[0].replace("void ", "").replace("lmcd::", "")
+short = lambda k: k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("lmcd::", "")
 by = collections.defaultdict(list)
 for r in rows:
     by[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))

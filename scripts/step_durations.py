@@ -9,7 +9,7 @@ last = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 f = src if src.endswith(".csv") else sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-short = lambda k: k.split("(")[0].replace("void ", "").replace("lmcd::", "")
+short = lambda k: k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("lmcd::", "")
 marks = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("k_build_lists")]
 print("%4s %8s %8s %8s %8s  %s" % ("step", "ms", "hot", "large", "side", "side launches (ms)"))
 for k in range(max(first, 1), min(last, len(marks) - 1) + 1):

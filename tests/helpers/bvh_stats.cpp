@@ -128,6 +128,66 @@ static int Traverse4(const lmc::Bvh4Result &B, V3 org, V3 dir, float tnear, floa
     return best;
 }
 
+// device/dscene.h: VisitNode4Q<true> on the quantised nodes (build option LMC_BVH_QUANT): same arithmetic (fused multiply-add of the 8-bit
+// offsets), same widened comparison; the boxes only cull, so the hits must be those of the exact nodes
+static int Traverse4Q(const lmc::Bvh4Result &B, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stats &st) {
+    V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    int stack[BVH_STACK], sp = 0, best = -1, cur = 0;
+    float bestT = tfar;
+    st.rays++;
+    for (;;) {
+        bool done = false;
+        while (cur >= 0) {
+            const BvhNode4Q &nd = B.qnodes[cur];
+            st.nodes++;
+            const float A[3] = {(nd.org[0] - org.x) * invd.x, (nd.org[1] - org.y) * invd.y, (nd.org[2] - org.z) * invd.z};
+            const float Bq[3] = {nd.scale[0] * invd.x, nd.scale[1] * invd.y, nd.scale[2] * invd.z};
+            float tk[4];
+            int ck[4];
+            for (int k = 0; k < 4; k++) {
+                const float ax = fmaf((float)nd.qmin[0][k], Bq[0], A[0]), bx = fmaf((float)nd.qmax[0][k], Bq[0], A[0]);
+                const float ay = fmaf((float)nd.qmin[1][k], Bq[1], A[1]), by = fmaf((float)nd.qmax[1][k], Bq[1], A[1]);
+                const float az = fmaf((float)nd.qmin[2][k], Bq[2], A[2]), bz = fmaf((float)nd.qmax[2][k], Bq[2], A[2]);
+                const float t0 = fmaxf(fmaxf(tnear, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+                const float t1 = fminf(fminf(bestT, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+                const bool h = nd.child[k] != BVH4_EMPTY && t0 * 0.9999992f <= t1 * 1.0000008f;
+                tk[k] = h ? t0 : INFINITY, ck[k] = h ? nd.child[k] : BVH4_EMPTY;
+            }
+            auto cswap = [&](int a, int b) {
+                if (tk[b] < tk[a]) std::swap(tk[a], tk[b]), std::swap(ck[a], ck[b]);
+            };
+            cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+            for (int k = 3; k >= 1; k--)
+                if (ck[k] != BVH4_EMPTY) stack[sp++] = ck[k];
+            if (sp > st.maxStack) st.maxStack = sp;
+            cur = ck[0];
+            if (cur == BVH4_EMPTY) {
+                if (!sp) {
+                    done = true;
+                    break;
+                }
+                cur = stack[--sp];
+            }
+        }
+        if (done) break;
+        const unsigned code = (unsigned)~cur;
+        const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+        st.leaves++;
+        for (int i = 0; i < cnt; i++) {
+            const LeafTri &tr = B.leafTris[first + i];
+            st.tris++;
+            float t;
+            if (TriTest(tr.p0, tr.e1, tr.e2, org, dir, tnear, bestT, t))
+                if (best < 0 || t < bestT || (t == bestT && tr.id < best)) bestT = t, best = tr.id;
+        }
+        if (!sp) break;
+        cur = stack[--sp];
+    }
+    tHit = bestT;
+    if (best >= 0) st.hits++;
+    return best;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     lmc::LoadOverrides ov;
@@ -146,8 +206,8 @@ int main(int argc, char **argv) {
     }
     lmc::LbvhResult trees[2] = {lmc::BuildLbvh(tris), lmc::BuildSahBvh(tris, 4)};
     const lmc::Bvh4Result wide = lmc::CollapseToBvh4(trees[1]);
-    const char *names[3] = {"lbvh", "sah", "sah_4wide"};
-    Stats st[3];
+    const char *names[4] = {"lbvh", "sah", "sah_4wide", "sah_4wide_quantised"};
+    Stats st[4];
     std::mt19937 gen(7);
     std::uniform_real_distribution<float> U(0.f, 1.f);
     const lmc::Camera &cam = scene->camera;
@@ -174,6 +234,9 @@ int main(int argc, char **argv) {
             float t4;
             const int id4 = Traverse4(wide, org, dir, tnear, INFINITY, t4, st[2]);
             if (id4 != id[1] || (id4 >= 0 && t4 != t[1])) mismatches++;
+            float tq;
+            const int idq = Traverse4Q(wide, org, dir, tnear, INFINITY, tq, st[3]);
+            if (idq != id[1] || (idq >= 0 && tq != t[1])) mismatches++;
             if (id[0] < 0) break;
             const TriData &T = tris[id[0]];
             V3 e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
@@ -188,11 +251,11 @@ int main(int argc, char **argv) {
             tnear = 5e-4f;
         }
     }
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
         printf("{\"tree\": \"%s\", \"nodes\": %zu, \"depth\": %d, \"rays\": %lld, \"node_visits_per_ray\": %.2f, \"leaf_visits_per_ray\": %.2f, \"tri_tests_per_ray\": %.2f, \"max_stack\": %lld, \"stack_bound\": %d}\n",
                names[k], k < 2 ? trees[k].nodes.size() : wide.nodes.size(), k < 2 ? trees[k].depth : wide.depth, st[k].rays, (double)st[k].nodes / st[k].rays,
                (double)st[k].leaves / st[k].rays, (double)st[k].tris / st[k].rays, st[k].maxStack, k < 2 ? trees[k].depth : wide.stackNeed);
-    if (st[2].maxStack > wide.stackNeed) mismatches++;  // the bound the host sizes the traversal stack with must hold
+    if (st[2].maxStack > wide.stackNeed || st[3].maxStack > wide.stackNeed) mismatches++;  // the bound the host sizes the traversal stack with must hold
     printf("{\"mismatches\": %lld}\n", mismatches);
     return mismatches ? 1 : 0;
 }

@@ -310,6 +310,11 @@ def test_bvh_builders_agree_and_stack_bound_holds(tmp_path):
     assert rows[-1] == {"mismatches": 0}
     wide = rows[2]
     assert wide["tree"] == "sah_4wide" and wide["max_stack"] <= wide["stack_bound"] <= 32
+    # the 64-byte nodes with 8-bit child boxes (build option LMC_BVH_QUANT, dscene.h BvhNode4Q): walked with the device's arithmetic they return
+    # the same (triangle id, t) -- counted in `mismatches` above -- at the price of a few more visits
+    quant = rows[3]
+    assert quant["tree"] == "sah_4wide_quantised" and quant["max_stack"] <= wide["stack_bound"]
+    assert quant["node_visits_per_ray"] < 1.25 * wide["node_visits_per_ray"]
     assert wide["node_visits_per_ray"] < 0.65 * rows[1]["node_visits_per_ray"]
 
 
