@@ -97,7 +97,13 @@ struct PssSink {
 
 // The nanoflann-ordered radius search (dchain.h KdRadiusSearch) for the rare query that has a point within its radius.
 // Out of line: its frame stack lives in private memory that the common path never touches.
-__device__ __noinline__ int KdRadiusSearchRare(const DCacheDim &C, int dim, const float *q, float radiusSq, int *idx, float *dist) {
+// The query point is read from the caller's LDS words here, not handed over as a private array: an array whose address escapes into a call lives in
+// scratch memory, and the caller -- the hot path, in which 99.98 % of the queries end at the existence test -- paid twelve scratch stores (and the
+// reloads of the spilled LDS addresses they were filled from) per query for it (hipcc -S of the round-4 kernel).
+__device__ __noinline__ int KdRadiusSearchRare(const DCacheDim &C, int dim, const float *ldsQ, int ldsStride, float radiusSq, int *idx, float *dist) {
+    float q[MD];
+#pragma unroll
+    for (int k = 0; k < MD; k++) q[k] = k < dim ? ldsQ[k * ldsStride] : 0.f;
     return KdRadiusSearch(C, dim, q, radiusSq, 5, idx, dist);
 }
 
@@ -203,13 +209,14 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     st.cacheQueries++;
     const DCacheDim &C = cache.d[dim];
     const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
-    float q[MD];
-#pragma unroll
-    for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
     if (C.gridStart) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
         int cell = 0;
-        for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(q[k], C.gridG);
+        for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(L.Q(k), C.gridG);
         const int s0 = C.gridStart[cell], s1 = C.gridStart[cell + 1];
+        if (s0 == s1) return;  // the common case: the point is read no further
+        float q[MD];
+#pragma unroll
+        for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
         bool any = false;
         for (int j = s0; j < s1; j++) {
             const float2 *row = reinterpret_cast<const float2 *>(C.gridRows + (size_t)j * dim);
@@ -228,7 +235,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         if (!any) return;
     }
     float dist[5];
-    const int n = KdRadiusSearchRare(C, dim, q, radiusSq, vs.idx, dist);
+    const int n = KdRadiusSearchRare(C, dim, &L.Q(0), L.stride, radiusSq, vs.idx, dist);
     if (n > 0) {  // global_cache.h:106-123
         st.cacheHits++;
         vs.mode = VS_BLEND;
