@@ -27,15 +27,18 @@ struct alignas(16) BvhNode4 {
     int pad[4];
 };
 static_assert(sizeof(BvhNode4) == 128, "one node = two cache lines of 64 B");
-// The same node in 64 B (build option LMC_BVH_QUANT=1; off by default): the children's boxes as 8-bit offsets inside the node's own box,
+// The same node in 64 B (build option LMC_BVH_QUANT=1, off by default): the children's boxes as 8-bit offsets inside the node's own box,
 //   child k, axis a:  [org[a] + qmin[a][k] * scale[a],  org[a] + qmax[a][k] * scale[a]]  contains  [bmin[k][a], bmax[k][a]]
-// with one quantisation step of margin wherever the offset is not already at the node's face (host/accel.cpp QuantizeBvh4 checks every
-// bound in double precision).  Why it was built: once the chains are grouped by technique (relocate.hip) the closest-hit traversal is 41 % of
-// the lean kernel (profiles/r04_reloc_g_*), and what a node visit costs is the vector L1's work for 64 lanes x 128 B from 64 different lines
-// -- seven 16-byte loads per lane; this node takes four, from one 64 B half line.  Boxes only cull: a larger box means a visit more, never
-// another hit, so every intersection result stays what the exact boxes give.  Measured (profiles/r04_quant_a_*): torus +2.5 % (headline) /
-// +6 % (full materials, maxdepth 12), veach-door -9 % (LMC) / -5 % (H2MC): its tree mixes room-sized and small boxes in one node, and a
-// step of 1/255 of the node inflates the small ones.  Scene dependent, hence not the default.
+// rounded outwards with a checked margin (host/accel.cpp QuantizeBvh4 verifies every bound in double precision; none at the node's own lower
+// face, where offset 0 is exact).  Why it was built: once the chains are grouped by technique (relocate.hip) the closest-hit traversal is 41 % of
+// the lean kernel (profiles/r04_reloc_g_*), and what a node visit costs is the vector L1's work for 64 lanes x 128 B from 64 different lines --
+// seven 16-byte loads per lane; this node takes four, from one 64 B half line.  Boxes only cull: a larger box means a visit more, never another
+// hit, so every intersection result stays what the exact boxes give (tests/helpers/bvh_stats.cpp walks both forms with the device's arithmetic).
+// What the format cannot represent is a FLAT child away from its node's lower face (a wall): thickened to a step or two, it is entered again by
+// every ray that leaves that surface (veach-door: leaf visits per ray 1.22 -> 1.71, -9 % chain-steps/s; torus: 1.03 -> 1.04, +2.5 .. +6 %;
+// accel.cpp ThickenedFlatLeafShare tells the two kinds of scene apart: 0.005 vs 0.55).  Both formats in one build, chosen per scene at load
+// time, was measured too (profiles/r04_nodes_a_*): the kernels lose on the exact path what the torus gains (veach-door 181 -> 140 M), so the
+// format stays a build option.
 struct alignas(16) BvhNode4Q {
     float org[3], scale[3];
     unsigned char qmin[3][4], qmax[3][4];  // [axis][child]
@@ -43,7 +46,7 @@ struct alignas(16) BvhNode4Q {
 };
 static_assert(sizeof(BvhNode4Q) == 64, "one node = one 64 B half line");
 #ifndef LMC_BVH_QUANT
-#define LMC_BVH_QUANT 0
+#define LMC_BVH_QUANT 0  // build option: 1 = the kernels walk the quantised nodes
 #endif
 // triangle in BVH leaf order, 48 B: Moeller-Trumbore operands + global triangle id
 struct alignas(16) LeafTri {

@@ -235,7 +235,8 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         if (!any) return;
     }
     float dist[5];
-    const int n = KdRadiusSearchRare(C, dim, &L.Q(0), L.stride, radiusSq, vs.idx, dist);
+    int idx[5];  // not vs.idx: an array handed to the search by address lives in private memory, and with it would the whole of vs
+    const int n = KdRadiusSearchRare(C, dim, &L.Q(0), L.stride, radiusSq, idx, dist);
     if (n > 0) {  // global_cache.h:106-123
         st.cacheHits++;
         vs.mode = VS_BLEND;
@@ -243,6 +244,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
 #pragma unroll
         for (int m = 0; m < 5; m++)
             if (m < n) {
+                vs.idx[m] = idx[m];
                 vs.w[m] = inverse(dist[m] * dist[m] + 1e-6f);
                 vs.sum_w += vs.w[m];
             }

@@ -350,6 +350,8 @@ static void QuantizeBvh4(Bvh4Result &t) {
                     // rounding errors of ~1e-4 step at most); none at the node's own faces, where the offset is exact
                     const double x0 = ((double)nd.bmin[k][a] - (double)lo) / (double)scale, x1 = ((double)nd.bmax[k][a] - (double)lo) / (double)scale;
                     a0 = (int)std::floor(x0 - QUANT_SLACK), a1 = (int)std::ceil(x1 + QUANT_SLACK);
+                    if (nd.bmax[k][a] == lo) a1 = 0;  // a flat child in the node's lower face (a floor): offset 0 is exact, the box stays flat --
+                                                      // a thick one is entered by every ray that leaves that surface
                     a0 = std::max(0, std::min(255, a0)), a1 = std::max(0, std::min(255, a1));
                     while (a0 > 0 && (double)lo + a0 * (double)scale > (double)nd.bmin[k][a]) a0--;
                     while (a1 < 255 && (double)lo + a1 * (double)scale < (double)nd.bmax[k][a]) a1++;
@@ -362,6 +364,28 @@ static void QuantizeBvh4(Bvh4Result &t) {
         for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
         t.qnodes[i] = q;
     }
+}
+
+double ThickenedFlatLeafShare(const Bvh4Result &t) {
+    double all = 0, thick = 0;
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        const lmcd::BvhNode4 &nd = t.nodes[i];
+        const lmcd::BvhNode4Q &q = t.qnodes[i];
+        for (int k = 0; k < 4; k++) {
+            if (nd.child[k] == lmcd::BVH4_EMPTY || nd.child[k] >= 0) continue;  // leaf children only
+            double e[3];
+            bool thickened = false;
+            for (int a = 0; a < 3; a++) {
+                e[a] = (double)nd.bmax[k][a] - (double)nd.bmin[k][a];
+                const double g = ((double)q.qmax[a][k] - (double)q.qmin[a][k]) * (double)q.scale[a];
+                if (e[a] < 0.25 * (double)q.scale[a] && g >= (double)q.scale[a] && g > 0) thickened = true;
+            }
+            const double sa = e[0] * e[1] + e[1] * e[2] + e[0] * e[2];
+            all += sa;
+            if (thickened) thick += sa;
+        }
+    }
+    return all > 0 ? thick / all : 0.0;
 }
 
 Bvh4Result CollapseToBvh4(const LbvhResult &bvh) {

@@ -32,6 +32,12 @@ struct Bvh4Result {
     int depth = 0, stackNeed = 0;
 };
 Bvh4Result CollapseToBvh4(const LbvhResult &bvh);
+// Do the quantised nodes suit this tree?  What they cannot represent is a FLAT child away from its node's lower face (a wall, a table top): it gets a
+// thickness of one or two steps, and every ray that leaves such a surface enters its box again (veach-door: 1.22 -> 1.71 leaf visits per ray, the torus
+// scene, whose only flat surface is the floor in the lower face of the root: 1.03 -> 1.04; tests/helpers/bvh_stats.cpp).  Returns the share of the leaf
+// children's surface area that belongs to such thickened flat children; an analysis aid (tests/helpers/bvh_stats.cpp prints it):
+// the quantised nodes are a build option, see dscene.h.
+double ThickenedFlatLeafShare(const Bvh4Result &t);
 
 struct KdTreeResult {
     std::vector<lmcd::KdNode> nodes;

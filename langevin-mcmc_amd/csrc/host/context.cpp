@@ -321,12 +321,15 @@ static void UploadScene(lmc_ctx *c) {
         for (int k = 0; k < 3; k++) d.pos[k] = L.position[k], d.intensity[k] = L.intensity[k], d.radiance[k] = L.radiance[k];
         lights.push_back(d);
     }
-    c->nodes.Upload(bvh.nodes), c->qnodes.Upload(bvh.qnodes), c->leafTris.Upload(bvh.leafTris), c->tris.Upload(tris), c->meshes.Upload(meshes), c->materials.Upload(mats),
+    c->nodes.Upload(bvh.nodes), c->leafTris.Upload(bvh.leafTris), c->tris.Upload(tris), c->meshes.Upload(meshes), c->materials.Upload(mats),
         c->lights.Upload(lights);
     c->areaFunc.Upload(areaFunc), c->areaCdf.Upload(areaCdf), c->lightFunc.Upload(sc.lightFunc), c->lightCdf.Upload(sc.lightCdf);
     DScene &S = c->S;
     memset(&S, 0, sizeof(S));
-    S.nodes = c->nodes.p, S.qnodes = c->qnodes.p, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
+    if (LMC_BVH_QUANT) c->qnodes.Upload(bvh.qnodes);  // build option (dscene.h BvhNode4Q)
+    else
+        c->qnodes.Free();
+    S.nodes = c->nodes.p, S.qnodes = LMC_BVH_QUANT ? c->qnodes.p : nullptr, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
     S.areaFunc = c->areaFunc.p, S.areaCdf = c->areaCdf.p, S.lightFunc = c->lightFunc.p, S.lightCdf = c->lightCdf.p;
     S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
     S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size();

@@ -255,6 +255,7 @@ int main(int argc, char **argv) {
         printf("{\"tree\": \"%s\", \"nodes\": %zu, \"depth\": %d, \"rays\": %lld, \"node_visits_per_ray\": %.2f, \"leaf_visits_per_ray\": %.2f, \"tri_tests_per_ray\": %.2f, \"max_stack\": %lld, \"stack_bound\": %d}\n",
                names[k], k < 2 ? trees[k].nodes.size() : wide.nodes.size(), k < 2 ? trees[k].depth : wide.depth, st[k].rays, (double)st[k].nodes / st[k].rays,
                (double)st[k].leaves / st[k].rays, (double)st[k].tris / st[k].rays, st[k].maxStack, k < 2 ? trees[k].depth : wide.stackNeed);
+    printf("{\"thickened_flat_leaf_share\": %.4f}\n", lmc::ThickenedFlatLeafShare(wide));  // accel.h: what tells scenes the quantised nodes suit from the others
     if (st[2].maxStack > wide.stackNeed || st[3].maxStack > wide.stackNeed) mismatches++;  // the bound the host sizes the traversal stack with must hold
     printf("{\"mismatches\": %lld}\n", mismatches);
     return mismatches ? 1 : 0;
