@@ -575,6 +575,12 @@ def main():
             "accept_rate": stats["accepted"] / max(stats["steps"], 1),
             "large_step_frac": stats["largeSteps"] / max(stats["steps"], 1),
         }
+        try:  # how the resident chains are laid out (device/relocate.hip): grouped by technique unless LMC_RELOCATE=0
+            rs = ren.relocation_stats()
+            out["chain_relocation"] = ({"on": True, "relocations": rs["relocations"], "chains_moved_by_the_last": rs["moved"],
+                                        "technique_breaks_along_the_slots": rs["breaks"], "slots": rs["slots"]} if rs else {"on": False})
+        except Exception as e:
+            out["chain_relocation"] = {"failed": str(e)}
         if standalone is not None and standalone[0] > 0:
             sa_ach = ALGO_BYTES_PER_STEP * standalone[1] / (standalone[0] * 1e-3) / 1e9
             out["roofline"]["standalone"] = {"avg_launch_ms": standalone[0], "chain_steps_per_launch": standalone[1], "achieved": sa_ach,

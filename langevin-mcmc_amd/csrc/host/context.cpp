@@ -1423,7 +1423,7 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
     }
     // group the chains of the generic launch by technique: always for H2MC (a wave then runs ONE (c,l) program with one pass
     // count instead of the longest of 64; LMC_SORT_H2MC=0 for the A/B), optional for the gradient launch of LMC
-    if (c->needGeneric && !c->genericTokenOnly && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala))) {
+    if (c->needGeneric && !c->genericTokenOnly && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala && !c->relocate))) {  // relocated chains are grouped already (LMC: every chain moves; H2MC: chains holding a Gaussian stay, the sort still pays: 58.9 vs 61.7 M)
         LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
         std::swap(c->lists[nxt][1].p, c->listScratch.p);
     }
