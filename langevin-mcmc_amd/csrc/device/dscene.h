@@ -29,14 +29,15 @@ struct alignas(16) BvhNode4 {
 static_assert(sizeof(BvhNode4) == 128, "one node = two cache lines of 64 B");
 // The same node in 64 B (build option LMC_BVH_QUANT=1, off by default): the children's boxes as 8-bit offsets inside the node's own box,
 //   child k, axis a:  [org[a] + qmin[a][k] * scale[a],  org[a] + qmax[a][k] * scale[a]]  contains  [bmin[k][a], bmax[k][a]]
-// rounded outwards with a checked margin (host/accel.cpp QuantizeBvh4 verifies every bound in double precision; none at the node's own lower
-// face, where offset 0 is exact).  Why it was built: once the chains are grouped by technique (relocate.hip) the closest-hit traversal is 41 % of
+// rounded outwards with a checked margin (host/accel.cpp QuantizeBvh4 verifies every bound in double precision; none in the face the node's
+// frame is anchored at, where offset 0 is exact).  Why it was built: once the chains are grouped by technique (relocate.hip) the closest-hit traversal is 41 % of
 // the lean kernel (profiles/r04_reloc_g_*), and what a node visit costs is the vector L1's work for 64 lanes x 128 B from 64 different lines --
 // seven 16-byte loads per lane; this node takes four, from one 64 B half line.  Boxes only cull: a larger box means a visit more, never another
 // hit, so every intersection result stays what the exact boxes give (tests/helpers/bvh_stats.cpp walks both forms with the device's arithmetic).
 // What the format cannot represent is a FLAT child away from its node's lower face (a wall): thickened to a step or two, it is entered again by
 // every ray that leaves that surface (veach-door: leaf visits per ray 1.22 -> 1.71, -9 % chain-steps/s; torus: 1.03 -> 1.04, +2.5 .. +6 %;
-// accel.cpp ThickenedFlatLeafShare tells the two kinds of scene apart: 0.005 vs 0.55).  Both formats in one build, chosen per scene at load
+// accel.cpp ThickenedFlatLeafShare tells the two kinds of scene apart: 0.005 vs 0.55).  Anchoring a node's frame at whichever face holds more
+// flat-child area (negative scale; same device code) brings the door to 1.55 -- interior flat children remain.  Both formats in one build, chosen per scene at load
 // time, was measured too (profiles/r04_nodes_a_*): the kernels lose on the exact path what the torus gains (veach-door 181 -> 140 M), so the
 // format stays a build option.
 struct alignas(16) BvhNode4Q {

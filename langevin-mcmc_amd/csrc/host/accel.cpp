@@ -341,23 +341,38 @@ static void QuantizeBvh4(Bvh4Result &t) {
             if (!(lo <= hi)) lo = hi = 0.f;  // no child
             float scale = (float)(((double)hi - (double)lo) / 255.0);
             while ((double)lo + 255.0 * (double)scale < (double)hi) scale = std::nextafter(scale, INFINITY);
-            q.org[a] = lo, q.scale[a] = scale;
+            // The frame is anchored at the node's lower OR upper face (org = hi, negative scale): offset 0 is exact there, so a FLAT child lying in
+            // the anchored face stays flat.  The face that holds more flat-child area wins.  (A thickened flat child -- a wall, a floor -- is entered
+            // again by every ray that leaves that surface.)  The device code is the same either way: the slab test takes min / max of the two bounds.
+            double flatLo = 0, flatHi = 0;
+            for (int k = 0; k < 4; k++) {
+                if (nd.child[k] == lmcd::BVH4_EMPTY || nd.bmin[k][a] != nd.bmax[k][a]) continue;
+                const int b = (a + 1) % 3, c = (a + 2) % 3;
+                const double area = ((double)nd.bmax[k][b] - nd.bmin[k][b]) * ((double)nd.bmax[k][c] - nd.bmin[k][c]);
+                if (nd.bmin[k][a] == lo) flatLo += area;
+                else if (nd.bmin[k][a] == hi) flatHi += area;
+            }
+            const bool fromHi = flatHi > flatLo;
+            const double org = fromHi ? (double)hi : (double)lo, sc = fromHi ? -(double)scale : (double)scale;
+            q.org[a] = (float)org, q.scale[a] = (float)sc;
             for (int k = 0; k < 4; k++) {
                 if (nd.child[k] == lmcd::BVH4_EMPTY) continue;
+                // offsets of the child's two bounds, measured from the anchored face: u0 <= u1 in steps
+                const double near = fromHi ? (double)hi - (double)nd.bmax[k][a] : (double)nd.bmin[k][a] - (double)lo;
+                const double far = fromHi ? (double)hi - (double)nd.bmin[k][a] : (double)nd.bmax[k][a] - (double)lo;
                 int a0 = 0, a1 = 255;
                 if (scale > 0.f) {
                     // outwards, with at least QUANT_SLACK of a step between the offset and the exact bound (the device's slab distances carry
-                    // rounding errors of ~1e-4 step at most); none at the node's own faces, where the offset is exact
-                    const double x0 = ((double)nd.bmin[k][a] - (double)lo) / (double)scale, x1 = ((double)nd.bmax[k][a] - (double)lo) / (double)scale;
-                    a0 = (int)std::floor(x0 - QUANT_SLACK), a1 = (int)std::ceil(x1 + QUANT_SLACK);
-                    if (nd.bmax[k][a] == lo) a1 = 0;  // a flat child in the node's lower face (a floor): offset 0 is exact, the box stays flat --
-                                                      // a thick one is entered by every ray that leaves that surface
+                    // rounding errors of ~1e-4 step at most); none in the anchored face, where the offset is exact
+                    a0 = (int)std::floor(near / (double)scale - QUANT_SLACK), a1 = (int)std::ceil(far / (double)scale + QUANT_SLACK);
+                    if (far == 0.0) a1 = 0;  // a flat child in the anchored face stays flat
                     a0 = std::max(0, std::min(255, a0)), a1 = std::max(0, std::min(255, a1));
-                    while (a0 > 0 && (double)lo + a0 * (double)scale > (double)nd.bmin[k][a]) a0--;
-                    while (a1 < 255 && (double)lo + a1 * (double)scale < (double)nd.bmax[k][a]) a1++;
+                    while (a0 > 0 && a0 * (double)scale > near) a0--;
+                    while (a1 < 255 && a1 * (double)scale < far) a1++;
                 }
-                if ((double)lo + a0 * (double)scale > (double)nd.bmin[k][a] || (double)lo + a1 * (double)scale < (double)nd.bmax[k][a])
-                    throw std::runtime_error("internal: a quantised BVH box does not contain its exact box");
+                // decoded bounds in world coordinates, checked in double precision
+                const double d0 = org + a0 * sc, d1 = org + a1 * sc, dlo = std::min(d0, d1), dhi = std::max(d0, d1);
+                if (dlo > (double)nd.bmin[k][a] || dhi < (double)nd.bmax[k][a]) throw std::runtime_error("internal: a quantised BVH box does not contain its exact box");
                 q.qmin[a][k] = (unsigned char)a0, q.qmax[a][k] = (unsigned char)a1;
             }
         }
