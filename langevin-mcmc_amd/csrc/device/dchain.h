@@ -33,6 +33,13 @@ constexpr float PSS_QUERY_DIST = 0.01f, PSS_REUSE_DIST = 0.10f;
 constexpr float PCD_MIN = 0.01f, PCD_MAX = 100.f, MTM_MIN = -5.0f, MTM_MAX = 5.0f, LS_RATIO = 0.1f;
 constexpr int OUTLIER_WEAK_REJECT_CNT = 10000, OUTLIER_STRONG_REJECT_CNT = 1000;
 constexpr float OUTLIER_RATIO_THRESHOLD = 30.0f;
+// REMOVE_OUTLIERS, mlt.cpp:147-169: the chain is reset after this many adjacent rejections.  expFlags bit 128 (LMC_EXP_OUTLIER_TEST=1, tests only)
+// lowers the two counts to 6 / 2 so that a short run resets thousands of chains -- the path the counts of the reference make all but
+// unreachable in a test (tests/test_gpu_relocate.py: the reset walks CHAIN ids, which relocated chains carry in A.chainId)
+LMC_HD bool OutlierReset(int rej, bool strongReject, int expFlags) {
+    const int weak = (expFlags & 128) ? 6 : OUTLIER_WEAK_REJECT_CNT, strong = (expFlags & 128) ? 2 : OUTLIER_STRONG_REJECT_CNT;
+    return rej > weak || (strongReject && rej > strong);
+}
 
 LMC_HD int CacheGridG(int dim) {  // cells per axis: the largest G with 1 / G >= radius = sqrt(dim) * PSS_QUERY_DIST
     int G = (int)(1.0f / (sqrtf((float)dim) * PSS_QUERY_DIST));

@@ -719,7 +719,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         int rej = A.adjacentReject[i] + 1;  // REMOVE_OUTLIERS, mlt.cpp:147-169
         A.adjacentReject[i] = rej;
         const bool strongReject = curLs > OUTLIER_RATIO_THRESHOLD * P.normalization;
-        if (rej > OUTLIER_WEAK_REJECT_CNT || (strongReject && rej > OUTLIER_STRONG_REJECT_CNT)) {
+        if (OutlierReset(rej, strongReject, P.expFlags)) {
             ResetToInitState(A, P.chainBegin, P.numChains, OUTLIER_RATIO_THRESHOLD * P.normalization, i, sampleIdx, sel ? A.pathBuf1 : A.curPath);
             A.curSplatCount[i] = 0;
             flags &= ~(F_VALID | F_GAUSS | F_GAUSS_ISO);

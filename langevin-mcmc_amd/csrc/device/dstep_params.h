@@ -8,7 +8,7 @@ struct StepParams {
     int numChains;   // all chains of the job (stride of the init-state arrays)
     int chainBegin;  // global id of this rank's chain 0
     int useGradient;  // 0: derivative library "absent" (isotropic until the cache is ready, path.cpp:4042-4053), 1: in-kernel gradient
-    int expFlags;      // measurement aids, never set in production: bit 0 = skip the film splats of the lean kernel (LMC_EXP_NOSPLAT), bit 1 = skip its cache queries, bit 2 = skip the gradient program of the generic kernel (LMC_EXP_NOGRAD), bit 3 = no statistics reduction in the lean kernel, bits 4 / 5 = H2MC without the Hessian program / without the eigen-solve
+    int expFlags;      // measurement aids, never set in production: bit 0 = skip the film splats of the lean kernel (LMC_EXP_NOSPLAT), bit 1 = skip its cache queries, bit 2 = skip the gradient program of the generic kernel (LMC_EXP_NOGRAD), bit 3 = no statistics reduction in the lean kernel, bits 4 / 5 = H2MC without the Hessian program / without the eigen-solve, bit 7 = outlier reset after 2 / 6 adjacent rejections (tests: dchain.h OutlierReset)
     // lengthDist of the multiplexed large step (mlt.h:99, mutation_large.h:45-47,90-101): PiecewiseConstant1D over the per-length
     // score sums of MLTInit (distribution.h:8-60); lengthCount = 0 unless `largestepmultiplexed` is set
     int lengthCount;

@@ -452,6 +452,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_EXP_NOSTATS")) c->expFlags |= atoi(e) ? 8 : 0;
     if (const char *e = getenv("LMC_EXP_NOHESS")) c->expFlags |= atoi(e) ? 16 : 0;    // H2MC: skip the second-order path program
     if (const char *e = getenv("LMC_EXP_NOEIGEN")) c->expFlags |= atoi(e) ? 32 : 0;   // H2MC: skip the eigen-solve (isotropic Gaussian)
+    if (const char *e = getenv("LMC_EXP_OUTLIER_TEST")) c->expFlags |= atoi(e) ? 128 : 0;  // tests: outlier reset after 6 / 2 adjacent rejections (dchain.h OutlierReset)
     if (const char *e = getenv("LMC_EXP_NOHESSLAUNCH")) c->expFlags |= atoi(e) ? 64 : 0;  // H2MC: the stages are built but the Hessian launch is skipped (stale h2Out: timing only)
     UploadScene(c.get());
     SyncOptions(c.get());

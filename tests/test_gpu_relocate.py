@@ -12,8 +12,9 @@ from tests import gpu_checks as gc
 pytestmark = pytest.mark.gpu
 
 
-def _run(relocate, mala, n_chains, steps, opts, checkpoints=(), max_depth=6):
+def _run(relocate, mala, n_chains, steps, opts, checkpoints=(), max_depth=6, outlier_test=False):
     os.environ["LMC_RELOCATE"] = "1" if relocate else "0"
+    os.environ["LMC_EXP_OUTLIER_TEST"] = "1" if outlier_test else "0"
     try:
         p = gc.pkg()
         ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=max_depth, width=128, height=96, seed_offset=0, use_gradient=1 if gc.pathref() else 0)
@@ -23,7 +24,7 @@ def _run(relocate, mala, n_chains, steps, opts, checkpoints=(), max_depth=6):
             ren.set_option("mala", 0)
         ren.init_chains(200000, n_chains, 64, 10 ** 6)
     finally:
-        del os.environ["LMC_RELOCATE"]
+        del os.environ["LMC_RELOCATE"], os.environ["LMC_EXP_OUTLIER_TEST"]
     out = []
     done = 0
     for upto in list(checkpoints) + [steps]:
@@ -84,6 +85,23 @@ def test_relocation_is_transparent_h2mc():
     off, film0 = _run(False, True, 4096, 30, opts, checkpoints=(2, 9))
     on, film1 = _run(True, True, 4096, 30, opts, checkpoints=(2, 9))
     assert on[-1][2]["relocations"] > 0 and on[-1][2]["moved"] > 0
+    for (s0, st0, r0), (s1, st1, r1) in zip(off, on):
+        _same_states(s0, s1)
+        for k in ("steps", "largeSteps", "accepted", "resets"):
+            assert st0[k] == st1[k], k
+    l0, l1 = gc.lum(film0), gc.lum(film1)
+    assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
+
+
+@pytest.mark.parametrize("mala", [False, True])
+def test_relocated_chains_reset_to_the_init_state_of_their_own_id(mala):
+    """The outlier reset (mlt.cpp:147-169) walks CHAIN ids from the chain's own (`chainId = (chainId + sampleIdx + cnt) % numChains`); a relocated
+    chain lives in another slot and carries its id in `chainId`.  With the reference's counts (1000 / 10000 adjacent rejections) no test reaches
+    the reset, so `LMC_EXP_OUTLIER_TEST=1` lowers them to 2 / 6 on BOTH sides: thousands of resets, and still every chain in the same state."""
+    opts = {"largestepprob": 0.1, "largestepscale": 1.0}
+    off, film0 = _run(False, mala, 8192, 40, opts, checkpoints=(10,), outlier_test=True)
+    on, film1 = _run(True, mala, 8192, 40, opts, checkpoints=(10,), outlier_test=True)
+    assert off[-1][1]["resets"] > 1000, "test set-up: too few resets"
     for (s0, st0, r0), (s1, st1, r1) in zip(off, on):
         _same_states(s0, s1)
         for k in ("steps", "largeSteps", "accepted", "resets"):
