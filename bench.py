@@ -485,6 +485,7 @@ def main():
     ren.step(args.warmup)
     ren.step_timing()  # discard warm-up launches
     lean_before = ren.kernel_timing()[2]
+    steps_before = ren.stats()["steps"]
     barrier()
     t0 = time.time()
     ren.step(args.steps)
@@ -572,6 +573,9 @@ def main():
                         "large_and_generic": large_ms / max(launches, 1)},
             "init_seconds": t_init,
             "normalization": norm,
+            # the same rate from the device's own step counter of THIS rank over the timed region (equals `value` / n_gpus unless a chain ran out
+            # of mutations inside the window, or an A/B build advances a chain more than once per launch)
+            "value_from_step_counter": (stats["steps"] - steps_before) / dt,
             "accept_rate": stats["accepted"] / max(stats["steps"], 1),
             "large_step_frac": stats["largeSteps"] / max(stats["steps"], 1),
         }

@@ -85,6 +85,13 @@ int lmc_group_chains_step(lmc_ctx **ctxs, int n, int n_steps);
  * splat-weight sum) becomes the sum over the members, through peer copies -- lmc_film_allreduce without a communicator.  Once per stepped
  * film, like it.  *ms (may be NULL): wall time of the merge. */
 int lmc_group_film_reduce(lmc_ctx **ctxs, int n, double *ms);
+/* out4 = [distinct devices among the members, ordered pairs of distinct member devices, of which with direct peer access enabled
+ * (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess, once, when the group is set up), host threads that drive the group's steps (one per
+ * member; LMC_GROUP_THREADS=0: one for all)] */
+int lmc_group_info(lmc_ctx **ctxs, int n, long long *out4);
+/* host wall time (ms) this context's steps took to QUEUE (launches, event operations, the exchange's copies) since the last call, and the
+ * number of steps: what a rank-step costs the host thread that drives it, to be read next to the step's GPU time */
+int lmc_host_issue_timing(lmc_ctx *ctx, double *ms, long long *steps);
 /* CPU test hooks (need no GPU): the host-side plan of the sharded MLTInit from the padded blocks the ranks all-gather.
  * lmc_shard_layout: out5 = [first stream, end stream, first sample, end sample, samples of the largest rank] of `rank`;
  * lmc_shard_counts_probe: rank_first[world + 1] = first contribution of every rank's block (and the total);
@@ -152,6 +159,11 @@ int lmc_kernel_timing_split(lmc_ctx *ctx, double *out4);
 int lmc_comm_unique_id(unsigned char *out128);
 int lmc_comm_init(lmc_ctx *ctx, int n_ranks, int rank, const unsigned char *id128);
 int lmc_film_allreduce(lmc_ctx *ctx);
+/* Driver plumbing over the job's own communicator (no second communication library): n <= LMC_COMM_MAX_SCALARS host doubles reduced over
+ * the ranks in place (op 0 sum, 1 max, 2 min), blocking; and a barrier (own stream drained, then a one-word all-reduce). */
+#define LMC_COMM_MAX_SCALARS 64
+int lmc_comm_allreduce_f64(lmc_ctx *ctx, double *vals, int n, int op);
+int lmc_comm_barrier(lmc_ctx *ctx);
 void *lmc_film_device_ptr(lmc_ctx *ctx, long long *n_floats);
 
 /* Batched path program: n evaluations of technique (c,l); SoA, word-major: primary_soa[(2L+1)*n],

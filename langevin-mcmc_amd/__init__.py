@@ -81,6 +81,10 @@ def lib():
         L.lmc_film_allreduce.argtypes = [vp]
         L.lmc_film_device_ptr.argtypes = [vp, vp]
         L.lmc_film_device_ptr.restype = vp
+        L.lmc_comm_allreduce_f64.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
+        L.lmc_comm_barrier.argtypes = [vp]
+        L.lmc_host_issue_timing.argtypes = [vp, vp, vp]
+        L.lmc_group_info.argtypes = [vp, ctypes.c_int, vp]
         _lib = L
     return _lib
 
@@ -161,6 +165,28 @@ class Renderer:
     def film_allreduce(self):
         if lib().lmc_film_allreduce(self.h) != 0:
             raise RuntimeError("lmc_film_allreduce failed: " + _err())
+
+    def comm_allreduce(self, values, op="sum"):
+        """host doubles reduced over the ranks of the job's communicator (op: sum / max / min); returns a list"""
+        v = (ctypes.c_double * len(values))(*[float(x) for x in values])
+        if lib().lmc_comm_allreduce_f64(self.h, v, len(values), {"sum": 0, "max": 1, "min": 2}[op]) != 0:
+            raise RuntimeError("lmc_comm_allreduce_f64 failed: " + _err())
+        return list(v)
+
+    def comm_gather(self, value, rank, world):
+        """every rank's scalar, in rank order, on every rank (a sum of one-hot vectors over the job's communicator)"""
+        return self.comm_allreduce([float(value) if k == rank else 0.0 for k in range(world)], "sum")
+
+    def comm_barrier(self):
+        if lib().lmc_comm_barrier(self.h) != 0:
+            raise RuntimeError("lmc_comm_barrier failed: " + _err())
+
+    def host_issue_timing(self):
+        """(ms of host time spent queueing this context's steps since the last call, steps covered)"""
+        ms, n = ctypes.c_double(), c_ll()
+        if lib().lmc_host_issue_timing(self.h, ctypes.byref(ms), ctypes.byref(n)) != 0:
+            raise RuntimeError(_err())
+        return ms.value, n.value
 
     def direct_lighting(self, direct_spp):
         """DirectLighting pre-pass (direct.cpp); returns the un-normalised direct buffer [H, W, 3]."""
@@ -285,6 +311,13 @@ class Group:
         L.lmc_group_chains_step.argtypes = [vp, ctypes.c_int, ctypes.c_int]
         if L.lmc_group_chains_step(self._arr, len(self.rens), n) != 0:
             raise RuntimeError("lmc_group_chains_step failed: " + _err())
+
+    def info(self):
+        """distinct devices, ordered device pairs, pairs with direct peer access enabled, host threads driving the steps"""
+        o = (c_ll * 4)()
+        if lib().lmc_group_info(self._arr, len(self.rens), o) != 0:
+            raise RuntimeError(_err())
+        return dict(devices=o[0], peer_pairs=o[1], peer_pairs_enabled=o[2], host_threads=o[3])
 
     def film_reduce(self):
         """Every member's device film becomes the sum over the members (peer copies: the in-process lmc_film_allreduce); returns its wall time in ms."""

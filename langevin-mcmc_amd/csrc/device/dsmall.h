@@ -58,23 +58,32 @@ enum : int {
     PW_TIME = 0, PW_SCREEN0, PW_SCREEN1, PW_LGTPOS0, PW_LGTPOS1, PW_LGTDIR0, PW_LGTDIR1, PW_LGTLIGHT, PW_LGTPRIM, PW_ENVPRIM, PW_CAMDEPTH,
     PW_LGTDEPTH, PW_CAMCOUNT, PW_LGTCOUNT, PW_LENS0, PW_LENS1
 };
+// LMC_NT_STATE (A/B build): the streamed path words are loaded / stored non-temporally -- every word of a chain's path record is touched once
+// per step and the resident population (2-3 GB) is a hundred times the L2, so a line of it that stays in L2 only evicts scene data
+#ifdef LMC_NT_STATE
+LMC_D float LdS(const float *p) { return __builtin_nontemporal_load(p); }
+LMC_D void StS(float *p, float v) { __builtin_nontemporal_store(v, p); }
+#else
+LMC_D float LdS(const float *p) { return *p; }
+LMC_D void StS(float *p, float v) { *p = v; }
+#endif
 LMC_D int VertWord(bool lgt, int d, int field) { return DPATH_HEAD_WORDS + ((lgt ? MAXD : 0) + d) * DVERTEX_WORDS + field; }
 
 LMC_D DVertex LoadVertex(const float *buf, size_t N, int i, bool lgt, int d) {
     const float *p = buf + (size_t)VertWord(lgt, d, 0) * N + i;
     DVertex v;
-    v.tri = __float_as_int(p[0]);
-    v.st0 = p[N], v.st1 = p[2 * N], v.rnd0 = p[3 * N], v.rnd1 = p[4 * N], v.bsdfDiscrete = p[5 * N], v.useAbs = p[6 * N], v.rrWeight = p[7 * N];
-    v.dirLight = __float_as_int(p[8 * N]), v.dirPrim = __float_as_int(p[9 * N]);
-    v.dirRnd0 = p[10 * N], v.dirRnd1 = p[11 * N];
+    v.tri = __float_as_int(LdS(p));
+    v.st0 = LdS(p + N), v.st1 = LdS(p + 2 * N), v.rnd0 = LdS(p + 3 * N), v.rnd1 = LdS(p + 4 * N), v.bsdfDiscrete = LdS(p + 5 * N), v.useAbs = LdS(p + 6 * N), v.rrWeight = LdS(p + 7 * N);
+    v.dirLight = __float_as_int(LdS(p + 8 * N)), v.dirPrim = __float_as_int(LdS(p + 9 * N));
+    v.dirRnd0 = LdS(p + 10 * N), v.dirRnd1 = LdS(p + 11 * N);
     return v;
 }
 LMC_D void StoreVertex(float *buf, size_t N, int i, bool lgt, int d, const DVertex &v) {
     float *p = buf + (size_t)VertWord(lgt, d, 0) * N + i;
-    p[0] = __int_as_float(v.tri);
-    p[N] = v.st0, p[2 * N] = v.st1, p[3 * N] = v.rnd0, p[4 * N] = v.rnd1, p[5 * N] = v.bsdfDiscrete, p[6 * N] = v.useAbs, p[7 * N] = v.rrWeight;
-    p[8 * N] = __int_as_float(v.dirLight), p[9 * N] = __int_as_float(v.dirPrim);
-    p[10 * N] = v.dirRnd0, p[11 * N] = v.dirRnd1;
+    StS(p, __int_as_float(v.tri));
+    StS(p + N, v.st0), StS(p + 2 * N, v.st1), StS(p + 3 * N, v.rnd0), StS(p + 4 * N, v.rnd1), StS(p + 5 * N, v.bsdfDiscrete), StS(p + 6 * N, v.useAbs), StS(p + 7 * N, v.rrWeight);
+    StS(p + 8 * N, __int_as_float(v.dirLight)), StS(p + 9 * N, __int_as_float(v.dirPrim));
+    StS(p + 10 * N, v.dirRnd0), StS(p + 11 * N, v.dirRnd1);
 }
 
 // The proposal offsets are consumed in PerturbPathBidir's order through a cursor
@@ -403,14 +412,14 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             // GetPathPss(currentState.path) into LDS, path.cpp:2588-2632
             PssSink qs{L, shortState};
             if (l > 1) {
-                qs.Push(cur[(size_t)PW_LGTPOS0 * N + i]), qs.Push(cur[(size_t)PW_LGTPOS1 * N + i]);
-                qs.Push(cur[(size_t)PW_LGTDIR0 * N + i]), qs.Push(cur[(size_t)PW_LGTDIR1 * N + i]);
-                for (int d = 0; d < lgtCount - 1; d++) qs.Push(cur[(size_t)VertWord(true, d, 3) * N + i]), qs.Push(cur[(size_t)VertWord(true, d, 4) * N + i]);
+                qs.Push(LdS(&cur[(size_t)PW_LGTPOS0 * N + i])), qs.Push(LdS(&cur[(size_t)PW_LGTPOS1 * N + i]));
+                qs.Push(LdS(&cur[(size_t)PW_LGTDIR0 * N + i])), qs.Push(LdS(&cur[(size_t)PW_LGTDIR1 * N + i]));
+                for (int d = 0; d < lgtCount - 1; d++) qs.Push(LdS(&cur[(size_t)VertWord(true, d, 3) * N + i])), qs.Push(LdS(&cur[(size_t)VertWord(true, d, 4) * N + i]));
             }
             if (c > 1) {
-                qs.Push(cur[(size_t)PW_SCREEN0 * N + i]), qs.Push(cur[(size_t)PW_SCREEN1 * N + i]);
-                for (int d = 0; d < camCount - 1; d++) qs.Push(cur[(size_t)VertWord(false, d, 3) * N + i]), qs.Push(cur[(size_t)VertWord(false, d, 4) * N + i]);
-                if (l == 1) qs.Push(cur[(size_t)VertWord(false, camCount - 1, 10) * N + i]), qs.Push(cur[(size_t)VertWord(false, camCount - 1, 11) * N + i]);
+                qs.Push(LdS(&cur[(size_t)PW_SCREEN0 * N + i])), qs.Push(LdS(&cur[(size_t)PW_SCREEN1 * N + i]));
+                for (int d = 0; d < camCount - 1; d++) qs.Push(LdS(&cur[(size_t)VertWord(false, d, 3) * N + i])), qs.Push(LdS(&cur[(size_t)VertWord(false, d, 4) * N + i]));
+                if (l == 1) qs.Push(LdS(&cur[(size_t)VertWord(false, camCount - 1, 10) * N + i])), qs.Push(LdS(&cur[(size_t)VertWord(false, camCount - 1, 11) * N + i]));
             }
             const GradState gs{cur, c, l, curSs, false, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
@@ -484,11 +493,11 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         OffsetCursor off{L, offBase};
         PssSink qs{L, shortState};
         NormalDist normDist(0.0f, S.opt.discreteStdDev);
-        const float time = Modulo1(cur[(size_t)PW_TIME * N + i] + normDist(rng));
-        prop[(size_t)PW_TIME * N + i] = time;
-        prop[(size_t)PW_CAMDEPTH * N + i] = __int_as_float(c), prop[(size_t)PW_LGTDEPTH * N + i] = __int_as_float(l);
-        prop[(size_t)PW_CAMCOUNT * N + i] = __int_as_float(camCount), prop[(size_t)PW_LGTCOUNT * N + i] = __int_as_float(lgtCount);
-        int envPrim = (l == 0) ? __float_as_int(cur[(size_t)PW_ENVPRIM * N + i]) : -1;  // ToSubpath: -1 unless lgtDepth == 0
+        const float time = Modulo1(LdS(&cur[(size_t)PW_TIME * N + i]) + normDist(rng));
+        StS(&prop[(size_t)PW_TIME * N + i], time);
+        StS(&prop[(size_t)PW_CAMDEPTH * N + i], __int_as_float(c)), StS(&prop[(size_t)PW_LGTDEPTH * N + i], __int_as_float(l));
+        StS(&prop[(size_t)PW_CAMCOUNT * N + i], __int_as_float(camCount)), StS(&prop[(size_t)PW_LGTCOUNT * N + i], __int_as_float(lgtCount));
+        int envPrim = (l == 0) ? __float_as_int(LdS(&cur[(size_t)PW_ENVPRIM * N + i])) : -1;  // ToSubpath: -1 unless lgtDepth == 0
         BPS lps, cps;
         DVertex lastLgt;
         lastLgt.tri = -1;
@@ -498,9 +507,9 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         int lgtLight = -1;
         bool lightPhase = false;
         auto BeginCamera = [&]() {  // EmitFromCamera with the perturbed screen position, path.cpp:2032-2038
-            const float screen0 = Modulo1(cur[(size_t)PW_SCREEN0 * N + i] + off.Pop());
-            const float screen1 = Modulo1(cur[(size_t)PW_SCREEN1 * N + i] + off.Pop());
-            prop[(size_t)PW_SCREEN0 * N + i] = screen0, prop[(size_t)PW_SCREEN1 * N + i] = screen1;
+            const float screen0 = Modulo1(LdS(&cur[(size_t)PW_SCREEN0 * N + i]) + off.Pop());
+            const float screen1 = Modulo1(LdS(&cur[(size_t)PW_SCREEN1 * N + i]) + off.Pop());
+            StS(&prop[(size_t)PW_SCREEN0 * N + i], screen0), StS(&prop[(size_t)PW_SCREEN1 * N + i], screen1);
             qs.Push(screen0), qs.Push(screen1);
             screenPos = V2{screen0, screen1};
             EmitFromCamera(S, screenPos, org, dir, cps);
@@ -509,20 +518,20 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         };
         if (l > 1) {
             lightPhase = true;
-            lgtLight = __float_as_int(cur[(size_t)PW_LGTLIGHT * N + i]);
+            lgtLight = __float_as_int(LdS(&cur[(size_t)PW_LGTLIGHT * N + i]));
             const float lightPickProb = PickLightProb(S, lgtLight);
             DPath hd;  // only the emitter fields are used by EmitFromLight
-            hd.lgtPos0 = Modulo1(cur[(size_t)PW_LGTPOS0 * N + i] + off.Pop());
-            hd.lgtPos1 = Modulo1(cur[(size_t)PW_LGTPOS1 * N + i] + off.Pop());
-            hd.lgtDir0 = Modulo1(cur[(size_t)PW_LGTDIR0 * N + i] + off.Pop());
-            hd.lgtDir1 = Modulo1(cur[(size_t)PW_LGTDIR1 * N + i] + off.Pop());
+            hd.lgtPos0 = Modulo1(LdS(&cur[(size_t)PW_LGTPOS0 * N + i]) + off.Pop());
+            hd.lgtPos1 = Modulo1(LdS(&cur[(size_t)PW_LGTPOS1 * N + i]) + off.Pop());
+            hd.lgtDir0 = Modulo1(LdS(&cur[(size_t)PW_LGTDIR0 * N + i]) + off.Pop());
+            hd.lgtDir1 = Modulo1(LdS(&cur[(size_t)PW_LGTDIR1 * N + i]) + off.Pop());
             hd.lgtLight = lgtLight;
-            hd.lgtPrim = __float_as_int(cur[(size_t)PW_LGTPRIM * N + i]);
+            hd.lgtPrim = __float_as_int(LdS(&cur[(size_t)PW_LGTPRIM * N + i]));
             qs.Push(hd.lgtPos0), qs.Push(hd.lgtPos1), qs.Push(hd.lgtDir0), qs.Push(hd.lgtDir1);
             EmitFromLight(S, lightPickProb, hd, org, dir, lps);
-            prop[(size_t)PW_LGTPOS0 * N + i] = hd.lgtPos0, prop[(size_t)PW_LGTPOS1 * N + i] = hd.lgtPos1;
-            prop[(size_t)PW_LGTDIR0 * N + i] = hd.lgtDir0, prop[(size_t)PW_LGTDIR1 * N + i] = hd.lgtDir1;
-            prop[(size_t)PW_LGTLIGHT * N + i] = __int_as_float(lgtLight), prop[(size_t)PW_LGTPRIM * N + i] = __int_as_float(hd.lgtPrim);
+            StS(&prop[(size_t)PW_LGTPOS0 * N + i], hd.lgtPos0), StS(&prop[(size_t)PW_LGTPOS1 * N + i], hd.lgtPos1);
+            StS(&prop[(size_t)PW_LGTDIR0 * N + i], hd.lgtDir0), StS(&prop[(size_t)PW_LGTDIR1 * N + i], hd.lgtDir1);
+            StS(&prop[(size_t)PW_LGTLIGHT * N + i], __int_as_float(lgtLight)), StS(&prop[(size_t)PW_LGTPRIM * N + i], __int_as_float(hd.lgtPrim));
         } else {
             BeginCamera();
         }
@@ -627,7 +636,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             tfar = INFINITY;
             depth++;
         }
-        prop[(size_t)PW_ENVPRIM * N + i] = __int_as_float(envPrim);
+        StS(&prop[(size_t)PW_ENVPRIM * N + i], __int_as_float(envPrim));
     }
     prof.Mark(PR_LOOP_EXIT);  // the last segment's vertex work: connection strategy / emitter hit
     // the one shadow ray of the step (scene.cpp:128-149), cast after its strategy has been evaluated

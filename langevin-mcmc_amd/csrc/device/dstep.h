@@ -171,7 +171,7 @@ LMC_D bool NeedsGeneric(const DCache &cache, const StepParams &P, int camDepth, 
 // (TechniqueKey itself: dchain.h)
 // End of a step: decide the next step's kind now (mlt.cpp:96-97; nothing else draws in between, so the RNG order is the
 // reference's) and publish it for k_build_lists.
-LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, Rng &rng) {
+LMC_D unsigned char QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, Rng &rng) {
     unsigned char nk = NEXT_DONE;
     if (A.sampleIdx[i] < A.numSamples[i]) {
         if (DecideKind(S, A, i, rng) == KIND_LARGE) {
@@ -184,6 +184,7 @@ LMC_D void QueueNext(const DScene &S, const DCache &cache, const ChainArrays &A,
         }
     }
     A.nextKind[i] = nk;
+    return nk;
 }
 
 // PiecewiseConstant1D::SampleDiscrete / Pmf (distribution.h:43-53) on StepParams' lengthDist

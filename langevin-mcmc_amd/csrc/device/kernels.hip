@@ -871,6 +871,15 @@ __global__ void k_add_into(T *dst, const T *src, size_t n) {
 }
 void LaunchAddInto(float *dst, const float *src, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_into<float>, dim3(GridFor((long long)n, 256)), dim3(256), 0, s, dst, src, n); }
 void LaunchAddIntoF64(double *dst, const double *src, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_into<double>, dim3(GridFor((long long)n, 256)), dim3(256), 0, s, dst, src, n); }
+// dst[0] = src[0] + .. + src[n - 1], left to right (the splat-weight sums of a group's members, in rank order: the same double on every member)
+__global__ void k_sum_f64(double *dst, const double *src, int n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double a = 0;
+        for (int k = 0; k < n; k++) a += src[k];
+        dst[0] = a;
+    }
+}
+void LaunchSumF64(double *dst, const double *src, int n, hipStream_t s) { hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(64), 0, s, dst, src, n); }
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }

@@ -14,6 +14,9 @@
 using namespace lmcd;
 
 template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = false>
+#ifndef LMC_LEAN_K
+#define LMC_LEAN_K 1
+#endif
 #ifndef LMC_LEAN_WAVES
 #define LMC_LEAN_WAVES 2  // waves per SIMD the register allocation aims at
 #endif
@@ -32,6 +35,10 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
         rng.state = A.rngState[i];
         rng.tab = A.rngTab + (size_t)i * 64;
         rng.ticks = 0;
+#if LMC_LEAN_K > 1  // A/B build (DESIGN.md "K small steps of a chain per launch"): the chain stays in its lane for up to K consecutive plain small steps
+#pragma unroll 1
+        for (int rep = 0;; rep++) {
+#endif
         if (USE_LDS_STACK) {
             LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
             SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
@@ -39,7 +46,13 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
             LocalStackT<GLOSSY> stk;
             SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         }
-        QueueNext(S, *cache, A, P, i, rng);
+        const unsigned char nk = QueueNext(S, *cache, A, P, i, rng);
+#if LMC_LEAN_K > 1
+            if (rep + 1 >= LMC_LEAN_K || (nk & 3) != NEXT_SMALL_PLAIN) break;
+        }
+#else
+        (void)nk;
+#endif
         A.rngState[i] = rng.state;
         prof.Mark(PR_QUEUE);
     }

@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,6 +123,16 @@ struct lmc_ctx {
     hipStream_t sideStream[2] = {nullptr, nullptr};
     hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
     hipEvent_t packedEvent = nullptr, copiedEvent = nullptr;  // in-process group: this member's stage is complete / this member has copied every stage (ExchangeStagesAsync)
+    // in-process group, film merge (lmc_group_film_reduce): staging for the slices pulled from the peers + the peers' weight sums, allocated when the
+    // group is set up (nothing is allocated inside the merge); events: this member's film is final / this member's slice holds the sum
+    DevBuf<float> filmStage;
+    DevBuf<double> weightStage;
+    hipEvent_t filmReadyEvent = nullptr, sliceReducedEvent = nullptr, weightsCopiedEvent = nullptr;
+    int groupPeerPairs = 0, groupPeerEnabled = 0, groupDevices = 0;  // ordered pairs of distinct member devices / ... with direct peer access enabled (lmc_group_info)
+    // host time spent queueing the launches of this member's steps (StepPhase1 + exchange + StepPhase2) and the steps it covers (lmc_host_issue_timing)
+    double hostIssueMs = 0;
+    long long hostIssueSteps = 0;
+    DevBuf<double> commScratch;  // RCCL job: device words of lmc_comm_allreduce_f64 / lmc_comm_barrier, allocated by lmc_comm_init
     bool overlap = true;
     // scene buffers
     DevBuf<BvhNode4> nodes;
@@ -233,7 +245,7 @@ struct lmc_ctx {
         }
         if (hostCounts) (void)hipHostFree(hostCounts);
         if (countsEvent) (void)hipEventDestroy(countsEvent);
-        for (auto e : {forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent})
+        for (auto e : {forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent, filmReadyEvent, sliceReducedEvent, weightsCopiedEvent})
             if (e) (void)hipEventDestroy(e);
         for (auto st : sideStream)
             if (st) (void)hipStreamDestroy(st);
@@ -677,6 +689,26 @@ void AllGatherBlocks(const std::vector<lmc_ctx *> &g, const std::function<void *
 // same stream).  RCCL rank: ncclAllGather on the step stream.  In-process group: every member's stream waits for every member's stage
 // (packedEvent), copies the stages device to device, and before any member may overwrite its stage again waits for every member's
 // copies (copiedEvent) -- a barrier among the streams, not among the host threads: the host runs ahead and queues the next step.
+// The three parts of one member's share (every member's part A must be queued before any member's part B, every part B before any part C:
+// the sequential driver runs them member by member, the threaded driver of RunSteps puts a barrier of its host threads in between)
+void ExchangeStagePartA(lmc_ctx *c) {
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipEventRecord(c->packedEvent, c->stream));
+}
+void ExchangeStagePartB(lmc_ctx *c, size_t bytes) {
+    HIP_CHECK(hipSetDevice(c->device));
+    const std::vector<lmc_ctx *> &g = c->group;
+    for (size_t q = 0; q < g.size(); q++) {
+        if (g[q] != c) HIP_CHECK(hipStreamWaitEvent(c->stream, g[q]->packedEvent, 0));
+        HIP_CHECK(hipMemcpyAsync((char *)c->pushGather.p + q * bytes, g[q]->pushStage.p, bytes, hipMemcpyDefault, c->stream));
+    }
+    HIP_CHECK(hipEventRecord(c->copiedEvent, c->stream));
+}
+void ExchangeStagePartC(lmc_ctx *c) {
+    HIP_CHECK(hipSetDevice(c->device));
+    for (lmc_ctx *peer : c->group)
+        if (peer != c) HIP_CHECK(hipStreamWaitEvent(c->stream, peer->copiedEvent, 0));
+}
 void ExchangeStagesAsync(const std::vector<lmc_ctx *> &g, size_t bytes) {
     if (bytes == 0) return;
     if (g.size() == 1) {
@@ -686,23 +718,61 @@ void ExchangeStagesAsync(const std::vector<lmc_ctx *> &g, size_t bytes) {
         RcclCheck(GetRccl().AllGather(c->pushStage.p, c->pushGather.p, bytes, ncclUint8, (ncclComm_t)c->comm, c->stream), "ncclAllGather(cache pushes)");
         return;
     }
-    for (lmc_ctx *c : g) {
-        HIP_CHECK(hipSetDevice(c->device));
-        HIP_CHECK(hipEventRecord(c->packedEvent, c->stream));
-    }
-    for (lmc_ctx *c : g) {
-        HIP_CHECK(hipSetDevice(c->device));
-        for (size_t q = 0; q < g.size(); q++) {
-            if (g[q] != c) HIP_CHECK(hipStreamWaitEvent(c->stream, g[q]->packedEvent, 0));
-            HIP_CHECK(hipMemcpyAsync((char *)c->pushGather.p + q * bytes, g[q]->pushStage.p, bytes, hipMemcpyDefault, c->stream));
+    for (lmc_ctx *c : g) ExchangeStagePartA(c);
+    for (lmc_ctx *c : g) ExchangeStagePartB(c, bytes);
+    for (lmc_ctx *c : g) ExchangeStagePartC(c);
+}
+
+// Host threads of an in-process group: one per member, so that the launches of the members' steps are queued side by side instead of one member
+// after the other from a single thread (about 15 launches + 8 event operations per member and step).  fn(k) runs for every member; the first
+// exception is re-thrown on the caller's thread.  LMC_GROUP_THREADS=0: the members one after the other on the caller's thread (A/B).
+bool GroupThreads() {
+    static const bool on = !(getenv("LMC_GROUP_THREADS") && atoi(getenv("LMC_GROUP_THREADS")) == 0);
+    return on;
+}
+struct GroupBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n, count = 0, gen = 0;
+    bool aborted = false;
+    explicit GroupBarrier(int n_) : n(n_) {}
+    bool Wait() {  // false: another member failed, give up
+        std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
+        const int g = gen;
+        if (++count == n) {
+            count = 0, gen++;
+            cv.notify_all();
+            return true;
         }
-        HIP_CHECK(hipEventRecord(c->copiedEvent, c->stream));
+        cv.wait(lk, [&] { return gen != g || aborted; });
+        return !aborted;
     }
-    for (lmc_ctx *c : g) {
-        HIP_CHECK(hipSetDevice(c->device));
-        for (lmc_ctx *peer : g)
-            if (peer != c) HIP_CHECK(hipStreamWaitEvent(c->stream, peer->copiedEvent, 0));
+    void Abort() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
     }
+};
+void ForEachMember(size_t n, const std::function<void(size_t)> &fn, GroupBarrier *bar = nullptr) {
+    if (n <= 1 || !GroupThreads()) {
+        for (size_t k = 0; k < n; k++) fn(k);
+        return;
+    }
+    std::vector<std::exception_ptr> err(n);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < n; k++)
+        th.emplace_back([&, k] {
+            try {
+                fn(k);
+            } catch (...) {
+                err[k] = std::current_exception();
+                if (bar) bar->Abort();
+            }
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
 }
 
 void InitPhase1(lmc_ctx *c, InitJob &J) {
@@ -1026,17 +1096,51 @@ void RunInit(const std::vector<lmc_ctx *> &g, long long numInitSamples, int numC
             if (g[k] == c) return *jobs[k];
         throw std::runtime_error("internal: context outside its group");
     };
-    for (size_t k = 0; k < g.size(); k++) InitPhase1(g[k], *jobs[k]);
+    ForEachMember(g.size(), [&](size_t k) { InitPhase1(g[k], *jobs[k]); });
     AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).count.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherCount.p; }, (size_t)jobs[0]->maxLocalSamples);
-    for (size_t k = 0; k < g.size(); k++) InitPhase2(g[k], *jobs[k]);
+    ForEachMember(g.size(), [&](size_t k) { InitPhase2(g[k], *jobs[k]); });
     AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).outCL.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherCL.p; }, (size_t)jobs[0]->maxLocalContribs);
     AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).outLs.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherLs.p; }, (size_t)jobs[0]->maxLocalContribs * sizeof(float));
-    for (size_t k = 0; k < g.size(); k++) InitPhase3(g[k], *jobs[k]);
+    ForEachMember(g.size(), [&](size_t k) { InitPhase3(g[k], *jobs[k]); });
     AllGatherBlocks(g, [&](lmc_ctx *c) { return (void *)jobOf(c).sendCk.p; }, [&](lmc_ctx *c) { return (void *)jobOf(c).gatherCk.p; }, (size_t)std::max(jobs[0]->maxOwned, 1) * 2 * sizeof(uint64_t));
-    for (size_t k = 0; k < g.size(); k++) InitPhase4(g[k], *jobs[k]);
+    ForEachMember(g.size(), [&](size_t k) { InitPhase4(g[k], *jobs[k]); });
 }
 }  // namespace
 }  // extern "C++"
+
+// What the film merge of an in-process group needs, set up ONCE when the group is: direct peer access between the members' devices (checked
+// with hipDeviceCanAccessPeer, enabled once per ordered pair; without it the runtime stages every peer copy through the host), every member's
+// staging for the slices it pulls, the events the merge is ordered by.  Nothing is allocated inside lmc_group_film_reduce.
+static void GroupSetUpMerge(const std::vector<lmc_ctx *> &g) {
+    const size_t n = g.size();
+    std::vector<int> devs;
+    for (lmc_ctx *c : g)
+        if (std::find(devs.begin(), devs.end(), c->device) == devs.end()) devs.push_back(c->device);
+    int pairs = 0, enabled = 0;
+    for (int a : devs)
+        for (int b : devs) {
+            if (a == b) continue;
+            pairs++;
+            int can = 0;
+            HIP_CHECK(hipDeviceCanAccessPeer(&can, a, b));
+            if (!can) continue;
+            HIP_CHECK(hipSetDevice(a));
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) enabled++;
+            (void)hipGetLastError();  // "already enabled" is not an error to carry into the next check
+        }
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        c->groupDevices = (int)devs.size(), c->groupPeerPairs = pairs, c->groupPeerEnabled = enabled;
+        if (n > 1) {
+            const size_t slice = (c->film.n + n - 1) / n;
+            c->filmStage.Alloc(slice * (n - 1), false);
+            c->weightStage.Alloc(n, false);
+        }
+        for (hipEvent_t *e : {&c->filmReadyEvent, &c->sliceReducedEvent, &c->weightsCopiedEvent})
+            if (!*e) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+}
 
 int lmc_chains_init(lmc_ctx *c, long long numInitSamples, int numChainsTotal, int initThreads, int chainBegin, int chainEnd, long long perChain,
                     long long chainsNeedExtra) {
@@ -1064,10 +1168,21 @@ int lmc_group_chains_init(lmc_ctx **ctxs, int n, long long numInitSamples, int n
     }
     try {
         RunInit(g, numInitSamples, numChainsTotal, initThreads, ranges, perChain, chainsNeedExtra);
+        GroupSetUpMerge(g);
     } catch (...) {  // a failed init (too few contributions, a bad range) must not leave the contexts marked as ranks of an n-rank job
         for (lmc_ctx *c : g) c->group.clear(), c->world = 1, c->rank = 0, c->N = 0;
         throw;
     }
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// out4 = [distinct devices among the members, ordered pairs of distinct member devices, ... of which have direct peer access enabled (the rest
+// of the peer copies are staged by the runtime), host threads that drive the group's steps]
+int lmc_group_info(lmc_ctx **ctxs, int n, long long *out4) {
+    LMC_TRY
+    if (n < 1 || ctxs[0]->group.size() != (size_t)n) throw std::runtime_error("lmc_group_info: not a group lmc_group_chains_init set up");
+    out4[0] = ctxs[0]->groupDevices, out4[1] = ctxs[0]->groupPeerPairs, out4[2] = ctxs[0]->groupPeerEnabled, out4[3] = GroupThreads() ? n : 1;
     return 0;
     LMC_CATCH(-1)
 }
@@ -1464,16 +1579,55 @@ extern "C++" {
 namespace {
 void RunSteps(const std::vector<lmc_ctx *> &g, int nSteps) {
     for (lmc_ctx *c : g) CheckSteppable(c);
-    std::vector<lmc_ctx::StepEvents> ev(g.size());
-    for (int it = 0; it < nSteps; it++) {
-        bool exchange = false;
-        for (size_t k = 0; k < g.size(); k++) {
-            const bool e = StepPhase1(g[k], ev[k]);
-            if (k > 0 && e != exchange) throw std::runtime_error("internal: the ranks of a job disagree on the state of the global cache");
-            exchange = e;
+    typedef std::chrono::steady_clock Clock;
+    const size_t stageBytes = (size_t)g[0]->stageLayout.totalFloats * sizeof(float);
+    if (g.size() == 1 || !GroupThreads()) {  // one rank (of an RCCL job or on its own), or the A/B form of a group: every member from this thread
+        std::vector<lmc_ctx::StepEvents> ev(g.size());
+        for (int it = 0; it < nSteps; it++) {
+            const auto t0 = Clock::now();
+            bool exchange = false;
+            for (size_t k = 0; k < g.size(); k++) {
+                const bool e = StepPhase1(g[k], ev[k]);
+                if (k > 0 && e != exchange) throw std::runtime_error("internal: the ranks of a job disagree on the state of the global cache");
+                exchange = e;
+            }
+            if (exchange && g[0]->world > 1) ExchangeStagesAsync(g, stageBytes);
+            for (size_t k = 0; k < g.size(); k++) StepPhase2(g[k], ev[k], exchange);
+            const double ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+            for (lmc_ctx *c : g) c->hostIssueMs += ms / (double)g.size(), c->hostIssueSteps++;
         }
-        if (exchange && g[0]->world > 1) ExchangeStagesAsync(g, (size_t)g[0]->stageLayout.totalFloats * sizeof(float));
-        for (size_t k = 0; k < g.size(); k++) StepPhase2(g[k], ev[k], exchange);
+    } else {
+        // in-process group: a host thread per member.  The members only meet while a gradient cache is filling (the exchange of the step's pushes:
+        // two barriers of the host threads around the copies' queueing, none of the streams'); afterwards every thread runs ahead on its own.
+        GroupBarrier bar((int)g.size());
+        std::vector<char> wants(g.size(), 0);
+        ForEachMember(g.size(), [&](size_t k) {
+            lmc_ctx *c = g[k];
+            lmc_ctx::StepEvents ev;
+            for (int it = 0; it < nSteps; it++) {
+                const auto t0 = Clock::now();
+                const bool fill = !c->allCachesReady;  // equal on all members: they hold the same cache at every step
+                const bool e = StepPhase1(c, ev);
+                if (fill) {
+                    wants[k] = e ? 1 : 0;
+                    if (!bar.Wait()) return;
+                    for (size_t q = 0; q < g.size(); q++)
+                        if ((wants[q] != 0) != e) throw std::runtime_error("internal: the ranks of a job disagree on the state of the global cache");
+                    if (e && stageBytes) {
+                        ExchangeStagePartA(c);
+                        if (!bar.Wait()) return;
+                        ExchangeStagePartB(c, stageBytes);
+                        if (!bar.Wait()) return;
+                        ExchangeStagePartC(c);
+                    }
+                    if (!bar.Wait()) return;  // wants[] is rewritten by the next step
+                } else if (e) {
+                    throw std::runtime_error("internal: a cache push after every cache became ready");
+                }
+                StepPhase2(c, ev, e);
+                c->hostIssueMs += std::chrono::duration<double, std::milli>(Clock::now() - t0).count(), c->hostIssueSteps++;
+            }
+        }, &bar);
     }
     for (lmc_ctx *c : g) {
         HIP_CHECK(hipSetDevice(c->device));
@@ -1567,9 +1721,14 @@ int lmc_prof_read(lmc_ctx *c, unsigned long long *out16) {
 }
 
 // The film merge of an in-process job (mlt.cpp:203-207 MergeBuffer over the per-thread films; here: over the per-GPU films of the group's
-// members): member 0 pulls every other member's film over xGMI into a staging buffer on its device and adds it, then the sum is copied
-// back to every member -- the in-process counterpart of lmc_film_allreduce (same semantics: in place, once per stepped film).
-// out_ms (may be NULL): wall time of the merge, for bench.py's scaling line.
+// members), the in-process counterpart of lmc_film_allreduce (same semantics: in place, once per stepped film).  A direct reduce-scatter +
+// all-gather over the point-to-point links: member k owns slice k of the film; it pulls slice k of every peer's film (n - 1 copies from n - 1
+// different peers, i.e. over different xGMI links at once) into its staging and adds them in rank order, then every member pulls the finished
+// slices of the others.  Per member 2 (n - 1) / n films cross the links, none of them through one member's links only, and nothing waits on
+// the host in between: the copies and adds are ordered by events among the members' streams (filmReady -> pulls; sliceReduced -> the pulls of
+// that slice, which also guarantees that the owner has finished reading the slice it is about to be overwritten with... of its peers).
+// The weight sums: every member copies all n scalars, then adds them in rank order (the same double on every member).
+// Staging, events and peer access were set up with the group (GroupSetUpMerge); out_ms (may be NULL): wall time of the merge.
 int lmc_group_film_reduce(lmc_ctx **ctxs, int n, double *out_ms) {
     LMC_TRY
     std::vector<lmc_ctx *> g(ctxs, ctxs + n);
@@ -1577,30 +1736,58 @@ int lmc_group_film_reduce(lmc_ctx **ctxs, int n, double *out_ms) {
         if (c->group != g) throw std::runtime_error("lmc_group_film_reduce: not the group lmc_group_chains_init set up");
         if (c->filmReduced) throw std::runtime_error("lmc_group_film_reduce: the films already hold the sum over the members; step or clear them first");
         if (c->film.n != g[0]->film.n) throw std::runtime_error("lmc_group_film_reduce: the members' films differ in size");
-        HIP_CHECK(hipSetDevice(c->device));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     const auto t0 = std::chrono::steady_clock::now();
-    lmc_ctx *r = g[0];
-    HIP_CHECK(hipSetDevice(r->device));
-    DevBuf<float> stage;
-    DevBuf<double> wstage;
-    if (n > 1) stage.Alloc(r->film.n, false), wstage.Alloc(1, false);
-    for (int k = 1; k < n; k++) {
-        HIP_CHECK(hipMemcpyPeerAsync(stage.p, r->device, g[k]->film.p, g[k]->device, r->film.n * sizeof(float), r->stream));
-        LaunchAddInto(r->film.p, stage.p, r->film.n, r->stream);
-        HIP_CHECK(hipMemcpyPeerAsync(wstage.p, r->device, g[k]->weightSum.p, g[k]->device, sizeof(double), r->stream));
-        LaunchAddIntoF64(r->weightSum.p, wstage.p, 1, r->stream);
+    const size_t total = g[0]->film.n, slice = (total + n - 1) / n;
+    auto sliceLen = [&](int k) { return (size_t)k * slice >= total ? (size_t)0 : std::min(slice, total - (size_t)k * slice); };
+    if (n > 1) {
+        for (lmc_ctx *c : g) {  // every member's film (and weight sum) is final once its stream gets here
+            HIP_CHECK(hipSetDevice(c->device));
+            HIP_CHECK(hipEventRecord(c->filmReadyEvent, c->stream));
+        }
+        for (int k = 0; k < n; k++) {  // reduce-scatter: slice k summed on member k, peers added in rank order
+            lmc_ctx *c = g[k];
+            HIP_CHECK(hipSetDevice(c->device));
+            int slot = 0;
+            for (int m = 0; m < n; m++) {
+                if (m != k) HIP_CHECK(hipStreamWaitEvent(c->stream, g[m]->filmReadyEvent, 0));
+                HIP_CHECK(hipMemcpyPeerAsync(c->weightStage.p + m, c->device, g[m]->weightSum.p, g[m]->device, sizeof(double), c->stream));
+                if (m == k || sliceLen(k) == 0) continue;
+                float *st = c->filmStage.p + (size_t)slot * slice;
+                HIP_CHECK(hipMemcpyPeerAsync(st, c->device, g[m]->film.p + (size_t)k * slice, g[m]->device, sliceLen(k) * sizeof(float), c->stream));
+                LaunchAddInto(c->film.p + (size_t)k * slice, st, sliceLen(k), c->stream);
+                slot++;
+            }
+            HIP_CHECK(hipEventRecord(c->sliceReducedEvent, c->stream));
+            HIP_CHECK(hipEventRecord(c->weightsCopiedEvent, c->stream));
+        }
+        for (int k = 0; k < n; k++) {  // all-gather: the finished slices of the peers; the weight sums once every member has read the old ones
+            lmc_ctx *c = g[k];
+            HIP_CHECK(hipSetDevice(c->device));
+            for (int m = 0; m < n; m++) {
+                if (m == k) continue;
+                HIP_CHECK(hipStreamWaitEvent(c->stream, g[m]->sliceReducedEvent, 0));  // == weightsCopiedEvent of m: m has read this member's scalar
+                if (sliceLen(m)) HIP_CHECK(hipMemcpyPeerAsync(c->film.p + (size_t)m * slice, c->device, g[m]->film.p + (size_t)m * slice, g[m]->device, sliceLen(m) * sizeof(float), c->stream));
+            }
+            LaunchSumF64(c->weightSum.p, c->weightStage.p, n, c->stream);
+        }
     }
-    HIP_CHECK(hipStreamSynchronize(r->stream));
-    for (int k = 1; k < n; k++) {
-        HIP_CHECK(hipSetDevice(g[k]->device));
-        HIP_CHECK(hipMemcpyPeerAsync(g[k]->film.p, g[k]->device, r->film.p, r->device, r->film.n * sizeof(float), g[k]->stream));
-        HIP_CHECK(hipMemcpyPeerAsync(g[k]->weightSum.p, g[k]->device, r->weightSum.p, r->device, sizeof(double), g[k]->stream));
-        HIP_CHECK(hipStreamSynchronize(g[k]->stream));
+    for (lmc_ctx *c : g) {
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->filmReduced = true;
     }
-    for (lmc_ctx *c : g) c->filmReduced = true;
     if (out_ms) *out_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+    LMC_CATCH(-1)
+}
+
+// host time spent queueing the launches of this context's steps since the last call, and the steps it covers (an in-process group: per member)
+int lmc_host_issue_timing(lmc_ctx *c, double *ms, long long *steps) {
+    LMC_TRY
+    if (ms) *ms = c->hostIssueMs;
+    if (steps) *steps = c->hostIssueSteps;
+    c->hostIssueMs = 0, c->hostIssueSteps = 0;
     return 0;
     LMC_CATCH(-1)
 }
@@ -1700,8 +1887,33 @@ int lmc_comm_init(lmc_ctx *c, int nranks, int rank, const unsigned char *id128) 
     RcclCheck(GetRccl().CommInitRank(&comm, nranks, id, rank), "ncclCommInitRank");
     c->comm = comm;
     c->world = nranks, c->rank = rank;
+    c->commScratch.Alloc(LMC_COMM_MAX_SCALARS);
     return 0;
     LMC_CATCH(-1)
+}
+
+// Host scalars reduced over the ranks of the job (op 0 sum, 1 max, 2 min), through the job's own communicator on the step stream: what a
+// driver needs around the data path (max-over-ranks timing, per-rank figures gathered as a sum of one-hot vectors) without a second
+// communication library.  Blocks until the result is back.
+int lmc_comm_allreduce_f64(lmc_ctx *c, double *vals, int n, int op) {
+    LMC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->comm) throw std::runtime_error("lmc_comm_allreduce_f64 before lmc_comm_init");
+    if (n < 1 || n > LMC_COMM_MAX_SCALARS) throw std::runtime_error("lmc_comm_allreduce_f64: between 1 and LMC_COMM_MAX_SCALARS values");
+    if (op < 0 || op > 2) throw std::runtime_error("lmc_comm_allreduce_f64: op is 0 (sum), 1 (max) or 2 (min)");
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    HIP_CHECK(hipMemcpyAsync(c->commScratch.p, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RcclCheck(GetRccl().AllReduce(c->commScratch.p, c->commScratch.p, (size_t)n, ncclFloat64, ops[op], (ncclComm_t)c->comm, c->stream), "ncclAllReduce(host scalars)");
+    HIP_CHECK(hipMemcpyAsync(vals, c->commScratch.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+    LMC_CATCH(-1)
+}
+// every rank's queued work is done when this returns on any rank: own stream drained, then a one-word all-reduce
+int lmc_comm_barrier(lmc_ctx *c) {
+    double one = 1.0;
+    if (lmc_sync(c) != 0) return -1;
+    return lmc_comm_allreduce_f64(c, &one, 1, 0);
 }
 
 int lmc_film_allreduce(lmc_ctx *c) {

@@ -19,11 +19,11 @@ run() {
   local v="$1"
   [ "$v" = "-" ] && v="LMC_X=default"
   echo "== $v" >&2
-  env $v timeout 300 python bench.py --no-cpu-baseline --no-rmse --steps $STEPS --warmup $WARM $EXTRA 2>/dev/null | tail -1 | VARIANT="$v" python -c "
+  env $v timeout 300 python bench.py --no-cpu-baseline --no-rmse --no-configs --steps $STEPS --warmup $WARM $EXTRA 2>/dev/null | tail -1 | VARIANT="$v" python -c "
 import json,os,sys
 d=json.loads(sys.stdin.read())
 r=d['roofline']
-print(json.dumps({'variant': os.environ['VARIANT'], 'steps': d['steps'], 'warmup': d['warmup'], 'value': d['value'], 'ms_per_step': d['ms_per_step'],
+print(json.dumps({'variant': os.environ['VARIANT'], 'steps': d['steps'], 'warmup': d['warmup'], 'value': d['value'], 'value_from_step_counter': d.get('value_from_step_counter'), 'ms_per_step': d['ms_per_step'],
   'k_step_small_ms': d['step_ms']['k_step_small'], 'large_and_generic_ms': d['step_ms']['large_and_generic'], 'frac': r['frac'],
   'standalone_ms': r.get('standalone', {}).get('avg_launch_ms'), 'standalone_frac': r.get('standalone', {}).get('frac'), 'accept_rate': d['accept_rate']}))" | tee -a "$OUT"
 }
