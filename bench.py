@@ -3,15 +3,19 @@
 torus geometry, every BSDF diffuse, maxdepth 6, 2^20 persistent chains per GPU, sunsky environment light).
 
 One "step" = one lock-step pass of the chain loop body (mlt.cpp:91-170) over every resident chain.
-Multi-GPU, chains sharded by contiguous global chain-id range (weak scaling: 2^20 chains per GPU), one sum of the per-GPU films at
-the end.  Two launch modes, same sharding, same trajectories:
-  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's): one process per GPU, the exchanges
-    are RCCL collectives inside the library (WORLD_SIZE must equal --gpus);
-  * plain `python bench.py --gpus N`: ONE process drives N contexts, one per device, as an in-process job (lmc_group_*; the
-    exchanges and the film merge are peer copies -- the reference merges its per-thread films in-process too, mlt.cpp:203-207).
-Either way fewer than N visible devices is an error (exit code 2), never a silently smaller job.
+Multi-GPU: chains sharded by contiguous global chain-id range (weak scaling: 2^20 chains per GPU), ONE PROCESS PER GPU, the exchanges are RCCL
+collectives inside the library (sharded MLTInit: ncclAllGather; cache pushes while the gradient caches fill: ncclAllGather per step; one
+ncclAllReduce of the per-GPU films at the end, inside the timed region).  Launch forms, same sharding, same trajectories:
+  * `python bench.py --gpus N`: this script starts the N rank processes itself (main_spawn; the 128-byte RCCL id travels through a private
+    directory, barriers and max-over-ranks timing through the job's communicator -- no torch);
+  * `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's N > 1 command): the launcher starts the ranks, the id
+    travels over its gloo rendezvous (WORLD_SIZE must equal --gpus); everything else as above;
+  * `python bench.py --gpus N --in-process`: explicit fallback, ONE process drives N contexts with device copies instead of RCCL (lmc_group_*;
+    the reference merges its per-thread films in-process too, mlt.cpp:203-207); with LMC_BENCH_OVERSUBSCRIBE=1 the N contexts may share devices
+    (bring-up, reported as `oversubscribed`).
+Every form refuses (exit code 2) to run with fewer than N visible devices: never a silently smaller job.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects."""
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (every N) and, at N = 1, `cpu_baseline`, `equal_time_rmse`, `configs`."""
 import argparse
 import importlib
 import json
@@ -41,6 +45,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json workloads (the `configs` array of the JSON line)")
     ap.add_argument("--rmse-seconds", type=float, default=2.0, help="GPU wall time of the equal-time RMSE leg")
     ap.add_argument("--rmse-gt-spp", type=int, default=8192)
+    ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 without a launcher: ONE process drives N contexts (device copies instead of RCCL); the default is one process per GPU over RCCL")
     return ap.parse_args()
 
 
@@ -326,15 +331,16 @@ def pmc_traffic_meta():
         return None
 
 
-def die(msg):
+def die(msg, code=2):
     sys.stderr.write("bench.py: " + msg + "\n")
-    sys.exit(2)
+    sys.exit(code)
 
 
-def inprocess_job(args, p, gc, name, xml, kw, devices, warm, steps):
-    """One workload on len(devices) GPUs driven from THIS process: one context per device, joined into an in-process job (sharded MLTInit,
-    contiguous chain ranges, per-step exchange of the cache pushes while the gradient caches fill, one film merge at the end).
-    Timed like the single-GPU line: `warm` untimed steps, then `steps` steps + the film merge bracketed by syncs of every context."""
+def inprocess_job(args, p, gc, name, xml, kw, devices, warm, steps, algo_bytes):
+    """One workload on len(devices) GPUs driven from THIS process (`--in-process`): one context per device, joined into an in-process job (sharded
+    MLTInit, contiguous chain ranges, per-step exchange of the cache pushes while the gradient caches fill, one film merge at the end); a host thread
+    per member queues its launches.  Timed like the single-GPU line: `warm` untimed steps, then `steps` steps + the film merge bracketed by syncs
+    of every context."""
     n = len(devices)
     per_gpu, total = args.chains, args.chains * n
     rens = [p.Renderer(xml, seed_offset=0, device=d, use_gradient=1, **kw) for d in devices]
@@ -347,34 +353,47 @@ def inprocess_job(args, p, gc, name, xml, kw, devices, warm, steps):
     grp.step(warm)
     for r in rens:
         r.step_timing()
+        r.host_issue_timing()
         r.sync()
     s0 = [r.stats() for r in rens]
+    k0 = [r.kernel_timing_split() for r in rens]
     t0 = time.time()
     grp.step(steps)
     reduce_ms = grp.film_reduce()
     for r in rens:
         r.sync()
     dt = time.time() - t0
-    per_rank = []
-    for r in rens:
-        ms, launches = r.step_timing()
-        per_rank.append(ms / max(launches, 1))
+    per_rank, fracs, dom_ms_r, dom_names, issue = [], [], [], [], []
     s1 = [r.stats() for r in rens]
+    for r, kk0, ss0, ss1 in zip(rens, k0, s0, s1):
+        ms, launches = r.step_timing()
+        launches = max(launches, 1)
+        per_rank.append(ms / launches)
+        dom, dom_ms, dom_steps, ach = dominant_kernel(kk0, r.kernel_timing_split(), ss0, ss1, launches, algo_bytes, "k_step_small (plain small steps)")
+        dom_ms_r.append(dom_ms), dom_names.append(dom), fracs.append(ach / HBM_PEAK_GBS)
+        ims, isteps = r.host_issue_timing()
+        issue.append(ims / max(isteps, 1))
     steps_total = sum(b["steps"] - a["steps"] for a, b in zip(s0, s1))
     film_sum = float(rens[0].film().sum())
+    info = grp.info()
     for r in rens:
         r.close()
     return {
         "workload": name, "n_gpus": n, "devices": list(devices), "chains_per_gpu": per_gpu, "value": steps_total / dt, "unit": "chain-steps/s",
         "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warm, "init_seconds": t_init, "normalization": norm,
         "per_rank_step_ms": per_rank, "per_rank_step_ms_spread": (max(per_rank) - min(per_rank)) if per_rank else 0.0,
+        "host_issue_ms_per_step_per_rank": issue, "group": info,
         "film_merge_ms": reduce_ms, "film_sum": film_sum,
         "accept_rate": sum(b["accepted"] - a["accepted"] for a, b in zip(s0, s1)) / max(steps_total, 1),
+        "roofline": {"bound": "hbm", "kernel": dom_names[0] + " (rank 0's dominant launch; each rank's own HIP-event bracket)", "frac": sum(fracs) / len(fracs), "achieved": sum(fracs) / len(fracs) * HBM_PEAK_GBS,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_per_rank": fracs, "frac_min": min(fracs), "frac_max": max(fracs), "avg_launch_ms_per_rank": dom_ms_r,
+                     "algorithmic_bytes_per_step": algo_bytes, "traffic": None},
     }
 
 
 def main_inprocess(args):
-    """`python bench.py --gpus N` without a launcher: N contexts in this process (see the module docstring)."""
+    """`python bench.py --gpus N --in-process`: N contexts in this process, device copies instead of RCCL (the explicit fallback; the default for
+    N > 1 is one process per GPU over RCCL, main_spawn)."""
     p = importlib.import_module("langevin-mcmc_amd")
     from tests import gpu_checks as gc
 
@@ -389,132 +408,155 @@ def main_inprocess(args):
             die("--gpus %d but only %d HIP device(s) visible to this process: refusing to measure a smaller job under that name" % (args.gpus, have))
     door = os.path.join(ROOT, "scenes", "veachdoor", "lmc.xml")
     head = inprocess_job(args, p, gc, "torus scene, %d persistent chains per GPU, Lambertian-only BSDF, max path length 6 (BASELINE.json configs[1])" % args.chains,
-                         gc.TORUS, dict(force_diffuse=1, max_depth=6), devices, args.warmup, args.steps)
+                         gc.TORUS, dict(force_diffuse=1, max_depth=6), devices, args.warmup, args.steps, ALGO_BYTES_PER_STEP)
     out = {
         "metric": "MALA chain-steps/sec, torus scene", "value": head["value"], "unit": "chain-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic chains on the shipped torus geometry + sunsky env map (random-seeded PCG streams)",
         "config": {"workload": head["workload"], "chains_per_gpu": args.chains, "init_samples": 8 * args.chains * args.gpus, "samples_per_chain": args.samples_per_chain,
-                   "parallelism": "chains sharded x%d, one process, one context per device" % args.gpus,
-                   "collective": "in-process job: device-to-device copies for the sharded MLTInit, the cache pushes and the film merge (lmc_group_*)",
-                   "devices": devices, "oversubscribed": oversub},
-        "multi_gpu": {k: head[k] for k in ("per_rank_step_ms", "per_rank_step_ms_spread", "film_merge_ms", "init_seconds", "accept_rate", "film_sum")},
+                   "parallelism": "chains sharded x%d, one process, one context per device, one host thread per context" % args.gpus,
+                   "collective": "in-process job (--in-process): device-to-device copies for the sharded MLTInit and the cache pushes, a reduce-scatter + all-gather of peer copies for the film merge (lmc_group_*); NOT RCCL",
+                   "rccl_ranks": 0, "devices": devices, "oversubscribed": oversub},
+        "roofline": head["roofline"],
+        "multi_gpu": {k: head[k] for k in ("per_rank_step_ms", "per_rank_step_ms_spread", "host_issue_ms_per_step_per_rank", "group", "film_merge_ms", "init_seconds", "accept_rate", "film_sum")},
+        "lmc_env": lmc_env(),
     }
     if not args.no_configs:
         try:  # north_star names both scenes: the veach-door LMC workload as a second multi-GPU line
-            out["configs"] = [inprocess_job(args, p, gc, "veach-door, shipped lmc.xml, LMC (BASELINE.json configs[3]), chains sharded over the GPUs", door, {}, devices, 40, 40)]
+            out["configs"] = [inprocess_job(args, p, gc, "veach-door, shipped lmc.xml, LMC (BASELINE.json configs[3]), chains sharded over the GPUs", door, {}, devices, 40, 40, algorithmic_bytes(8))]
         except Exception as e:  # noqa: BLE001 -- the headline line must still come out
             out["configs"] = [{"workload": "veach-door lmc.xml", "failed": str(e)[:300]}]
     print(json.dumps(out))
 
 
-def main():
-    args = parse()
-    if args.gpus < 1:
-        die("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return main_inprocess(args)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and not os.environ.get("LMC_BENCH_FORCE_DIST"):
-        die("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE): launch with --nproc-per-node %d, or without a launcher for the in-process job" % (args.gpus, world, args.gpus))
-    dist = None
-    if world > 1 or os.environ.get("LMC_BENCH_FORCE_DIST"):  # the env switch runs the multi-rank code path with one rank (launch under torch.distributed.run)
-        import torch
-        import torch.distributed as dist_
+# ------------------------------------------------------------------------------------------------ one process per GPU
+class FileBoot:
+    """Side channel of a job spawned by this script (`python bench.py --gpus N` without a launcher): a private directory the parent made.
+    Only two things ever cross it: the 128-byte RCCL id of a job (rank 0 writes it, atomically; the others wait for the file) and, in the
+    dry run, the ranks' reports.  Everything else -- barriers, max-over-ranks timing, the per-rank figures -- goes through the job's own
+    communicator inside the library (lmc_comm_barrier / lmc_comm_allreduce_f64)."""
 
-        torch.cuda.set_device(local)
-        dist_.init_process_group("nccl")  # RCCL
-        dist = dist_
-    import numpy as np
+    kind = "file"
 
-    p = importlib.import_module("langevin-mcmc_amd")
-    from tests import gpu_checks as gc
+    def __init__(self, rank, world, directory):
+        self.rank, self.world, self.dir, self.seq = rank, world, directory, 0
 
-    if p.device_count() <= local:
-        die("rank %d: local device %d is not visible (%d HIP device(s))" % (rank, local, p.device_count()))
-    per_gpu = args.chains
-    total = per_gpu * world
+    def share_id(self, make_id, timeout=300.0):
+        path = os.path.join(self.dir, "id_%d" % self.seq)
+        self.seq += 1
+        if self.rank == 0:
+            data = bytes(make_id())
+            with open(path + ".tmp", "wb") as f:
+                f.write(data)
+            os.rename(path + ".tmp", path)  # atomic: a reader sees all 128 bytes or no file
+            return data
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                die("rank %d: no RCCL id from rank 0 after %.0f s (%s)" % (self.rank, timeout, path), 3)
+            time.sleep(0.005)
+        return open(path, "rb").read()
+
+    def gather_reports(self, rep, timeout=120.0):
+        """dry run only: every rank's report on rank 0 (files in the private directory)"""
+        mine = os.path.join(self.dir, "report_%d.json" % self.rank)
+        with open(mine + ".tmp", "w") as f:
+            json.dump(rep, f)
+        os.rename(mine + ".tmp", mine)
+        if self.rank != 0:
+            return None
+        reps, t0 = [], time.time()
+        for k in range(self.world):
+            pth = os.path.join(self.dir, "report_%d.json" % k)
+            while not os.path.exists(pth):
+                if time.time() - t0 > timeout:
+                    die("dry run: no report from rank %d" % k, 3)
+                time.sleep(0.01)
+            reps.append(json.load(open(pth)))
+        return reps
+
+    def close(self):
+        pass
+
+
+class TorchBoot:
+    """Side channel under `python -m torch.distributed.run` (the driver's N > 1 command): the launcher's own rendezvous, through a gloo
+    process group -- used for the id hand-off only, like FileBoot."""
+
+    kind = "torch.distributed (gloo)"
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+
+        self.rank, self.world, self.dist = rank, world, dist
+        dist.init_process_group("gloo")
+
+    def share_id(self, make_id, timeout=300.0):
+        obj = [bytes(make_id()) if self.rank == 0 else None]
+        self.dist.broadcast_object_list(obj, 0)
+        return obj[0]
+
+    def gather_reports(self, rep, timeout=120.0):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, rep)
+        return out if self.rank == 0 else None
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def rank_job(args, p, gc, boot, rank, world, local, name, xml, kw, warm, steps, algo_bytes, kernel_name, standalone_ok):
+    """One workload on this rank's GPU as rank `rank` of a `world`-rank job: scene, communicator (world > 1: RCCL inside the library, its id over
+    `boot`), sharded MLTInit, `warm` untimed steps, then EXACTLY `steps` steps + the film all-reduce bracketed by a barrier + stream sync on
+    both sides; the time is the MAX over the ranks.  Returns the job's figures on every rank (per-rank lists gathered through the communicator)."""
+    import numpy as np  # noqa: F401
+
+    sharding = importlib.import_module("langevin-mcmc_amd.sharding")
+    per_gpu, total = args.chains, args.chains * world
     init_samples = args.init_samples or 8 * total
-    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, seed_offset=0, device=local, use_gradient=1)
-
-    collective = "in-library RCCL: MLTInit sharded by init stream (3 all-gathers), per-step all-gather of the cache pushes while the gradient caches fill, one all-reduce of the device film (lmc_film_allreduce)"
+    ren = p.Renderer(xml, seed_offset=0, device=local, use_gradient=1, **kw)
+    multi = world > 1 or bool(os.environ.get("LMC_BENCH_FORCE_DIST"))
+    if multi:
+        ren.comm_init(world, rank, boot.share_id(p.comm_unique_id))  # a failure here is fatal (exit 1 with the library's message): no fallback transport
 
     def barrier():
-        ren.sync()
-        if dist is not None:
-            import torch
+        if multi:
+            ren.comm_barrier()  # own stream drained, then a one-word all-reduce over the job's communicator
+        else:
+            ren.sync()
 
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    if dist is not None:
-        import torch
-
-        # bootstrap of the in-library RCCL communicator: rank 0's 128-byte id over torch.distributed (the only use of torch here)
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt = torch.tensor(list(p.comm_unique_id()), dtype=torch.uint8, device="cuda")
-        dist.broadcast(idt, 0)
-        # If the in-library communicator cannot be created on this node, the film sum still runs over RCCL, through
-        # torch.distributed on a staged copy -- reported in the JSON line ("collective"), never silently.
-        try:
-            ren.comm_init(world, rank, bytes(idt.cpu().tolist()))
-        except Exception as e:  # noqa: BLE001
-            collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed: %s)" % str(e)[:200]
-            sys.stderr.write("bench.py rank %d: %s\n" % (rank, collective))
-        ok_t = torch.tensor([1 if collective.startswith("in-library") else 0], device="cuda")
-        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        if int(ok_t.item()) == 0:
-            if collective.startswith("in-library"):
-                collective = "torch.distributed all_reduce of a staged film copy (in-library RCCL init failed on another rank)"
-            # a job in which only SOME ranks hold a communicator would dead-lock in the sharded MLTInit (its all-gathers): every rank
-            # starts over with a context that has none -- each then runs the whole deterministic init for its own chain range and
-            # keeps its gradient cache to itself (the round-2 scheme)
-            ren.close()
-            ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, seed_offset=0, device=local, use_gradient=1)
-    # MLTInit + chain set-up AFTER the communicator exists: the ranks of the job shard the init by stream and exchange what the seeding
-    # needs (include/lmc_abi.h); without a communicator every rank runs the whole (deterministic) init for its own chain range
     t_init = time.time()
-    sharding = importlib.import_module("langevin-mcmc_amd.sharding")
     chain_begin, chain_end = sharding.chain_range(rank, world, per_gpu)  # contiguous global chain ids, weak scaling: per_gpu chains on every rank
     norm, ncontrib = ren.init_chains(init_samples, total, args.init_threads, args.samples_per_chain, 0, chain_begin, chain_end)
     t_init = time.time() - t_init
-    ren.set_option("timing", 1)  # per-step HIP events on the launch stream (lmc_step_timing / lmc_kernel_timing)
-    ren.step(args.warmup)
+    ren.set_option("timing", 1)  # per-step HIP events on the launch streams (lmc_step_timing / lmc_kernel_timing)
+    ren.step(warm)
     ren.step_timing()  # discard warm-up launches
-    lean_before = ren.kernel_timing()[2]
-    steps_before = ren.stats()["steps"]
+    ren.host_issue_timing()
+    k0 = ren.kernel_timing_split()
+    s0 = ren.stats()
     barrier()
     t0 = time.time()
-    ren.step(args.steps)
-    film = None
-    if dist is not None:
-        import torch
-
-        # the data-path collective at the end: the device films are summed in place by the library (RCCL over xGMI, on the step
-        # stream, no host staging); `normalization` is identical on all ranks (the sharded MLTInit ends in the same host walk everywhere)
-        if collective.startswith("in-library"):
-            ren.film_allreduce()
-        else:
-            sharding.allreduce_film(ren.film(), norm, dist, device="cuda")  # staged copy over torch.distributed; also checks that the ranks agree on `normalization`
+    ren.step(steps)
+    if multi:
+        ren.film_allreduce()  # the data-path collective: the device films summed in place (RCCL over xGMI, on the step stream, no host staging)
     barrier()
     dt = time.time() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if multi:
+        dt = ren.comm_allreduce([dt], "max")[0]
     kernel_ms, launches = ren.step_timing()
-    small_ms, large_ms, lean_after = ren.kernel_timing()
-    stats = ren.stats()
-    # outside the timed region: the dominant kernel with the GPU to itself (the large-step launch normally runs beside it on
-    # another stream and stretches its bracket); only meaningful once the start-up launches are over
+    k1 = ren.kernel_timing_split()
+    issue_ms, issue_steps = ren.host_issue_timing()
+    s1 = ren.stats()
+    launches = max(launches, 1)
+    lean_ms = k1["lean_ms"] / launches
+    large_ms, generic_ms = k1["large_ms"] / launches, k1["generic_ms"] / launches
+    steps_rank = s1["steps"] - s0["steps"]
+    dom, dom_ms, dom_steps, achieved = dominant_kernel(k0, k1, s0, s1, launches, algo_bytes, kernel_name)  # of THIS rank
     standalone = None
-    extra = max(0, 48 - (args.warmup + args.steps))  # a short window (the driver's 5 + 20) ends inside the start-up: run past it, untimed, first
-    if world == 1 and args.warmup + args.steps + extra + 20 <= args.samples_per_chain:
+    extra = max(0, 48 - (warm + steps))  # a short window (the driver's 5 + 20) ends inside the start-up: run past it, untimed, first
+    if standalone_ok and not multi and warm + steps + extra + 20 <= args.samples_per_chain:
+        # outside the timed region: the dominant kernel with the GPU to itself (the large-step launch normally runs beside it on another stream)
         if extra:
             ren.step(extra)
             ren.step_timing()
@@ -527,12 +569,117 @@ def main():
         sa_small_ms, _, lean1 = ren.kernel_timing()
         ren.set_option("overlap", 1)
         standalone = (sa_small_ms / max(n_sa, 1), (lean1 - lean0) / max(n_sa, 1))
+    out = {
+        "workload": name, "value": steps * total / dt, "unit": "chain-steps/s", "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warm,
+        "value_from_step_counter": steps_rank / dt, "init_seconds": t_init, "normalization": norm, "init_samples": init_samples, "film": [ren.width, ren.height],
+        "accept_rate": (s1["accepted"] - s0["accepted"]) / max(steps_rank, 1), "large_step_frac": (s1["largeSteps"] - s0["largeSteps"]) / max(steps_rank, 1),
+        "cache_queries_per_step": (s1["cacheQueries"] - s0["cacheQueries"]) / max(steps_rank, 1), "cache_hits_per_query": (s1["cacheHits"] - s0["cacheHits"]) / max(s1["cacheQueries"] - s0["cacheQueries"], 1),
+        "step_ms": {"all_launches": kernel_ms / launches, "k_step_small": lean_ms, "large_and_generic": large_ms + generic_ms},
+        "host_issue_ms_per_step": issue_ms / max(issue_steps, 1),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "kernel": dom, "avg_launch_ms": dom_ms,
+                     "chain_steps_per_launch": dom_steps, "algorithmic_bytes_per_step": algo_bytes,
+                     "concurrent_launches": "the step's other launches run beside this kernel on their own streams inside the bracket"},
+    }
+    if standalone is not None and standalone[0] > 0:
+        sa_ach = algo_bytes * standalone[1] / (standalone[0] * 1e-3) / 1e9
+        out["roofline"]["standalone"] = {"avg_launch_ms": standalone[0], "chain_steps_per_launch": standalone[1], "achieved": sa_ach, "frac": sa_ach / HBM_PEAK_GBS,
+                                         "note": "same kernel, 16 launches after the timed region (and, for a window shorter than 48 steps, after enough further untimed steps to be past the cache fill) with the side launches serialised"}
+    try:  # how the resident chains are laid out (device/relocate.hip): grouped by technique unless LMC_RELOCATE=0
+        rs = ren.relocation_stats()
+        out["chain_relocation"] = ({"on": True, "relocations": rs["relocations"], "chains_moved_by_the_last": rs["moved"],
+                                    "technique_breaks_along_the_slots": rs["breaks"], "slots": rs["slots"]} if rs else {"on": False})
+    except Exception as e:  # noqa: BLE001
+        out["chain_relocation"] = {"failed": str(e)}
+    if multi:
+        # every rank's own figures, in rank order, on every rank (sums of one-hot vectors over the job's communicator)
+        g = lambda v: ren.comm_gather(v, rank, world)
+        fr, ms_, st_, iss = g(out["roofline"]["frac"]), g(dom_ms), g(out["step_ms"]["all_launches"]), g(out["host_issue_ms_per_step"])
+        out["roofline"].update({"frac_per_rank": fr, "frac_min": min(fr), "frac_max": max(fr), "avg_launch_ms_per_rank": ms_, "frac": sum(fr) / len(fr),
+                                "achieved": sum(fr) / len(fr) * HBM_PEAK_GBS, "note": "frac / achieved: mean over the ranks of each rank's own dominant-kernel bracket; rank 0's kernel named"})
+        out["multi_gpu"] = {"rccl_ranks": world, "per_rank_step_ms": st_, "per_rank_step_ms_spread": max(st_) - min(st_), "host_issue_ms_per_step_per_rank": iss,
+                            "film_sum": float(ren.film().sum()) if rank == 0 else None, "boot": boot.kind if boot else None,
+                            "collective": "in-library RCCL (librccl, one communicator per job, created from a 128-byte id): MLTInit sharded by init stream (ncclAllGather x 4), "
+                                          "per-step ncclAllGather of the cache pushes while the gradient caches fill, ONE ncclAllReduce of the device film + the splat-weight scalar "
+                                          "inside the timed region (lmc_film_allreduce); barriers / max-over-ranks timing: ncclAllReduce of host scalars (lmc_comm_allreduce_f64)"}
+    ren.close()
+    return out
+
+
+def dominant_kernel(k0, k1, s0, s1, launches, algo_bytes, lean_name):
+    """the step launch with the longest HIP-event bracket over the timed launches and its roofline figures:
+    (name, avg launch ms, chain-steps per launch, achieved GB/s of algorithmic bytes)"""
+    launches = max(launches, 1)
+    steps_rank = s1["steps"] - s0["steps"]
+    large_steps = (s1["largeSteps"] - s0["largeSteps"]) / launches
+    lean_ms, lean_steps = k1["lean_ms"] / launches, (k1["lean_steps"] - k0["lean_steps"]) / launches
+    ker = {lean_name: (lean_ms, lean_steps), "k_step<large>": (k1["large_ms"] / launches, large_steps),
+           "generic small-step launches (cache-filling gradient pipeline / H2MC pipeline)": (k1["generic_ms"] / launches, steps_rank / launches - large_steps - lean_steps)}
+    dom = max(ker, key=lambda k: ker[k][0])
+    dom_ms, dom_steps = ker[dom]
+    return dom, dom_ms, dom_steps, (algo_bytes * dom_steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0)
+
+
+def lmc_env():
+    """every LMC_* switch in the environment: a number measured with one set must say so (INTEGRATION.md has the table of switches)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("LMC_")}
+
+
+WORK_SKIPPING = ("LMC_EXP_NOSPLAT", "LMC_EXP_NOQUERY", "LMC_EXP_NOGRAD", "LMC_EXP_NOSTATS", "LMC_EXP_NOHESS", "LMC_EXP_NOEIGEN", "LMC_EXP_NOHESSLAUNCH", "LMC_EXP_QUERY_STOP")
+
+
+def main_rank(args):
+    """one rank of the job: the whole of a one-GPU run; rank r of `--gpus N` when spawned by main_spawn or by torch.distributed.run"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("LMC_BENCH_FORCE_DIST"):
+        die("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE): launch with --nproc-per-node %d, or without a launcher (bench.py then starts one process per GPU itself)" % (args.gpus, world, args.gpus))
+    skipping = [k for k in WORK_SKIPPING if os.environ.get(k, "0") not in ("", "0")]
+    if skipping and not os.environ.get("LMC_BENCH_ALLOW_EXP"):
+        die("work-skipping measurement switches set (%s): such a run is an ablation, not a benchmark -- run it through scripts/pmc_ab.sh / scripts/ab_bench.sh (LMC_BENCH_ALLOW_EXP=1), which label it" % ", ".join(skipping))
+    dry = bool(os.environ.get("LMC_BENCH_DRY_RUN"))
+    boot = None
+    if "LMC_BENCH_BOOT" in os.environ:
+        boot = FileBoot(rank, world, os.environ["LMC_BENCH_BOOT"])
+    elif world > 1 or os.environ.get("LMC_BENCH_FORCE_DIST"):
+        boot = TorchBoot(rank, world)
+    if dry:  # CPU test of the launch path (tests/test_host.py): the id hand-off of two consecutive jobs, no GPU work
+        import hashlib
+
+        ids = [boot.share_id(lambda: os.urandom(128)) for _ in range(2)]
+        rep = {"rank": rank, "world": world, "local": local, "ids": [hashlib.sha256(i).hexdigest() for i in ids], "lens": [len(i) for i in ids]}
+        reps = boot.gather_reports(rep)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "boot": boot.kind, "ranks": reps, "ids_equal": all(r["ids"] == reps[0]["ids"] for r in reps),
+                              "ids_distinct_per_job": reps[0]["ids"][0] != reps[0]["ids"][1]}))
+        boot.close()
+        return
+    p = importlib.import_module("langevin-mcmc_amd")
+    from tests import gpu_checks as gc
+
+    if p.device_count() <= local:
+        die("rank %d: local device %d is not visible (%d HIP device(s))" % (rank, local, p.device_count()))
+    multi = world > 1 or bool(os.environ.get("LMC_BENCH_FORCE_DIST"))
+    head_name = "torus scene, %d persistent chains per GPU, Lambertian-only BSDF, max path length 6 (BASELINE.json configs[1])" % args.chains
+    head = rank_job(args, p, gc, boot, rank, world, local, head_name, gc.TORUS, dict(force_diffuse=1, max_depth=6), args.warmup, args.steps, ALGO_BYTES_PER_STEP,
+                    "k_step_small<true,false,false,true> (plain small steps; the instantiation without light sub-paths: this scene is lit by its environment map alone)", True)
+    door = None
+    if multi and not args.no_configs:  # north_star names both scenes at 1 / 2 / 4 / 8 GPUs: the veach-door LMC workload as the job's second line
+        try:
+            door = rank_job(args, p, gc, boot, rank, world, local, "veach-door, shipped lmc.xml (area light, textures, max path length 8), LMC (BASELINE.json configs[3]), chains sharded over the GPUs",
+                            os.path.join(ROOT, "scenes", "veachdoor", "lmc.xml"), {}, 40, 40, algorithmic_bytes(8), "k_step_small<glossy> (plain small steps)", False)
+        except Exception as e:  # noqa: BLE001 -- the headline line must still come out
+            door = {"workload": "veach-door lmc.xml", "failed": str(e)[:300]}
     if rank == 0:
-        value = args.steps * total / dt
-        # dominant kernel: k_step_small (plain small steps); its own HIP-event bracket on the launch stream
-        avg_launch_s = (small_ms / max(launches, 1)) * 1e-3
-        lean_steps_per_launch = (lean_after - lean_before) / max(launches, 1)
-        achieved = ALGO_BYTES_PER_STEP * lean_steps_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        value = head["value"]
+        roof = head["roofline"]
+        if roof["kernel"].startswith("k_step_small"):  # the counter figure belongs to the lean kernel
+            roof["traffic"] = pmc_traffic()
+            roof["traffic_measured_at"] = pmc_traffic_meta()
+            roof["traffic_source"] = ("REPLAYED from the committed rocprofv3 --pmc summary profiles/pmc_step_kernel.json (gated on the fingerprint of the kernel's sources); "
+                                      "not counted during this run: counters need their own rocprofv3 passes (scripts/pmc_passes.sh)")
+        else:
+            roof["traffic"] = None
         out = {
             "metric": "MALA chain-steps/sec, torus scene",
             "value": value,
@@ -540,73 +687,123 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic chains on the shipped torus geometry + sunsky env map (random-seeded PCG streams)",
             "config": {
-                "workload": "torus scene, %d persistent chains per GPU, Lambertian-only BSDF, max path length 6 (BASELINE.json configs[1])" % per_gpu,
-                "chains_per_gpu": per_gpu,
-                "init_samples": init_samples,
+                "workload": head_name,
+                "chains_per_gpu": args.chains,
+                "init_samples": head["init_samples"],
                 "samples_per_chain": args.samples_per_chain,
-                "film": [ren.width, ren.height],
-                "parallelism": "chains sharded x%d" % world,
-                "collective": collective if world > 1 else "none (one GPU)",
+                "film": head["film"],
+                "parallelism": "chains sharded x%d, one process per GPU" % world,
+                "collective": head["multi_gpu"]["collective"] if multi else "none (one GPU)",
+                "rccl_ranks": world if multi else 0,
+                "launch": ("spawned by bench.py, id over a private directory" if boot and boot.kind == "file" else "torch.distributed.run, id over its gloo rendezvous") if multi else "single process",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(),
-                "kernel": "k_step_small<true,false,false,true> (plain small steps; the instantiation without light sub-paths: this scene is lit by its environment map alone)",
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "chain_steps_per_launch": lean_steps_per_launch,
-                "algorithmic_bytes_per_step": ALGO_BYTES_PER_STEP,
-                "traffic_measured_at": pmc_traffic_meta(),
-                "concurrent_launches": "k_step<large> runs beside this kernel on a second stream inside the bracket",
-            },
-            "step_ms": {"all_launches": kernel_ms / max(launches, 1), "k_step_small": small_ms / max(launches, 1),
-                        "large_and_generic": large_ms / max(launches, 1)},
-            "init_seconds": t_init,
-            "normalization": norm,
-            # the same rate from the device's own step counter of THIS rank over the timed region (equals `value` / n_gpus unless a chain ran out
-            # of mutations inside the window, or an A/B build advances a chain more than once per launch)
-            "value_from_step_counter": (stats["steps"] - steps_before) / dt,
-            "accept_rate": stats["accepted"] / max(stats["steps"], 1),
-            "large_step_frac": stats["largeSteps"] / max(stats["steps"], 1),
+            "roofline": roof,
+            "step_ms": head["step_ms"],
+            "host_issue_ms_per_step": head["host_issue_ms_per_step"],
+            "init_seconds": head["init_seconds"],
+            "normalization": head["normalization"],
+            "value_from_step_counter": head["value_from_step_counter"],
+            "accept_rate": head["accept_rate"],
+            "large_step_frac": head["large_step_frac"],
+            "cache_queries_per_step": head["cache_queries_per_step"],
+            "cache_hits_per_query": head["cache_hits_per_query"],
+            "chain_relocation": head.get("chain_relocation"),
+            "lmc_env": lmc_env(),
         }
-        try:  # how the resident chains are laid out (device/relocate.hip): grouped by technique unless LMC_RELOCATE=0
-            rs = ren.relocation_stats()
-            out["chain_relocation"] = ({"on": True, "relocations": rs["relocations"], "chains_moved_by_the_last": rs["moved"],
-                                        "technique_breaks_along_the_slots": rs["breaks"], "slots": rs["slots"]} if rs else {"on": False})
-        except Exception as e:
-            out["chain_relocation"] = {"failed": str(e)}
-        if standalone is not None and standalone[0] > 0:
-            sa_ach = ALGO_BYTES_PER_STEP * standalone[1] / (standalone[0] * 1e-3) / 1e9
-            out["roofline"]["standalone"] = {"avg_launch_ms": standalone[0], "chain_steps_per_launch": standalone[1], "achieved": sa_ach,
-                                             "frac": sa_ach / HBM_PEAK_GBS, "note": "same kernel, 16 launches after the timed region (and, for a window shorter than 48 steps, after enough further untimed steps to be past the cache fill) with the side launches serialised"}
-        if not args.no_configs and world == 1:
-            ren.close()
+        if multi:
+            out["multi_gpu"] = head["multi_gpu"]
+            if door is not None:
+                out["configs"] = [door]
+        if not args.no_configs and not multi:
             out["configs"] = other_configs(args, p, gc)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"value": None, "unit": "chain-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %s" % e}
             if not args.no_rmse and out["cpu_baseline"].get("value"):
                 try:
-                    ren.close()
                     out["equal_time_rmse"] = equal_time_rmse(args, p, gc, value, out["cpu_baseline"]["value"], out["cpu_baseline"].get("threads", out["cpu_baseline"]["cores"]))
                 except Exception as e:
                     out["equal_time_rmse"] = {"failed": str(e)}
         print(json.dumps(out))
-    ren.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if boot:
+        boot.close()
+
+
+def main_spawn(args):
+    """`python bench.py --gpus N` without a launcher: this process starts N workers, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE in their
+    environment, a private directory as the side channel of the RCCL id), relays rank 0's JSON line and waits for all of them.  It touches no
+    GPU itself beyond counting the devices."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    dry = bool(os.environ.get("LMC_BENCH_DRY_RUN"))
+    if not dry:
+        p = importlib.import_module("langevin-mcmc_amd")
+        have = p.device_count()
+        if have < args.gpus:
+            die("--gpus %d but only %d HIP device(s) visible to this process: refusing to measure a smaller job under that name "
+                "(RCCL cannot place two ranks on one device; for bring-up on fewer devices: --in-process with LMC_BENCH_OVERSUBSCRIBE=1)" % (args.gpus, have))
+    boot_dir = tempfile.mkdtemp(prefix="lmc_bench_")
+    procs = []
+    try:
+        for k in range(args.gpus):
+            env = dict(os.environ, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(args.gpus), LMC_BENCH_BOOT=boot_dir)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL's peer-to-peer transport needs on this host driver
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if k == 0 else subprocess.DEVNULL))
+        line, code = None, 0
+        out0 = procs[0].stdout
+        pending = set(range(args.gpus))
+        import threading
+
+        buf = []
+        th = threading.Thread(target=lambda: buf.extend(out0.read().decode().splitlines()), daemon=True)
+        th.start()
+        while pending:
+            for k in list(pending):
+                rc = procs[k].poll()
+                if rc is None:
+                    continue
+                pending.discard(k)
+                if rc != 0:  # one rank failed: the others would wait in a collective for ever
+                    code = code or rc
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (k, rc))
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+        th.join(timeout=10)
+        for l in buf:
+            if l.startswith("{"):
+                line = l
+        if code:
+            sys.exit(code)
+        if line is None:
+            die("rank 0 printed no JSON line", 3)
+        print(line)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(boot_dir, ignore_errors=True)
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        die("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("LMC_BENCH_FORCE_SPAWN")):  # the switch: the spawned form with ONE rank (tests on a one-GPU box)
+        return main_inprocess(args) if args.in_process else main_spawn(args)
+    return main_rank(args)
 
 
 if __name__ == "__main__":

@@ -189,7 +189,8 @@ int lmc_cache_probe(lmc_ctx *ctx, int dim, int n, const float *u, int *row, cons
 /* rays: n x [ox,oy,oz,dx,dy,dz,tnear,tfar]; closest hit -> global triangle id (or -1) and t */
 int lmc_trace(lmc_ctx *ctx, int n, const float *rays, int *prim, float *t);
 int lmc_occluded(lmc_ctx *ctx, int n, const float *rays, int *occluded);
-/* mode 0 raw u32, 1 uniform01 bits, 2 one normal_distribution object, 3 mixed (u,u,7 normals per round);
+/* mode 0 raw u32, 1 uniform01 bits, 2 one normal_distribution object, 3 mixed (u,u,7 normals per round); + 8: the extension table synthesised from
+ * the seed until the stream ticks, as the chain kernels do (device/drng.h) instead of read from memory;
  * out: n_seeds x (n + 66) words, the last 66 = RNG state after the draws [lo, hi, table 64] */
 int lmc_rng_probe(int n_seeds, const unsigned long long *seeds, int mode, int n, float mean, float stddev, unsigned *out);
 int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, float radius_sq, int knn, int *out_n, int *out_idx, float *out_dist);

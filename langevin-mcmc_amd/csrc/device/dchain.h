@@ -65,16 +65,23 @@ struct DCacheDim {
     const KdNode *nodes;
     const int *vind;
     const float *pts, *v1, *v2;  // PSS_MAX_SIZE x dim, row-major
-    // Exact existence test in front of the radius query (lean kernel): a uniform grid over the first gridM coordinates with
-    // cells no smaller than the query radius (G = floor(1 / sqrt(dim) / 0.01)).  Every cell lists the points of its 3^gridM
-    // neighbourhood (rows copied: gridRows[gridStart[c] .. gridStart[c+1]) x dim), so a point within the radius of a query is
-    // among the candidates of the query's own cell: two adjacent loads find them, and testing them with the search's own
-    // distance arithmetic decides "any match?" exactly.  Only then (0.015 % of the queries on the torus) is the
-    // nanoflann-ordered search needed.  The search itself cost 40 % of the lean kernel
+    // Exact existence test in front of the radius query (lean kernel): a uniform grid over gridM coordinates (gridCoord: the ones in which the
+    // cache rows collide least, chosen when the dim becomes ready -- host/accel.h ChooseGridCoords) with cells no smaller than the query radius
+    // (G = floor(1 / sqrt(dim) / 0.01)).  Every cell lists the rows of its 3^gridM neighbourhood, so a row within the radius of a query is
+    // among the candidates of the query's own cell, and testing them with the search's own distance arithmetic decides "any match?" exactly.
+    // Only then (0.015 % of the queries on the torus) is the nanoflann-ordered search needed.  The search itself cost 40 % of the lean kernel
     // (profiles/r02_f_ablation_splat_query.jsonl): in 6-12 dimensions its split planes prune little.
-    const int *gridStart;
-    const float *gridRows;
+    // Layout (round 5): COMPACT, so that what a query touches stays in L2 instead of 22 MB of offsets + 30 MB of copied rows that every
+    // query missed (profiles/r05_a_pmc_read_attribution_*: 377 B of HBM-side reads per chain-step, a sixth of the kernel's):
+    //   gridWords[cell / 32] = {occupancy bits of 32 cells, number of non-empty cells before them}   (0.15 - 0.64 MB per dim)
+    //   gridCellStart[r], [r + 1] = the candidate range of the r-th non-empty cell                    (<= 1 MB)
+    //   gridIdx[j] = row index of candidate j (16 bit), the row itself read from `pts` (72 - 144 KB)  (<= 0.5 MB)
+    // An empty cell -- 52 - 67 % of the queries of the headline workload -- ends at one 8-byte load.
+    const uint2 *gridWords;
+    const int *gridCellStart;
+    const unsigned short *gridIdx;
     int gridG, gridM;
+    int gridCoord[4];
     float rootLow[MAXPSS], rootHigh[MAXPSS];
     // `samplecache` (LargeStepCache, global_cache.h:21-23,42-47,57-58,126-164): every row's path and contribution (CACHE_ROW_EXTRA
     // words), its weight, PiecewiseConstant1D over the weights (cdf of PSS_MAX_SIZE + 1 entries), their double sum in row order,
@@ -117,7 +124,8 @@ LMC_HD PushStageLayout MakePushStageLayout(bool withPaths) {  // withPaths (`sam
 struct ChainArrays {
     int N;
     uint64_t *rngState;
-    uint32_t *rngTab;  // N x 64 (AoS)
+    uint32_t *rngTab;  // N x 64 (AoS): a chain's extension table once its stream has ticked (drng.h); until then synthesised from the seed, never read
+    unsigned char *rngTicked;  // N: the chain's stream has ticked, its table lives in rngTab
     float *curPath;    // DPATH_WORDS x N: path buffer 0
     float *pathBuf1;   // DPATH_WORDS x N: path buffer 1 (see F_SEL)
     float *curContrib; // CONTRIB_WORDS x N
@@ -148,6 +156,21 @@ struct ChainArrays {
     unsigned long long *prof;  // region cycle sums of the profiling instantiation of the lean kernel (dsmall.h WaveProf), 16 words
     double *weightSum;
 };
+
+// A chain's RNG for the duration of a kernel: the LCG word from HBM, the extension table synthesised from the chain's seed
+// RNG(chainId + seedOffset) (mlt.cpp:61-62; i is the SLOT, the chain that lives in it: A.chainId) unless the stream has ticked.
+LMC_D Rng LoadChainRng(const ChainArrays &A, int chainBegin, int seedOffset, int i) {
+    Rng rng;
+    rng.state = A.rngState[i];
+    rng.tab = A.rngTab + (size_t)i * 64;
+    rng.ticks = 0;
+    if (!A.rngTicked[i]) rng.SetSynth((uint64_t)(chainBegin + (A.chainId ? A.chainId[i] : i) + seedOffset));
+    return rng;
+}
+LMC_D void StoreChainRng(const ChainArrays &A, int i, const Rng &rng) {
+    A.rngState[i] = rng.state;
+    if (rng.ticks) A.rngTicked[i] = 1;  // Rng::Tick has materialised the table into the chain's slot
+}
 
 // Technique key of a state (c,l), 6 bits: path length first, then the light-subpath length.  Work lists (dstep.h QueueNext, kernels.hip)
 // and the relocation of chains (relocate.hip) group by it.

@@ -4,7 +4,8 @@
 //   uniform_real_distribution<float>  = one 32-bit draw, float(x) * 2^-32, clamped below 1
 //   normal_distribution<float>        = Marsaglia polar, returns y*m first and keeps x*m for the next call
 // State per chain: the 64-bit LCG word (kept in registers while a kernel runs) and the 64 x u32 extension
-// table (256 B per chain, AoS in HBM, read-mostly: it only changes on a "tick", once per 2^32 draws).
+// table (256 B per chain, AoS in HBM; it only changes on a "tick", once per 2^32 draws -- until then it is synthesised from
+// the seed and never read, see PcgJumpTable below).
 #pragma once
 #include "dmath.h"
 
@@ -76,18 +77,81 @@ LMC_HD uint64_t PcgSeed(uint64_t seed, uint32_t *tab) {
     return state;
 }
 
+// ---- The extension table of a stream that has never ticked is a pure function of its seed (PcgSeed above): entry k is the XSH-RS output of the
+// LCG state k steps behind S0 (the state the fill loop starts from), xored with xdiff.  A chain's stream is RNG(chainId + seedOffset)
+// (mlt.cpp:61-62), so a step kernel need not READ the chain's 256-byte table at all: entry k = XshRs(A_k S0 + C_k) ^ xdiff with the 64 jump
+// constants (A_k, C_k) = (MULT^k, INC (MULT^k - 1) / (MULT - 1)) -- one 16-byte constant look-up and a 64-bit multiply-add per draw instead of
+// a 4-byte load from a table that, with 16 K resident chains per XCD, is 4 MB of live data by itself: the whole L2 of an XCD.  Measured
+// (profiles/r05_g_*): the lean kernel read 2106 B per chain-step from the HBM side with the tables in memory, 1259 B without -- the 256-byte
+// table was fetched 3.3 times per step.  A stream that ticks (once per 2^32 draws: the table then changes for good) materialises its table
+// into the chain's slot of A.rngTab and reads it from there from then on (Rng::synth, A.rngTicked).
+struct PcgJump {
+    uint64_t a, c;
+};
+struct PcgJumpTable {
+    PcgJump j[64];
+    constexpr PcgJumpTable() : j{} {
+        uint64_t a = 1, c = 0;
+        for (int k = 0; k < 64; k++) {
+            j[k].a = a, j[k].c = c;
+            a = a * PCG_MULT;
+            c = c * PCG_MULT + PCG_INC;
+        }
+    }
+};
+#if defined(__HIPCC__)
+__device__ __constant__ const PcgJumpTable c_pcgJump{};
+#endif
+LMC_HD PcgJump PcgJumpOf(unsigned k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return c_pcgJump.j[k];
+#else
+    static const PcgJumpTable t{};
+    return t.j[k];
+#endif
+}
+// S0 and xdiff of RNG(seed) (the first lines of PcgSeed); the stream's first state is 64 LCG steps behind S0
+LMC_HD void PcgSeedConstants(uint64_t seed, uint64_t &s0, uint32_t &xdiff) {
+    uint64_t state = (seed + PCG_INC) * PCG_MULT + PCG_INC;
+    const uint32_t a = PcgOutputXshRs(state);
+    state = state * PCG_MULT + PCG_INC;
+    const uint32_t b = PcgOutputXshRs(state);
+    state = state * PCG_MULT + PCG_INC;
+    s0 = state, xdiff = a - b;
+}
+
 struct Rng {
     uint64_t state;
-    uint32_t *tab;  // 64 entries, this chain's extension table
+    uint32_t *tab;  // 64 entries, this stream's extension table in memory (contents undefined while `synth`)
     uint32_t ticks; // number of table advances seen (only used by the MLTInit checkpoints)
+    // the table synthesised from the seed (SetSynth): valid until the stream's first tick
+    uint64_t s0 = 0;
+    uint32_t xdiff = 0;
+    bool synth = false;
+    LMC_HD void SetSynth(uint64_t seed) {
+        PcgSeedConstants(seed, s0, xdiff);
+        synth = true;
+    }
+    LMC_HD uint32_t Entry(unsigned k) const {
+        if (synth) {
+            const PcgJump j = PcgJumpOf(k);
+            return PcgOutputXshRs(j.a * s0 + j.c) ^ xdiff;
+        }
+        return tab[k];
+    }
+    LMC_HD void Tick() {  // the table changes for good: from here on it lives in memory
+        if (synth) {
+            for (unsigned k = 0; k < 64; k++) tab[k] = Entry(k);
+            synth = false;
+        }
+        PcgAdvanceTable(tab);
+        ticks++;
+    }
 
     LMC_HD uint32_t Next() {  // extended::operator(), pcg_random.hpp:1187-1213
         uint64_t s = state;
-        if ((s & 0xFFFFFFFFull) == 0ull) {
-            PcgAdvanceTable(tab);
-            ticks++;
-        }
-        uint32_t rhs = tab[(unsigned)(s & 63u)];
+        if ((s & 0xFFFFFFFFull) == 0ull) Tick();
+        uint32_t rhs = Entry((unsigned)(s & 63u));
         state = s * PCG_MULT + PCG_INC;
         return PcgOutputXshRs(s) ^ rhs;
     }
@@ -99,15 +163,15 @@ struct Rng {
     // away, so its table slot is known before the first value has arrived.  Same stream as two Uniform() calls; the
     // once-per-2^32 table advance takes the sequential path.
     LMC_HD void Uniform2(float &a, float &b) {
-        const uint64_t s0 = state, s1 = s0 * PCG_MULT + PCG_INC;
-        if ((s0 & 0xFFFFFFFFull) == 0ull || (s1 & 0xFFFFFFFFull) == 0ull) {
+        const uint64_t st0 = state, st1 = st0 * PCG_MULT + PCG_INC;
+        if ((st0 & 0xFFFFFFFFull) == 0ull || (st1 & 0xFFFFFFFFull) == 0ull) {
             a = Uniform();
             b = Uniform();
             return;
         }
-        const uint32_t r0 = tab[(unsigned)(s0 & 63u)], r1 = tab[(unsigned)(s1 & 63u)];
-        state = s1 * PCG_MULT + PCG_INC;
-        const float fa = (float)(PcgOutputXshRs(s0) ^ r0) * 2.3283064365386963e-10f, fb = (float)(PcgOutputXshRs(s1) ^ r1) * 2.3283064365386963e-10f;
+        const uint32_t r0 = Entry((unsigned)(st0 & 63u)), r1 = Entry((unsigned)(st1 & 63u));
+        state = st1 * PCG_MULT + PCG_INC;
+        const float fa = (float)(PcgOutputXshRs(st0) ^ r0) * 2.3283064365386963e-10f, fb = (float)(PcgOutputXshRs(st1) ^ r1) * 2.3283064365386963e-10f;
         a = fa >= 1.0f ? 0.99999994f : fa;
         b = fb >= 1.0f ? 0.99999994f : fb;
     }

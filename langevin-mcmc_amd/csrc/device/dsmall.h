@@ -216,19 +216,23 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         }
     }
     st.cacheQueries++;
+    if (P.expFlags & 256) return;  // LMC_EXP_QUERY_STOP=1 (measurement): the query ends before its cell is computed
     const DCacheDim &C = cache.d[dim];
     const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
-    if (C.gridStart) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
+    if (C.gridWords) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
         int cell = 0;
-        for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(L.Q(k), C.gridG);
-        const int s0 = C.gridStart[cell], s1 = C.gridStart[cell + 1];
-        if (s0 == s1) return;  // the common case: the point is read no further
+        for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(L.Q(C.gridCoord[k]), C.gridG);
+        const uint2 word = C.gridWords[cell >> 5];
+        const unsigned bit = 1u << (cell & 31);
+        if (!(word.x & bit) || (P.expFlags & 512)) return;  // the common case: the point is read no further (LMC_EXP_QUERY_STOP=2: every cell counts as empty)
+        const int r = (int)word.y + __popc(word.x & (bit - 1u));
+        const int s0 = C.gridCellStart[r], s1 = C.gridCellStart[r + 1];
         float q[MD];
 #pragma unroll
         for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
         bool any = false;
         for (int j = s0; j < s1; j++) {
-            const float2 *row = reinterpret_cast<const float2 *>(C.gridRows + (size_t)j * dim);
+            const float2 *row = reinterpret_cast<const float2 *>(C.pts + (size_t)C.gridIdx[j] * dim);
             float d = 0.f;  // same arithmetic, same order as the leaf scan of the search
 #pragma unroll
             for (int k = 0; k < MD / 2; ++k)

@@ -114,4 +114,5 @@ void LaunchRelocIota(int n, int *v, hipStream_t s);
 // withoutGaussianOnly (H2MC renders): chains that hold a stored Gaussian stay where they are (the pipeline's Gaussian buffers are per slot)
 void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
-void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s);
+void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, const int *coord, int *scratchStart, int *scratchCursor, int *scratchWordCount, int *tileSums,
+                          uint2 *words, int *cellStart, unsigned short *idx, hipStream_t s);

@@ -28,6 +28,11 @@ __global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mod
     rng.tab = tabScratch + (size_t)i * 64;
     rng.state = PcgSeed(seeds[i], rng.tab);
     rng.ticks = 0;
+    if (mode & 8) {  // the form the chain kernels use (dchain.h LoadChainRng): the table synthesised from the seed, the memory behind it poisoned until a tick materialises it
+        for (int k = 0; k < 64; k++) rng.tab[k] = 0xDEADBEEFu;
+        rng.SetSynth(seeds[i]);
+        mode &= 7;
+    }
     uint32_t *o = out + (size_t)i * (n + 66);
     if (mode == 0) {
         for (int k = 0; k < n; k++) o[k] = rng.Next();
@@ -47,7 +52,7 @@ __global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mod
     }
     // state dump after the draws: [lo, hi, table 64]
     o[n] = (uint32_t)rng.state, o[n + 1] = (uint32_t)(rng.state >> 32);
-    for (int k = 0; k < 64; k++) o[n + 2 + k] = rng.tab[k];
+    for (int k = 0; k < 64; k++) o[n + 2 + k] = rng.Entry(k);
 }
 
 // ---------------------------------------------------------------------------------------------- probes
@@ -415,12 +420,9 @@ __global__ void k_setup_chains(ChainArrays A, int chainBegin, long long perChain
 __global__ void k_first_kind(DScene S, const DCache *cache, ChainArrays A, StepParams P) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.N) return;
-    Rng rng;
-    rng.state = A.rngState[i];
-    rng.tab = A.rngTab + (size_t)i * 64;
-    rng.ticks = 0;
+    Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
     QueueNext(S, *cache, A, P, i, rng);
-    A.rngState[i] = rng.state;
+    StoreChainRng(A, i, rng);
 }
 
 // Work lists of the next step.  Each block owns a tile of 1024 consecutive chains and reserves one contiguous range per
@@ -752,12 +754,13 @@ void LaunchFirstKind(const DScene &S, const DCache *cache, const ChainArrays &A,
 // depends on the atomics; the existence test ORs over a cell's rows, so it does not see it.
 struct GridShape {
     int G, m, nbrs, dim, n;
+    int coord[4];
 };
 __device__ inline bool GridNeighbourCell(const GridShape &g, const float *p, int o, int &cell) {
     cell = 0;
     bool inside = true;
     for (int k = 0; k < g.m; k++, o /= 3) {
-        const int ck = CacheGridCell(p[k], g.G) + (o % 3) - 1;
+        const int ck = CacheGridCell(p[g.coord[k]], g.G) + (o % 3) - 1;
         inside = inside && ck >= 0 && ck < g.G;
         cell = cell * g.G + ck;
     }
@@ -825,28 +828,55 @@ void LaunchInclusiveScan(int *v, int n, int *tileSums, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, tileSums, nTiles);
     hipLaunchKernelGGL(k_scan_carry, dim3(nTiles), dim3(256), 0, s, v, n, tileSums);
 }
-__global__ void __launch_bounds__(256) k_grid_scatter(GridShape g, const float *pts, const int *start, int *cursor, float *rows) {
+__global__ void __launch_bounds__(256) k_grid_scatter(GridShape g, const float *pts, const int *start, int *cursor, unsigned short *idx) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.n * g.nbrs) return;
-    const float *p = pts + (size_t)(t / g.nbrs) * g.dim;
+    const int row = t / g.nbrs;
     int cell;
-    if (!GridNeighbourCell(g, p, t % g.nbrs, cell)) return;
-    float *dst = rows + (size_t)(start[cell] + atomicAdd(&cursor[cell], 1)) * g.dim;
-    for (int k = 0; k < g.dim; k++) dst[k] = p[k];
+    if (!GridNeighbourCell(g, pts + (size_t)row * g.dim, t % g.nbrs, cell)) return;
+    idx[start[cell] + atomicAdd(&cursor[cell], 1)] = (unsigned short)row;
 }
-// start: cells + 1 ints; cursor: cells ints; rows: n * 3^m * dim floats; tileSums: ceil((cells + 1) / 2048) ints
-void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, int *start, int *cursor, float *rows, int *tileSums, hipStream_t s) {
-    GridShape g{G, m, 1, dim, n};
+// occupancy word of 32 cells (start: the inclusive scan of the per-cell counts, start[c] .. start[c + 1] = cell c's range) and its number of
+// non-empty cells, which the scan below turns into ranks
+__global__ void __launch_bounds__(256) k_grid_words(const int *start, int cells, int nWords, uint2 *words, int *wordCount) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nWords) return;
+    unsigned bits = 0;
+    for (int b = 0; b < 32; b++) {
+        const int c = w * 32 + b;
+        if (c < cells && start[c + 1] > start[c]) bits |= 1u << b;
+    }
+    words[w].x = bits;
+    wordCount[w] = __popc(bits);
+}
+// wordCount: inclusive scan of the counts -> rank of every word's first cell; the r-th non-empty cell's range start (and, behind the last, the total)
+__global__ void __launch_bounds__(256) k_grid_compact(const int *start, int cells, int nWords, uint2 *words, const int *wordCountIncl, int *cellStart) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nWords) return;
+    const unsigned bits = words[w].x;
+    int r = wordCountIncl[w] - __popc(bits);
+    words[w].y = (unsigned)r;
+    for (int b = 0; b < 32; b++)
+        if (bits & (1u << b)) cellStart[r++] = start[w * 32 + b];
+    if (w == nWords - 1) cellStart[wordCountIncl[w]] = start[cells];
+}
+// scratchStart: cells + 1 ints, scratchCursor: cells ints, scratchWordCount: ceil(cells / 32) ints, tileSums: ceil((cells + 1) / 2048) + 1 ints -- build-time
+// scratch, shared by the dims (the builds are stream-ordered); words: ceil(cells / 32); cellStart: min(cells, n * 3^m) + 1 ints; idx: n * 3^m
+void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, const int *coord, int *scratchStart, int *scratchCursor, int *scratchWordCount, int *tileSums,
+                          uint2 *words, int *cellStart, unsigned short *idx, hipStream_t s) {
+    GridShape g{G, m, 1, dim, n, {0, 1, 2, 3}};
+    for (int k = 0; k < m && k < 4; k++) g.coord[k] = coord[k];
     size_t cells = 1;
     for (int k = 0; k < m; k++) cells *= G, g.nbrs *= 3;
-    (void)hipMemsetAsync(start, 0, (cells + 1) * sizeof(int), s);
-    (void)hipMemsetAsync(cursor, 0, cells * sizeof(int), s);
-    const int pairs = n * g.nbrs, nScan = (int)cells + 1, nTiles = (nScan + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_grid_count, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, start);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nTiles), dim3(256), 0, s, start, nScan, tileSums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, tileSums, nTiles);
-    hipLaunchKernelGGL(k_scan_carry, dim3(nTiles), dim3(256), 0, s, start, nScan, tileSums);
-    hipLaunchKernelGGL(k_grid_scatter, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, start, cursor, rows);
+    (void)hipMemsetAsync(scratchStart, 0, (cells + 1) * sizeof(int), s);
+    (void)hipMemsetAsync(scratchCursor, 0, cells * sizeof(int), s);
+    const int pairs = n * g.nbrs, nScan = (int)cells + 1, nWords = (int)((cells + 31) / 32);
+    hipLaunchKernelGGL(k_grid_count, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, scratchStart);
+    LaunchInclusiveScan(scratchStart, nScan, tileSums, s);
+    hipLaunchKernelGGL(k_grid_scatter, dim3((pairs + 255) / 256), dim3(256), 0, s, g, pts, scratchStart, scratchCursor, idx);
+    hipLaunchKernelGGL(k_grid_words, dim3((nWords + 255) / 256), dim3(256), 0, s, scratchStart, (int)cells, nWords, words, scratchWordCount);
+    LaunchInclusiveScan(scratchWordCount, nWords, tileSums, s);
+    hipLaunchKernelGGL(k_grid_compact, dim3((nWords + 255) / 256), dim3(256), 0, s, scratchStart, (int)cells, nWords, words, scratchWordCount, cellStart);
 }
 
 void LaunchCachePush(const ChainArrays &A, const CachePushTargets &T, unsigned long long *tileCounts, int *stageCounts, hipStream_t s) {

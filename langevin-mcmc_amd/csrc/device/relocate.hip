@@ -25,7 +25,7 @@
 namespace lmcd {
 namespace {
 
-enum : int { RW_FLAGS = 0, RW_SAMPLEIDX, RW_NUMSAMPLES, RW_ADJREJECT, RW_SPLATCOUNT, RW_CHAINID, RW_SCORESUM, RW_LASTSCORESUM, RW_LASTSCORE, RW_PATHWEIGHT, RW_NEXTKIND, RW_RNG_LO, RW_RNG_HI, RW_KEY, RW_SCALARS = 16 };
+enum : int { RW_FLAGS = 0, RW_SAMPLEIDX, RW_NUMSAMPLES, RW_ADJREJECT, RW_SPLATCOUNT, RW_CHAINID, RW_SCORESUM, RW_LASTSCORESUM, RW_LASTSCORE, RW_PATHWEIGHT, RW_NEXTKIND, RW_RNG_LO, RW_RNG_HI, RW_KEY, RW_RNG_TICKED, RW_SCALARS = 16 };
 constexpr int RW_TAB = RW_SCALARS, RW_HEAD = RW_TAB + 64, RW_VERT = RW_HEAD + DPATH_HEAD_WORDS;
 
 struct RecordLayout {
@@ -155,10 +155,14 @@ __global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout
         r[RW_SCORESUM] = A.scoreSum[i], r[RW_LASTSCORESUM] = A.lastScoreSum[i], r[RW_LASTSCORE] = A.lastScore[i], r[RW_PATHWEIGHT] = A.pathWeight[i];
         r[RW_NEXTKIND] = __int_as_float((int)A.nextKind[i]), r[RW_RNG_LO] = __int_as_float((int)(uint32_t)rs), r[RW_RNG_HI] = __int_as_float((int)(uint32_t)(rs >> 32));
         r[RW_KEY] = __int_as_float(SlotKey(A, i));
-        const uint4 *tab = reinterpret_cast<const uint4 *>(A.rngTab + (size_t)i * 64);
-        uint4 *rt = reinterpret_cast<uint4 *>(r + RW_TAB);
+        const int ticked = A.rngTicked[i];  // the extension table travels only once the stream has ticked: until then it is a function of the chain's seed (drng.h)
+        r[RW_RNG_TICKED] = __int_as_float(ticked);
+        if (ticked) {
+            const uint4 *tab = reinterpret_cast<const uint4 *>(A.rngTab + (size_t)i * 64);
+            uint4 *rt = reinterpret_cast<uint4 *>(r + RW_TAB);
 #pragma unroll 4
-        for (int k = 0; k < 16; k++) rt[k] = tab[k];
+            for (int k = 0; k < 16; k++) rt[k] = tab[k];
+        }
         const float *path = CurPathBuf(A, flags);
 #pragma unroll 4
         for (int k = 0; k < DPATH_HEAD_WORDS; k++) r[RW_HEAD + k] = path[(size_t)k * N + i];
@@ -204,10 +208,14 @@ __global__ void __launch_bounds__(64) k_reloc_scatter(ChainArrays A, RecordLayou
         A.scoreSum[i] = r[RW_SCORESUM], A.lastScoreSum[i] = r[RW_LASTSCORESUM], A.lastScore[i] = r[RW_LASTSCORE], A.pathWeight[i] = r[RW_PATHWEIGHT];
         A.nextKind[i] = (unsigned char)__float_as_int(r[RW_NEXTKIND]);
         A.rngState[i] = (uint64_t)(uint32_t)__float_as_int(r[RW_RNG_LO]) | ((uint64_t)(uint32_t)__float_as_int(r[RW_RNG_HI]) << 32);
-        uint4 *tab = reinterpret_cast<uint4 *>(A.rngTab + (size_t)i * 64);
-        const uint4 *rt = reinterpret_cast<const uint4 *>(r + RW_TAB);
+        const int ticked = __float_as_int(r[RW_RNG_TICKED]);
+        A.rngTicked[i] = (unsigned char)ticked;
+        if (ticked) {
+            uint4 *tab = reinterpret_cast<uint4 *>(A.rngTab + (size_t)i * 64);
+            const uint4 *rt = reinterpret_cast<const uint4 *>(r + RW_TAB);
 #pragma unroll 4
-        for (int k = 0; k < 16; k++) tab[k] = rt[k];
+            for (int k = 0; k < 16; k++) tab[k] = rt[k];
+        }
         float *path = CurPathBuf(A, flags);
 #pragma unroll 4
         for (int k = 0; k < DPATH_HEAD_WORDS; k++) path[(size_t)k * N + i] = r[RW_HEAD + k];

@@ -41,10 +41,7 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
         int t = 0, i = 0;
         if (j < total) {
             i = list[j];
-            Rng rng;
-            rng.state = A.rngState[i];
-            rng.tab = A.rngTab + (size_t)i * 64;
-            rng.ticks = 0;
+            Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
             int flags = A.flags[i];
             const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)N + i]);
             const float curSs = A.curContrib[(size_t)8 * N + i];
@@ -78,7 +75,7 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
             }
             H.step[i] = (h2 ? H2S_H2 : 0) | (useDense ? H2S_DENSE : 0);
             H.kind[i] = sample ? 1 : 0;
-            A.rngState[i] = rng.state;
+            StoreChainRng(A, i, rng);
         }
         H2Enqueue(H.bins[0], N, want, t, i);
     }
@@ -98,10 +95,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
         int t = 0, i = 0;
         if (j < total) {
             i = list[j];
-            Rng rng;
-            rng.state = A.rngState[i];
-            rng.tab = A.rngTab + (size_t)i * 64;
-            rng.ticks = 0;
+            Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
             const int flags = A.flags[i];
             int bits = H.step[i];
             DPath prop;
@@ -159,7 +153,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
                 }
             }
             H.step[i] = bits;
-            A.rngState[i] = rng.state;
+            StoreChainRng(A, i, rng);
         }
         H2Enqueue(H.bins[1], N, want, t, i);
     }
@@ -173,10 +167,7 @@ __global__ void __launch_bounds__(64) k_h2_finish(DScene S, const DCache *cache,
     const size_t N = A.N;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
+        Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
         int flags = A.flags[i];
         const int bits = H.step[i];
         const bool curValid = flags & F_VALID, h2 = bits & H2S_H2, useDense = bits & H2S_DENSE;
@@ -241,7 +232,7 @@ __global__ void __launch_bounds__(64) k_h2_finish(DScene S, const DCache *cache,
         A.flags[i] = flags & ~F_VSYNC;
         A.sampleIdx[i] = sampleIdx + 1;
         QueueNext(S, *cache, A, P, i, rng);
-        A.rngState[i] = rng.state;
+        StoreChainRng(A, i, rng);
     }
     __shared__ int sStats[9];
     BlockReduceStats(st, A.counters, A.weightSum, sStats);

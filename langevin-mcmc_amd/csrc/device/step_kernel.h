@@ -55,10 +55,7 @@ __global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DC
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
+        Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
         GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
         const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
         if constexpr (LDS_STACK) {
@@ -69,7 +66,7 @@ __global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DC
             StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD, MUX>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
         }
         QueueNext(S, *cache, A, P, i, rng);
-        A.rngState[i] = rng.state;
+        StoreChainRng(A, i, rng);
     }
     __shared__ int sStats[9];
     BlockReduceStats(st, A.counters, A.weightSum, sStats);

@@ -35,10 +35,7 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
         int t = 0, i = 0;
         if (j < total) {
             i = list[j];
-            Rng rng;
-            rng.state = A.rngState[i];
-            rng.tab = A.rngTab + (size_t)i * 64;
-            rng.ticks = 0;
+            Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
             const int flags = A.flags[i];
             const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)N + i]);
             const float curSs = A.curContrib[(size_t)8 * N + i];
@@ -59,7 +56,7 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
                 bits |= MS_GRAD_CUR;
             }
             M.step[i] = bits;
-            A.rngState[i] = rng.state;
+            StoreChainRng(A, i, rng);
         }
         H2Enqueue(M.bins[0], N, want, t, i);
     }
@@ -80,10 +77,7 @@ __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, c
         int t = 0, i = 0;
         if (j < total) {
             i = list[j];
-            Rng rng;
-            rng.state = A.rngState[i];
-            rng.tab = A.rngTab + (size_t)i * 64;
-            rng.ticks = 0;
+            Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
             int flags = A.flags[i];
             int bits = M.step[i];
             const bool mala = bits & MS_MALA;
@@ -138,7 +132,7 @@ __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, c
             }
             A.flags[i] = flags;
             M.step[i] = bits;
-            A.rngState[i] = rng.state;
+            StoreChainRng(A, i, rng);
         }
         H2Enqueue(M.bins[1], N, want, t, i);
     }
@@ -153,10 +147,7 @@ __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cach
     const size_t N = A.N;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
+        Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
         int flags = A.flags[i];
         const int bits = M.step[i];
         const bool curValid = flags & F_VALID, mala = bits & MS_MALA;
@@ -235,7 +226,7 @@ __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cach
         A.flags[i] = flags & ~F_VSYNC;  // these kernels do not track the v1 / v2 equality (dchain.h)
         A.sampleIdx[i] = sampleIdx + 1;
         QueueNext(S, cache, A, P, i, rng);
-        A.rngState[i] = rng.state;
+        StoreChainRng(A, i, rng);
     }
     // the stages' bin counts are zero again for the next step (both stages have been consumed: this launch is queued behind them).  No fill
     // launch in front of k_mala_begin: queued beside the hot launch, that small launch waited 0.25 ms for a slot (profiles/r04_fill_s_*)

@@ -23,15 +23,12 @@ __global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DSc
     const LdsView L{lds + threadIdx.x, (int)blockDim.x, stackWords};
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
+        Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
         LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
         NoProf prof;
         SmallStepLean<true>(S, *cache, A, film, P, i, rng, L, stk, st, prof, gradBuf, (size_t)gradStride, (size_t)tid);
         QueueNext(S, *cache, A, P, i, rng);
-        A.rngState[i] = rng.state;
+        StoreChainRng(A, i, rng);
     }
     BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
 }

@@ -31,10 +31,7 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
     if constexpr (PROF) prof.Start();
     for (int j = tid; j < total; j += gridDim.x * blockDim.x) {
         const int i = list[j];
-        Rng rng;
-        rng.state = A.rngState[i];
-        rng.tab = A.rngTab + (size_t)i * 64;
-        rng.ticks = 0;
+        Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
 #if LMC_LEAN_K > 1  // A/B build (DESIGN.md "K small steps of a chain per launch"): the chain stays in its lane for up to K consecutive plain small steps
 #pragma unroll 1
         for (int rep = 0;; rep++) {
@@ -53,7 +50,7 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
 #else
         (void)nk;
 #endif
-        A.rngState[i] = rng.state;
+        StoreChainRng(A, i, rng);
         prof.Mark(PR_QUEUE);
     }
     if constexpr (PROF) {  // one lane per wave adds the wave's region totals (A.prof: PR_COUNT cycle sums + the number of waves)

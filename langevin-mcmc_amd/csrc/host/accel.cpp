@@ -557,10 +557,38 @@ struct KdBuilder {
 };
 }  // namespace
 
-CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m) {
+void ChooseGridCoords(const float *pts, int n, int dim, int m, int *coord) {
+    using namespace lmcd;
+    m = std::min(std::min(m, dim), 4);
+    const char *e = getenv("LMC_GRID_COORDS");
+    if (e && std::string(e) == "first") {
+        for (int k = 0; k < m; k++) coord[k] = k;
+        return;
+    }
+    const int G = CacheGridG(dim);
+    std::vector<long long> score(dim, 0);
+    std::vector<int> hist(G);
+    for (int c = 0; c < dim; c++) {
+        std::fill(hist.begin(), hist.end(), 0);
+        for (int i = 0; i < n; i++) hist[CacheGridCell(pts[(size_t)i * dim + c], G)]++;
+        for (int h : hist) score[c] += (long long)h * h;
+    }
+    std::vector<int> order(dim);
+    for (int c = 0; c < dim; c++) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return score[a] < score[b]; });
+    std::sort(order.begin(), order.begin() + m);
+    for (int k = 0; k < m; k++) coord[k] = order[k];
+}
+
+CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m, const int *coord) {
     using namespace lmcd;
     CacheGrid g;
-    g.G = CacheGridG(dim), g.m = std::min(m, dim);
+    g.G = CacheGridG(dim), g.m = std::min(std::min(m, dim), 4);
+    if (coord) {
+        for (int k = 0; k < g.m; k++) g.coord[k] = coord[k];
+    } else {
+        ChooseGridCoords(pts, n, dim, g.m, g.coord);
+    }
     const int G = g.G;
     size_t cells = 1;
     for (int k = 0; k < g.m; k++) cells *= G;
@@ -572,7 +600,7 @@ CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m) {
     g.start.assign(cells + 1, 0);
     auto forNeighbours = [&](const float *p, auto &&fn) {
         int c[8];
-        for (int k = 0; k < g.m; k++) c[k] = CacheGridCell(p[k], G);
+        for (int k = 0; k < g.m; k++) c[k] = CacheGridCell(p[g.coord[k]], G);
         for (int o = 0; o < nbrs; o++) {
             int cell = 0, t = o;
             bool inside = true;
@@ -598,7 +626,7 @@ bool CacheGrid::Exists(const float *q, int dim) const {
     using namespace lmcd;
     const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
     int cell = 0;
-    for (int k = 0; k < m; k++) cell = cell * G + CacheGridCell(q[k], G);
+    for (int k = 0; k < m; k++) cell = cell * G + CacheGridCell(q[coord[k]], G);
     bool any = false;
     for (int j = start[cell]; j < start[cell + 1]; j++) {
         const float *p = rows.data() + (size_t)j * dim;

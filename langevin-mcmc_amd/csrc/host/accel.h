@@ -46,14 +46,22 @@ struct KdTreeResult {
     int depth = 0;
 };
 KdTreeResult BuildKdTree(const float *pts, int n, int dim);
-// dilated uniform grid over the first m coordinates of the cache points (DCacheDim::gridStart / gridRows):
+// Which m coordinates the existence grid of a cache dim is laid over.  The test is exact for any choice (a row within the query radius lies within
+// one cell of the query in EVERY coordinate); the choice decides how many candidate rows a query scans.  The first coordinates -- screen position
+// and first bounce -- are where both the cache rows and the queries cluster (profiles/r05_c_query_filter_study.txt: with coordinates 0..3 71-93 %
+// of the queries of the headline workload scan candidates and a wave scans 6-33 rows; with the m coordinates in which the ROWS collide least,
+// measured by the sum of squared occupancies of the G one-dimensional cells, 33-48 % and 3-4.5 rows).  Deterministic: integer scores, ties to
+// the lower index, result ascending.  LMC_GRID_COORDS=first restores coordinates 0 .. m-1 (A/B).
+void ChooseGridCoords(const float *pts, int n, int dim, int m, int *coord);
+// dilated uniform grid over m coordinates of the cache points (DCacheDim::gridStart / gridRows / gridCoord):
 // start[G^m + 1]; rows = the points of every cell's 3^m neighbourhood, dim floats each
 struct CacheGrid {
     int G = 0, m = 0;
+    int coord[4] = {0, 1, 2, 3};
     std::vector<int> start;
     std::vector<float> rows;
     bool Exists(const float *q, int dim) const;  // the kernel's test, on the host
 };
-CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m);
+CacheGrid BuildCacheGrid(const float *pts, int n, int dim, int m, const int *coord = nullptr);  // coord == nullptr: ChooseGridCoords
 
 }  // namespace lmc

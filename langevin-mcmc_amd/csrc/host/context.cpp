@@ -89,9 +89,11 @@ struct CacheDimHost {
     DevBuf<float> pss, v1, v2, weight;
     DevBuf<float> extra, distCdf;  // `samplecache`: the rows' paths + contributions (CACHE_ROW_EXTRA words each), PiecewiseConstant1D over the weights
     DevBuf<KdNode> nodes;
-    DevBuf<int> gridStart, gridCursor, gridTileSums;
-    DevBuf<float> gridRows;
+    DevBuf<uint2> gridWords;           // the compact existence grid (dchain.h DCacheDim): occupancy words + ranks,
+    DevBuf<int> gridCellStart;         // the candidate range of every non-empty cell,
+    DevBuf<unsigned short> gridIdx;    // the candidates' row indices
     int gridG = 0, gridM = 0;
+    int gridCoord[4] = {0, 1, 2, 3};  // the coordinates the grid is laid over, chosen from the rows when the dim becomes ready (accel.h ChooseGridCoords)
     DevBuf<int> vind;
     bool ready = false;
     bool relevant = false;
@@ -158,6 +160,7 @@ struct lmc_ctx {
     ChainArrays A;
     DevBuf<uint64_t> rngState;
     DevBuf<uint32_t> rngTab;
+    DevBuf<unsigned char> rngTicked;
     DevBuf<float> curPath, pathBuf1, curContrib, scoreSum, gaussian, gaussian1, curSplat, chV1, chV2, chCurrNewV2, chPropNewV1, chPropNewV2, chPss, chLastPss, chPath, chContrib, pathWeight,
         lastScoreSum, lastScore, contribList, pushData, initPath, initContrib, initScoreSum, initLsAll;
     DevBuf<unsigned char> initCLAll;
@@ -196,6 +199,7 @@ struct lmc_ctx {
     DevBuf<DCache> cacheDev;
     DevBuf<int> cacheCounts;                 // rows filled per slot (dims 6, 8, 10, 12)
     DevBuf<unsigned long long> pushTiles;    // scratch of the push launches: one word per 1024 chains
+    DevBuf<int> gridScratchStart, gridScratchCursor, gridScratchWordCount, gridTileSums;  // build-time scratch of the existence grids, sized for the largest dim's cell count (the builds are stream-ordered)
     CachePushTargets pushT;                  // the cache rows themselves
     CachePushTargets stageT;                 // ... and this rank's stage of a step's pushes (same row layout; kernels.hip k_push_apply)
     PushStageLayout stageLayout;
@@ -460,6 +464,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
     if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
     if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
+    if (const char *e = getenv("LMC_EXP_QUERY_STOP")) c->expFlags |= atoi(e) == 1 ? 256 : atoi(e) == 2 ? 512 : 0;  // the cache query cut short before its cell / after its occupancy word
     if (const char *e = getenv("LMC_EXP_NOGRAD")) c->expFlags |= atoi(e) ? 4 : 0;
     if (const char *e = getenv("LMC_EXP_NOSTATS")) c->expFlags |= atoi(e) ? 8 : 0;
     if (const char *e = getenv("LMC_EXP_NOHESS")) c->expFlags |= atoi(e) ? 16 : 0;    // H2MC: skip the second-order path program
@@ -922,7 +927,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     }
     J.sendCk.Free(), J.gatherCk.Free();
     // ---- chain arrays
-    c->rngState.Alloc(N), c->rngTab.Alloc(N * 64, false);
+    c->rngState.Alloc(N), c->rngTab.Alloc(N * 64, false), c->rngTicked.Alloc(N);
     c->curPath.Alloc(N * DPATH_WORDS), c->pathBuf1.Alloc(N * DPATH_WORDS), c->curContrib.Alloc(N * CONTRIB_WORDS), c->scoreSum.Alloc(N), c->gaussian.Alloc(N * GAUSS_WORDS), c->gaussian1.Alloc(N * GAUSS_WORDS);
     c->curSplat.Alloc(N * MAXCONTRIB * SPLAT_WORDS), c->curSplatCount.Alloc(N);
     c->chV1.Alloc(N * MAXPSS), c->chV2.Alloc(N * MAXPSS), c->chCurrNewV2.Alloc(N * MAXPSS), c->chPropNewV1.Alloc(N * MAXPSS),
@@ -936,7 +941,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->counters.Alloc(8), c->weightSum.Alloc(1), c->prof.Alloc(16);
     ChainArrays &A = c->A;
     A.N = (int)N;
-    A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.curPath = c->curPath.p, A.pathBuf1 = c->pathBuf1.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
+    A.rngState = c->rngState.p, A.rngTab = c->rngTab.p, A.rngTicked = c->rngTicked.p, A.curPath = c->curPath.p, A.pathBuf1 = c->pathBuf1.p, A.curContrib = c->curContrib.p, A.scoreSum = c->scoreSum.p;
     A.flags = c->flags.p, A.gaussian = c->gaussian.p, A.gaussian1 = c->gaussian1.p, A.curSplat = c->curSplat.p, A.curSplatCount = c->curSplatCount.p;
     A.chV1 = c->chV1.p, A.chV2 = c->chV2.p, A.chCurrNewV2 = c->chCurrNewV2.p, A.chPropNewV1 = c->chPropNewV1.p, A.chPropNewV2 = c->chPropNewV2.p,
     A.chPss = c->chPss.p, A.chLastPss = c->chLastPss.p;
@@ -981,6 +986,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->leanGrid = (int)std::min<size_t>((N + c->leanBlock - 1) / c->leanBlock, (size_t)4096 * 256 / c->leanBlock);
     c->gradBuf.Alloc(c->useGradient ? (size_t)c->gradStride * 640 : 1, false);  // V <= 238 + 59*6 = 592 words for c+l <= 9
     // global cache: dims 2L for L in [3, maxDepth], capped by PSS_MAX_LENGTH
+    size_t maxGridCells = 0;
     for (int d = 0; d <= PSS_MAX_LENGTH; d++) {
         CacheDimHost &cd = c->cacheDims[d];
         cd.ready = false;
@@ -994,10 +1000,14 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
             cd.gridG = CacheGridG(d), cd.gridM = std::min(c->gridDims, d);
             size_t cells = 1, nbrs = 1;
             for (int k = 0; k < cd.gridM; k++) cells *= cd.gridG, nbrs *= 3;
-            cd.gridStart.Alloc(cells + 1, false), cd.gridCursor.Alloc(cells, false), cd.gridTileSums.Alloc((cells + 1) / 2048 + 1, false);
-            cd.gridRows.Alloc((size_t)PSS_MAX_SIZE * nbrs * d, false);
+            cd.gridWords.Alloc((cells + 31) / 32, false), cd.gridCellStart.Alloc(std::min(cells, (size_t)PSS_MAX_SIZE * nbrs) + 1, false), cd.gridIdx.Alloc((size_t)PSS_MAX_SIZE * nbrs, false);
+            maxGridCells = std::max(maxGridCells, cells);
             cd.nodes.Alloc(KD_MAX_NODES, false), cd.vind.Alloc(PSS_MAX_SIZE, false);
         }
+    }
+    if (maxGridCells) {
+        c->gridScratchStart.Alloc(maxGridCells + 1, false), c->gridScratchCursor.Alloc(maxGridCells, false), c->gridScratchWordCount.Alloc((maxGridCells + 31) / 32, false);
+        c->gridTileSums.Alloc((maxGridCells + 1) / 2048 + 2, false);
     }
     c->cacheCounts.Alloc(CACHE_SLOTS), c->pushTiles.Alloc((N + 1023) / 1024);
     if (!c->hostCounts) HIP_CHECK(hipHostMalloc((void **)&c->hostCounts, CACHE_SLOTS * sizeof(int)));
@@ -1342,7 +1352,9 @@ static void CacheApplyFinish(lmc_ctx *c) {
     }
     for (int r = 0; r < numReady; r++) {
         CacheDimHost &cd = c->cacheDims[readyDims[r]];
-        LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, readyDims[r], cd.gridG, cd.gridM, cd.gridStart.p, cd.gridCursor.p, cd.gridRows.p, cd.gridTileSums.p, s);
+        lmc::ChooseGridCoords(ptsOf[r].data(), PSS_MAX_SIZE, readyDims[r], cd.gridM, cd.gridCoord);
+        LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, readyDims[r], cd.gridG, cd.gridM, cd.gridCoord, c->gridScratchStart.p, c->gridScratchCursor.p, c->gridScratchWordCount.p, c->gridTileSums.p,
+                             cd.gridWords.p, cd.gridCellStart.p, cd.gridIdx.p, s);
     }
     {
         std::vector<std::thread> workers;
@@ -1373,7 +1385,8 @@ static void CacheApplyFinish(lmc_ctx *c) {
         HIP_CHECK(hipMemcpyAsync(cd.vind.p, t.vind.data(), t.vind.size() * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));  // the pageable copies above must have left the host before the trees go out of scope
         DCacheDim &D = c->cacheHost.d[d];
-        D.gridStart = c->useOccFilter ? cd.gridStart.p : nullptr, D.gridRows = cd.gridRows.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
+        D.gridWords = c->useOccFilter ? cd.gridWords.p : nullptr, D.gridCellStart = cd.gridCellStart.p, D.gridIdx = cd.gridIdx.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
+        for (int k = 0; k < 4; k++) D.gridCoord[k] = cd.gridCoord[k];
         if (t.depth >= KD_STACK) throw std::runtime_error("kd-tree deeper than the search stack (KD_STACK)");
         D.deep = 0;  // every kernel searches with KD_STACK private frames now; the field routed deep trees away from the former LDS search
         c->anyDeepCache = c->anyDeepCache || D.deep;
@@ -2232,24 +2245,37 @@ int lmc_cache_grid_check(lmc_ctx *c, int dim) {
     if (dim < 0 || dim > PSS_MAX_LENGTH || !c->cacheDims[dim].ready) return -2;
     CacheDimHost &cd = c->cacheDims[dim];
     std::vector<float> pts = cd.pss.Download();
-    lmc::CacheGrid g = lmc::BuildCacheGrid(pts.data(), PSS_MAX_SIZE, dim, cd.gridM);
+    lmc::CacheGrid g = lmc::BuildCacheGrid(pts.data(), PSS_MAX_SIZE, dim, cd.gridM, cd.gridCoord);
     if (g.G != cd.gridG) return 1 << 30;
-    std::vector<int> start = cd.gridStart.Download();
-    std::vector<float> rows = cd.gridRows.Download();
-    int bad = 0;
+    std::vector<uint2> words = cd.gridWords.Download();
+    std::vector<int> cellStart = cd.gridCellStart.Download();
+    std::vector<unsigned short> idx = cd.gridIdx.Download();
+    int bad = 0, rank = 0;
     const size_t cells = g.start.size() - 1;
     for (size_t cell = 0; cell < cells; cell++) {
-        if (start[cell] != g.start[cell] || start[cell + 1] != g.start[cell + 1]) {
+        const uint2 w = words[cell >> 5];
+        const bool occupied = (w.x >> (cell & 31)) & 1u;
+        if ((cell & 31) == 0 && (int)w.y != rank) {  // the word's rank = non-empty cells before it
+            bad++;
+            rank = (int)w.y;
+        }
+        if (occupied != (g.start[cell + 1] > g.start[cell])) {
+            bad++;
+            if (occupied) rank++;
+            continue;
+        }
+        if (!occupied) continue;
+        const int s0 = cellStart[rank], s1 = cellStart[rank + 1];
+        rank++;
+        if (s1 - s0 != g.start[cell + 1] - g.start[cell]) {
             bad++;
             continue;
         }
-        auto sorted = [&](const std::vector<float> &r) {
-            std::vector<std::vector<float>> v;
-            for (int j = g.start[cell]; j < g.start[cell + 1]; j++) v.emplace_back(r.begin() + (size_t)j * dim, r.begin() + (size_t)(j + 1) * dim);
-            std::sort(v.begin(), v.end());
-            return v;
-        };
-        if (g.start[cell + 1] > g.start[cell] && sorted(rows) != sorted(g.rows)) bad++;
+        std::vector<std::vector<float>> dv, hv;  // the same set of rows (the device lists indices into the point table, in the order of its atomics)
+        for (int j = s0; j < s1; j++) dv.emplace_back(pts.begin() + (size_t)idx[j] * dim, pts.begin() + (size_t)(idx[j] + 1) * dim);
+        for (int j = g.start[cell]; j < g.start[cell + 1]; j++) hv.emplace_back(g.rows.begin() + (size_t)j * dim, g.rows.begin() + (size_t)(j + 1) * dim);
+        std::sort(dv.begin(), dv.end()), std::sort(hv.begin(), hv.end());
+        if (dv != hv) bad++;
     }
     return bad;
     LMC_CATCH(-1)
@@ -2260,14 +2286,18 @@ int lmc_cache_grid_check(lmc_ctx *c, int dim) {
 int lmc_cache_filter_probe(int dim, int npts, const float *pts, int nq, const float *q, int *out) {
     LMC_TRY
     if (dim < 3 || dim > MAXPSS) throw std::runtime_error("lmc_cache_filter_probe: bad dim");
-    for (int m = 3; m <= 4; m++) {  // both grid ranks the kernel can be configured with must agree
-        lmc::CacheGrid g = lmc::BuildCacheGrid(pts, npts, dim, m);
-        for (int i = 0; i < nq; i++) {
-            const int e = g.Exists(q + (size_t)i * dim, dim) ? 1 : 0;
-            if (m > 3 && e != out[i]) throw std::runtime_error("lmc_cache_filter_probe: grid ranks disagree");
-            out[i] = e;
+    bool first = true;
+    const int lead[4] = {0, 1, 2, 3};
+    for (int m = 3; m <= 4; m++)  // both grid ranks the kernel can be configured with ...
+        for (int chosen = 0; chosen < 2; chosen++) {  // ... over the leading coordinates and over the ones ChooseGridCoords picks: all must agree
+            lmc::CacheGrid g = lmc::BuildCacheGrid(pts, npts, dim, m, chosen ? nullptr : lead);
+            for (int i = 0; i < nq; i++) {
+                const int e = g.Exists(q + (size_t)i * dim, dim) ? 1 : 0;
+                if (!first && e != out[i]) throw std::runtime_error("lmc_cache_filter_probe: the grids disagree");
+                out[i] = e;
+            }
+            first = false;
         }
-    }
     return 0;
     LMC_CATCH(-1)
 }

@@ -5,6 +5,7 @@
 # usage: scripts/ab_bench.sh OUT.jsonl [-s STEPS] [-w WARMUP] [-b "extra bench.py args"] -- "VAR=1 VAR2=x" "VAR=2" ...
 #   e.g. scripts/ab_bench.sh gpurun_out/ab.jsonl -- - "LMC_SORT_PLAIN=1" "LMC_LIB=$PWD/langevin-mcmc_amd/csrc/_build/alt/liblmc_hip.so"
 OUT=$1; shift
+export LMC_BENCH_ALLOW_EXP=1  # variants may carry work-skipping LMC_EXP_* switches: every line names its variant
 STEPS=64; WARM=40; EXTRA=""
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do
   case "$1" in

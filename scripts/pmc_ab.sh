@@ -6,6 +6,7 @@
 # usage (GPU box): scripts/pmc_ab.sh OUT.jsonl [-g "extra counter group"] -- "VAR=1" "-" ...
 OUT=$(realpath -m "$1"); shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+export LMC_BENCH_ALLOW_EXP=1  # variants may carry work-skipping LMC_EXP_* switches: every line names its variant
 GROUPS_=("FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum")
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do
   case "$1" in
@@ -32,11 +33,12 @@ steps = None
 try:
     line = [l for l in open(sys.argv[2]) if l.startswith('{"metric"')][-1]
     b = json.loads(line)
-    steps = b["roofline"]["chain_steps_per_launch"]
+    steps = b["roofline"]["chain_steps_per_launch"] if b["roofline"]["kernel"].startswith("k_step_small") else None
     rate = b["value"]
+    extra = {k: b.get(k) for k in ("accept_rate", "cache_queries_per_step", "cache_hits_per_query")}
 except Exception:
     rate = None
-out = {"variant": os.environ["VARIANT"], "value_under_pmc": rate, "lean_chain_steps_per_launch": steps, "kernels": {}}
+out = {"variant": os.environ["VARIANT"], "value_under_pmc": rate, "run": extra if rate else None, "lean_chain_steps_per_launch": steps, "kernels": {}}
 for k, v in d.items():
     if not ("k_step" in k or "k_h2" in k or "k_mala" in k or "k_reloc" in k):
         continue

@@ -79,49 +79,37 @@ for dim in (6, 8, 10, 12):
     if nq == 0:
         print(json.dumps(out))
         continue
-    # the grid in force: coordinates 0..3
-    groups = {"0-3": (0, 1, 2, 3)}
-    if dim >= 8:
-        groups["4-7"] = (4, 5, 6, 7)
-    if dim >= 12:
-        groups["8-11"] = (8, 9, 10, 11)
-    if dim == 10:
-        groups["6-9"] = (6, 7, 8, 9)
-    if dim == 6:
-        groups["2-5"] = (2, 3, 4, 5)
-    cnt = {}
-    for name, co in groups.items():
-        d = dilated(rows, co, g)
-        cnt[name] = d[tuple(cells(Q[:, c], g) for c in co)]
-        out["pass_" + name] = float((cnt[name] > 0).mean())
-    base = cnt["0-3"]
-    allpass = np.ones(nq, bool)
-    for name in groups:
-        allpass &= cnt[name] > 0
-    out["pass_all_groups"] = float(allpass.mean())
-    # exact matches (first 16 coordinates are all the summary carries: exact for dim <= 16)
-    match = np.zeros(nq, bool)
-    idx = np.nonzero(allpass)[0]
-    for i0 in range(0, len(idx), 4096):
-        ii = idx[i0:i0 + 4096]
-        d2 = ((Q[ii, None, :] - rows[None, :, :Q.shape[1]]) ** 2).sum(-1)
-        match[ii] = (d2 < radius_sq).any(1)
-    out["queries_with_a_row_in_radius"] = float(match.mean())
-
     def wave_stats(c):
         nw = len(c) // 64
         if nw == 0:
             return None
         m = c[:nw * 64].reshape(nw, 64)
-        return {"mean_scan_per_query": float(c.mean()), "mean_wave_scan(max over lanes)": float(m.max(1).mean()), "waves_with_no_scan": float((m.max(1) == 0).mean()),
-                "lanes_scanning": float((m > 0).mean())}
+        return {"lanes_scanning": round(float((m > 0).mean()), 4), "mean_scan_per_query": round(float(c.mean()), 3), "mean_wave_scan": round(float(m.max(1).mean()), 3)}
 
-    out["scan_today"] = wave_stats(base)
-    out["scan_with_all_bitmaps"] = wave_stats(np.where(allpass, base, 0))
-    # a finer split of the scan: the candidate list of the cell restricted to rows that also pass the other groups cannot be had without per-row
-    # work; what CAN be had cheaply is the shortest of the groups' lists
-    shortest = np.where(allpass, np.min(np.stack([cnt[k] for k in groups]), 0), 0)
-    out["scan_shortest_group_list"] = wave_stats(shortest)
-    out["bitmap_bytes_per_group"] = g ** 4 // 8
+    # which four coordinates should the grid use?  The test is exact for ANY choice (a row within the radius is within a cell of the query in every
+    # coordinate); the choice decides how many candidates a query scans.  Heuristic available at build time: the coordinates in which the cache rows
+    # themselves collide least (sum of squared 1-D cell occupancies).
+    coll = [float((np.bincount(cells(rows[:, c], g), minlength=g).astype(np.float64) ** 2).sum()) / 3000.0 ** 2 for c in range(dim)]
+    heur = tuple(sorted(np.argsort(coll)[:4].tolist()))
+    out["collision_1d_per_coordinate"] = [round(x, 4) for x in coll]
+    sets = {"first4 (in force)": (0, 1, 2, 3), "last4": tuple(range(dim - 4, dim)), "least_colliding4": heur}
+    rng = np.random.default_rng(1)
+    allsets = list(itertools.combinations(range(dim), 4))
+    for k in rng.choice(len(allsets), size=min(12, len(allsets)), replace=False):
+        sets["random " + str(allsets[k])] = allsets[k]
+    res = {}
+    for name, co in sets.items():
+        d = dilated(rows, co, g)
+        c = d[tuple(cells(Q[:, cc], g) for cc in co)]
+        res[name] = dict(coords=list(co), **wave_stats(c))
+    out["grids"] = res
+    best = min(res, key=lambda k: res[k]["mean_wave_scan"])
+    out["best"] = {best: res[best]}
+    # exact matches
+    match = 0
+    for i0 in range(0, min(nq, 200000), 4096):
+        d2 = ((Q[i0:i0 + 4096, None, :] - rows[None, :, :Q.shape[1]]) ** 2).sum(-1)
+        match += int((d2 < radius_sq).any(1).sum())
+    out["queries_with_a_row_in_radius"] = match / float(min(nq, 200000))
     print(json.dumps(out))
 ren.close()

@@ -59,6 +59,10 @@ def check_rng(L):
     uni = rng_probe(seeds, 1, n)
     nor = rng_probe(seeds, 2, n - 1, 0.0, 0.01)
     mix = rng_probe(seeds, 3, 9 * 64)
+    # the chain kernels never read a stream's extension table before its first tick: they synthesise the entries from the seed (drng.h).  Same
+    # streams, same state and table afterwards -- including the seed whose stream ticks inside the window (the table is then materialised)
+    for mode, ref, nn in ((0, raw, n), (1, uni, n), (2, nor, n - 1), (3, mix, 9 * 64)):
+        assert np.array_equal(rng_probe(seeds, mode | 8, nn, 0.0, 0.01 if mode == 2 else 1.0), ref), "synthesised extension table: mode %d differs" % mode
     res = {}
     for k, s in enumerate(seeds):
         a = np.zeros(n, np.uint32)

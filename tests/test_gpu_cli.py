@@ -79,30 +79,49 @@ def test_bench_multi_rank_code_path_with_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 1e6
     assert d["roofline"]["avg_launch_ms"] > 0
+    assert d["multi_gpu"]["rccl_ranks"] == 1 and len(d["roofline"]["frac_per_rank"]) == 1 and d["multi_gpu"]["boot"].startswith("torch.distributed")
+    assert d["configs"][0]["value"] > 1e5 and d["configs"][0]["multi_gpu"]["rccl_ranks"] == 1  # the second workload of the line: its own communicator
+    # the same through the form plain `python bench.py --gpus N` takes: bench.py starts the rank process(es) itself, the id travels through a
+    # private directory, barriers and timing through the library's communicator -- no torch anywhere
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, LMC_BENCH_FORCE_DIST="1", LMC_BENCH_FORCE_SPAWN="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(gc.ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--chains", "65536", "--no-configs"], capture_output=True, text=True, timeout=600, cwd=gc.ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["multi_gpu"]["rccl_ranks"] == 1 and d["multi_gpu"]["boot"] == "file" and d["value"] > 1e6 and d["multi_gpu"]["film_sum"] > 0
 
 
 def test_bench_gpus_n_drives_n_ranks_or_fails(tmp_path):
-    """`python bench.py --gpus 2` without a launcher: on a box with one GPU it exits 2 with a message (never a one-GPU number under
-    `n_gpus: 2`); with LMC_BENCH_OVERSUBSCRIBE=1 (bring-up aid: the two ranks share the device, reported as `oversubscribed`) the
-    in-process job itself runs -- sharded MLTInit, group steps, film merge -- and its line carries the per-rank step times and the
-    merge time; the merged film holds every rank's splats (film luminance = normalization x steps, the energy identity)."""
+    """`python bench.py --gpus 2` without a launcher is a job of two PROCESSES over RCCL: on a box with one GPU it exits 2 with a message (never
+    a one-GPU number under `n_gpus: 2`), on a box with two it runs and its line says `rccl_ranks: 2` and carries a `roofline`.  The explicit
+    `--in-process` fallback with LMC_BENCH_OVERSUBSCRIBE=1 (bring-up aid: the two contexts share the device, reported as `oversubscribed`) runs the
+    in-process job -- sharded MLTInit, group steps driven by a host thread per member, the reduce-scatter film merge -- and its line carries the
+    per-rank step times, the host's issue time per rank-step, the peer-access state, a roofline and the merge time; the merged film holds every
+    rank's splats."""
     import json
     import sys
 
     p = gc.pkg()
     bench = os.path.join(gc.ROOT, "bench.py")
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LMC_BENCH_OVERSUBSCRIBE", "LMC_BENCH_FORCE_DIST")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LMC_BENCH_OVERSUBSCRIBE", "LMC_BENCH_FORCE_DIST", "LMC_BENCH_DRY_RUN", "LMC_BENCH_BOOT")}
     argv = [sys.executable, bench, "--gpus", "2", "--chains", "8192", "--steps", "6", "--warmup", "3", "--samples-per-chain", "64", "--init-threads", "2048", "--no-configs"]
     if p.device_count() < 2:
         r = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 2 and "HIP device(s) visible" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-400:])
-        env = dict(env, LMC_BENCH_OVERSUBSCRIBE="1")
-    r = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    else:
+        r = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["multi_gpu"]["rccl_ranks"] == 2 and len(d["roofline"]["frac_per_rank"]) == 2
+        assert d["roofline"]["frac_min"] > 0 and len(d["multi_gpu"]["per_rank_step_ms"]) == 2 and d["multi_gpu"]["film_sum"] > 0
+    env = dict(env, LMC_BENCH_OVERSUBSCRIBE="1")
+    r = subprocess.run(argv + ["--in-process"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["n_gpus"] == 2 and len(d["config"]["devices"]) == 2 and d["config"]["oversubscribed"] == (p.device_count() < 2)
+    assert d["n_gpus"] == 2 and len(d["config"]["devices"]) == 2 and d["config"]["oversubscribed"] == (p.device_count() < 2) and d["config"]["rccl_ranks"] == 0
     m = d["multi_gpu"]
     assert len(m["per_rank_step_ms"]) == 2 and all(t > 0 for t in m["per_rank_step_ms"]) and m["film_merge_ms"] > 0
+    assert len(m["host_issue_ms_per_step_per_rank"]) == 2 and all(0 < t < 50 for t in m["host_issue_ms_per_step_per_rank"]) and m["group"]["host_threads"] == 2
+    assert len(d["roofline"]["frac_per_rank"]) == 2 and d["roofline"]["frac_min"] > 0
     assert d["value"] > 0 and abs(d["value"] - 2 * 8192 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     lum = m["film_sum"]  # sum of R + G + B over the merged film; every step of every chain of BOTH ranks deposits `normalization` of luminance
     assert lum > 0
