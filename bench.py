@@ -571,6 +571,7 @@ def rank_job(args, p, gc, boot, rank, world, local, name, xml, kw, warm, steps, 
         standalone = (sa_small_ms / max(n_sa, 1), (lean1 - lean0) / max(n_sa, 1))
     out = {
         "workload": name, "value": steps * total / dt, "unit": "chain-steps/s", "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warm,
+        "bvh_nodes": "quantised 64 B" if ren.get_option("bvh_quantised") else "exact 128 B", "bvh_thick_flat_share": ren.get_option("bvh_thick_flat_share"),
         "value_from_step_counter": steps_rank / dt, "init_seconds": t_init, "normalization": norm, "init_samples": init_samples, "film": [ren.width, ren.height],
         "accept_rate": (s1["accepted"] - s0["accepted"]) / max(steps_rank, 1), "large_step_frac": (s1["largeSteps"] - s0["largeSteps"]) / max(steps_rank, 1),
         "cache_queries_per_step": (s1["cacheQueries"] - s0["cacheQueries"]) / max(steps_rank, 1), "cache_hits_per_query": (s1["cacheHits"] - s0["cacheHits"]) / max(s1["cacheQueries"] - s0["cacheQueries"], 1),
@@ -699,6 +700,7 @@ def main_rank(args):
                 "init_samples": head["init_samples"],
                 "samples_per_chain": args.samples_per_chain,
                 "film": head["film"],
+                "bvh_nodes": head["bvh_nodes"],
                 "parallelism": "chains sharded x%d, one process per GPU" % world,
                 "collective": head["multi_gpu"]["collective"] if multi else "none (one GPU)",
                 "rccl_ranks": world if multi else 0,

@@ -59,7 +59,8 @@ int lmc_scene_params(lmc_ctx *ctx, float *out38);
  * at any time, but once one of them differs from its value at lmc_chains_init, lmc_chains_step returns -1 until the chains are initialised again */
 int lmc_set_option(lmc_ctx *ctx, const char *name, double value);
 /* <dpt> options as parsed: spp, numinitsamples, numchains, directspp, mindepth, maxdepth, largestepprob, largestepscale,
- * mala, h2mc, seedoffset (dptoptions.h:7-34) */
+ * mala, h2mc, seedoffset (dptoptions.h:7-34); back-end state: bvh_quantised (the scene's hot launches walk the 64-byte quantised BVH nodes),
+ * bvh_thick_flat_share (the figure that choice is made by) */
 int lmc_get_option(lmc_ctx *ctx, const char *name, double *value);
 /* film "filename" of the scene (outputName); the reference appends "_timeuse_<seconds>s.exr" (mlt.cpp:208) */
 const char *lmc_output_name(lmc_ctx *ctx);

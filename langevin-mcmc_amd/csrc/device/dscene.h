@@ -47,7 +47,7 @@ struct alignas(16) BvhNode4Q {
 };
 static_assert(sizeof(BvhNode4Q) == 64, "one node = one 64 B half line");
 #ifndef LMC_BVH_QUANT
-#define LMC_BVH_QUANT 0  // build option: 1 = the kernels walk the quantised nodes
+#define LMC_BVH_QUANT 0  // build option: 1 = EVERY kernel walks the quantised nodes (A/B; the product chooses per scene and per launch: LdsStackT::kQuant)
 #endif
 // triangle in BVH leaf order, 48 B: Moeller-Trumbore operands + global triangle id
 struct alignas(16) LeafTri {
@@ -192,9 +192,14 @@ constexpr int BVH_LDS_STACK = 40;
 // Both policies also carry kGlossy: whether the scene has non-Lambertian BSDFs.  Every kernel is instantiated for both
 // values so that Lambertian-only scenes (BASELINE.json configs[1]) do not pay registers / code for Phong and the rough
 // dielectric.
-template <bool GLOSSY>
+// ... and kQuant (round 5): whether the launch walks the 64-byte quantised nodes (DScene::qnodes) or the exact 128-byte ones.  Chosen PER SCENE
+// when the scene is loaded (host/context.cpp UploadScene: the quantised nodes suit a tree unless it is full of flat leaves away from their node's
+// faces -- accel.h ThickenedFlatLeafShare) and compiled in as a template parameter of the two hot launches (the lean small steps, the large
+// steps): a run-time branch inside the kernels cost more than the smaller nodes save (profiles/r04_nodes_a_*).
+template <bool GLOSSY, bool QUANT = false>
 struct LocalStackT {
     static constexpr bool kGlossy = GLOSSY;
+    static constexpr bool kQuant = QUANT;
     int s[BVH_STACK];
     int sp = 0;
     LMC_D void Reset() { sp = 0; }
@@ -204,9 +209,10 @@ struct LocalStackT {
     }
     LMC_D int Pop() { return s[--sp]; }
 };
-template <bool GLOSSY>
+template <bool GLOSSY, bool QUANT = false>
 struct LdsStackT {
     static constexpr bool kGlossy = GLOSSY;
+    static constexpr bool kQuant = QUANT;
     int *base;   // &lds[threadIdx.x]
     int stride;  // blockDim.x
     int sp;
@@ -318,13 +324,13 @@ LMC_D int VisitNode4Q(const BvhNode4Q &nd, V3 org, V3 invd, float tnear, float t
 // one visit of inner node `cur`: the nearest hit child (or BVH4_EMPTY), the others pushed
 template <bool ORDERED, class Stk>
 LMC_D int VisitInner(const DScene &S, int cur, V3 org, V3 invd, float tnear, float tfar, Stk &stk) {
-#if LMC_BVH_QUANT
-    const BvhNode4Q nd = S.qnodes[cur];
-    return VisitNode4Q<ORDERED>(nd, org, invd, tnear, tfar, stk);
-#else
-    const BvhNode4 nd = S.nodes[cur];
-    return VisitNode4<ORDERED>(nd, org, invd, tnear, tfar, stk);
-#endif
+    if constexpr (Stk::kQuant || LMC_BVH_QUANT) {
+        const BvhNode4Q nd = S.qnodes[cur];
+        return VisitNode4Q<ORDERED>(nd, org, invd, tnear, tfar, stk);
+    } else {
+        const BvhNode4 nd = S.nodes[cur];
+        return VisitNode4<ORDERED>(nd, org, invd, tnear, tfar, stk);
+    }
 }
 
 // closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer).

@@ -46,7 +46,7 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
 #ifndef LMC_STEP_WAVES
 #define LMC_STEP_WAVES 2
 #endif
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, int MUX = 0>
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, int MUX = 0, bool QUANT = false>
 __global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
     extern __shared__ int ldsStack[];
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DC
         GradWork gw{gradBuf, (size_t)gradStride, (size_t)tid};
         const int kind = WITH_LARGE ? KIND_LARGE : KIND_SMALL;  // decided (and its uniform drawn) at the end of the previous step
         if constexpr (LDS_STACK) {
-            LdsStackT<GLOSSY> stk{ldsStack + threadIdx.x, (int)blockDim.x, 0};
+            LdsStackT<GLOSSY, QUANT> stk{ldsStack + threadIdx.x, (int)blockDim.x, 0};
             StepChain<WITH_LARGE, WITH_SMALL, WITH_GRAD, MUX>(S, *cache, A, film, P, i, kind, rng, gw, st, stk);
         } else {
             LocalStackT<GLOSSY> stk;

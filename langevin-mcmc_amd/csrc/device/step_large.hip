@@ -8,7 +8,10 @@ void LaunchStepLarge(const DScene &S, const DCache *cache, const ChainArrays &A,
     if (bvhStackNeed <= BVH_LDS_STACK) {  // traversal stack in LDS; gridBlocks was sized for 256-thread blocks
         const int blocks = gridBlocks * (256 / blockThreads);
         const size_t ldsBytes = (size_t)blockThreads * ((bvhStackNeed + 7) / 8 * 8) * sizeof(int);  // the scene's own stack need, not the cap
-        if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        const bool quant = S.qnodes != nullptr;  // the scene's choice of node format (host/context.cpp UploadScene, dscene.h LdsStackT::kQuant)
+        if (glossy && quant) hipLaunchKernelGGL((k_step<true, false, false, true, true, 0, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        else if (glossy) hipLaunchKernelGGL((k_step<true, false, false, true, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
+        else if (quant) hipLaunchKernelGGL((k_step<true, false, false, false, true, 0, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
         else
             hipLaunchKernelGGL((k_step<true, false, false, false, true>), dim3(blocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride);
         return;

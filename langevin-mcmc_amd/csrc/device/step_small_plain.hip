@@ -13,7 +13,7 @@
 
 using namespace lmcd;
 
-template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = false>
+template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = false, bool QUANT = false>
 #ifndef LMC_LEAN_K
 #define LMC_LEAN_K 1
 #endif
@@ -37,10 +37,10 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
         for (int rep = 0;; rep++) {
 #endif
         if (USE_LDS_STACK) {
-            LdsStackT<GLOSSY> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
+            LdsStackT<GLOSSY, QUANT> stk{reinterpret_cast<int *>(L.base), L.stride, 0};
             SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         } else {
-            LocalStackT<GLOSSY> stk;
+            LocalStackT<GLOSSY, QUANT> stk;
             SmallStepLean<false, LIGHTLESS>(S, *cache, A, film, P, i, rng, L, stk, st, prof);
         }
         const unsigned char nk = QueueNext(S, *cache, A, P, i, rng);
@@ -68,18 +68,27 @@ void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArray
     size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float);
     if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code
     const bool lds = bvhDepth <= BVH_LDS_STACK;
-#define LMC_LAUNCH_SMALL(LDS, G) hipLaunchKernelGGL((k_step_small<LDS, G>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords)
-    if (profile && lds && glossy) hipLaunchKernelGGL((k_step_small<true, true, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
-    else if (profile && lds && !glossy) hipLaunchKernelGGL((k_step_small<true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
-    else if (lds && !glossy && S.opt.leanLightless)
-        hipLaunchKernelGGL((k_step_small<true, false, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
-    else if (lds && glossy && S.opt.leanLightless)
-        hipLaunchKernelGGL((k_step_small<true, true, false, true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords);
-    else if (lds && !glossy)
-        LMC_LAUNCH_SMALL(true, false);
-    else if (lds && glossy)
-        LMC_LAUNCH_SMALL(true, true);
-    else if (!glossy)
+#define LMC_LAUNCH_SMALL(...) hipLaunchKernelGGL((k_step_small<__VA_ARGS__>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, stackWords)
+    const bool quant = S.qnodes != nullptr && lds && !profile;  // the scene's choice (host/context.cpp UploadScene); the profiling and fallback instantiations stay on the exact nodes
+    if (profile && lds && glossy) LMC_LAUNCH_SMALL(true, true, true);
+    else if (profile && lds && !glossy) LMC_LAUNCH_SMALL(true, false, true);
+    else if (lds && !glossy && S.opt.leanLightless) {
+        if (quant) LMC_LAUNCH_SMALL(true, false, false, true, true);
+        else
+            LMC_LAUNCH_SMALL(true, false, false, true);
+    } else if (lds && glossy && S.opt.leanLightless) {
+        if (quant) LMC_LAUNCH_SMALL(true, true, false, true, true);
+        else
+            LMC_LAUNCH_SMALL(true, true, false, true);
+    } else if (lds && !glossy) {
+        if (quant) LMC_LAUNCH_SMALL(true, false, false, false, true);
+        else
+            LMC_LAUNCH_SMALL(true, false);
+    } else if (lds && glossy) {
+        if (quant) LMC_LAUNCH_SMALL(true, true, false, false, true);
+        else
+            LMC_LAUNCH_SMALL(true, true);
+    } else if (!glossy)
         LMC_LAUNCH_SMALL(false, false);
     else
         LMC_LAUNCH_SMALL(false, true);

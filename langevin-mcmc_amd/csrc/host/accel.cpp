@@ -328,7 +328,7 @@ static void TopLevelsFirst(Bvh4Result &t, int topCount) {
 // dscene.h BvhNode4Q: child boxes as 8-bit offsets inside the node's box, rounded outwards with a minimum margin (none at the node's own
 // faces, where the offset is exact), every bound checked in double precision
 static constexpr double QUANT_SLACK = 1.0 / 64;
-static void QuantizeBvh4(Bvh4Result &t) {
+void QuantizeBvh4(Bvh4Result &t) {
     t.qnodes.resize(t.nodes.size());
     for (size_t i = 0; i < t.nodes.size(); i++) {
         const lmcd::BvhNode4 &nd = t.nodes[i];
@@ -372,7 +372,10 @@ static void QuantizeBvh4(Bvh4Result &t) {
                 }
                 // decoded bounds in world coordinates, checked in double precision
                 const double d0 = org + a0 * sc, d1 = org + a1 * sc, dlo = std::min(d0, d1), dhi = std::max(d0, d1);
-                if (dlo > (double)nd.bmin[k][a] || dhi < (double)nd.bmax[k][a]) throw std::runtime_error("internal: a quantised BVH box does not contain its exact box");
+                if (dlo > (double)nd.bmin[k][a] || dhi < (double)nd.bmax[k][a]) {  // never seen; the scene then simply keeps the exact nodes
+                    t.qnodes.clear();
+                    return;
+                }
                 q.qmin[a][k] = (unsigned char)a0, q.qmax[a][k] = (unsigned char)a1;
             }
         }
@@ -383,6 +386,7 @@ static void QuantizeBvh4(Bvh4Result &t) {
 
 double ThickenedFlatLeafShare(const Bvh4Result &t) {
     double all = 0, thick = 0;
+    if (t.qnodes.size() != t.nodes.size()) return 0.0;
     for (size_t i = 0; i < t.nodes.size(); i++) {
         const lmcd::BvhNode4 &nd = t.nodes[i];
         const lmcd::BvhNode4Q &q = t.qnodes[i];

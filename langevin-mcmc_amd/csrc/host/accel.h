@@ -36,8 +36,10 @@ Bvh4Result CollapseToBvh4(const LbvhResult &bvh);
 // thickness of one or two steps, and every ray that leaves such a surface enters its box again (veach-door: 1.22 -> 1.71 leaf visits per ray, the torus
 // scene, whose only flat surface is the floor in the lower face of the root: 1.03 -> 1.04; tests/helpers/bvh_stats.cpp).  Returns the share of the leaf
 // children's surface area that belongs to such thickened flat children; an analysis aid (tests/helpers/bvh_stats.cpp prints it):
-// the quantised nodes are a build option, see dscene.h.
+// host/context.cpp UploadScene chooses the node format of the scene's hot launches by it (torus 0.0006, veach-door 0.55).  0 for a tree without quantised nodes.
 double ThickenedFlatLeafShare(const Bvh4Result &t);
+// t.qnodes from t.nodes (called by CollapseToBvh4); leaves t.qnodes EMPTY when a box cannot be represented conservatively (never seen)
+void QuantizeBvh4(Bvh4Result &t);
 
 struct KdTreeResult {
     std::vector<lmcd::KdNode> nodes;

@@ -139,6 +139,7 @@ struct lmc_ctx {
     // scene buffers
     DevBuf<BvhNode4> nodes;
     DevBuf<BvhNode4Q> qnodes;
+    double thickFlatShare = 0;  // accel.h ThickenedFlatLeafShare of the scene's tree: decides the node format of the hot launches (UploadScene)
     DevBuf<LeafTri> leafTris;
     DevBuf<TriData> tris;
     DevBuf<DMesh> meshes;
@@ -342,10 +343,18 @@ static void UploadScene(lmc_ctx *c) {
     c->areaFunc.Upload(areaFunc), c->areaCdf.Upload(areaCdf), c->lightFunc.Upload(sc.lightFunc), c->lightCdf.Upload(sc.lightCdf);
     DScene &S = c->S;
     memset(&S, 0, sizeof(S));
-    if (LMC_BVH_QUANT) c->qnodes.Upload(bvh.qnodes);  // build option (dscene.h BvhNode4Q)
+    // Node format of the scene's hot launches (lean small steps, large steps; dscene.h LdsStackT::kQuant): the 64-byte quantised nodes unless the tree
+    // is full of flat leaves away from their node's faces, which the format thickens and every ray leaving such a surface then re-enters
+    // (profiles/r05_n_ab_configs_quant.jsonl: torus headline +5 %, full-material torus +10 %, veach-door -7 %; the share separates them: 0.0006 vs 0.55).
+    // LMC_BVH_NODES=exact|quant overrides (A/B); a build with -DLMC_BVH_QUANT=1 walks the quantised nodes in every kernel.
+    c->thickFlatShare = lmc::ThickenedFlatLeafShare(bvh);
+    bool quant = !bvh.qnodes.empty() && c->thickFlatShare < 0.05;
+    if (const char *e = getenv("LMC_BVH_NODES")) quant = !bvh.qnodes.empty() && std::string(e) == "quant" ? true : std::string(e) == "exact" ? false : quant;
+    if (LMC_BVH_QUANT) quant = true;
+    if (quant) c->qnodes.Upload(bvh.qnodes);
     else
         c->qnodes.Free();
-    S.nodes = c->nodes.p, S.qnodes = LMC_BVH_QUANT ? c->qnodes.p : nullptr, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
+    S.nodes = c->nodes.p, S.qnodes = quant ? c->qnodes.p : nullptr, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
     S.areaFunc = c->areaFunc.p, S.areaCdf = c->areaCdf.p, S.lightFunc = c->lightFunc.p, S.lightCdf = c->lightCdf.p;
     S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
     S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size();
@@ -549,6 +558,8 @@ int lmc_get_option(lmc_ctx *c, const char *name, double *v) {
     else if (n == "uselightcoordinatesampling") *v = o.useLightCoordinateSampling ? 1 : 0;
     else if (n == "largestepmultiplexed") *v = o.largeStepMultiplexed ? 1 : 0;
     else if (n == "samplecache") *v = o.sampleFromGlobalCache ? 1 : 0;
+    else if (n == "bvh_quantised") *v = c->S.qnodes ? 1 : 0;            // back-end state, not a <dpt> option: the node format of the scene's hot launches ...
+    else if (n == "bvh_thick_flat_share") *v = c->thickFlatShare;       // ... and the figure it was chosen by (UploadScene)
     else throw std::runtime_error("Unknown dpt option:" + n);
     return 0;
     LMC_CATCH(-1)
