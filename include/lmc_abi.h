@@ -49,6 +49,11 @@ void lmc_destroy(lmc_ctx *ctx);
 /* number of HIP devices visible to this process (0 without a GPU): `device` of lmc_scene_desc must be below it */
 int lmc_device_count(void);
 
+/* Host-only (no GPU needed): what the front end parsed from a scene file (parsescene.cpp:535-639, loadserialized.cpp:153-325, parseobj.cpp:57-275,
+ * image.cpp) as one JSON document: per mesh triangle / vertex counts, bounds, area, material, emitter; per material type and parameters
+ * (textures: file, size, gamma, average); lights with their sampling weights and the light-pick CDF; camera; <dpt> options; output name.
+ * Writes at most cap - 1 characters + NUL; returns the document's full length, -1 on error.  The cross-check surface of the parsers. */
+long long lmc_scene_dump(const char *scene_xml, int force_diffuse, char *out, long long cap);
 /* [width, height, numTriangles, maxDepth, numBvhNodes, bvhDepth, numLights, mala] */
 int lmc_info(lmc_ctx *ctx, int *out8);
 /* the 38-float scene block of the plugin ABI (scene.cpp:160-169) */
@@ -137,9 +142,11 @@ int lmc_stats(lmc_ctx *ctx, long long *out8, double *weight_sum);
  * mutation_large.h:87-116), and after an outlier reset (mlt.cpp:151-158) onto an init state that lives on another rank of the job only those
  * are copied -- the path words (time, pss, screen) of such a row are the previous state's. */
 int lmc_chain_summary(lmc_ctx *ctx, int which, float *out, int stride);
-/* chain relocation (device/relocate.hip; no counterpart in the reference, whose chains are objects a thread walks, mlt.cpp:60-196): once every
- * gradient cache is ready the resident chains are kept physically grouped by technique (c,l).  Invisible in every result except the order of
- * the film's atomics; lmc_chain_summary reports rows in chain order regardless.
+/* chain relocation (device/relocate.hip; no counterpart in the reference, whose chains are objects a thread walks, mlt.cpp:60-196): from the
+ * FIRST step on -- the cache-fill phase included -- the resident chains are kept physically grouped by technique (c,l): after every step's large-step
+ * launch, on its stream, the chains that launch gave another technique move to the slots of their technique (the small-step launches' chains are not
+ * touched; the step's cache pushes are packed before the move, in chain order).  Invisible in every result except the order of the film's atomics;
+ * lmc_chain_summary reports rows in chain order regardless.
  * out4 = [relocations run, chains moved by the last one, adjacent slot pairs whose chains differ in technique key, slots]; -1 when off */
 int lmc_relocation_stats(lmc_ctx *ctx, long long *out4);
 /* kernel time (ms, HIP events on the launch stream) and launch count of the chain-step kernel since the last call */

@@ -173,7 +173,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
 #pragma unroll
         for (int k = 0; k < MD; k++) g[k] = 0.f;
         if (gs.ssScore > 1e-10f) {
-            if (!(P.expFlags & 4)) LeanStateGradient(S, gs.pathBuf, (int)N, i, gs.workBuf, gs.workStride, gs.workSlot, g);
+            if (!LMC_EXP(P.expFlags, 4)) LeanStateGradient(S, gs.pathBuf, (int)N, i, gs.workBuf, gs.workStride, gs.workSlot, g);
             st.gradCalls++;
             bool finite = true;
             for (int k = 0; k < dim; k++) finite = finite && isfinite(g[k]);
@@ -216,7 +216,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         }
     }
     st.cacheQueries++;
-    if (P.expFlags & 256) return;  // LMC_EXP_QUERY_STOP=1 (measurement): the query ends before its cell is computed
+    if (LMC_EXP(P.expFlags, 256)) return;  // LMC_EXP_QUERY_STOP=1 (measurement): the query ends before its cell is computed
     const DCacheDim &C = cache.d[dim];
     const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
     if (C.gridWords) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
@@ -224,7 +224,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(L.Q(C.gridCoord[k]), C.gridG);
         const uint2 word = C.gridWords[cell >> 5];
         const unsigned bit = 1u << (cell & 31);
-        if (!(word.x & bit) || (P.expFlags & 512)) return;  // the common case: the point is read no further (LMC_EXP_QUERY_STOP=2: every cell counts as empty)
+        if (!(word.x & bit) || LMC_EXP(P.expFlags, 512)) return;  // the common case: the point is read no further (LMC_EXP_QUERY_STOP=2: every cell counts as empty)
         const int r = (int)word.y + __popc(word.x & (bit - 1u));
         const int s0 = C.gridCellStart[r], s1 = C.gridCellStart[r + 1];
         float q[MD];
@@ -426,7 +426,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 if (l == 1) qs.Push(LdS(&cur[(size_t)VertWord(false, camCount - 1, 10) * N + i])), qs.Push(LdS(&cur[(size_t)VertWord(false, camCount - 1, 11) * N + i]));
             }
             const GradState gs{cur, c, l, curSs, false, workBuf, workStride, workSlot};
-            PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
+            PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, LMC_EXP(P.expFlags, 2));
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;  // the blend rewrote chain->v1 / v2
             if (vs.wrotePss || vs.mode == VS_BLEND || vs.mode == VS_GRAD) flags |= F_VDIRTY;
             flags |= F_GAUSS;
@@ -655,7 +655,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             float *G = PropGaussBuf(A, flags);
             VSource vs;
             const GradState gs{prop, c, l, pc.ssScore, true, workBuf, workStride, workSlot};
-            PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, (P.expFlags & 2) != 0);
+            PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, LMC_EXP(P.expFlags, 2));
 #ifdef LMC_PROF_FINE
             prof.Mark(PR_RESET);
 #endif
@@ -685,7 +685,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 
     prof.Mark(PR_GAUSS_PROP);
     // ---- splats, mlt.cpp:103-112
-    const bool doSplat = !(P.expFlags & 1);
+    const bool doSplat = !LMC_EXP(P.expFlags, 1);
     if (curValid && a < 1.0f && doSplat) {
         const int n = A.curSplatCount[i];
         for (int k = 0; k < n; k++) {

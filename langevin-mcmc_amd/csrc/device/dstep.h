@@ -70,7 +70,7 @@ LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArra
             // ready (NeedsGradient below), so this branch is unreachable there; NaN -> zeroed keeps it defined
             if (gradIn) {  // evaluated by the launch in front of this one (step_mala_phases.hip, gradcoop.hip)
                 for (int k = 0; k < dim; k++) vGrad[k] = gradIn[k];
-            } else if (WITH_GRAD && !(P.expFlags & 4)) ComputeGradient(S, path, sp, vGrad, gw);
+            } else if (WITH_GRAD && !LMC_EXP(P.expFlags, 4)) ComputeGradient(S, path, sp, vGrad, gw);
             else
                 for (int k = 0; k < dim; k++) vGrad[k] = NAN;
             st.gradCalls++;

@@ -16,6 +16,12 @@ using namespace lmcd;
 // and order included) as the serial form the CPU oracle runs.  The matrices live in LDS (row stride 17: lanes k = 0..15 reading
 // [k][p] hit 16 banks).  Only the two reductions (Frobenius norm of the early-out, off-diagonal norm of the convergence test) are
 // summed in another order than the serial code.
+// Deliberate deviation: the finite test (mutation_h2mc.h:80-85 IsFinite over the whole vHess) and the Frobenius-norm early-out
+// (h2mc.cpp:84 hess.norm()) are evaluated on the matrix SYMMETRISED FROM THE TRIANGLE EIGEN READS -- the only entries h2hess.hip delivers.  The
+// reference's programs deliver the full matrix, whose other triangle can differ where chad's adjoint overwrite makes the "Hessian" asymmetric
+// (DESIGN.md "chad's adjoint overwrite"): a non-finite or asymmetric entry there would move the reference's iso / dense decision and not ours.
+// The oracle (oracle/h2mc_serial.h) keeps the same convention so that the two sides stay comparable; the size of the effect is what
+// test_h2mc_per_step_agreement measures (0.6 - 3 % of the chains part per 6 mutations, all causes together).
 // Writes the state's Gaussian (AoS, dh2coop.h) into the chain's current (stage 0) or proposal (stage 1) buffer; stage 1 also
 // returns px = GaussianLogPdf(-offset, proposalGaussian) (mutation_h2mc.h:104, gaussian.cpp:24-36).
 namespace {
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
         const unsigned long long finMask = __ballot(fin || !act);
         const bool allFinite = ((finMask >> (16 * g)) & 0xffffull) == 0xffffull;  // mutation_h2mc.h:80-85: any non-finite entry zeroes gradient and Hessian
         const float hnorm = sqrtf(GroupSum(act ? sq : 0.f));
-        const bool iso = !allFinite || (expFlags & 32) || hnorm < 0.5f / (sigma * sigma) || !(hnorm == hnorm);  // h2mc.cpp:84-92
+        const bool iso = !allFinite || LMC_EXP(expFlags, 32) || hnorm < 0.5f / (sigma * sigma) || !(hnorm == hnorm);  // h2mc.cpp:84-92
         bool run = has && !iso;
         __syncthreads();
         // ---- cyclic Jacobi: the rotation sequence of oracle/h2mc_serial.h JacobiEigenSymT

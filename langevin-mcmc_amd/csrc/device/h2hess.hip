@@ -6,8 +6,8 @@
 // record is staged in LDS once per wave and read by broadcast; a lane evaluates its block in two passes of 6-float values (four of
 // 4-float values for the techniques with both sub-paths), seeded on the fly: no indexable array of second-order values, hence no private
 // memory for it.  A wave's states also share a material signature (the stage's bins, dh2coop.h), so they take the same BSDF branches.
+#ifndef LMC_H2HESS_EXACT_MATH  // the strict build (scripts/build_h2strict.sh; tests/test_gpu_h2mc.py runs the chain-parity tests on it): neither
 #define LMC_PF_CONTRACT  // the dual-number arithmetic of this translation unit may fuse a * b + c (pathfunc.h)
-#ifndef LMC_H2HESS_EXACT_MATH
 #define LMC_PF_FASTMATH  // ... and sin / cos / exp / log / pow are the hardware's approximate instructions
 #endif
 #include "dh2coop.h"

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
                     G[H2_GAUSS_LOGDET] = H2IsoLogDetNoDerv(dim, sigma), G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_NODERV;
                 } else {
                     if (curSs > 1e-15f) st.gradCalls++;
-                    if (curSs > 1e-15f && !(P.expFlags & 16)) {
+                    if (curSs > 1e-15f && !LMC_EXP(P.expFlags, 16)) {
                         DPath path;
                         LoadPath(CurPathBuf(A, flags), N, i, path);
                         H2Serialize(S, path, H.rec + (size_t)i * H2_REC_WORDS);
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
                         G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_NODERV;
                     } else {
                         if (pc.ssScore > 1e-15f) st.gradCalls++;
-                        if (pc.ssScore > 1e-15f && !(P.expFlags & 16)) {
+                        if (pc.ssScore > 1e-15f && !LMC_EXP(P.expFlags, 16)) {
                             H2Serialize(S, prop, H.rec + (size_t)i * H2_REC_WORDS);
                             want = true, t = H2BinIndex(H2TechIndex(prop.camDepth, prop.lgtDepth), H2MaterialSignature(S, prop)), iso = false;
                         } else {

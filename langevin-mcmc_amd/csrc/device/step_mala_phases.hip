@@ -19,7 +19,7 @@ namespace {
 
 // does InitGaussianFor evaluate the path program for this state?  (dstep.h: the branch `inRange && !ready && haveDerv`, then sp.ssScore > 1e-10)
 __device__ __forceinline__ bool WantsGradient(const DCache &cache, const StepParams &P, int c, int l, float ssScore) {
-    return NeedsGradient(cache, P, c, l) && ssScore > 1e-10f && !(P.expFlags & 4);
+    return NeedsGradient(cache, P, c, l) && ssScore > 1e-10f && !LMC_EXP(P.expFlags, 4);
 }
 
 }  // namespace

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, co
             atomicAdd(&A.prof[PR_COUNT], 1ull);
         }
     }
-    if (!(P.expFlags & 8)) BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
+    if (!LMC_EXP(P.expFlags, 8)) BlockReduceStats(st, A.counters, A.weightSum, reinterpret_cast<int *>(lds));
 }
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,

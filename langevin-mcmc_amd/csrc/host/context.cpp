@@ -184,7 +184,7 @@ struct lmc_ctx {
     // launch shape of the lean small-step kernel and the technique sort of its work list; LMC_LEAN_BLOCK / LMC_SORT_PLAIN
     // override them for A/B runs (profiles/)
     int leanBlock = 64, leanGrid = 0, sortPlain = 0;
-    // chain relocation (device/relocate.hip): the chains kept physically grouped by technique once every cache is ready; LMC_RELOCATE overrides
+    // chain relocation (device/relocate.hip): the chains kept physically grouped by technique from the first step on (fill phase included: the safety argument is at the launch site, StepPhase1); LMC_RELOCATE overrides
     bool relocate = false;
     DevBuf<int> chainId, slotOf, relocTileCount, relocTileHist, relocMembers, relocSorted, relocCount;
     DevBuf<unsigned char> relocPlacedKey, stepKind;
@@ -471,15 +471,24 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_SORT_H2MC")) c->sortH2mc = atoi(e) != 0;
     if (const char *e = getenv("LMC_SORT_GENERIC")) c->sortGeneric = atoi(e) != 0;
     if (const char *e = getenv("LMC_GRID_DIMS")) c->gridDims = std::min(4, std::max(3, atoi(e)));
-    if (const char *e = getenv("LMC_EXP_NOSPLAT")) c->expFlags |= atoi(e) ? 1 : 0;
-    if (const char *e = getenv("LMC_EXP_NOQUERY")) c->expFlags |= atoi(e) ? 2 : 0;
-    if (const char *e = getenv("LMC_EXP_QUERY_STOP")) c->expFlags |= atoi(e) == 1 ? 256 : atoi(e) == 2 ? 512 : 0;  // the cache query cut short before its cell / after its occupancy word
-    if (const char *e = getenv("LMC_EXP_NOGRAD")) c->expFlags |= atoi(e) ? 4 : 0;
-    if (const char *e = getenv("LMC_EXP_NOSTATS")) c->expFlags |= atoi(e) ? 8 : 0;
-    if (const char *e = getenv("LMC_EXP_NOHESS")) c->expFlags |= atoi(e) ? 16 : 0;    // H2MC: skip the second-order path program
-    if (const char *e = getenv("LMC_EXP_NOEIGEN")) c->expFlags |= atoi(e) ? 32 : 0;   // H2MC: skip the eigen-solve (isotropic Gaussian)
     if (const char *e = getenv("LMC_EXP_OUTLIER_TEST")) c->expFlags |= atoi(e) ? 128 : 0;  // tests: outlier reset after 6 / 2 adjacent rejections (dchain.h OutlierReset)
-    if (const char *e = getenv("LMC_EXP_NOHESSLAUNCH")) c->expFlags |= atoi(e) ? 64 : 0;  // H2MC: the stages are built but the Hessian launch is skipped (stale h2Out: timing only)
+    {   // work-skipping measurement switches (dstep_params.h): compiled into -DLMC_EXP_SWITCHES builds only (scripts/build_exp.sh); the shipped library
+        // refuses to run while one is set -- a number produced with work skipped must not look like any other
+        static const struct {
+            const char *name;
+            int one, two;
+        } sw[] = {{"LMC_EXP_NOSPLAT", 1, 1}, {"LMC_EXP_NOQUERY", 2, 2}, {"LMC_EXP_QUERY_STOP", 256, 512}, {"LMC_EXP_NOGRAD", 4, 4}, {"LMC_EXP_NOSTATS", 8, 8},
+                  {"LMC_EXP_NOHESS", 16, 16}, {"LMC_EXP_NOEIGEN", 32, 32}, {"LMC_EXP_NOHESSLAUNCH", 64, 64}};
+        for (const auto &w : sw) {
+            const char *e = getenv(w.name);
+            if (!e || atoi(e) == 0) continue;
+#ifdef LMC_EXP_SWITCHES
+            c->expFlags |= atoi(e) == 2 ? w.two : w.one;
+#else
+            throw std::runtime_error(std::string(w.name) + " is set, but this build of liblmc_hip.so has no work-skipping measurement switches (they exist in -DLMC_EXP_SWITCHES builds only: scripts/build_exp.sh, selected with LMC_LIB)");
+#endif
+        }
+    }
     UploadScene(c.get());
     SyncOptions(c.get());
     memset(&c->cacheHost, 0, sizeof(c->cacheHost));
@@ -1455,7 +1464,7 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * H2_COUNT_WORDS * sizeof(int), sG));
         LaunchH2Begin(c->S, c->A, P, H, list, n, laneGrid, sG);
         for (int stage = 0; stage < 2; stage++) {
-            if (!(P.expFlags & 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sG);
+            if (!LMC_EXP(P.expFlags, 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sG);
             LaunchH2Gauss(H.bins[stage], N, H.hout, param, P.expFlags, c->A.flags, stage, H.gauss, H.offset, H.px, c->h2GaussGrid, sG);
             if (stage == 0) {
                 LaunchH2Sample(list, n, N, c->A.flags, H.kind, c->A.curContrib, H.gauss, param.sigma, H.offset, H.py, laneGrid, sG);
@@ -2289,6 +2298,141 @@ int lmc_cache_grid_check(lmc_ctx *c, int dim) {
         if (dv != hv) bad++;
     }
     return bad;
+    LMC_CATCH(-1)
+}
+
+// Host-only (no GPU): what the front end made of a scene file, as one JSON document -- the cross-check surface of the parsers (XML, .serialized,
+// OBJ, textures) against independent ones (tests/test_scene_io.py).  Returns the document's length (it is truncated to cap - 1 characters), -1 on error.
+long long lmc_scene_dump(const char *scene_xml, int force_diffuse, char *out, long long cap) {
+    LMC_TRY
+    lmc::LoadOverrides ov;
+    ov.forceDiffuse = force_diffuse != 0;
+    std::unique_ptr<lmc::Scene> sc = lmc::ParseScene(scene_xml, ov);
+    std::string j;
+    char buf[512];
+    auto num = [&](double v) {
+        snprintf(buf, sizeof(buf), "%.9g", v);
+        j += buf;
+    };
+    auto vec = [&](const float *v, int n) {
+        j += "[";
+        for (int k = 0; k < n; k++) {
+            if (k) j += ",";
+            num(v[k]);
+        }
+        j += "]";
+    };
+    auto tex = [&](const lmc::TextureRef &t) {
+        j += "{\"bitmap\":";
+        if (t.bitmap >= 0) {
+            const lmc::Bitmap &b = sc->bitmaps[t.bitmap];
+            std::string fn = b.filename;
+            const size_t slash = fn.find_last_of('/');
+            if (slash != std::string::npos) fn = fn.substr(slash + 1);
+            j += "\"" + fn + "\",\"width\":" + std::to_string(b.img.width) + ",\"height\":" + std::to_string(b.img.height) + ",\"gamma\":";
+            num(b.gamma);
+            j += ",\"average\":";
+            vec(b.avg, 3);
+        } else {
+            j += "null";
+        }
+        j += ",\"value\":";
+        vec(t.value, 3);
+        j += ",\"s_scale\":";
+        num(t.sScale);
+        j += ",\"t_scale\":";
+        num(t.tScale);
+        j += "}";
+    };
+    j += "{\"num_tris\":" + std::to_string(sc->numTris()) + ",\"meshes\":[";
+    for (size_t m = 0; m < sc->meshes.size(); m++) {
+        const lmc::Mesh &M = sc->meshes[m];
+        if (m) j += ",";
+        const float bmin[3] = {M.bmin.x, M.bmin.y, M.bmin.z}, bmax[3] = {M.bmax.x, M.bmax.y, M.bmax.z};
+        j += "{\"tris\":" + std::to_string(M.numTris()) + ",\"verts\":" + std::to_string(M.P.size()) + ",\"has_normals\":" + (M.N.empty() ? "false" : "true") + ",\"has_st\":" + (M.ST.empty() ? "false" : "true");
+        double area = 0;  // sum of the triangle areas, in double (Mesh::totalArea exists for emitters only)
+        for (size_t t = 0; t < M.numTris(); t++) {
+            const lmc::V3 &a = M.P[M.idx[3 * t]], &b = M.P[M.idx[3 * t + 1]], &c = M.P[M.idx[3 * t + 2]];
+            const double e1[3] = {(double)b.x - a.x, (double)b.y - a.y, (double)b.z - a.z}, e2[3] = {(double)c.x - a.x, (double)c.y - a.y, (double)c.z - a.z};
+            const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            area += 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        }
+        j += ",\"material\":" + std::to_string(M.material) + ",\"area_light\":" + std::to_string(M.areaLight) + ",\"area\":";
+        num(area);
+        j += ",\"emitter_total_area\":";
+        num(M.totalArea);
+        j += ",\"bmin\":";
+        vec(bmin, 3);
+        j += ",\"bmax\":";
+        vec(bmax, 3);
+        j += "}";
+    }
+    j += "],\"materials\":[";
+    for (size_t m = 0; m < sc->materials.size(); m++) {
+        const lmc::Material &M = sc->materials[m];
+        if (m) j += ",";
+        j += "{\"type\":" + std::to_string(M.type) + ",\"two_sided\":" + (M.twoSided ? "true" : "false") + ",\"kd\":";
+        tex(M.Kd);
+        j += ",\"ks\":";
+        tex(M.Ks);
+        j += ",\"kt\":";
+        tex(M.Kt);
+        j += ",\"exp_or_alpha\":";
+        tex(M.expOrAlpha);
+        j += ",\"eta\":";
+        num(M.eta);
+        j += ",\"ks_weight\":";
+        num(M.KsWeight);
+        j += "}";
+    }
+    j += "],\"lights\":[";
+    for (size_t l = 0; l < sc->lights.size(); l++) {
+        const lmc::Light &L = sc->lights[l];
+        if (l) j += ",";
+        const float rad[3] = {L.radiance.x, L.radiance.y, L.radiance.z}, inten[3] = {L.intensity.x, L.intensity.y, L.intensity.z}, pos[3] = {L.position.x, L.position.y, L.position.z};
+        j += "{\"type\":" + std::to_string(L.type) + ",\"sampling_weight\":";
+        num(L.samplingWeight);
+        j += ",\"mesh\":" + std::to_string(L.mesh) + ",\"radiance\":";
+        vec(rad, 3);
+        j += ",\"intensity\":";
+        vec(inten, 3);
+        j += ",\"position\":";
+        vec(pos, 3);
+        j += ",\"env_width\":" + std::to_string(L.image.width) + ",\"env_height\":" + std::to_string(L.image.height) + ",\"env_normalization\":";
+        num(L.sampleInfo.normalization);
+        j += "}";
+    }
+    j += "],\"env_light\":" + std::to_string(sc->envLight) + ",\"light_cdf\":";
+    vec(sc->lightCdf.data(), (int)sc->lightCdf.size());
+    j += ",\"light_func_int\":";
+    num(sc->lightFuncInt);
+    const float c3[3] = {sc->bsphereCenter.x, sc->bsphereCenter.y, sc->bsphereCenter.z};
+    j += ",\"bsphere_center\":";
+    vec(c3, 3);
+    j += ",\"bsphere_radius\":";
+    num(sc->bsphereRadius);
+    const lmc::Camera &C = sc->camera;
+    j += ",\"camera\":{\"width\":" + std::to_string(C.width) + ",\"height\":" + std::to_string(C.height) + ",\"fov\":";
+    num(C.fov);
+    j += ",\"near\":";
+    num(C.nearClip);
+    j += ",\"far\":";
+    num(C.farClip);
+    const lmc::DptOptions &o = sc->options;
+    j += "},\"options\":{\"spp\":" + std::to_string(o.spp) + ",\"numinitsamples\":" + std::to_string(o.numInitSamples) + ",\"maxdepth\":" + std::to_string(o.maxDepth) + ",\"mindepth\":" + std::to_string(o.minDepth) +
+         ",\"directspp\":" + std::to_string(o.directSpp) + ",\"numchains\":" + std::to_string(o.numChains) + ",\"mala\":" + (o.mala ? "true" : "false") + ",\"h2mc\":" + (o.h2mc ? "true" : "false") + ",\"largestepprob\":";
+    num(o.largeStepProbability);
+    j += ",\"largestepscale\":";
+    num(o.largeStepProbScale);
+    j += ",\"perturbstddev\":";
+    num(o.perturbStdDev);
+    j += "},\"output\":\"" + sc->outputName + "\"}";
+    if (out && cap > 0) {
+        const size_t n = std::min<size_t>(j.size(), (size_t)cap - 1);
+        memcpy(out, j.data(), n);
+        out[n] = 0;
+    }
+    return (long long)j.size();
     LMC_CATCH(-1)
 }
 

@@ -2,6 +2,7 @@
 gradient + Hessian programs, the H2MC chain loop against the CPU oracle, and the end-to-end image of the shipped veach-door
 h2mc.xml against the render the reference ships."""
 import ctypes
+import json
 import os
 
 import numpy as np
@@ -290,8 +291,13 @@ def test_h2mc_chain_parity_diffuse():
     assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.005 * so["largeSteps"] + 2  # the oracle's Hessians now come from the reference's programs (1e-2 agreement, not bit equality)
     assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"] + 2
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * so["gradCalls"] + 2 and sg["gradCalls"] > 256 * 10
-    assert r["film_rel_l2"] < 0.5  # 0.28 measured (round 4, fused arithmetic in the device's Hessian program; 0.16 with the strict round-3 kernel): 16 of the 256 chains part ways within 30 steps
-    assert r["final_state_match"] > 0.875  # 0.9375 measured: twice the mismatch
+    if os.environ.get("LMC_H2_REPORT"):  # test_h2mc_chain_parity_on_the_strict_build reads the figures of BOTH builds from here
+        print("H2REPORT diffuse " + json.dumps({"film_rel_l2": r["film_rel_l2"], "final_state_match": r["final_state_match"], "accepted": [sg["accepted"], so["accepted"]]}))
+    # measured in round 5 (scripts/debug/h2_strict_vs_shipped.sh): shipped build 0.233 / 0.949, strict-arithmetic build 0.243 / 0.941 -- 13 .. 15 of the
+    # 256 chains part ways within 30 steps on EITHER build (the oracle's Hessians are the reference's programs': 1e-2 .. 1e-4 agreement, and one
+    # accept test that lands on the other side of its uniform draw is enough).  Bars at 1.25 x the measured mismatch.
+    assert r["film_rel_l2"] < 0.3
+    assert r["final_state_match"] > 0.93
     assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
@@ -309,9 +315,50 @@ def test_h2mc_chain_parity_full_materials():
     assert abs(sg["accepted"] - so["accepted"]) <= 0.02 * so["accepted"]  # measured 3048 vs 3017: 1.0 %
     assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.025 * so["gradCalls"]  # 3523 vs 3480: 1.2 %
     assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.016 * so["largeSteps"]  # 2212 vs 2195: 0.8 %
-    assert r["film_rel_l2"] < 0.5
-    assert r["final_state_match"] > 0.75
+    if os.environ.get("LMC_H2_REPORT"):
+        print("H2REPORT full " + json.dumps({"film_rel_l2": r["film_rel_l2"], "final_state_match": r["final_state_match"], "accepted": [sg["accepted"], so["accepted"]]}))
+    # bars at 1.25 x the measured mismatch (round 5): shipped build 0.350 / 0.805, strict-arithmetic build 0.315 / 0.820
+    assert r["film_rel_l2"] < 0.44
+    assert r["final_state_match"] > 0.755
     assert r["nonfinite_gpu"] == 0 and abs(r["energy_gpu"] - 1.0) < 1e-4
+
+
+def test_h2mc_chain_parity_on_the_strict_build():
+    """the shipped build evaluates the H2MC step's Hessian with fused multiply-adds and the hardware's approximate
+    sin / cos / exp / log / pow, and its eigen-solve with approximate division (h2hess.hip, h2gauss.hip; +8 .. 13 % chain-steps/s).  Does that
+    cost agreement with the oracle?  The SAME sources built with strict arithmetic (scripts/build_h2strict.sh: csrc/_ab/h2strict/liblmc_hip.so,
+    built by __graft_entry__.build()) run the two chain-parity tests in a child process (LMC_LIB selects the library at import), and so does
+    the shipped build.  Measured (round 5): diffuse film rel. L2 / chains in the oracle's final state 0.243 / 0.941 strict vs 0.233 / 0.949
+    shipped; full materials 0.315 / 0.820 vs 0.350 / 0.805 -- the same within two chains of 256.  The chains part from the oracle's because the
+    oracle's Hessians are the REFERENCE's programs' (agreement 1e-2 .. 1e-4 whatever the device's arithmetic), not because of the fast
+    arithmetic.  Asserted: both builds pass the same bars, and neither is further from the oracle than the other by more than three chains
+    / 0.06 of film distance."""
+    import subprocess
+    import sys
+
+    var = os.path.join(gc.ROOT, "langevin-mcmc_amd", "csrc", "_ab", "h2strict", "liblmc_hip.so")
+    if not os.path.exists(var):
+        pytest.skip("strict variant not built (python __graft_entry__.py builds it)")
+
+    def run(env_extra):
+        env = dict({k: v for k, v in os.environ.items() if k != "LMC_LIB"}, LMC_H2_REPORT="1", **env_extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(gc.ROOT, "tests", "test_gpu_h2mc.py"), "-q", "-s", "-x", "-k", "chain_parity_diffuse or chain_parity_full", "-p", "no:cacheprovider"],
+                           cwd=gc.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1800)
+        rep = {}
+        for l in r.stdout.splitlines():
+            if "H2REPORT " in l:
+                tag, body = l[l.index("H2REPORT ") + 9:].split(None, 1)
+                rep[tag] = json.loads(body)
+        return r.returncode, rep, r.stdout[-3000:]
+
+    rc_s, strict, out_s = run({"LMC_LIB": var})
+    assert rc_s == 0 and set(strict) == {"diffuse", "full"}, out_s
+    rc_f, fast, out_f = run({})
+    assert rc_f == 0 and set(fast) == {"diffuse", "full"}, out_f
+    print("H2 strict vs shipped build:", json.dumps({"strict": strict, "shipped": fast}))
+    for k in ("diffuse", "full"):
+        assert abs(strict[k]["film_rel_l2"] - fast[k]["film_rel_l2"]) <= 0.06, (k, strict[k], fast[k])
+        assert abs(strict[k]["final_state_match"] - fast[k]["final_state_match"]) <= 0.0235, (k, strict[k], fast[k])
 
 
 @pytest.mark.parametrize("diffuse", [1, 0])

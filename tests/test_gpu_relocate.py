@@ -63,14 +63,17 @@ def test_relocation_is_transparent_plain_mlt():
     assert r["breaks"] < 0.35 * r["slots"], r  # ~30 % of the chains changed technique in the step just run and have not been placed yet
 
 
-def test_relocation_is_transparent_once_the_caches_are_ready():
-    """MALA with the gradient cache (the set-up of test_cache_phase_parity): relocation starts when every cache is ready; the chains then carry
+def test_relocation_is_transparent_through_the_cache_fill_phase_and_after():
+    """MALA with the gradient cache (the set-up of test_cache_phase_parity): relocation runs from the first step on, through the whole cache-fill phase (beside the MALA gradient pipeline and the early apply of the pushes); the chains carry
     stored Gaussians, moment vectors and cache look-ups -- all of which must travel with them."""
     opts = {"largestepprob": 0.5, "largestepscale": 1.0}  # maxdepth 4: two cache dims (6, 8), both full after ~25 steps of 16384 chains
     off, film0 = _run(False, True, 16384, 72, opts, checkpoints=(8, 40), max_depth=4)
     on, film1 = _run(True, True, 16384, 72, opts, checkpoints=(8, 40), max_depth=4)
     assert off[-1][1]["cacheReadyMask"] != 0, "test set-up: the cache never filled"
     assert on[-1][2]["relocations"] > 0, "test set-up: relocation never started"
+    # the first checkpoint lies INSIDE the fill phase (ADVICE r4: the contract is "relocated from the first step on", beside the gradient pipeline
+    # and the early apply of the cache pushes): a cache is still filling, gradients are being evaluated, and eight relocations have already run
+    assert off[0][1]["cacheReadyMask"] != off[-1][1]["cacheReadyMask"] and off[0][1]["gradCalls"] > 0 and on[0][2]["relocations"] >= 8
     for (s0, st0, r0), (s1, st1, r1) in zip(off, on):
         _same_states(s0, s1)
         for k in ("steps", "largeSteps", "accepted", "resets", "cacheQueries", "cacheHits", "gradCalls", "cacheReadyMask"):
