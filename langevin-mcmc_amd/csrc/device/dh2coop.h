@@ -38,14 +38,20 @@ LMC_HD int H2TechDim(int t) {  // 2 * max(c + l - 1, 2)
 // lanes one state occupies in the Hessian launch: the 2 x 2 blocks of the upper triangle of a dim x dim matrix
 LMC_HD int H2BlocksOfDim(int dim) { return (dim / 2) * (dim / 2 + 1) / 2; }
 
-// Work lists of one pipeline stage: a bin holds the chains whose state of ONE technique needs its Gaussian, items[bin * N + k].  A technique has
-// H2_NSIG bins, chosen by a signature of the state's materials (the BSDF type and the sampling mode of every surface vertex, hashed to three
-// bits): the three to ten states that share a wave of the Hessian launch then take the same BSDF branches as well as the same path structure
-// (lanes active per issued instruction 0.74-0.77 with one bin per technique: profiles/r04_final_h2mc_pmc_*.json).
+// Work lists of one pipeline stage: a bin holds the chains whose state of ONE technique needs its Gaussian.  A technique has H2_NSIG bins, chosen
+// by a signature of the state's materials (the BSDF type and the sampling mode of every surface vertex, hashed to three bits): the three to
+// ten states that share a wave of the Hessian launch then take the same BSDF branches as well as the same path structure (lanes active per
+// issued instruction 0.74-0.77 with one bin per technique: profiles/r04_final_h2mc_pmc_*.json).
+// Layout (round 5; ADVICE r4: the bins used to be 336 arrays of N entries each, 2.8 GB at 2^20 chains): ONE array of N entries per stage.  The
+// lane-per-chain launch that fills a stage records every chain's bin (binOf) and counts the bins; dpipe.h LaunchBinsCompact then turns the
+// counts into offsets (start) and scatters the chain ids: bin b's entries are items[start[b] .. start[b] + count[b]).
 constexpr int H2_NSIG = 8, H2_NBINS = H2_NTECH * H2_NSIG;
 struct H2Bins {
-    int *items;  // H2_NBINS x N
-    int *count;  // H2_NBINS (+ padding to a multiple of 64)
+    int *items;   // N: the chains of the stage, grouped by bin
+    int *count;   // H2_NBINS (+ padding to a multiple of 64)
+    int *start;   // H2_NBINS (+ padding): first entry of every bin
+    int *cursor;  // H2_NBINS (+ padding): scatter cursors
+    int *binOf;   // N: the bin of a chain that takes part in the stage, -1 otherwise (valid for the chains of the step's list)
 };
 constexpr int H2_COUNT_WORDS = (H2_NBINS + 63) / 64 * 64;
 LMC_HD int H2BinIndex(int tech, unsigned sigHash) { return tech * H2_NSIG + (int)((sigHash ^ (sigHash >> 3) ^ (sigHash >> 6) ^ (sigHash >> 9) ^ (sigHash >> 12)) & (unsigned)(H2_NSIG - 1)); }

@@ -7,18 +7,17 @@
 
 namespace lmcd {
 
-// one entry of a stage's work list (t = its bin): wave-aggregated (the chains of a wave are grouped by technique, so a few atomics per wave are the rule)
+// one chain's part in a stage (t = its bin): the bin recorded, the bin's count raised -- wave-aggregated (the chains of a wave are grouped by
+// technique, so a few atomics per wave are the rule).  Every lane of the wave calls it (want = false: the chain takes no part).
 LMC_D void H2Enqueue(const H2Bins &bins, int N, bool want, int t, int i) {
     unsigned long long todo = __ballot(want);
     const int lane = threadIdx.x & 63;
+    if (i >= 0 && i < N) bins.binOf[i] = want ? t : -1;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int tl = __shfl(t, leader);
         const unsigned long long mask = __ballot(want && t == tl);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&bins.count[tl], __popcll(mask));
-        base = __shfl(base, leader);
-        if (want && t == tl) bins.items[(size_t)tl * N + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+        if (lane == leader) atomicAdd(&bins.count[tl], __popcll(mask));
         todo &= ~mask;
     }
 }

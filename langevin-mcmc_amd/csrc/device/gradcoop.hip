@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64, 2) k_mala_grad(const float *__restrict__ r
         const int first = j * tIpw, n = min(tIpw, tCnt - first);
         int c, l;
         H2TechOf(t, c, l);
-        const int *items = bins.items + (size_t)bin * N + first;
+        const int *items = bins.items + bins.start[bin] + first;
         for (int s = 0; s < n; s++) {  // stage the records: whole lines
             const float *src = rec + (size_t)items[s] * H2_REC_WORDS;
             for (int k = lane; k < tRecW; k += 64) lds[s * tRecW + k] = src[k];

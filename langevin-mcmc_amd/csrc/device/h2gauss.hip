@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
         const int n = H2TechDim(t);
         const int first = 4 * j, nItems = min(4, tCnt - first);
         const bool has = g < nItems;
-        const int item = has ? bins.items[(size_t)bin * N + first + g] : 0;
+        const int item = has ? bins.items[bins.start[bin] + first + g] : 0;
         const bool act = has && k < n;
         const float *o = hout + (size_t)item * H2_OUT_WORDS;
         // the triangle Eigen reads (h2mc.cpp:78: the program's rows as a column-major matrix, lower triangle = the UPPER triangle of the rows)

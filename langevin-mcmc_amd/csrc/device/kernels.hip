@@ -1,6 +1,7 @@
 // gfx950 kernels of the LMC hot path.  One thread = one Markov chain (or one MLT-init stream / sample);
 // launches are grid-stride ("persistent thread") loops over index lists so that large steps and small
 // steps run in separate, divergence-free launches.  Launch glue is in host/context.cpp.
+#include "dh2coop.h"
 #include "kernels.h"
 
 #include "ddirect.h"
@@ -910,6 +911,46 @@ __global__ void k_sum_f64(double *dst, const double *src, int n) {
     }
 }
 void LaunchSumF64(double *dst, const double *src, int n, hipStream_t s) { hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(64), 0, s, dst, src, n); }
+// ---- the work lists of a pipeline stage (dh2coop.h H2Bins): counts -> offsets, then the chain ids scattered into ONE N-entry array
+__global__ void __launch_bounds__(64) k_bins_scan(H2Bins bins) {
+    constexpr int PER = H2_COUNT_WORDS / 64;
+    const int lane = threadIdx.x;
+    int c[PER], sum = 0;
+    for (int k = 0; k < PER; k++) c[k] = bins.count[lane * PER + k], sum += c[k];
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    int run = incl - sum;
+    for (int k = 0; k < PER; k++) {
+        bins.start[lane * PER + k] = run, bins.cursor[lane * PER + k] = 0;
+        run += c[k];
+    }
+}
+__global__ void __launch_bounds__(64) k_bins_scatter(H2Bins bins, const int *list, const int *listCount) {
+    const int total = *listCount, lane = threadIdx.x & 63;
+    for (int j0 = blockIdx.x * 64; j0 < total; j0 += gridDim.x * 64) {  // whole waves: the ballots below need every lane
+        const int j = j0 + lane;
+        const int i = j < total ? list[j] : -1;
+        const int t = i >= 0 ? bins.binOf[i] : -1;
+        unsigned long long todo = __ballot(t >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int tl = __shfl(t, leader);
+            const unsigned long long mask = __ballot(t == tl);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&bins.cursor[tl], __popcll(mask));
+            base = __shfl(base, leader);
+            if (t == tl) bins.items[bins.start[tl] + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+            todo &= ~mask;
+        }
+    }
+}
+void LaunchBinsCompact(const H2Bins &bins, const int *list, const int *listCount, int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_bins_scan, dim3(1), dim3(64), 0, s, bins);
+    hipLaunchKernelGGL(k_bins_scatter, dim3(gridBlocks), dim3(64), 0, s, bins, list, listCount);
+}
 void LaunchStreamProbe(long long nWords, const float *in, float *out, hipStream_t s) {
     hipLaunchKernelGGL(k_stream_probe, dim3(8192), dim3(256), 0, s, nWords, in, out);
 }

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
             H.kind[i] = sample ? 1 : 0;
             StoreChainRng(A, i, rng);
         }
-        H2Enqueue(H.bins[0], N, want, t, i);
+        H2Enqueue(H.bins[0], N, want, t, j < total ? i : -1);
     }
     __shared__ int sStats[9];
     BlockReduceStats(st, A.counters, A.weightSum, sStats);
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
             H.step[i] = bits;
             StoreChainRng(A, i, rng);
         }
-        H2Enqueue(H.bins[1], N, want, t, i);
+        H2Enqueue(H.bins[1], N, want, t, j < total ? i : -1);
     }
     __shared__ int sStats[9];
     BlockReduceStats(st, A.counters, A.weightSum, sStats);

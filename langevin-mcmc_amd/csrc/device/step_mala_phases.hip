@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
             M.step[i] = bits;
             StoreChainRng(A, i, rng);
         }
-        H2Enqueue(M.bins[0], N, want, t, i);
+        H2Enqueue(M.bins[0], N, want, t, j < total ? i : -1);
     }
 }
 
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, c
             M.step[i] = bits;
             StoreChainRng(A, i, rng);
         }
-        H2Enqueue(M.bins[1], N, want, t, i);
+        H2Enqueue(M.bins[1], N, want, t, j < total ? i : -1);
     }
     __shared__ int sStats[9];
     BlockReduceStats(st, A.counters, A.weightSum, sStats);

@@ -173,7 +173,7 @@ struct lmc_ctx {
     DevBuf<float> gradBuf;
     // H2MC renders: hand-off state of the wave-cooperative pipeline (device/dh2coop.h)
     DevBuf<float> h2Rec, h2Out, h2Gauss, h2Offset, h2Py, h2Px, h2PropContrib;
-    DevBuf<int> h2Step, h2Items, h2Counts;
+    DevBuf<int> h2Step, h2Items, h2BinOf, h2Counts;
     DevBuf<unsigned char> h2Kind;
     H2Arrays H2{};
     int h2HessGrid = 0, h2GaussGrid = 0;
@@ -1065,11 +1065,11 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         c->allCachesReady = true;
         c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)H2_OUT_WORDS), c->h2Gauss.Alloc(2 * N * (size_t)H2_GAUSS_AOS, false);
         c->h2Offset.Alloc(N * (size_t)MAXPSS), c->h2Py.Alloc(N), c->h2Px.Alloc(N), c->h2PropContrib.Alloc(N * (size_t)CONTRIB_WORDS), c->h2Step.Alloc(N), c->h2Kind.Alloc(N);
-        c->h2Items.Alloc(2 * (size_t)H2_NBINS * N, false), c->h2Counts.Alloc(2 * H2_COUNT_WORDS);  // 336 bins x N chain ids per stage: sized for "every chain in one bin" (2.8 GB at 2^20 chains), never compacted
+        c->h2Items.Alloc(2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc(2 * 3 * H2_COUNT_WORDS);  // per stage: N chain ids grouped by bin + every chain's bin; count | start | cursor of the 336 bins (dh2coop.h H2Bins)
         H2Arrays &H = c->H2;
         H.rec = c->h2Rec.p, H.hout = c->h2Out.p, H.gauss = c->h2Gauss.p, H.offset = c->h2Offset.p, H.py = c->h2Py.p, H.px = c->h2Px.p, H.propContrib = c->h2PropContrib.p;
         H.step = c->h2Step.p, H.kind = c->h2Kind.p;
-        for (int st = 0; st < 2; st++) H.bins[st] = H2Bins{c->h2Items.p + (size_t)st * H2_NBINS * N, c->h2Counts.p + H2_COUNT_WORDS * st};
+        for (int st = 0; st < 2; st++) H.bins[st] = H2Bins{c->h2Items.p + (size_t)st * N, c->h2Counts.p + H2_COUNT_WORDS * st, c->h2Counts.p + H2_COUNT_WORDS * (2 + st), c->h2Counts.p + H2_COUNT_WORDS * (4 + st), c->h2BinOf.p + (size_t)st * N};
         // the Hessian launch is persistent: one wave per SIMD (its waves take the whole register file), grid-stride over the tasks
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
@@ -1080,10 +1080,10 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     if (c->S.opt.mala && !c->S.opt.h2mc && c->useGradient && c->malaPipe && !c->S.opt.sampleCache) {
         c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)MG_OUT_WORDS);
         c->h2Offset.Alloc(N * (size_t)MAXPSS), c->h2Py.Alloc(N), c->h2PropContrib.Alloc(N * (size_t)CONTRIB_WORDS), c->h2Step.Alloc(N);
-        c->h2Items.Alloc(2 * (size_t)H2_NBINS * N, false), c->h2Counts.Alloc(2 * H2_COUNT_WORDS);
+        c->h2Items.Alloc(2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc(2 * 3 * H2_COUNT_WORDS);
         MalaPipe &M = c->MP;
         M.rec = c->h2Rec.p, M.gout = c->h2Out.p, M.offset = c->h2Offset.p, M.py = c->h2Py.p, M.propContrib = c->h2PropContrib.p, M.step = c->h2Step.p;
-        for (int st = 0; st < 2; st++) M.bins[st] = H2Bins{c->h2Items.p + (size_t)st * H2_NBINS * N, c->h2Counts.p + H2_COUNT_WORDS * st};
+        for (int st = 0; st < 2; st++) M.bins[st] = H2Bins{c->h2Items.p + (size_t)st * N, c->h2Counts.p + H2_COUNT_WORDS * st, c->h2Counts.p + H2_COUNT_WORDS * (2 + st), c->h2Counts.p + H2_COUNT_WORDS * (4 + st), c->h2BinOf.p + (size_t)st * N};
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
         c->h2HessGrid = prop.multiProcessorCount * 4;  // persistent, grid-stride over the tasks
@@ -1463,12 +1463,14 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         const lmcd::H2MCParam param = lmcd::MakeH2MCParam(c->S.opt.perturbStdDev);
         HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * H2_COUNT_WORDS * sizeof(int), sG));
         LaunchH2Begin(c->S, c->A, P, H, list, n, laneGrid, sG);
+        LaunchBinsCompact(H.bins[0], list, n, laneGrid, sG);
         for (int stage = 0; stage < 2; stage++) {
             if (!LMC_EXP(P.expFlags, 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sG);
             LaunchH2Gauss(H.bins[stage], N, H.hout, param, P.expFlags, c->A.flags, stage, H.gauss, H.offset, H.px, c->h2GaussGrid, sG);
             if (stage == 0) {
                 LaunchH2Sample(list, n, N, c->A.flags, H.kind, c->A.curContrib, H.gauss, param.sigma, H.offset, H.py, laneGrid, sG);
                 LaunchH2Perturb(c->S, c->A, P, H, list, n, c->bvhDepth, laneGrid, sG);
+                LaunchBinsCompact(H.bins[1], list, n, laneGrid, sG);
             }
         }
         LaunchH2Finish(c->S, c->cacheDev.p, c->A, film, P, H, list, n, laneGrid, sG);
@@ -1479,8 +1481,10 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         const int N = (int)c->N, laneGrid = laneGridEnv > 0 ? std::min(laneGridEnv, c->stepGrid * 4) : c->stepGrid * 4;
         const MalaPipe &M = c->MP;  // the bin counts: zero-filled at set-up, zeroed again by k_mala_finish
         LaunchMalaBegin(c->S, c->cacheDev.p, c->A, P, M, list, n, laneGrid, sG);
+        LaunchBinsCompact(M.bins[0], list, n, laneGrid, sG);
         LaunchMalaGrad(M.rec, M.bins[0], N, c->S.sceneParams, M.gout, c->h2HessGrid, sG);
         LaunchMalaMid(c->S, c->cacheDev.p, c->A, P, M, list, n, c->bvhDepth, c->S.glossy != 0, laneGrid, sG);
+        LaunchBinsCompact(M.bins[1], list, n, laneGrid, sG);
         LaunchMalaGrad(M.rec, M.bins[1], N, c->S.sceneParams, M.gout, c->h2HessGrid, sG);
         LaunchMalaFinish(c->S, c->cacheDev.p, c->A, film, P, M, list, n, laneGrid, sG);
     } else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
@@ -2482,14 +2486,14 @@ int lmc_h2_hess_probe(int c, int l, int n, const float *primary, const float *sc
         memcpy(r + H2_REC_C, &c, 4), memcpy(r + H2_REC_L, &l, 4);
         memcpy(r + H2_REC_VP, vert + (size_t)i * V, V * sizeof(float));
     }
-    std::vector<int> items((size_t)H2_NBINS * n, 0), counts(H2_COUNT_WORDS, 0);
+    std::vector<int> items((size_t)n, 0), counts(2 * H2_COUNT_WORDS, 0);  // one bin holds everything: start (the second half of `counts`) is 0 everywhere
     const int bin = t * H2_NSIG;
-    for (int i = 0; i < n; i++) items[(size_t)bin * n + i] = i;
+    for (int i = 0; i < n; i++) items[i] = i;
     counts[bin] = n;
     DevBuf<float> dRec, dOut;
     DevBuf<int> dItems, dCounts;
     dRec.Upload(rec.data(), rec.size()), dItems.Upload(items.data(), items.size()), dCounts.Upload(counts.data(), counts.size()), dOut.Alloc((size_t)n * H2_OUT_WORDS);
-    LaunchH2Hess(dRec.p, H2Bins{dItems.p, dCounts.p}, n, scene38, dOut.p, 1024, 0);
+    LaunchH2Hess(dRec.p, H2Bins{dItems.p, dCounts.p, dCounts.p + H2_COUNT_WORDS, nullptr, nullptr}, n, scene38, dOut.p, 1024, 0);
     HIP_CHECK(hipDeviceSynchronize());
     const std::vector<float> o = dOut.Download();
     for (int i = 0; i < n; i++) {
@@ -2518,15 +2522,15 @@ int lmc_h2_gauss_probe(int n, int dim, const float *grad, const float *hess, flo
         if (offset)
             for (int k = 0; k < dim; k++) off[(size_t)k * n + i] = offset[(size_t)i * dim + k];
     }
-    std::vector<int> items((size_t)H2_NBINS * n, 0), counts(H2_COUNT_WORDS, 0);
+    std::vector<int> items((size_t)n, 0), counts(2 * H2_COUNT_WORDS, 0);  // one bin holds everything: start (the second half of `counts`) is 0 everywhere
     const int bin = t * H2_NSIG;
-    for (int i = 0; i < n; i++) items[(size_t)bin * n + i] = i;
+    for (int i = 0; i < n; i++) items[i] = i;
     counts[bin] = n;
     DevBuf<float> dOut, dOff, dGauss, dPx;
     DevBuf<int> dItems, dCounts, dFlags;
     dOut.Upload(out.data(), out.size()), dOff.Upload(off.data(), off.size()), dItems.Upload(items.data(), items.size()), dCounts.Upload(counts.data(), counts.size());
     dGauss.Alloc(2 * (size_t)n * H2_GAUSS_AOS), dPx.Alloc(n), dFlags.Alloc(n);
-    LaunchH2Gauss(H2Bins{dItems.p, dCounts.p}, n, dOut.p, lmcd::MakeH2MCParam(sigma), 0, dFlags.p, 1, dGauss.p, dOff.p, dPx.p, 256, 0);
+    LaunchH2Gauss(H2Bins{dItems.p, dCounts.p, dCounts.p + H2_COUNT_WORDS, nullptr, nullptr}, n, dOut.p, lmcd::MakeH2MCParam(sigma), 0, dFlags.p, 1, dGauss.p, dOff.p, dPx.p, 256, 0);
     HIP_CHECK(hipDeviceSynchronize());
     if (gauss) HIP_CHECK(hipMemcpy(gauss, dGauss.p + (size_t)n * H2_GAUSS_AOS, (size_t)n * H2_GAUSS_AOS * sizeof(float), hipMemcpyDeviceToHost));  // stage 1 with F_GSEL clear: the second buffer
     if (px) HIP_CHECK(hipMemcpy(px, dPx.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
