@@ -25,6 +25,7 @@ void LaunchAddInto(float *dst, const float *src, size_t n, hipStream_t s);  // d
 void LaunchAddIntoF64(double *dst, const double *src, size_t n, hipStream_t s);
 // a pipeline stage's work lists (dh2coop.h H2Bins): the counts turned into offsets, the chains of `list` scattered into the stage's N-entry array by bin
 void LaunchBinsCompact(const lmcd::H2Bins &bins, const int *list, const int *listCount, int gridBlocks, hipStream_t s);
+void LaunchSplitList(const int *list, const int *listCount, int parts, int *sub, int stride, int *subCount, int gridBlocks, hipStream_t s);
 void LaunchSumF64(double *dst, const double *src, int n, hipStream_t s);  // dst[0] = sum of src[0 .. n), left to right
 void LaunchTrace(const lmcd::DScene &S, int n, const float *rays, int *prim, float *t, int anyHit, hipStream_t s);
 void LaunchKdProbe(const lmcd::DCacheDim &C, int dim, int nq, const float *q, float radiusSq, int knn, int *outN, int *outIdx, float *outDist, hipStream_t s);

@@ -947,6 +947,24 @@ __global__ void __launch_bounds__(64) k_bins_scatter(H2Bins bins, const int *lis
         }
     }
 }
+// The generic list cut into `parts` interleaved sub-lists (groups of 64 entries go round robin: every part sees the same technique mix), each with
+// its own count: the H2MC pipeline of every part then runs on a stream of its own (host/context.cpp LaunchGeneric).  sub: parts x stride entries.
+__global__ void __launch_bounds__(256) k_split_list(const int *list, const int *listCount, int parts, int *sub, int stride, int *subCount) {
+    const int total = *listCount;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+        const int g = j >> 6, h = g % parts;
+        sub[(size_t)h * stride + (g / parts) * 64 + (j & 63)] = list[j];
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < parts) {
+        const int h = threadIdx.x, groups = total >> 6, rem = total & 63;
+        int n = (groups / parts + (h < groups % parts ? 1 : 0)) * 64;
+        if (rem && groups % parts == h) n += rem;
+        subCount[h] = n;
+    }
+}
+void LaunchSplitList(const int *list, const int *listCount, int parts, int *sub, int stride, int *subCount, int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_list, dim3(gridBlocks), dim3(256), 0, s, list, listCount, parts, sub, stride, subCount);
+}
 void LaunchBinsCompact(const H2Bins &bins, const int *list, const int *listCount, int gridBlocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bins_scan, dim3(1), dim3(64), 0, s, bins);
     hipLaunchKernelGGL(k_bins_scatter, dim3(gridBlocks), dim3(64), 0, s, bins, list, listCount);

@@ -123,6 +123,8 @@ struct lmc_ctx {
     // (gradient) small steps on two side streams, the lean small steps on the main stream, joined before k_build_lists.
     // LMC_OVERLAP=0 serialises them on the main stream (A/B).
     hipStream_t sideStream[2] = {nullptr, nullptr};
+    hipStream_t partStream = nullptr;  // H2MC: the pipeline of the second half of the chain population (LaunchGeneric)
+    hipEvent_t partFork = nullptr, partJoin = nullptr;
     hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
     hipEvent_t packedEvent = nullptr, copiedEvent = nullptr;  // in-process group: this member's stage is complete / this member has copied every stage (ExchangeStagesAsync)
     // in-process group, film merge (lmc_group_film_reduce): staging for the slices pulled from the peers + the peers' weight sums, allocated when the
@@ -173,7 +175,9 @@ struct lmc_ctx {
     DevBuf<float> gradBuf;
     // H2MC renders: hand-off state of the wave-cooperative pipeline (device/dh2coop.h)
     DevBuf<float> h2Rec, h2Out, h2Gauss, h2Offset, h2Py, h2Px, h2PropContrib;
-    DevBuf<int> h2Step, h2Items, h2BinOf, h2Counts;
+    DevBuf<int> h2Step, h2Items, h2BinOf, h2Counts, h2SubList, h2SubCount;
+    H2Bins h2Bins[2][2] = {};  // [part][stage]
+    int h2Parts = 1, h2PartStride = 0;
     DevBuf<unsigned char> h2Kind;
     H2Arrays H2{};
     int h2HessGrid = 0, h2GaussGrid = 0;
@@ -250,7 +254,8 @@ struct lmc_ctx {
         }
         if (hostCounts) (void)hipHostFree(hostCounts);
         if (countsEvent) (void)hipEventDestroy(countsEvent);
-        for (auto e : {forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent, filmReadyEvent, sliceReducedEvent, weightsCopiedEvent})
+        if (partStream) (void)hipStreamDestroy(partStream);
+        for (auto e : {partFork, partJoin, forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent, filmReadyEvent, sliceReducedEvent, weightsCopiedEvent})
             if (e) (void)hipEventDestroy(e);
         for (auto st : sideStream)
             if (st) (void)hipStreamDestroy(st);
@@ -455,7 +460,10 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
             const int m = k == 0 ? modeL : mode;
             HIP_CHECK(hipStreamCreateWithPriority(&c->sideStream[k], hipStreamNonBlocking, m > 0 ? hi : m < 0 ? lo : 0));
         }
+        HIP_CHECK(hipStreamCreateWithPriority(&c->partStream, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
     }
+    HIP_CHECK(hipEventCreateWithFlags(&c->partFork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->partJoin, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&c->packedEvent, hipEventDisableTiming));
@@ -1065,11 +1073,24 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         c->allCachesReady = true;
         c->h2Rec.Alloc(N * (size_t)H2_REC_WORDS, false), c->h2Out.Alloc(N * (size_t)H2_OUT_WORDS), c->h2Gauss.Alloc(2 * N * (size_t)H2_GAUSS_AOS, false);
         c->h2Offset.Alloc(N * (size_t)MAXPSS), c->h2Py.Alloc(N), c->h2Px.Alloc(N), c->h2PropContrib.Alloc(N * (size_t)CONTRIB_WORDS), c->h2Step.Alloc(N), c->h2Kind.Alloc(N);
-        c->h2Items.Alloc(2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc(2 * 3 * H2_COUNT_WORDS);  // per stage: N chain ids grouped by bin + every chain's bin; count | start | cursor of the 336 bins (dh2coop.h H2Bins)
+        // Two halves of the chain population run the pipeline side by side, each on its own stream (LaunchGeneric; LMC_H2_PARTS=1: one pipeline).
+        // Per (part, stage): a bin table (count | start | cursor) and the part's share of the stage's N-entry item array; binOf is per stage
+        // (the parts' chains are disjoint).  The generic list is cut into the parts' sub-lists every step (kernels.hip k_split_list).
+        c->h2Parts = 2;
+        if (const char *e = getenv("LMC_H2_PARTS")) c->h2Parts = std::max(1, std::min(2, atoi(e)));
+        c->h2PartStride = (int)(((N + 127) / 128) * 64 + 64);  // the most entries the interleaved split gives one of two parts
+        c->h2Items.Alloc(2 * 2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc(2 * 2 * 3 * H2_COUNT_WORDS);
+        c->h2SubList.Alloc(2 * (size_t)c->h2PartStride, false), c->h2SubCount.Alloc(2);
         H2Arrays &H = c->H2;
         H.rec = c->h2Rec.p, H.hout = c->h2Out.p, H.gauss = c->h2Gauss.p, H.offset = c->h2Offset.p, H.py = c->h2Py.p, H.px = c->h2Px.p, H.propContrib = c->h2PropContrib.p;
         H.step = c->h2Step.p, H.kind = c->h2Kind.p;
-        for (int st = 0; st < 2; st++) H.bins[st] = H2Bins{c->h2Items.p + (size_t)st * N, c->h2Counts.p + H2_COUNT_WORDS * st, c->h2Counts.p + H2_COUNT_WORDS * (2 + st), c->h2Counts.p + H2_COUNT_WORDS * (4 + st), c->h2BinOf.p + (size_t)st * N};
+        for (int part = 0; part < 2; part++)
+            for (int st = 0; st < 2; st++) {
+                int *tab = c->h2Counts.p + (size_t)(part * 2 + st) * 3 * H2_COUNT_WORDS;
+                int *items = c->h2Items.p + (size_t)(part * 2 + st) * N;  // N entries each: a part may be the whole population (LMC_H2_PARTS=1, or the side streams switched off)
+                c->h2Bins[part][st] = H2Bins{items, tab, tab + H2_COUNT_WORDS, tab + 2 * H2_COUNT_WORDS, c->h2BinOf.p + (size_t)st * N};
+            }
+        for (int st = 0; st < 2; st++) H.bins[st] = c->h2Bins[0][st];
         // the Hessian launch is persistent: one wave per SIMD (its waves take the whole register file), grid-stride over the tasks
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
@@ -1459,21 +1480,44 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
     if (c->needGeneric && c->S.opt.h2mc) {  // the H2MC small step: lane-per-chain phases around the wave-cooperative Hessian / eigen-solve launches (device/dh2coop.h)
         const int *list = c->lists[cur][1].p, *n = cnt + 1;
         const int N = (int)c->N, laneGrid = c->stepGrid * 4;
-        const H2Arrays &H = c->H2;
         const lmcd::H2MCParam param = lmcd::MakeH2MCParam(c->S.opt.perturbStdDev);
-        HIP_CHECK(hipMemsetAsync(c->h2Counts.p, 0, 2 * H2_COUNT_WORDS * sizeof(int), sG));
-        LaunchH2Begin(c->S, c->A, P, H, list, n, laneGrid, sG);
-        LaunchBinsCompact(H.bins[0], list, n, laneGrid, sG);
-        for (int stage = 0; stage < 2; stage++) {
-            if (!LMC_EXP(P.expFlags, 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sG);
-            LaunchH2Gauss(H.bins[stage], N, H.hout, param, P.expFlags, c->A.flags, stage, H.gauss, H.offset, H.px, c->h2GaussGrid, sG);
-            if (stage == 0) {
-                LaunchH2Sample(list, n, N, c->A.flags, H.kind, c->A.curContrib, H.gauss, param.sigma, H.offset, H.py, laneGrid, sG);
-                LaunchH2Perturb(c->S, c->A, P, H, list, n, c->bvhDepth, laneGrid, sG);
-                LaunchBinsCompact(H.bins[1], list, n, laneGrid, sG);
-            }
+        // One launch owns the GPU at a time inside a pipeline (the Hessian launch's waves take a SIMD's whole register file; the lane-per-chain
+        // phases wait for memory), so TWO halves of the chain population run it side by side, each on its own stream: the tail of one half's launch
+        // is filled by the other half's (measured as two contexts on one device before it was built, profiles/r05_s_h2mc_two_halves.jsonl:
+        // veach-door +6 %, torus +9 %; four parts: nothing).  Same chains, same arithmetic: every chain's trajectory is untouched.
+        const int parts = c->overlap ? c->h2Parts : 1;
+        const int *lists[2] = {list, list}, *counts[2] = {n, n};
+        hipStream_t streams[2] = {sG, sG};
+        if (parts == 2) {
+            LaunchSplitList(list, n, 2, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, laneGrid / 4 + 1, sG);
+            HIP_CHECK(hipEventRecord(c->partFork, sG));
+            HIP_CHECK(hipStreamWaitEvent(c->partStream, c->partFork, 0));
+            for (int h = 0; h < 2; h++) lists[h] = c->h2SubList.p + (size_t)h * c->h2PartStride, counts[h] = c->h2SubCount.p + h;
+            streams[1] = c->partStream;
         }
-        LaunchH2Finish(c->S, c->cacheDev.p, c->A, film, P, H, list, n, laneGrid, sG);
+        for (int h = 0; h < parts; h++) {
+            hipStream_t sp = streams[h];
+            H2Arrays H = c->H2;
+            H.bins[0] = c->h2Bins[h][0], H.bins[1] = c->h2Bins[h][1];
+            const int grid = parts == 2 ? laneGrid / 2 + 1 : laneGrid;
+            HIP_CHECK(hipMemsetAsync(c->h2Bins[h][0].count, 0, 2 * 3 * H2_COUNT_WORDS * sizeof(int), sp));  // both stages' tables of this part are contiguous
+            LaunchH2Begin(c->S, c->A, P, H, lists[h], counts[h], grid, sp);
+            LaunchBinsCompact(H.bins[0], lists[h], counts[h], grid, sp);
+            for (int stage = 0; stage < 2; stage++) {
+                if (!LMC_EXP(P.expFlags, 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sp);
+                LaunchH2Gauss(H.bins[stage], N, H.hout, param, P.expFlags, c->A.flags, stage, H.gauss, H.offset, H.px, c->h2GaussGrid, sp);
+                if (stage == 0) {
+                    LaunchH2Sample(lists[h], counts[h], N, c->A.flags, H.kind, c->A.curContrib, H.gauss, param.sigma, H.offset, H.py, grid, sp);
+                    LaunchH2Perturb(c->S, c->A, P, H, lists[h], counts[h], c->bvhDepth, grid, sp);
+                    LaunchBinsCompact(H.bins[1], lists[h], counts[h], grid, sp);
+                }
+            }
+            LaunchH2Finish(c->S, c->cacheDev.p, c->A, film, P, H, lists[h], counts[h], grid, sp);
+        }
+        if (parts == 2) {  // the generic slot of the launch plan ends when both halves have
+            HIP_CHECK(hipEventRecord(c->partJoin, c->partStream));
+            HIP_CHECK(hipStreamWaitEvent(sG, c->partJoin, 0));
+        }
     } else if (c->needGeneric && c->MP.rec && !c->allCachesReady && !c->S.opt.useLightCoord) {
         // while a cache fills: the gradient steps as a pipeline, the path program wave-cooperative between lane-per-chain phases
         const int *list = c->lists[cur][1].p, *n = cnt + 1;
