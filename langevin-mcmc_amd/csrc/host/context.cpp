@@ -1818,6 +1818,11 @@ int lmc_group_film_reduce(lmc_ctx **ctxs, int n, double *out_ms) {
         if (c->filmReduced) throw std::runtime_error("lmc_group_film_reduce: the films already hold the sum over the members; step or clear them first");
         if (c->film.n != g[0]->film.n) throw std::runtime_error("lmc_group_film_reduce: the members' films differ in size");
     }
+    if (out_ms)  // only so that the reported time is the merge's own: the merge is stream-ordered behind the members' steps either way
+        for (lmc_ctx *c : g) {
+            HIP_CHECK(hipSetDevice(c->device));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
     const auto t0 = std::chrono::steady_clock::now();
     const size_t total = g[0]->film.n, slice = (total + n - 1) / n;
     auto sliceLen = [&](int k) { return (size_t)k * slice >= total ? (size_t)0 : std::min(slice, total - (size_t)k * slice); };
