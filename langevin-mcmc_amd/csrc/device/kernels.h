@@ -109,7 +109,8 @@ struct RelocBuffers {
     int *members;               // N: the slots that take part, ascending
     int *sorted;                // N: member indices by key
     int *count;                 // 1: number of members
-    float *staging;             // RelocRecordWords(maxDepth) floats per member (capacity: see host/context.cpp)
+    float *staging;             // RelocRecordWords(maxDepth) floats per member
+    int capacity;               // records the staging buffer holds: a step with more movers leaves them where they are (host/context.cpp)
 };
 size_t RelocTiles(int N);
 size_t RelocRecordWords(int maxDepth);

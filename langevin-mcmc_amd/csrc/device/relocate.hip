@@ -126,10 +126,19 @@ __global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsign
     for (int j = 0; j < RELOC_TILE / 64; j++) {
         const int key = MemberKey(A, placedKey, base + 64 * j, noGauss);
         const unsigned long long mask = __ballot(key >= 0);
-        if (key >= 0) {
-            const int m = m0 + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
-            members[m] = base + 64 * j;
-            sorted[atomicAdd(&cursor[key], 1)] = m;
+        const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+        if (key >= 0) members[m0 + __popcll(mask & below)] = base + 64 * j;
+        // a member's position inside its (tile, key) group = its rank among the members of that key, in slot order: the chain-to-slot assignment
+        // is the same from run to run (it used to follow the arrival order of an LDS atomic)
+        unsigned long long todo = mask;
+        while (todo) {
+            const int k = __shfl(key, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(key == k);
+            if (key == k) sorted[cursor[k] + __popcll(same & below)] = m0 + __popcll(mask & below);
+            __syncthreads();
+            if (threadIdx.x == 0) cursor[k] += __popcll(same);
+            __syncthreads();
+            todo &= ~same;
         }
         m0 += __popcll(mask);
     }
@@ -141,8 +150,9 @@ LMC_D float *VectorBase(const ChainArrays &A, int v) {
 }
 
 // member m's chain -> staging record m
-__global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, float *staging) {
+__global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, float *staging, int capacity) {
     const int M = *count;
+    if (M > capacity) return;  // more movers than staging records (host/context.cpp sizes the buffer): this step's movers stay where they are, nothing depends on a slot
     const size_t N = A.N;
     for (int m = blockIdx.x * 64 + threadIdx.x; m < M; m += gridDim.x * 64) {
         const int i = members[m];
@@ -193,8 +203,9 @@ __global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout
 // staging record sorted[d] -> member slot d.  Record d still holds what the slot contained: its flags say whether the slot's MALA
 // vectors have to be zeroed for an incoming chain whose vectors are zero by the invariant.
 __global__ void __launch_bounds__(64) k_reloc_scatter(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, const float *staging,
-                                                       unsigned char *placedKey) {
+                                                       unsigned char *placedKey, int capacity) {
     const int M = *count;
+    if (M > capacity) return;
     const size_t N = A.N;
     for (int d = blockIdx.x * 64 + threadIdx.x; d < M; d += gridDim.x * 64) {
         const int i = members[d], m = sorted[d];
@@ -277,6 +288,6 @@ void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, b
     hipLaunchKernelGGL(k_reloc_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.tileHist, B.count);
     hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted, withoutGaussianOnly);
     const int moveBlocks = std::min((N + 63) / 64, 4096);
-    hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging);
-    hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey);
+    hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.capacity);
+    hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey, B.capacity);
 }

@@ -987,11 +987,11 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     if (c->relocate) {
         c->chainId.Alloc(N, false), c->slotOf.Alloc(N, false), c->relocTileCount.Alloc(RelocTiles((int)N) + 1, false), c->relocTileHist.Alloc(RelocTiles((int)N) * 64, false), c->relocMembers.Alloc(N, false);
         c->relocSorted.Alloc(N, false), c->relocCount.Alloc(1), c->relocPlacedKey.Alloc(N, false), c->stepKind.Alloc(N + 4, false);
-        c->relocStaging.Alloc(N * RelocRecordWords(c->S.opt.maxDepth), false);  // the first step is a large step of every chain
+        c->relocStaging.Alloc(N * RelocRecordWords(c->S.opt.maxDepth), false);  // the first step is a large step of every chain: N records, cut to N / 2 after it (StepPhase1)
         HIP_CHECK(hipMemsetAsync(c->relocPlacedKey.p, 0xff, N, s));
         HIP_CHECK(hipMemsetAsync(c->stepKind.p, NEXT_LARGE, N, s));  // k_init_lists: every chain starts with a large step
         LaunchRelocIota((int)N, c->chainId.p, s), LaunchRelocIota((int)N, c->slotOf.p, s);
-        c->RB = RelocBuffers{c->relocPlacedKey.p, c->relocTileCount.p, c->relocTileHist.p, c->relocMembers.p, c->relocSorted.p, c->relocCount.p, c->relocStaging.p};
+        c->RB = RelocBuffers{c->relocPlacedKey.p, c->relocTileCount.p, c->relocTileHist.p, c->relocMembers.p, c->relocSorted.p, c->relocCount.p, c->relocStaging.p, (int)N};
         A.chainId = c->chainId.p, A.slotOf = c->slotOf.p, A.stepKind = c->stepKind.p;
     } else {
         A.chainId = nullptr, A.slotOf = nullptr, A.stepKind = nullptr;
@@ -1578,7 +1578,18 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         }
         // the chains this launch gave a new technique move to the slots of their technique (relocate.hip) -- on this stream, beside the small-step
         // launches, whose chains it does not touch, and behind the pack, which reads the pushes of these very chains (in chain order: A.slotOf)
-        if (c->relocate) LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, c->S.opt.h2mc != 0, sL), c->relocations++;
+        if (c->relocate) {
+            // the staging buffer is 3-4 KB per record.  Only the first relocation (every chain took a large step: the full sort) can
+            // need N records; from the third step on it holds N / 2 (the most movers seen in a later step: 0.3 N, step 1 of a fresh population);
+            // the move kernels skip a step that would need more (relocate.hip).  The free is a device-wide wait, once, in the second step.
+            if (c->relocations == 2 && c->RB.capacity == (int)c->N && c->N >= 65536 && !getenv("LMC_RELOC_STAGING_FULL")) {
+                HIP_CHECK(hipStreamSynchronize(sL));
+                const size_t cap = c->N / 2;
+                c->relocStaging.Alloc(cap * RelocRecordWords(c->S.opt.maxDepth), false);
+                c->RB.staging = c->relocStaging.p, c->RB.capacity = (int)cap;
+            }
+            LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, c->S.opt.h2mc != 0, sL), c->relocations++;
+        }
     };
     if (!genericFirst) large();
     // the generic small-step launch: chains that evaluate a gradient (until their dim's cache is ready) or whose
