@@ -949,9 +949,9 @@ __global__ void __launch_bounds__(64) k_bins_scatter(H2Bins bins, const int *lis
 }
 // The generic list cut into `parts` interleaved sub-lists (groups of 64 entries go round robin: every part sees the same technique mix), each with
 // its own count: the H2MC pipeline of every part then runs on a stream of its own (host/context.cpp LaunchGeneric).  sub: parts x stride entries.
-__global__ void __launch_bounds__(256) k_split_list(const int *list, const int *listCount, int parts, int *sub, int stride, int *subCount) {
+__global__ void __launch_bounds__(64) k_split_list(const int *list, const int *listCount, int parts, int *sub, int stride, int *subCount) {  // one-wave blocks: they take the first free slot
     const int total = *listCount;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+    for (int j = blockIdx.x * 64 + threadIdx.x; j < total; j += gridDim.x * 64) {
         const int g = j >> 6, h = g % parts;
         sub[(size_t)h * stride + (g / parts) * 64 + (j & 63)] = list[j];
     }
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(256) k_split_list(const int *list, const int *
     }
 }
 void LaunchSplitList(const int *list, const int *listCount, int parts, int *sub, int stride, int *subCount, int gridBlocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_split_list, dim3(gridBlocks), dim3(256), 0, s, list, listCount, parts, sub, stride, subCount);
+    hipLaunchKernelGGL(k_split_list, dim3(gridBlocks), dim3(64), 0, s, list, listCount, parts, sub, stride, subCount);
 }
 void LaunchBinsCompact(const H2Bins &bins, const int *list, const int *listCount, int gridBlocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bins_scan, dim3(1), dim3(64), 0, s, bins);

@@ -7,8 +7,12 @@
 //   [k_h2_hess, k_h2_gauss on stage 1: the proposal's Gaussian and px]
 //   k_h2_finish   acceptance, splats, accept / reject (mlt.cpp:103-170), the next step's kind
 // The RNG order of a chain is the reference's: nothing between these draws consumes numbers (the Gaussians draw nothing).
+#include <cstdlib>
+#include <cstring>
+
 #include "dh2mc.h"
 #include "dpipe.h"
+#include "dwalk.h"
 
 using namespace lmcd;
 
@@ -62,10 +66,9 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
                 } else {
                     if (curSs > 1e-15f) st.gradCalls++;
                     if (curSs > 1e-15f && !LMC_EXP(P.expFlags, 16)) {
-                        DPath path;
-                        LoadPath(CurPathBuf(A, flags), N, i, path);
-                        H2Serialize(S, path, H.rec + (size_t)i * H2_REC_WORDS);
-                        want = true, t = H2BinIndex(H2TechIndex(c, l), H2MaterialSignature(S, path));
+                        // serialised straight from the SoA path buffer (dwalk.h): no DPath in private memory
+                        const unsigned sig = H2SerializeStreamed(S, SoAPathView{CurPathBuf(A, flags), (size_t)N, i}, H.rec + (size_t)i * H2_REC_WORDS);
+                        want = true, t = H2BinIndex(H2TechIndex(c, l), sig);
                     } else {  // zero gradient and Hessian: the early-out of ComputeGaussian
                         G[H2_GAUSS_LOGDET] = H2IsoLogDetEarlyOut(dim, sigma), G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_EARLYOUT;
                     }
@@ -143,6 +146,79 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
                         float q = 0.f;
                         for (int k = 0; k < dim; k++) {
                             const float d = -offset[k] - 0.0f;
+                            q += d * (inv * d);
+                        }
+                        float logPdf = dim * (-0.9189385332046727f);
+                        logPdf += 0.5f * logDet;
+                        logPdf -= 0.5f * q;
+                        H.px[i] = logPdf;
+                    }
+                }
+            }
+            H.step[i] = bits;
+            StoreChainRng(A, i, rng);
+        }
+        H2Enqueue(H.bins[1], N, want, t, j < total ? i : -1);
+    }
+    __shared__ int sStats[9];
+    BlockReduceStats(st, A.counters, A.weightSum, sStats);
+}
+
+// The same phase with the path streamed (dwalk.h): vertex by vertex from the chain's current path buffer into its other buffer, the record for
+// stage 1 serialised from that buffer afterwards; offsets and traversal stack in LDS ([word][lane]); no DPath in private memory.  The form for
+// every render whose tree fits the LDS stack and that does not use light-coordinate sampling (LMC_H2_PERTURB=generic selects the kernel above).
+__global__ void __launch_bounds__(64, 2) k_h2_perturb_streamed(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount, int stackWords) {
+    extern __shared__ int ldsStack[];
+    StepStats st;
+    const int total = *listCount, N = A.N;
+    const float sigma = S.opt.perturbStdDev;
+    float *const ldsF = reinterpret_cast<float *>(ldsStack) + threadIdx.x;
+    for (int j0 = blockIdx.x * blockDim.x; j0 < total; j0 += gridDim.x * blockDim.x) {
+        const int j = j0 + threadIdx.x;
+        bool want = false;
+        int t = 0, i = 0;
+        if (j < total) {
+            i = list[j];
+            Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
+            const int flags = A.flags[i];
+            int bits = H.step[i];
+            const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)N + i]);
+            const int dim = PathDimension(c, l);
+            const float *cur = CurPathBuf(A, flags);
+            float *prop = PropPathBuf(A, flags);
+            for (int k = 0; k < dim; k++) ldsF[(stackWords + k) * 64] = H.offset[(size_t)k * N + i];
+            Contrib pc;
+            pc.camDepth = pc.lightDepth = 0;
+            pc.lsScore = pc.ssScore = 0.f;
+            pc.screenPos = V2{0.f, 0.f};
+            pc.contrib = V3{0.f, 0.f, 0.f};
+            LdsStackT<true> stk{ldsStack + threadIdx.x, 64, 0};
+            const bool ok = PerturbPathStreamed(S, cur, prop, (size_t)N, i, c, l, LdsOffsets{ldsF, 64, stackWords}, rng, stk, pc);
+            if (ok) {
+                bits |= H2S_OK;
+                StoreContrib(H.propContrib, N, i, pc);
+                if ((bits & H2S_H2) && (bits & H2S_DENSE)) {  // initGaussian(proposalState), mutation_h2mc.h:100-102
+                    float *G = H2GaussRec(H, N, i, (flags & F_GSEL) == 0);
+                    float logDet = 0.f;
+                    bool iso = true;
+                    if (!H2HaveDerv(P, c, l, dim)) {
+                        logDet = H2IsoLogDetNoDerv(dim, sigma);
+                        G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_NODERV;
+                    } else {
+                        if (pc.ssScore > 1e-15f) st.gradCalls++;
+                        if (pc.ssScore > 1e-15f && !LMC_EXP(P.expFlags, 16)) {
+                            const unsigned sig = H2SerializeStreamed(S, SoAPathView{prop, (size_t)N, i}, H.rec + (size_t)i * H2_REC_WORDS);
+                            want = true, t = H2BinIndex(H2TechIndex(c, l), sig), iso = false;
+                        } else {
+                            logDet = H2IsoLogDetEarlyOut(dim, sigma);
+                            G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_ISO_EARLYOUT;
+                        }
+                    }
+                    if (iso) {  // px = GaussianLogPdf(-offset, isotropic), the dense form of gaussian.cpp:24-36 with a diagonal matrix
+                        const float inv = 1.0f / (sigma * sigma);
+                        float q = 0.f;
+                        for (int k = 0; k < dim; k++) {
+                            const float d = -ldsF[(stackWords + k) * 64] - 0.0f;
                             q += d * (inv * d);
                         }
                         float logPdf = dim * (-0.9189385332046727f);
@@ -243,7 +319,12 @@ void LaunchH2Begin(const DScene &S, const ChainArrays &A, const StepParams &P, c
 }
 void LaunchH2Perturb(const DScene &S, const ChainArrays &A, const StepParams &P, const H2Arrays &H, const int *list, const int *listCount, int bvhStackNeed, int gridBlocks,
                      hipStream_t s) {
-    if (bvhStackNeed <= BVH_LDS_STACK) {
+    const bool genericForm = getenv("LMC_H2_PERTURB") && !strcmp(getenv("LMC_H2_PERTURB"), "generic");
+    if (bvhStackNeed <= BVH_LDS_STACK && !S.opt.useLightCoord && !genericForm) {
+        const int stackWords = LeanStackWords(bvhStackNeed);
+        const size_t ldsBytes = (size_t)64 * LeanLdsWordsPerThread(stackWords) * sizeof(int);
+        hipLaunchKernelGGL(k_h2_perturb_streamed, dim3(gridBlocks), dim3(64), ldsBytes, s, S, A, P, H, list, listCount, stackWords);
+    } else if (bvhStackNeed <= BVH_LDS_STACK) {
         const size_t ldsBytes = (size_t)64 * ((bvhStackNeed + 7) / 8 * 8) * sizeof(int);
         hipLaunchKernelGGL(k_h2_perturb<true>, dim3(gridBlocks), dim3(64), ldsBytes, s, S, A, P, H, list, listCount);
     } else {

@@ -178,6 +178,7 @@ struct lmc_ctx {
     DevBuf<int> h2Step, h2Items, h2BinOf, h2Counts, h2SubList, h2SubCount;
     H2Bins h2Bins[2][2] = {};  // [part][stage]
     int h2Parts = 1, h2PartStride = 0;
+    const int *h2SplitOf = nullptr;  // the generic list h2SubList currently holds the two halves of (cut at the end of the step that built it, StepPhase2)
     DevBuf<unsigned char> h2Kind;
     H2Arrays H2{};
     int h2HessGrid = 0, h2GaussGrid = 0;
@@ -1489,7 +1490,10 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         const int *lists[2] = {list, list}, *counts[2] = {n, n};
         hipStream_t streams[2] = {sG, sG};
         if (parts == 2) {
-            LaunchSplitList(list, n, 2, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, laneGrid / 4 + 1, sG);
+            // the list was cut into its halves when it was built (StepPhase2); cut here only on the first use of a list that was not (warm-up).  At the head
+            // of the step the cut sat 1.5 ms in the queue beside the large-step launch, with the whole pipeline behind it (profiles/r05_x_h2mc_step_timeline_*.txt)
+            if (c->h2SplitOf != list) LaunchSplitList(list, n, 2, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, laneGrid + 1, sG);
+            c->h2SplitOf = nullptr;
             HIP_CHECK(hipEventRecord(c->partFork, sG));
             HIP_CHECK(hipStreamWaitEvent(c->partStream, c->partFork, 0));
             for (int h = 0; h < 2; h++) lists[h] = c->h2SubList.p + (size_t)h * c->h2PartStride, counts[h] = c->h2SubCount.p + h;
@@ -1599,7 +1603,9 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[7], sG));
     if (genericFirst) large();
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[1], s));
-    LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
+    // every small step of an H2MC render runs the pipeline: the lean list is empty by construction (QueueNext, LeanDims), and its launch of
+    // four-wave blocks sat in the queue for the length of the large-step launch
+    if (!c->S.opt.h2mc) LaunchStepSmallPlain(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][2].p, cnt + 2, next, c->bvhDepth, c->S.glossy != 0, c->leanGrid, c->leanBlock, c->profileLean, s);
     if (c->timing) HIP_CHECK(hipEventRecord(ev.e[2], s));
     if (c->overlap) {
         HIP_CHECK(hipEventRecord(c->joinEvent[0], sL));
@@ -1634,6 +1640,10 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
     if (c->needGeneric && !c->genericTokenOnly && (c->S.opt.h2mc ? c->sortH2mc : (c->sortGeneric && c->S.opt.mala && !c->relocate))) {  // relocated chains are grouped already (LMC: every chain moves; H2MC: chains holding a Gaussian stay, the sort still pays: 58.9 vs 61.7 M)
         LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
         std::swap(c->lists[nxt][1].p, c->listScratch.p);
+    }
+    if (c->needGeneric && c->S.opt.h2mc && c->overlap && c->h2Parts == 2) {  // the two halves of the H2MC pipeline's list (LaunchGeneric), while nothing else runs
+        LaunchSplitList(c->lists[nxt][1].p, c->listCounts[nxt].p + 1, 2, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, c->stepGrid * 4 + 1, s);
+        c->h2SplitOf = c->lists[nxt][1].p;
     }
     c->parity = nxt;
     if (c->timing) {

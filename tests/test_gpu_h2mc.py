@@ -409,3 +409,45 @@ def test_h2mc_door_render_matches_reference_image():
         for gx in range(4):
             a, b = lg[gy * 60:(gy + 1) * 60, gx * 80:(gx + 1) * 80].mean(), lr[gy * 60:(gy + 1) * 60, gx * 80:(gx + 1) * 80].mean()
             assert abs(a / b - 1) < 0.25, (gy, gx, a / b)
+
+
+def _h2_run(perturb_form, scene, n_chains, steps, checkpoints, **kw):
+    if perturb_form:
+        os.environ["LMC_H2_PERTURB"] = perturb_form
+    try:
+        p = gc.pkg()
+        ren = p.Renderer(scene, seed_offset=0, use_gradient=1, **kw)
+        ren.set_option("h2mc", 1)
+        ren.init_chains(100000, n_chains, 64, 10 ** 6)
+        out, done = [], 0
+        for upto in list(checkpoints) + [steps]:
+            ren.step(upto - done)
+            done = upto
+            out.append((ren.summary(0).copy(), ren.stats()))
+        film = ren.film().copy()
+        ren.close()
+    finally:
+        os.environ.pop("LMC_H2_PERTURB", None)
+    return out, film
+
+
+@pytest.mark.parametrize("scene", ["torus", "door"])
+def test_streamed_perturb_phase_equals_the_generic_phase_state_by_state(scene):
+    """k_h2_perturb_streamed (device/dwalk.h: the path streamed vertex by vertex between the chain's two SoA buffers, the stage-1 record serialised
+    from the buffer) against k_h2_perturb (PerturbPathBidir over a private-memory DPath, path.cpp:1953-2160): every chain's state, every counter
+    and -- up to the order of the float atomics -- the film are equal after 2, 9 and 24 steps, full materials, light sub-paths included (door)."""
+    if scene == "torus":
+        kw = dict(scene=gc.TORUS, force_diffuse=0, max_depth=8, width=128, height=96)
+    else:
+        kw = dict(scene=DOOR_H2, force_diffuse=0, width=128, height=96)
+    path = kw.pop("scene")
+    a, film0 = _h2_run("generic", path, 4096, 24, (2, 9), **kw)
+    b, film1 = _h2_run(None, path, 4096, 24, (2, 9), **kw)
+    for (s0, st0), (s1, st1) in zip(a, b):
+        valid = s0[:, 0] == 1
+        assert (s0[:, 0] == s1[:, 0]).all()
+        assert np.array_equal(s0[valid], s1[valid])
+        for k in ("steps", "largeSteps", "accepted", "resets", "gradCalls"):
+            assert st0[k] == st1[k], k
+    l0, l1 = gc.lum(film0), gc.lum(film1)
+    assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
