@@ -26,7 +26,7 @@ using namespace lmcd;
 // returns px = GaussianLogPdf(-offset, proposalGaussian) (mutation_h2mc.h:104, gaussian.cpp:24-36).
 namespace {
 constexpr int GS = 17, GW = 16 * GS;
-constexpr int G_LDS = 2 * GW + 6 * 16 + 16;  // A | V | w | eb | ob | post | grad | tmp | pad: 656 = 16 (mod 32), so the four groups of a wave sit on disjoint LDS banks (640 put all four on the same 16: profiles/r04_f: 250 M conflict cycles per launch)
+constexpr int G_LDS = 2 * GW + 6 * 16 + 16;  // (the pad holds the round's angles: 8 cos | 8 sin; the pairs live in a table of their own)  // A | V | w | eb | ob | post | grad | tmp | pad: 656 = 16 (mod 32), so the four groups of a wave sit on disjoint LDS banks (640 put all four on the same 16: profiles/r04_f: 250 M conflict cycles per launch)
 __device__ __forceinline__ float GroupSum(float v) {
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
@@ -34,13 +34,98 @@ __device__ __forceinline__ float GroupSum(float v) {
     v += __shfl_xor(v, 8);
     return v;
 }
+
+// pair j of round r of an n-player tournament (n even): player n - 1 stays, the others rotate (oracle/h2mc_serial.h JacobiRoundPair)
+template <int NN>
+__device__ __forceinline__ void RoundPair(int r, int j, int &p, int &q) {
+    int a, b;
+    if (j == 0) a = NN - 1, b = r;
+    else {
+        a = r + j, b = r - j + (NN - 1);
+        a = a >= NN - 1 ? a - (NN - 1) : a, b = b >= NN - 1 ? b - (NN - 1) : b;
+    }
+    p = min(a, b), q = max(a, b);
+}
+// The sweeps of one wave's (up to) four matrices, dimension NN at compile time.  A round = NN / 2 disjoint rotations = one similarity transform:
+// lane j < NN / 2 of a group works out pair j's angle from the matrix as the round finds it; then every lane updates ITS row of A and of V
+// (columns p, q of every pair); then ITS column of A (rows p, q).  The kernel is bound by its chain of dependent LDS round trips (2.6 k
+// instructions per wave-task in 100 k cycles, profiles/r05_x_h2mc_pmc_door.json), so every phase issues ALL its loads before the first use:
+// three round trips per round where the row-cyclic form (one rotation at a time, four barriers each) had about four per ROTATION.
+template <int NN>
+__device__ __forceinline__ void JacobiSweeps(float *A, float *V, float *rc, float *rs, int *rp, int k, bool act, bool run) {
+    constexpr int H = NN / 2;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        float offP = 0.f, diagP = 0.f;
+        if (act) {
+            diagP = A[k * GS + k] * A[k * GS + k];
+            for (int c = k + 1; c < NN; c++) offP += A[k * GS + c] * A[k * GS + c];
+        }
+        const float off = GroupSum(offP), diag = GroupSum(diagP);
+        if (!(off > 1e-14f * (diag + off))) run = false;  // also leaves on NaN
+        if (!__any(run)) break;
+#pragma unroll 1
+        for (int r = 0; r < NN - 1; r++) {
+            if (k < H) {
+                int p, q;
+                RoundPair<NN>(r, k, p, q);
+                const float apq = A[p * GS + q], app = A[p * GS + p], aqq = A[q * GS + q];
+                const float theta = (aqq - app) / (2.0f * apq);
+                const float tt = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                const float cs = 1.0f / sqrtf(tt * tt + 1.0f);
+                rc[k] = cs, rs[k] = tt * cs, rp[k] = (run && apq != 0.0f) ? 1 : 0;
+            }
+            __syncthreads();
+            const int kk = act ? k : 0;  // idle lanes read row 0 and write nothing
+            float cs[H], sn[H], ap[H], aq[H], vp[H], vq[H];
+            bool rot[H];
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                int p, q;
+                RoundPair<NN>(r, j, p, q);
+                cs[j] = rc[j], sn[j] = rs[j], rot[j] = rp[j] != 0;
+                ap[j] = A[kk * GS + p], aq[j] = A[kk * GS + q], vp[j] = V[kk * GS + p], vq[j] = V[kk * GS + q];
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    int p, q;
+                    RoundPair<NN>(r, j, p, q);
+                    A[k * GS + p] = rot[j] ? cs[j] * ap[j] - sn[j] * aq[j] : ap[j];
+                    A[k * GS + q] = rot[j] ? sn[j] * ap[j] + cs[j] * aq[j] : aq[j];
+                    V[k * GS + p] = rot[j] ? cs[j] * vp[j] - sn[j] * vq[j] : vp[j];
+                    V[k * GS + q] = rot[j] ? sn[j] * vp[j] + cs[j] * vq[j] : vq[j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                int p, q;
+                RoundPair<NN>(r, j, p, q);
+                ap[j] = A[p * GS + kk], aq[j] = A[q * GS + kk];
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    int p, q;
+                    RoundPair<NN>(r, j, p, q);
+                    A[p * GS + k] = rot[j] ? cs[j] * ap[j] - sn[j] * aq[j] : ap[j];
+                    A[q * GS + k] = rot[j] ? sn[j] * ap[j] + cs[j] * aq[j] : aq[j];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float *__restrict__ hout, H2MCParam param, int expFlags, const int *__restrict__ chainFlags,
                                                   int stage, float *__restrict__ gaussBuf, const float *__restrict__ offsetSoA, float *__restrict__ px) {
     __shared__ float lds[4 * G_LDS];
+    __shared__ int pairTab[4 * 8];
     const int lane = threadIdx.x, g = lane >> 4, k = lane & 15;
     float *A = lds + g * G_LDS, *V = A + GW, *w = V + GW, *eb = w + 16, *ob = eb + 16, *post = ob + 16, *grad = post + 16, *tmp = grad + 16;
+    float *rc = tmp + 16, *rs = rc + 8;
+    int *rp = pairTab + g * 8;
     __shared__ int taskIncl[H2_NBINS];
     const int total = H2BuildTaskTable(bins.count, taskIncl, [](int) { return 4; });
     const float sigma = param.sigma, invSigmaSq = 1.0f / (sigma * sigma);
@@ -77,42 +162,15 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
         const bool iso = !allFinite || LMC_EXP(expFlags, 32) || hnorm < 0.5f / (sigma * sigma) || !(hnorm == hnorm);  // h2mc.cpp:84-92
         bool run = has && !iso;
         __syncthreads();
-        // ---- cyclic Jacobi: the rotation sequence of oracle/h2mc_serial.h JacobiEigenSymT
-        for (int sweep = 0; sweep < 30; sweep++) {
-            float offP = 0.f, diagP = 0.f;
-            if (act) {
-                diagP = A[k * GS + k] * A[k * GS + k];
-                for (int c = k + 1; c < n; c++) offP += A[k * GS + c] * A[k * GS + c];
-            }
-            const float off = GroupSum(offP), diag = GroupSum(diagP);
-            if (!(off > 1e-14f * (diag + off))) run = false;  // also leaves on NaN
-            if (!__any(run)) break;
-            for (int p = 0; p < n - 1; p++)
-                for (int q = p + 1; q < n; q++) {
-                    const float apq = A[p * GS + q];
-                    const bool rot = run && apq != 0.0f;
-                    const float app = A[p * GS + p], aqq = A[q * GS + q];
-                    const float theta = (aqq - app) / (2.0f * apq);
-                    const float tt = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
-                    const float cs = 1.0f / sqrtf(tt * tt + 1.0f), sn = tt * cs;
-                    const float akp = A[k * GS + p], akq = A[k * GS + q];  // A <- A J (columns p, q): lane k = row k
-                    __syncthreads();
-                    if (rot && act) {
-                        A[k * GS + p] = cs * akp - sn * akq;
-                        A[k * GS + q] = sn * akp + cs * akq;
-                    }
-                    __syncthreads();
-                    const float apk = A[p * GS + k], aqk = A[q * GS + k];  // A <- J^T A (rows p, q): lane k = column k
-                    const float vkp = V[k * GS + p], vkq = V[k * GS + q];  // V <- V J: lane k = row k
-                    __syncthreads();
-                    if (rot && act) {
-                        A[p * GS + k] = cs * apk - sn * aqk;
-                        A[q * GS + k] = sn * apk + cs * aqk;
-                        V[k * GS + p] = cs * vkp - sn * vkq;
-                        V[k * GS + q] = sn * vkp + cs * vkq;
-                    }
-                    __syncthreads();
-                }
+        // ---- cyclic Jacobi, round-robin order: the rotation sequence of oracle/h2mc_serial.h JacobiEigenSymT
+        switch (n) {
+            case 4: JacobiSweeps<4>(A, V, rc, rs, rp, k, act, run); break;
+            case 6: JacobiSweeps<6>(A, V, rc, rs, rp, k, act, run); break;
+            case 8: JacobiSweeps<8>(A, V, rc, rs, rp, k, act, run); break;
+            case 10: JacobiSweeps<10>(A, V, rc, rs, rp, k, act, run); break;
+            case 12: JacobiSweeps<12>(A, V, rc, rs, rp, k, act, run); break;
+            case 14: JacobiSweeps<14>(A, V, rc, rs, rp, k, act, run); break;
+            default: JacobiSweeps<16>(A, V, rc, rs, rp, k, act, run); break;
         }
         float *G = gaussBuf + ((((chainFlags[item] & F_GSEL) != 0) != (stage != 0)) ? (size_t)N * H2_GAUSS_AOS : 0) + (size_t)item * H2_GAUSS_AOS;
         float logDet = 0.f, meanK = 0.f;

@@ -123,8 +123,9 @@ struct lmc_ctx {
     // (gradient) small steps on two side streams, the lean small steps on the main stream, joined before k_build_lists.
     // LMC_OVERLAP=0 serialises them on the main stream (A/B).
     hipStream_t sideStream[2] = {nullptr, nullptr};
-    hipStream_t partStream = nullptr;  // H2MC: the pipeline of the second half of the chain population (LaunchGeneric)
-    hipEvent_t partFork = nullptr, partJoin = nullptr;
+    static constexpr int H2_MAX_PARTS = 4;
+    hipStream_t partStream[H2_MAX_PARTS - 1] = {};  // H2MC: the pipelines of the other parts of the chain population (LaunchGeneric)
+    hipEvent_t partFork = nullptr, partJoin[H2_MAX_PARTS - 1] = {};
     hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
     hipEvent_t packedEvent = nullptr, copiedEvent = nullptr;  // in-process group: this member's stage is complete / this member has copied every stage (ExchangeStagesAsync)
     // in-process group, film merge (lmc_group_film_reduce): staging for the slices pulled from the peers + the peers' weight sums, allocated when the
@@ -176,7 +177,7 @@ struct lmc_ctx {
     // H2MC renders: hand-off state of the wave-cooperative pipeline (device/dh2coop.h)
     DevBuf<float> h2Rec, h2Out, h2Gauss, h2Offset, h2Py, h2Px, h2PropContrib;
     DevBuf<int> h2Step, h2Items, h2BinOf, h2Counts, h2SubList, h2SubCount;
-    H2Bins h2Bins[2][2] = {};  // [part][stage]
+    H2Bins h2Bins[H2_MAX_PARTS][2] = {};  // [part][stage]
     int h2Parts = 1, h2PartStride = 0;
     const int *h2SplitOf = nullptr;  // the generic list h2SubList currently holds the two halves of (cut at the end of the step that built it, StepPhase2)
     DevBuf<unsigned char> h2Kind;
@@ -255,8 +256,9 @@ struct lmc_ctx {
         }
         if (hostCounts) (void)hipHostFree(hostCounts);
         if (countsEvent) (void)hipEventDestroy(countsEvent);
-        if (partStream) (void)hipStreamDestroy(partStream);
-        for (auto e : {partFork, partJoin, forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent, filmReadyEvent, sliceReducedEvent, weightsCopiedEvent})
+        for (auto st : partStream)
+            if (st) (void)hipStreamDestroy(st);
+        for (auto e : {partFork, partJoin[0], partJoin[1], partJoin[2], forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent, filmReadyEvent, sliceReducedEvent, weightsCopiedEvent})
             if (e) (void)hipEventDestroy(e);
         for (auto st : sideStream)
             if (st) (void)hipStreamDestroy(st);
@@ -461,10 +463,10 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
             const int m = k == 0 ? modeL : mode;
             HIP_CHECK(hipStreamCreateWithPriority(&c->sideStream[k], hipStreamNonBlocking, m > 0 ? hi : m < 0 ? lo : 0));
         }
-        HIP_CHECK(hipStreamCreateWithPriority(&c->partStream, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
+        for (auto &ps : c->partStream) HIP_CHECK(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
     }
     HIP_CHECK(hipEventCreateWithFlags(&c->partFork, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&c->partJoin, hipEventDisableTiming));
+    for (auto &e : c->partJoin) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&c->packedEvent, hipEventDisableTiming));
@@ -1077,15 +1079,16 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         // Two halves of the chain population run the pipeline side by side, each on its own stream (LaunchGeneric; LMC_H2_PARTS=1: one pipeline).
         // Per (part, stage): a bin table (count | start | cursor) and the part's share of the stage's N-entry item array; binOf is per stage
         // (the parts' chains are disjoint).  The generic list is cut into the parts' sub-lists every step (kernels.hip k_split_list).
+        constexpr int MP = lmc_ctx::H2_MAX_PARTS;
         c->h2Parts = 2;
-        if (const char *e = getenv("LMC_H2_PARTS")) c->h2Parts = std::max(1, std::min(2, atoi(e)));
-        c->h2PartStride = (int)(((N + 127) / 128) * 64 + 64);  // the most entries the interleaved split gives one of two parts
-        c->h2Items.Alloc(2 * 2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc(2 * 2 * 3 * H2_COUNT_WORDS);
-        c->h2SubList.Alloc(2 * (size_t)c->h2PartStride, false), c->h2SubCount.Alloc(2);
+        if (const char *e = getenv("LMC_H2_PARTS")) c->h2Parts = std::max(1, std::min(MP, atoi(e)));
+        c->h2PartStride = (int)(((N + 127) / 128) * 64 + 64);  // the most entries the interleaved split gives one of two (or more) parts
+        c->h2Items.Alloc((size_t)MP * 2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc((size_t)MP * 2 * 3 * H2_COUNT_WORDS);
+        c->h2SubList.Alloc(MP * (size_t)c->h2PartStride, false), c->h2SubCount.Alloc(MP);
         H2Arrays &H = c->H2;
         H.rec = c->h2Rec.p, H.hout = c->h2Out.p, H.gauss = c->h2Gauss.p, H.offset = c->h2Offset.p, H.py = c->h2Py.p, H.px = c->h2Px.p, H.propContrib = c->h2PropContrib.p;
         H.step = c->h2Step.p, H.kind = c->h2Kind.p;
-        for (int part = 0; part < 2; part++)
+        for (int part = 0; part < MP; part++)
             for (int st = 0; st < 2; st++) {
                 int *tab = c->h2Counts.p + (size_t)(part * 2 + st) * 3 * H2_COUNT_WORDS;
                 int *items = c->h2Items.p + (size_t)(part * 2 + st) * N;  // N entries each: a part may be the whole population (LMC_H2_PARTS=1, or the side streams switched off)
@@ -1487,23 +1490,26 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         // is filled by the other half's (measured as two contexts on one device before it was built, profiles/r05_s_h2mc_two_halves.jsonl:
         // veach-door +6 %, torus +9 %; four parts: nothing).  Same chains, same arithmetic: every chain's trajectory is untouched.
         const int parts = c->overlap ? c->h2Parts : 1;
-        const int *lists[2] = {list, list}, *counts[2] = {n, n};
-        hipStream_t streams[2] = {sG, sG};
-        if (parts == 2) {
+        constexpr int MP = lmc_ctx::H2_MAX_PARTS;
+        const int *lists[MP] = {list, list, list, list}, *counts[MP] = {n, n, n, n};
+        hipStream_t streams[MP] = {sG, sG, sG, sG};
+        if (parts >= 2) {
             // the list was cut into its halves when it was built (StepPhase2); cut here only on the first use of a list that was not (warm-up).  At the head
             // of the step the cut sat 1.5 ms in the queue beside the large-step launch, with the whole pipeline behind it (profiles/r05_x_h2mc_step_timeline_*.txt)
-            if (c->h2SplitOf != list) LaunchSplitList(list, n, 2, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, laneGrid + 1, sG);
+            if (c->h2SplitOf != list) LaunchSplitList(list, n, parts, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, laneGrid + 1, sG);
             c->h2SplitOf = nullptr;
             HIP_CHECK(hipEventRecord(c->partFork, sG));
-            HIP_CHECK(hipStreamWaitEvent(c->partStream, c->partFork, 0));
-            for (int h = 0; h < 2; h++) lists[h] = c->h2SubList.p + (size_t)h * c->h2PartStride, counts[h] = c->h2SubCount.p + h;
-            streams[1] = c->partStream;
+            for (int h = 1; h < parts; h++) {
+                HIP_CHECK(hipStreamWaitEvent(c->partStream[h - 1], c->partFork, 0));
+                streams[h] = c->partStream[h - 1];
+            }
+            for (int h = 0; h < parts; h++) lists[h] = c->h2SubList.p + (size_t)h * c->h2PartStride, counts[h] = c->h2SubCount.p + h;
         }
         for (int h = 0; h < parts; h++) {
             hipStream_t sp = streams[h];
             H2Arrays H = c->H2;
             H.bins[0] = c->h2Bins[h][0], H.bins[1] = c->h2Bins[h][1];
-            const int grid = parts == 2 ? laneGrid / 2 + 1 : laneGrid;
+            const int grid = laneGrid / parts + 1;
             HIP_CHECK(hipMemsetAsync(c->h2Bins[h][0].count, 0, 2 * 3 * H2_COUNT_WORDS * sizeof(int), sp));  // both stages' tables of this part are contiguous
             LaunchH2Begin(c->S, c->A, P, H, lists[h], counts[h], grid, sp);
             LaunchBinsCompact(H.bins[0], lists[h], counts[h], grid, sp);
@@ -1518,9 +1524,9 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
             }
             LaunchH2Finish(c->S, c->cacheDev.p, c->A, film, P, H, lists[h], counts[h], grid, sp);
         }
-        if (parts == 2) {  // the generic slot of the launch plan ends when both halves have
-            HIP_CHECK(hipEventRecord(c->partJoin, c->partStream));
-            HIP_CHECK(hipStreamWaitEvent(sG, c->partJoin, 0));
+        for (int h = 1; h < parts; h++) {  // the generic slot of the launch plan ends when every part has
+            HIP_CHECK(hipEventRecord(c->partJoin[h - 1], c->partStream[h - 1]));
+            HIP_CHECK(hipStreamWaitEvent(sG, c->partJoin[h - 1], 0));
         }
     } else if (c->needGeneric && c->MP.rec && !c->allCachesReady && !c->S.opt.useLightCoord) {
         // while a cache fills: the gradient steps as a pipeline, the path program wave-cooperative between lane-per-chain phases
@@ -1641,8 +1647,8 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
         LaunchSortByTechnique(c->A.nextKind, c->lists[nxt][1].p, c->listScratch.p, c->listCounts[nxt].p + 1, c->sortBins.p, (int)c->N, s);
         std::swap(c->lists[nxt][1].p, c->listScratch.p);
     }
-    if (c->needGeneric && c->S.opt.h2mc && c->overlap && c->h2Parts == 2) {  // the two halves of the H2MC pipeline's list (LaunchGeneric), while nothing else runs
-        LaunchSplitList(c->lists[nxt][1].p, c->listCounts[nxt].p + 1, 2, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, c->stepGrid * 4 + 1, s);
+    if (c->needGeneric && c->S.opt.h2mc && c->overlap && c->h2Parts >= 2) {  // the two halves of the H2MC pipeline's list (LaunchGeneric), while nothing else runs
+        LaunchSplitList(c->lists[nxt][1].p, c->listCounts[nxt].p + 1, c->h2Parts, c->h2SubList.p, c->h2PartStride, c->h2SubCount.p, c->stepGrid * 4 + 1, s);
         c->h2SplitOf = c->lists[nxt][1].p;
     }
     c->parity = nxt;

@@ -12,10 +12,24 @@ namespace lmcd {
 // Symmetric eigen-decomposition by cyclic Jacobi rotations.  A (n x n, row-major, stride n) is destroyed; on return w holds
 // the eigenvalues in ascending order (Eigen's convention) and column j of V (row-major, stride n) the unit eigenvector of w[j].
 // MA / MV: anything indexable as a flat n x n array (float *, MatRef): the device keeps A in LDS (dh2step.h), same arithmetic
+// Rotation order (round 5): the ROUND-ROBIN cyclic order -- n - 1 rounds of n / 2 disjoint pairs per sweep ("chess tournament": player m - 1
+// stays, the others rotate; m = n rounded up to even, pairs with the bye skipped) -- instead of the row-cyclic (0,1), (0,2), ... order.  The
+// rotations of a round touch disjoint rows / columns, so a round is ONE similarity transform A <- J^T A J with J = the product of its rotations,
+// evaluated as: all angles from the matrix at the start of the round, then A <- A J (every pair's two columns), then A <- J^T A (every pair's two
+// rows), V <- V J.  The device (h2gauss.hip) runs exactly this with the lanes = rows / columns: 3 barriers per round instead of 4 per rotation.
+// Eigenvalues are those of the matrix either way; the eigenvector SIGNS follow the order, which is why both sides use the same one.
+LMC_HD void JacobiRoundPair(int m, int r, int j, int &p, int &q) {  // pair j (0 <= j < m / 2) of round r (0 <= r < m - 1)
+    int a, b;
+    if (j == 0) a = m - 1, b = r;
+    else
+        a = (r + j) % (m - 1), b = (r - j + (m - 1)) % (m - 1);
+    p = a < b ? a : b, q = a < b ? b : a;
+}
 template <class MA, class MV>
 LMC_HD void JacobiEigenSymT(int n, MA A, MV V, float *w) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0f : 0.0f;
+    const int m = (n + 1) & ~1;
     for (int sweep = 0; sweep < 30; sweep++) {
         float off = 0.f, diag = 0.f;
         for (int i = 0; i < n; i++) {
@@ -23,30 +37,48 @@ LMC_HD void JacobiEigenSymT(int n, MA A, MV V, float *w) {
             for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
         }
         if (!(off > 1e-14f * (diag + off))) break;  // also leaves on NaN
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
+        for (int r = 0; r < m - 1; r++) {
+            float cs[16], sn[16];
+            bool rot[16];
+            for (int j = 0; j < m / 2; j++) {  // the angles of the round, all from the matrix as the round finds it
+                int p, q;
+                JacobiRoundPair(m, r, j, p, q);
+                rot[j] = false;
+                if (q >= n) continue;  // the bye of an odd n
                 const float apq = A[p * n + q];
                 if (apq == 0.0f) continue;
                 const float app = A[p * n + p], aqq = A[q * n + q];
                 const float theta = (aqq - app) / (2.0f * apq);
                 const float t = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
-                const float c = 1.0f / sqrtf(t * t + 1.0f), s = t * c;
-                for (int k = 0; k < n; k++) {  // A <- A J  (columns p, q)
+                cs[j] = 1.0f / sqrtf(t * t + 1.0f), sn[j] = t * cs[j];
+                rot[j] = true;
+            }
+            for (int j = 0; j < m / 2; j++) {  // A <- A J, V <- V J (columns p, q of every pair)
+                if (!rot[j]) continue;
+                int p, q;
+                JacobiRoundPair(m, r, j, p, q);
+                const float c = cs[j], s = sn[j];
+                for (int k = 0; k < n; k++) {
                     const float akp = A[k * n + p], akq = A[k * n + q];
                     A[k * n + p] = c * akp - s * akq;
                     A[k * n + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; k++) {  // A <- J^T A (rows p, q)
-                    const float apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; k++) {  // V <- V J
                     const float vkp = V[k * n + p], vkq = V[k * n + q];
                     V[k * n + p] = c * vkp - s * vkq;
                     V[k * n + q] = s * vkp + c * vkq;
                 }
             }
+            for (int j = 0; j < m / 2; j++) {  // A <- J^T A (rows p, q of every pair)
+                if (!rot[j]) continue;
+                int p, q;
+                JacobiRoundPair(m, r, j, p, q);
+                const float c = cs[j], s = sn[j];
+                for (int k = 0; k < n; k++) {
+                    const float apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+            }
+        }
     }
     for (int i = 0; i < n; i++) w[i] = A[i * n + i];
     for (int i = 0; i < n - 1; i++) {  // ascending order (selection sort; ties keep their order)
