@@ -685,7 +685,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         for (int lgtDepth = 0; lgtDepth < path.lgtCount; lgtDepth++) {
             DVertex &sv = path.lgt[lgtDepth];
             SurfHit hit;
-            if (!IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lps.isect, stk)) return false;
+            if (!IntersectSurface(S, org, dir, c_IsectEpsilon, INFINITY, hit, lps.isect, stk, sv.tri)) return false;  // sv.tri: the state's triangle first (dscene.h)
             sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
             lps.wi = -dir;
             sv.bsdfDiscrete = Modulo1(sv.bsdfDiscrete + normDist(rng));
@@ -711,7 +711,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         DVertex &sv = path.cam[camDepth];
         SurfHit hit;
         hit.tri = -1;
-        bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect, stk);
+        bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, cps.isect, stk, sv.tri);
         sv.tri = hit.tri, sv.st0 = hit.st.x, sv.st1 = hit.st.y;
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);

@@ -17,9 +17,9 @@ struct SurfHit {
 
 // path.cpp:91-103 = scene.cpp:106-126 (BVH) + TriangleMesh::Intersect (recompute from primID)
 template <class Stk>
-LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float tfar, SurfHit &hit, Isect &isect, Stk &stk) {
+LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float tfar, SurfHit &hit, Isect &isect, Stk &stk, int hint = -1) {
     float tB;
-    int id = BvhIntersect(S, org, dir, tnear, tfar, tB, stk);
+    int id = BvhIntersect(S, org, dir, tnear, tfar, tB, stk, hint);
     if (id < 0) return false;
     const TriData T = S.tris[id];  // the whole record at once (by value: one round of loads, not one per early-out below)
     V3 p0{T.p0[0], T.p0[1], T.p0[2]}, e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};

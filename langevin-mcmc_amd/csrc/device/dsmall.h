@@ -559,7 +559,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 #ifndef LMC_PROF_FINE
             prof.Mark(PR_VERTEX_LOAD);
 #endif
-            const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk);
+            const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk, sv.tri);  // sv.tri: the current state's triangle, tried first (dscene.h)
             prof.Mark(PR_TRAVERSE);
             if (lightPhase) {
                 if (!hitSurface) break;

@@ -89,7 +89,7 @@ LMC_D bool PerturbPathStreamed(const DScene &S, const float *cur, float *prop, s
         hit.st = V2{0.f, 0.f};
         Isect isect;
         isect.position = isect.shadingNormal = isect.geomNormal = V3{0.f, 0.f, 0.f};
-        const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk);
+        const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk, sv.tri);  // the current state's triangle first (dscene.h)
         if (lightPhase) {
             if (!hitSurface) break;
             lps.isect = isect;

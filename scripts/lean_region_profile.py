@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where a wave of the lean small-step kernel spends its cycles (LMC_PROF=1 instantiation, dsmall.h WaveProf): steady state at
-2^20 chains.  usage: LMC_PROF=1 python scripts/lean_region_profile.py [full] > out.json   (GPU; `full` = the scene's own materials, maxdepth 8)"""
+2^20 chains.  usage: LMC_PROF=1 python scripts/lean_region_profile.py [full|full12|door] > out.json   (GPU; `full` = the torus scene's own materials, maxdepth 8;
+`full12` = BASELINE configs[2]: the same at maxdepth 12; `door` = the shipped veach-door lmc.xml)"""
 import ctypes, importlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,8 +12,12 @@ import gpu_checks as gc
 assert os.environ.get("LMC_PROF") == "1", "run with LMC_PROF=1"
 p = importlib.import_module("langevin-mcmc_amd")
 chains = 1 << 20
-full = len(sys.argv) > 1 and sys.argv[1] == "full"
-ren = p.Renderer(gc.TORUS, force_diffuse=0 if full else 1, max_depth=8 if full else 6, seed_offset=0, device=0, use_gradient=1)
+which = sys.argv[1] if len(sys.argv) > 1 else ""
+full = which in ("full", "full12", "door")
+if which == "door":
+    ren = p.Renderer(os.path.join(ROOT, "scenes", "veachdoor", "lmc.xml"), seed_offset=0, device=0, use_gradient=1)
+else:
+    ren = p.Renderer(gc.TORUS, force_diffuse=0 if full else 1, max_depth={"full": 8, "full12": 12}.get(which, 6), seed_offset=0, device=0, use_gradient=1)
 ren.init_chains(8 * chains, chains, 65536, 256, 0, 0, chains)
 ren.step(56 if full else 40)
 out = (ctypes.c_ulonglong * 16)()
