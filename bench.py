@@ -192,7 +192,7 @@ def truth_crosscheck(p, gc):
         lr, lr2 = lum(ref["lmc"]), lum(ref["h2mc"])
         W, H = 256, 192
         ren = p.Renderer(gc.TORUS, force_diffuse=0, max_depth=8, width=W, height=H, seed_offset=0, use_gradient=0)
-        dspp, spp = 256, 8192
+        dspp, spp = 256, 32768  # at 8192 spp the estimator's own noise (relMSE 0.018) exceeds SURVEY's bar; 32768: 0.0066 (profiles/r04_o_truth_crosscheck.jsonl)
         t0 = time.time()
         img = lum(ren.direct_lighting(dspp) / dspp + ren.bidir_mc(spp))
         dt = time.time() - t0
@@ -205,7 +205,11 @@ def truth_crosscheck(p, gc):
                 "against": "the reference's shipped render lmc_timeuse_44.689152s.exr (245 spp), box-downsampled 4x",
                 "relMSE": relmse(img, lr), "relMSE_trimmed_0.5pct": relmse(img, lr, 0.005), "mean_ratio": float(img.mean() / lr.mean()),
                 "relMSE_between_the_reference's_own_lmc_and_h2mc_renders": relmse(lr2, lr), "bar": "2 x that (SURVEY.md 8d)",
-                "convergence": "the figure is the plain-MC estimator's own noise: 0.057 / 0.018 / 0.0066 at 2048 / 8192 / 32768 spp, mean ratio 1.015 throughout (profiles/r04_o_truth_crosscheck.jsonl)"}
+                "passes_bar": bool(relmse(img, lr) <= 2 * relmse(lr2, lr)),
+                "convergence": "the figure is the plain-MC estimator's own noise: 0.057 / 0.018 / 0.0066 at 2048 / 8192 / 32768 spp, mean ratio 1.015 throughout (profiles/r04_o_truth_crosscheck.jsonl)",
+                "mean_offset": "the shipped render's own normaliser: the reference estimates `normalization` once from 300 000 init samples (mlt.h:41-154), an estimate with "
+                               "a standard deviation of 5.8 % on this scene; with the reference's init configuration (32 streams, seedoffset 0) it is 0.984 of the converged value, "
+                               "and a GPU render with that init is within 0.6 % of the shipped image (profiles/r05_k_*, r05_l_*, tests/test_gpu_round5.py)"}
     except Exception as e:  # noqa: BLE001
         return {"failed": str(e)[:300]}
 
