@@ -182,7 +182,7 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
     const float dist = sqrtf(distSq);
     dirToCamera = dirToCamera * inverse(dist);
     if (occ.Test(S, ps.isect.position, dirToCamera, dist, stk)) return false;
-    const DMaterial &m = MaterialOfTri(S, lgtVertex.tri);
+    const DMaterial m = LoadMaterial<Stk::kGlossy>(S, lgtVertex.tri);
     V2 st{lgtVertex.st0, lgtVertex.st1};
     V3 bsdfContrib;
     float cosToCamera, bsdfPdf, bsdfRevPdf;
@@ -215,7 +215,7 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
 // that BPS -- live across every traversal of the hot kernel -- does not carry it
 template <bool adjoint, bool perturb, bool GLOSSY>
 LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib, float *lcJacobian = nullptr) {
-    const DMaterial &m = MaterialOfTri(S, v.tri);
+    const DMaterial m = LoadMaterial<GLOSSY>(S, v.tri);
     V2 st{v.st0, v.st1};
     float cosWo, bsdfPdf, bsdfRevPdf;
     v.useAbs = (BsdfRoughness<GLOSSY>(S, m, st, v.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : 0.0f;
@@ -284,7 +284,7 @@ LMC_D bool HandleHitLight(const DScene &S, int camDepth, int light, bool hitSurf
 // path.cpp:969-1089 (doOcclusion = true, bidirMIS = true)
 template <class Stk, class Occ>
 LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk, Occ &occ) {
-    const DMaterial &m = MaterialOfTri(S, camVertex.tri);
+    const DMaterial m = LoadMaterial<Stk::kGlossy>(S, camVertex.tri);
     const int light = camVertex.dirLight;
     V3 dirToLight, lightContrib;
     float dist, cosAtLight, directPdf, emissionPdf;
@@ -324,7 +324,7 @@ LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS 
     if (occ.Test(S, cps.isect.position, dirToLight, dist, stk)) return false;
     V3 camBsdfFactor;
     float cosCamera, camBsdfPdf, camBsdfRevPdf;
-    BsdfEvaluate<Stk::kGlossy>(S, MaterialOfTri(S, camVertex.tri), false, cps.wi, cps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, camBsdfFactor,
+    BsdfEvaluate<Stk::kGlossy>(S, LoadMaterial<Stk::kGlossy>(S, camVertex.tri), false, cps.wi, cps.isect.shadingNormal, dirToLight, V2{camVertex.st0, camVertex.st1}, camBsdfFactor,
                  cosCamera, camBsdfPdf, camBsdfRevPdf);
     if (IsZero(camBsdfFactor)) return false;
     float camFactor = ShadingNormalCorrection<false>(cps.wi, cps.isect, dirToLight);
@@ -332,7 +332,7 @@ LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS 
     camBsdfFactor = camBsdfFactor * camFactor;
     V3 lgtBsdfFactor;
     float cosLight, lgtBsdfPdf, lgtBsdfRevPdf;
-    BsdfEvaluate<Stk::kGlossy>(S, MaterialOfTri(S, lgtVertex.tri), true, lps.wi, lps.isect.shadingNormal, -dirToLight, V2{lgtVertex.st0, lgtVertex.st1}, lgtBsdfFactor,
+    BsdfEvaluate<Stk::kGlossy>(S, LoadMaterial<Stk::kGlossy>(S, lgtVertex.tri), true, lps.wi, lps.isect.shadingNormal, -dirToLight, V2{lgtVertex.st0, lgtVertex.st1}, lgtBsdfFactor,
                  cosLight, lgtBsdfPdf, lgtBsdfRevPdf);
     if (IsZero(lgtBsdfFactor)) return false;
     float lgtFactor = ShadingNormalCorrection<true>(lps.wi, lps.isect, -dirToLight);

@@ -321,14 +321,32 @@ LMC_D int VisitNode4Q(const BvhNode4Q &nd, V3 org, V3 invd, float tnear, float t
     if (ck[1] != BVH4_EMPTY) stk.Push(ck[1]);
     return ck[0];
 }
+// hipcc sinks a load to its first use: a node's child indices (needed after the slab arithmetic) and a leaf triangle's p0 (needed after the
+// divisor test, inside a branch) were fetched there, each a dependent round trip through the vector L1 on a line the visit had already paid for
+// (hipcc -S of the round-5 lean kernel: `global_load_dwordx4 ... offset:48` + `s_waitcnt vmcnt(0)` behind the min / max chain; one
+// `global_load_dwordx3` per triangle behind `v_cmp_neq_f32 divisor`).  An empty asm that names the registers as in / out pins the loads where
+// the source has them: all of a visit's loads are in flight together.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LMC_NO_LOAD_PIN)
+#define LMC_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define LMC_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define LMC_PIN5(a, b, c, d, e) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
+#define LMC_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#else
+#define LMC_PIN2(a, b) ((void)0)
+#define LMC_PIN3(a, b, c) ((void)0)
+#define LMC_PIN5(a, b, c, d, e) ((void)0)
+#define LMC_PIN4(a, b, c, d) ((void)0)
+#endif
 // one visit of inner node `cur`: the nearest hit child (or BVH4_EMPTY), the others pushed
 template <bool ORDERED, class Stk>
 LMC_D int VisitInner(const DScene &S, int cur, V3 org, V3 invd, float tnear, float tfar, Stk &stk) {
     if constexpr (Stk::kQuant || LMC_BVH_QUANT) {
-        const BvhNode4Q nd = S.qnodes[cur];
+        BvhNode4Q nd = S.qnodes[cur];
+        LMC_PIN4(nd.child[0], nd.child[1], nd.child[2], nd.child[3]);
         return VisitNode4Q<ORDERED>(nd, org, invd, tnear, tfar, stk);
     } else {
-        const BvhNode4 nd = S.nodes[cur];
+        BvhNode4 nd = S.nodes[cur];
+        LMC_PIN4(nd.child[0], nd.child[1], nd.child[2], nd.child[3]);
         return VisitNode4<ORDERED>(nd, org, invd, tnear, tfar, stk);
     }
 }
@@ -351,8 +369,10 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     // smallest t, ties to the lowest id: the hinted triangle is met again in its leaf and changes nothing.
     if (hint >= 0) {
         const TriData &T = S.tris[hint];
+        float p0[3] = {T.p0[0], T.p0[1], T.p0[2]}, e1[3] = {T.e1[0], T.e1[1], T.e1[2]}, e2[3] = {T.e2[0], T.e2[1], T.e2[2]};
+        LMC_PIN3(p0[0], p0[1], p0[2]);  // one round of loads (below: LMC_PIN)
         float t;
-        if (TriTest(T.p0, T.e1, T.e2, org, dir, tnear, tfar, t)) best = hint, bestT = t;
+        if (TriTest(p0, e1, e2, org, dir, tnear, tfar, t)) best = hint, bestT = t;
     }
 #endif
     int cur = 0;  // root is an inner node
@@ -373,6 +393,8 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
             LeafTri tr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) tr[i] = S.leafTris[first + min(base + i, cnt - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; i++) LMC_PIN3(tr[i].p0[0], tr[i].p0[1], tr[i].p0[2]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float t;
@@ -412,6 +434,8 @@ LMC_D bool BvhOccluded(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
             LeafTri tr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) tr[i] = S.leafTris[first + min(base + i, cnt - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; i++) LMC_PIN3(tr[i].p0[0], tr[i].p0[1], tr[i].p0[2]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float t;

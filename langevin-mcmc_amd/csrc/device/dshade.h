@@ -21,7 +21,11 @@ LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float 
     float tB;
     int id = BvhIntersect(S, org, dir, tnear, tfar, tB, stk, hint);
     if (id < 0) return false;
-    const TriData T = S.tris[id];  // the whole record at once (by value: one round of loads, not one per early-out below)
+    TriData T = S.tris[id];  // the whole record at once: by value, and pinned (dscene.h LMC_PIN) -- hipcc fetched the normals and the st / material words
+                             // where they are first used, two more dependent round trips per hit
+    LMC_PIN3(T.n0[0], T.n1[0], T.n2[0]);
+    LMC_PIN3(T.n0[2], T.n1[2], T.n2[2]);
+    LMC_PIN4(T.st[0], T.st[3], T.st[5], T.hasST);
     V3 p0{T.p0[0], T.p0[1], T.p0[2]}, e1{T.e1[0], T.e1[1], T.e1[2]}, e2{T.e2[0], T.e2[1], T.e2[2]};
     isect.geomNormal = Normalize(Cross(e1, e2));
     V3 s1 = Cross(dir, e2);
@@ -70,27 +74,65 @@ LMC_D float PickLightProb(const DScene &S, int light) { return S.lights[light].s
 
 // ---------------------------------------------------------------------------------------------- BSDF
 LMC_D const DMaterial &MaterialOfTri(const DScene &S, int tri) { return S.materials[S.tris[tri].material]; }
+// ... the record by value, all the words the instantiation reads in ONE round of loads (dscene.h LMC_PIN: through the reference above every field
+// was fetched where it is first used, a dependent round trip each -- `twoSided` behind the cosine test, Ks / exponent / KsWeight one after the other)
+template <bool GLOSSY>
+LMC_D DMaterial LoadMaterial(const DScene &S, int tri) {
+    DMaterial m = S.materials[S.tris[tri].material];
+    LMC_PIN4(m.type, m.twoSided, m.Kd.bitmap, m.Kd.value[0]);
+    LMC_PIN4(m.Kd.value[1], m.Kd.value[2], m.Kd.sScale, m.Kd.tScale);
+    if constexpr (GLOSSY) {
+        LMC_PIN4(m.Ks.bitmap, m.Ks.value[0], m.Ks.value[1], m.Ks.value[2]);
+        LMC_PIN4(m.Ks.sScale, m.Ks.tScale, m.Kt.bitmap, m.Kt.value[0]);
+        LMC_PIN4(m.Kt.value[1], m.Kt.value[2], m.Kt.sScale, m.Kt.tScale);
+        LMC_PIN4(m.expOrAlpha.bitmap, m.expOrAlpha.value[0], m.expOrAlpha.sScale, m.expOrAlpha.tScale);
+        LMC_PIN3(m.eta, m.invEta, m.KsWeight);
+    }
+    return m;
+}
 
 // Texture::Eval.  Bitmaps: periodic bilinear lookup standing in for OIIO's TextureSystem::texture() with zero filter
 // width, then fastpow(max(v,0), gamma) (bitmaptexture.h:72-97); the same arithmetic as host/scene.cpp:EvalTexture.
 LMC_D V3 EvalTex(const DScene &S, const DTexRef &t, V2 st) {
     if (t.bitmap < 0) return V3{t.value[0], t.value[1], t.value[2]};
-    const DBitmap bm = S.bitmaps[t.bitmap];
-    const int W = bm.W, H = bm.H;
+    // every load below is pinned where it stands (dscene.h LMC_PIN): hipcc fetched the bitmap's fields and the twelve texel words one by one
+    // where each is used -- a chain of up to fourteen dependent round trips per look-up (hipcc -S of the round-5 door kernels: 77 of the 88
+    // loads of this function's inlined copies were waited for on their own)
+    const DBitmap *bp = S.bitmaps + t.bitmap;
+    const float *pix = bp->pix;
+    int W = bp->W, H = bp->H;
+    float gamma = bp->gamma;
+    LMC_PIN4(pix, W, H, gamma);
     const float fs = t.sScale * st.x * W - 0.5f, ft = t.tScale * st.y * H - 0.5f;
     const float x0f = floorf(fs), y0f = floorf(ft);
     const float dx = fs - x0f, dy = ft - y0f;
-    auto wrap = [](long long v, int n) {
-        long long r = v % n;
-        return (int)(r < 0 ? r + n : r);
+    // periodic wrap of floor(coordinate) and its right / upper neighbour.  The reference arithmetic is (long long) % n; inside +-2^30 the 32-bit
+    // remainder is the same number (and a tenth of the instructions: a 64-bit remainder is a software loop on this hardware)
+    auto wrap2 = [](float vf, int n, int &a, int &b) {
+        if (fabsf(vf) < 1073741824.0f) {
+            const int v = (int)vf;
+            int r = v % n;
+            r = r < 0 ? r + n : r;
+            a = r, b = r + 1 == n ? 0 : r + 1;
+        } else {
+            const long long v = (long long)vf;
+            long long r = v % n, r1 = (v + 1) % n;
+            a = (int)(r < 0 ? r + n : r), b = (int)(r1 < 0 ? r1 + n : r1);
+        }
     };
-    const int x0 = wrap((long long)x0f, W), x1 = wrap((long long)x0f + 1, W), y0 = wrap((long long)y0f, H), y1 = wrap((long long)y0f + 1, H);
-    const float *p00 = bm.pix + ((size_t)y0 * W + x0) * 3, *p10 = bm.pix + ((size_t)y0 * W + x1) * 3;
-    const float *p01 = bm.pix + ((size_t)y1 * W + x0) * 3, *p11 = bm.pix + ((size_t)y1 * W + x1) * 3;
+    int x0, x1, y0, y1;
+    wrap2(x0f, W, x0, x1), wrap2(y0f, H, y0, y1);
+    const float *p00 = pix + ((size_t)y0 * W + x0) * 3, *p10 = pix + ((size_t)y0 * W + x1) * 3;
+    const float *p01 = pix + ((size_t)y1 * W + x0) * 3, *p11 = pix + ((size_t)y1 * W + x1) * 3;
+    float a00[3] = {p00[0], p00[1], p00[2]}, a10[3] = {p10[0], p10[1], p10[2]}, a01[3] = {p01[0], p01[1], p01[2]}, a11[3] = {p11[0], p11[1], p11[2]};
+    LMC_PIN3(a00[0], a00[1], a00[2]);
+    LMC_PIN3(a10[0], a10[1], a10[2]);
+    LMC_PIN3(a01[0], a01[1], a01[2]);
+    LMC_PIN3(a11[0], a11[1], a11[2]);
     float o[3];
     for (int k = 0; k < 3; k++) {
-        const float v = (1 - dx) * (1 - dy) * p00[k] + dx * (1 - dy) * p10[k] + (1 - dx) * dy * p01[k] + dx * dy * p11[k];
-        o[k] = fastpow(fmaxf(v, 0.f), bm.gamma);
+        const float v = (1 - dx) * (1 - dy) * a00[k] + dx * (1 - dy) * a10[k] + (1 - dx) * dy * a01[k] + dx * dy * a11[k];
+        o[k] = fastpow(fmaxf(v, 0.f), gamma);
     }
     return V3{o[0], o[1], o[2]};
 }

@@ -384,6 +384,10 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     st.lean++;
 
     DVertex nextV = LoadVertex(cur, N, i, l > 1, 0);  // first vertex of the walk below, requested before the Gaussian work
+    // ... and so are the head words the walk perturbs first: time, screen position (each was a round trip of its own to the chain's state in HBM,
+    // at the point of use; dscene.h LMC_PIN)
+    float headTime = LdS(&cur[(size_t)PW_TIME * N + i]), headScreen0 = LdS(&cur[(size_t)PW_SCREEN0 * N + i]), headScreen1 = LdS(&cur[(size_t)PW_SCREEN1 * N + i]);
+    LMC_PIN3(headTime, headScreen0, headScreen1);
     prof.Mark(PR_PROLOGUE);
     // ---- proposal offsets
     const bool mala = S.opt.mala && !(rng.Uniform() < S.opt.uniformMixingProbability);  // mutation_mala.h:46-51
@@ -497,7 +501,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         OffsetCursor off{L, offBase};
         PssSink qs{L, shortState};
         NormalDist normDist(0.0f, S.opt.discreteStdDev);
-        const float time = Modulo1(LdS(&cur[(size_t)PW_TIME * N + i]) + normDist(rng));
+        const float time = Modulo1(headTime + normDist(rng));
         StS(&prop[(size_t)PW_TIME * N + i], time);
         StS(&prop[(size_t)PW_CAMDEPTH * N + i], __int_as_float(c)), StS(&prop[(size_t)PW_LGTDEPTH * N + i], __int_as_float(l));
         StS(&prop[(size_t)PW_CAMCOUNT * N + i], __int_as_float(camCount)), StS(&prop[(size_t)PW_LGTCOUNT * N + i], __int_as_float(lgtCount));
@@ -511,8 +515,8 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         int lgtLight = -1;
         bool lightPhase = false;
         auto BeginCamera = [&]() {  // EmitFromCamera with the perturbed screen position, path.cpp:2032-2038
-            const float screen0 = Modulo1(LdS(&cur[(size_t)PW_SCREEN0 * N + i]) + off.Pop());
-            const float screen1 = Modulo1(LdS(&cur[(size_t)PW_SCREEN1 * N + i]) + off.Pop());
+            const float screen0 = Modulo1(headScreen0 + off.Pop());
+            const float screen1 = Modulo1(headScreen1 + off.Pop());
             StS(&prop[(size_t)PW_SCREEN0 * N + i], screen0), StS(&prop[(size_t)PW_SCREEN1 * N + i], screen1);
             qs.Push(screen0), qs.Push(screen1);
             screenPos = V2{screen0, screen1};
@@ -690,7 +694,9 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
         const int n = A.curSplatCount[i];
         for (int k = 0; k < n; k++) {
             const float *p = A.curSplat + ((size_t)k * SPLAT_WORDS) * N + i;
-            Splat(film, V2{p[0], p[N]}, (1.0f - a) * V3{p[2 * N], p[3 * N], p[4 * N]});
+            float s0 = p[0], s1 = p[N], s2 = p[2 * N], s3 = p[3 * N], s4 = p[4 * N];
+            LMC_PIN5(s0, s1, s2, s3, s4);  // one round trip for the pending splat's five words
+            Splat(film, V2{s0, s1}, (1.0f - a) * V3{s2, s3, s4});
         }
     }
     const V3 smallSplat = mala ? (pc.contrib * P.normalization) / pc.lsScore : pc.contrib * (P.normalization / pc.lsScore);

@@ -11,7 +11,7 @@ timeout 400 python bench.py 2>"$OUT/bench_default.err" | tail -1 > "$OUT/bench_d
 timeout 400 python bench.py --steps 256 --warmup 0 --no-cpu-baseline --no-rmse --no-configs 2>/dev/null | tail -1 > "$OUT/bench_full_run_256_steps.json"
 # --gpus N without N devices: refused (exit code 2, message on stderr, no JSON line); the in-process job itself with the bring-up switch
 python bench.py --gpus 2 --chains 65536 --steps 8 --warmup 4 > "$OUT/bench_gpus2_refused.out" 2> "$OUT/bench_gpus2_refused.err"; echo "exit code $?" >> "$OUT/bench_gpus2_refused.err"
-LMC_BENCH_OVERSUBSCRIBE=1 timeout 400 python bench.py --gpus 2 --chains 262144 --steps 20 --warmup 30 2>/dev/null | tail -1 > "$OUT/bench_inprocess_2_ranks_one_device.json"
+LMC_BENCH_OVERSUBSCRIBE=1 timeout 400 python bench.py --gpus 2 --in-process --chains 262144 --steps 20 --warmup 30 2>/dev/null | tail -1 > "$OUT/bench_inprocess_2_ranks_one_device.json"
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kstats && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-rmse > "$OUT/rocprof_bench.log" 2>&1
   f=$(find /tmp/kstats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" )
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kstats2 && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats2 -- python "$ROOT/bench.py" --no-cpu-baseline --no-rmse --steps 20 --warmup 5 > "$OUT/rocprof_bench_driver.log" 2>&1
