@@ -102,8 +102,28 @@ struct PcgJumpTable {
 #if defined(__HIPCC__)
 __device__ __constant__ const PcgJumpTable c_pcgJump{};
 #endif
+#if defined(LMC_RNG_JUMP_LDS) && defined(__HIP_DEVICE_COMPILE__)
+// A translation unit that defines LMC_RNG_JUMP_LDS (the lean small-step launch) keeps the 1 KB of jump constants in LDS: a draw's look-up then is an LDS
+// read instead of a vector-memory load -- and a vector-memory load's wait (`vmcnt` retires in order) is also a wait for every load issued before
+// it, i.e. for the step's prefetched path words on their way from HBM.  The kernel fills the table once per block (PcgJumpLdsInit + barrier).
+__device__ __forceinline__ PcgJump *PcgJumpLds() {
+    __shared__ PcgJump t[64];
+    return t;
+}
+__device__ __forceinline__ void PcgJumpLdsInit() {
+    if (threadIdx.x < 64) PcgJumpLds()[threadIdx.x] = c_pcgJump.j[threadIdx.x];
+    __syncthreads();
+}
+#endif
+#if defined(LMC_RNG_JUMP_LDS) && defined(__HIP_DEVICE_COMPILE__)
+#define LMC_RNG_JUMP_INIT() lmcd::PcgJumpLdsInit()
+#else
+#define LMC_RNG_JUMP_INIT() ((void)0)  // this translation unit (or the host pass) reads the constants from memory
+#endif
 LMC_HD PcgJump PcgJumpOf(unsigned k) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(LMC_RNG_JUMP_LDS) && defined(__HIP_DEVICE_COMPILE__)
+    return PcgJumpLds()[k];
+#elif defined(__HIP_DEVICE_COMPILE__)
     return c_pcgJump.j[k];
 #else
     static const PcgJumpTable t{};

@@ -135,7 +135,7 @@ struct DScene {
     const float *areaFunc, *areaCdf;
     const float *lightFunc, *lightCdf;
     float lightFuncInt, lightWeightSum;
-    int numTris, numNodes, numMeshes, numLights, envLight;
+    int numTris, numNodes, numMeshes, numLights, envLight, numMaterials;
     int glossy;  // any non-Lambertian BSDF: selects the kernel instantiations that carry the Phong / rough-dielectric code
     DEnv env;
     DCamera cam;

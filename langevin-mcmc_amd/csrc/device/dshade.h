@@ -76,9 +76,34 @@ LMC_D float PickLightProb(const DScene &S, int light) { return S.lights[light].s
 LMC_D const DMaterial &MaterialOfTri(const DScene &S, int tri) { return S.materials[S.tris[tri].material]; }
 // ... the record by value, all the words the instantiation reads in ONE round of loads (dscene.h LMC_PIN: through the reference above every field
 // was fetched where it is first used, a dependent round trip each -- `twoSided` behind the cosine test, Ks / exponent / KsWeight one after the other)
+#if defined(LMC_MAT_LDS) && defined(__HIP_DEVICE_COMPILE__)
+// A/B build option, measured and NOT taken (profiles/r05_aj_ab_material_records_in_lds_rejected.jsonl: veach-door LMC -4.5 %, full-material torus -2 %, headline
+// -1 %: 29 LDS reads per BSDF evaluation cost more than the two vector loads they replace).  A translation unit that defines LMC_MAT_LDS keeps the scene's first LMC_MAT_LDS_MAX material records (116 B each; the torus
+// scene has 7, the veach-door scene 12) in LDS, filled once per block: a BSDF's parameters then are LDS reads, outside the in-order `vmcnt` queue
+// of the vector-memory loads (drng.h LMC_RNG_JUMP_LDS has the reasoning).  A scene with more materials reads the rest from memory as before.
+constexpr int LMC_MAT_LDS_MAX = 32;
+__device__ __forceinline__ DMaterial *MaterialLds() {
+    __shared__ DMaterial t[LMC_MAT_LDS_MAX];
+    return t;
+}
+__device__ __forceinline__ void MaterialLdsInit(const DScene &S) {
+    const int words = min(S.numMaterials, LMC_MAT_LDS_MAX) * (int)(sizeof(DMaterial) / 4);
+    const int *src = reinterpret_cast<const int *>(S.materials);
+    int *dst = reinterpret_cast<int *>(MaterialLds());
+    for (int w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    __syncthreads();
+}
+#define LMC_MAT_LDS_INIT(S) lmcd::MaterialLdsInit(S)
+#else
+#define LMC_MAT_LDS_INIT(S) ((void)0)
+#endif
 template <bool GLOSSY>
 LMC_D DMaterial LoadMaterial(const DScene &S, int tri) {
-    DMaterial m = S.materials[S.tris[tri].material];
+    const int mi = S.tris[tri].material;
+#if defined(LMC_MAT_LDS) && defined(__HIP_DEVICE_COMPILE__)
+    if (mi < LMC_MAT_LDS_MAX) return MaterialLds()[mi];
+#endif
+    DMaterial m = S.materials[mi];
     LMC_PIN4(m.type, m.twoSided, m.Kd.bitmap, m.Kd.value[0]);
     LMC_PIN4(m.Kd.value[1], m.Kd.value[2], m.Kd.sScale, m.Kd.tScale);
     if constexpr (GLOSSY) {

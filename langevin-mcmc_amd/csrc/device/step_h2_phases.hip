@@ -7,6 +7,9 @@
 //   [k_h2_hess, k_h2_gauss on stage 1: the proposal's Gaussian and px]
 //   k_h2_finish   acceptance, splats, accept / reject (mlt.cpp:103-170), the next step's kind
 // The RNG order of a chain is the reference's: nothing between these draws consumes numbers (the Gaussians draw nothing).
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include <cstdlib>
 #include <cstring>
 
@@ -35,6 +38,7 @@ __device__ __forceinline__ float *H2GaussRec(const H2Arrays &H, int N, int i, bo
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount) {
+    LMC_RNG_JUMP_INIT();
     StepStats st;
     const int total = *listCount, N = A.N;
     const float sigma = S.opt.perturbStdDev;
@@ -88,6 +92,8 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
 
 template <bool LDS_STACK>
 __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount) {
+    LMC_RNG_JUMP_INIT();
+    LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
     StepStats st;
     const int total = *listCount, N = A.N;
@@ -168,6 +174,8 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
 // stage 1 serialised from that buffer afterwards; offsets and traversal stack in LDS ([word][lane]); no DPath in private memory.  The form for
 // every render whose tree fits the LDS stack and that does not use light-coordinate sampling (LMC_H2_PERTURB=generic selects the kernel above).
 __global__ void __launch_bounds__(64, 2) k_h2_perturb_streamed(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount, int stackWords) {
+    LMC_RNG_JUMP_INIT();
+    LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
     StepStats st;
     const int total = *listCount, N = A.N;
@@ -238,6 +246,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb_streamed(DScene S, ChainAr
 }
 
 __global__ void __launch_bounds__(64) k_h2_finish(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, H2Arrays H, const int *list, const int *listCount) {
+    LMC_RNG_JUMP_INIT();
     StepStats st;
     const int total = *listCount;
     const size_t N = A.N;

@@ -49,6 +49,8 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
 template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, int MUX = 0, bool QUANT = false>
 __global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
+    LMC_RNG_JUMP_INIT();
+    LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
     StepStats st;
     const int total = *listCount;

@@ -1,4 +1,7 @@
 // k_step<true, false, false>: see step_kernel.h
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include "step_kernel.h"
 
 using namespace lmcd;

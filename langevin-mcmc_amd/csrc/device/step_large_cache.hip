@@ -1,5 +1,8 @@
 // k_step<true, false, false, ., ., MUX = 2>: LargeStepCache (`samplecache` with mala, mutation_large_cache.h:22-141), a TU of its own like
 // step_large_mux.hip
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include "step_kernel.h"
 
 using namespace lmcd;

@@ -1,5 +1,8 @@
 // k_step<true, false, false, ., ., MUX = true>: the multiplexed large step (`largestepmultiplexed`, mutation_large.h:45-58,87-102), a TU of
 // its own so that the default large step keeps its registers and the two compile in parallel
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include "step_kernel.h"
 
 using namespace lmcd;

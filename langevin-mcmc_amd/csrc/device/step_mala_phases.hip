@@ -11,6 +11,9 @@
 // While a dimension's cache fills, a chain of that dimension evaluates one or two gradients per small step; as a single lane-per-chain launch
 // beside the hot launch those few chains held SIMD slots for 2 ms per step.  The RNG order of a chain is the reference's:
 // nothing between these draws consumes numbers.
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include "dpipe.h"
 
 using namespace lmcd;
@@ -25,6 +28,7 @@ __device__ __forceinline__ bool WantsGradient(const DCache &cache, const StepPar
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+    LMC_RNG_JUMP_INIT();
     const DCache &cache = *cachePtr;
     const int total = *listCount, N = A.N;
     const float sigma = S.opt.perturbStdDev;
@@ -67,6 +71,8 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
 #endif
 template <bool LDS_STACK, bool GLOSSY>
 __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+    LMC_RNG_JUMP_INIT();
+    LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
     const DCache &cache = *cachePtr;
     StepStats st;
@@ -141,6 +147,7 @@ __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, c
 }
 
 __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cachePtr, ChainArrays A, Film film, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+    LMC_RNG_JUMP_INIT();
     const DCache &cache = *cachePtr;
     StepStats st;
     const int total = *listCount;

@@ -5,6 +5,9 @@
 // and took 3.6 ms per wave even with the gradient program skipped (profiles/r02_h_*) -- which remains the fallback for BVHs
 // deeper than the LDS traversal stack and for cache trees deeper than the LDS search frames.
 #define LMC_LEAN_GRAD
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include "dsmall.h"
 #include "step_kernel.h"
 
@@ -16,6 +19,8 @@ template <bool GLOSSY>
 #endif
 __global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                       const int *listCount, NextLists next, float *gradBuf, int gradStride, int stackWords) {
+    LMC_RNG_JUMP_INIT();
+    LMC_MAT_LDS_INIT(S);
     extern __shared__ float lds[];
     StepStats st;
     const int total = *listCount;

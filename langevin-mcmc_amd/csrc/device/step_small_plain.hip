@@ -8,6 +8,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef LMC_NO_RNG_JUMP_LDS
+#define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
+#endif
 #include "dsmall.h"
 #include "step_kernel.h"
 
@@ -23,6 +26,8 @@ template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = f
 __global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                     const int *listCount, NextLists next, int stackWords) {
     extern __shared__ float lds[];
+    LMC_RNG_JUMP_INIT();
+    LMC_MAT_LDS_INIT(S);
     StepStats st;
     const int total = *listCount;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;

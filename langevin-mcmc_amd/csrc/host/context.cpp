@@ -365,7 +365,7 @@ static void UploadScene(lmc_ctx *c) {
     S.nodes = c->nodes.p, S.qnodes = quant ? c->qnodes.p : nullptr, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
     S.areaFunc = c->areaFunc.p, S.areaCdf = c->areaCdf.p, S.lightFunc = c->lightFunc.p, S.lightCdf = c->lightCdf.p;
     S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
-    S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size();
+    S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size(), S.numMaterials = (int)mats.size();
     S.envLight = sc.envLight;
     S.glossy = glossy;
     if (sc.envLight >= 0) {
