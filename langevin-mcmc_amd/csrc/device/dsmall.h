@@ -544,9 +544,16 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             BeginCamera();
         }
         int depth = 0;  // vertex index inside the current sub-path
+#ifdef LMC_NO_VERTEX_PREFETCH
+        bool firstSegment = true;
+#endif
         // every iteration = one path segment; `break` = the step's contribution is decided (ok) or the path died
         while (lightPhase || depth < camCount) {
             prof.Mark(PR_SHADE);  // the previous segment's vertex work (the first time: the sub-path head)
+#ifdef LMC_NO_VERTEX_PREFETCH  // A/B build: every vertex record but the first is fetched where it is used (twelve registers fewer across the traversal)
+            DVertex sv = firstSegment ? nextV : LoadVertex(cur, N, i, lightPhase, depth);
+            firstSegment = false;
+#else
             DVertex sv = nextV;
             {   // the record of the vertex the next iteration perturbs (if the path goes on) is requested now: the path is
                 // streamed from HBM, and its round trip then runs behind this segment's traversal instead of in front of the next
@@ -555,6 +562,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 if (lightPhase && depth == lgtCount - 1) nl = false, nd = 0;
                 if (nl ? nd < lgtCount : nd < camCount) nextV = LoadVertex(cur, N, i, nl, nd);
             }
+#endif
             SurfHit hit;
             hit.tri = -1;
             hit.st = V2{0.f, 0.f};

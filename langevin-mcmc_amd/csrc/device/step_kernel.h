@@ -42,12 +42,17 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
 // LMC_STEP_WAVES: waves per SIMD the register allocation of these launches aims at.  Unconstrained, the glossy large-step
 // instantiation takes 256 VGPRs + 19 AGPRs = ONE wave per SIMD; with a budget of 256 (48 B more spills) two waves fit and the launch
 // is 2.9 x faster on the full-material torus (9.65 -> 3.32 ms), 1.3 x on the door scene (profiles/r03_b_ab_large_step_waves.jsonl);
-// three waves (168 VGPRs, 384 B of spills) give nothing more.
+// three waves (168 VGPRs, 384 B of spills) gave nothing more in round 3.  Round 5, after the load pinning (dscene.h LMC_PIN), measured again
+// (profiles/r05_ao_ab_waves_per_simd.jsonl): the GLOSSY large-step launch compiled for three waves: veach-door LMC +3 %, H2MC +2.3 % (a 168-register wave
+// fits beside two of the lean launch's), headline unchanged -- the Lambertian instantiation stays at two.
 #ifndef LMC_STEP_WAVES
 #define LMC_STEP_WAVES 2
 #endif
+#ifndef LMC_STEP_WAVES_GLOSSY_LARGE
+#define LMC_STEP_WAVES_GLOSSY_LARGE 3
+#endif
 template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, int MUX = 0, bool QUANT = false>
-__global__ void __launch_bounds__(256, LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
+__global__ void __launch_bounds__(256, (GLOSSY && WITH_LARGE && !WITH_SMALL && LDS_STACK) ? LMC_STEP_WAVES_GLOSSY_LARGE : LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);

@@ -23,7 +23,13 @@ template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = f
 #ifndef LMC_LEAN_WAVES
 #define LMC_LEAN_WAVES 2  // waves per SIMD the register allocation aims at
 #endif
-__global__ void __launch_bounds__(256, LMC_LEAN_WAVES) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
+#ifndef LMC_LEAN_WAVES_GLOSSY_LIGHTLESS
+// ... of the glossy instantiation without light sub-paths (full-material scenes lit by their environment map: BASELINE configs[2]): three.  Measured
+// (profiles/r05_ao_ab_waves_per_simd.jsonl): that workload +4 %; the glossy instantiation WITH light sub-paths (veach-door) loses 3 % at three waves and the
+// Lambertian one 5 % (it has no registers to give), so they stay at two.
+#define LMC_LEAN_WAVES_GLOSSY_LIGHTLESS 3
+#endif
+__global__ void __launch_bounds__(256, (GLOSSY && LIGHTLESS) ? LMC_LEAN_WAVES_GLOSSY_LIGHTLESS : LMC_LEAN_WAVES) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                     const int *listCount, NextLists next, int stackWords) {
     extern __shared__ float lds[];
     LMC_RNG_JUMP_INIT();
