@@ -215,9 +215,11 @@ struct LdsStackT {
     static constexpr bool kQuant = QUANT;
     int *base;   // &lds[threadIdx.x]
     int stride;  // blockDim.x
-    int sp;
+    int sp;      // the top's word offset from base = entries x stride, advanced by additions: with an entry COUNT every push and pop paid a 32-bit
+                 // integer multiply (v_mul_lo_u32, a quarter-rate instruction) for its address -- four per node visit of the closest-hit walk (hipcc -S)
     LMC_D void Reset() { sp = 0; }
     LMC_D bool Empty() const { return sp == 0; }
+#ifdef LMC_STACK_MUL  // A/B build: the entry-count form
     LMC_D void Push(int v) {
         if (sp < BVH_LDS_STACK) base[sp * stride] = v, sp++;
     }
@@ -225,6 +227,15 @@ struct LdsStackT {
         --sp;
         return base[sp * stride];
     }
+#else
+    LMC_D void Push(int v) {
+        if (sp < BVH_LDS_STACK * stride) base[sp] = v, sp += stride;
+    }
+    LMC_D int Pop() {
+        sp -= stride;
+        return base[sp];
+    }
+#endif
 };
 
 // closest hit: smallest t in [tnear, tfar]; ties -> lower global triangle id (tree-independent answer).
