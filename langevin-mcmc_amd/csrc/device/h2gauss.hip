@@ -146,15 +146,24 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
         float sq = 0.f;
         if (act) {
             const float gk = o[k];
+            // the row of the symmetrised matrix: all its loads in flight together (a loop of "load, wait, store to LDS" was n dependent round trips)
+            float hrow[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int cc = min(c, n - 1);
+                hrow[c] = cc >= k ? o[H2_OUT_HESS + k * n + cc] : o[H2_OUT_HESS + cc * n + k];
+            }
             fin = isfinite(gk);
             grad[k] = gk;
-            for (int c = 0; c < n; c++) {
-                const float h = c >= k ? o[H2_OUT_HESS + k * n + c] : o[H2_OUT_HESS + c * n + k];
-                fin = fin && isfinite(h);
-                A[k * GS + c] = h;
-                V[k * GS + c] = (k == c) ? 1.0f : 0.0f;
-                sq += h * h;
-            }
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                if (c < n) {
+                    const float h = hrow[c];
+                    fin = fin && isfinite(h);
+                    A[k * GS + c] = h;
+                    V[k * GS + c] = (k == c) ? 1.0f : 0.0f;
+                    sq += h * h;
+                }
         }
         const unsigned long long finMask = __ballot(fin || !act);
         const bool allFinite = ((finMask >> (16 * g)) & 0xffffull) == 0xffffull;  // mutation_h2mc.h:80-85: any non-finite entry zeroes gradient and Hessian

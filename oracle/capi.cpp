@@ -431,6 +431,8 @@ int orc_cache_points(void *h, int dim, float *out, int cap) {
 
 // H2MC Gaussian of one state (h2mc.cpp:70-142 through oracle/h2mc_serial.h): out = mean[dim], covL[dim*dim],
 // invCov[dim*dim], logDet
+// pair j of round r of the round-robin Jacobi order (h2mc_serial.h JacobiRoundPair; the device's h2gauss.hip RoundPair is its twin)
+void orc_jacobi_round_pair(int m, int r, int j, int *p, int *q) { lmcd::JacobiRoundPair(m, r, j, *p, *q); }
 void orc_h2mc_gaussian(int dim, float sigma, float sc, const float *grad, const float *hess, float *out) {
     lmcd::H2MCParam p = lmcd::MakeH2MCParam(sigma);
     std::vector<float> work((size_t)dim * dim + 4 * dim), h(hess, hess + (size_t)dim * dim);

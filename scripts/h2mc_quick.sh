@@ -1,4 +1,4 @@
-# usage (GPU box): scripts/debug/h2_rates_quick.sh <tag> [tests]  -- H2MC rates of the two shipped scenes at 2^20 chains, twice, + a kernel trace of one door step
+# usage (GPU box): scripts/h2mc_quick.sh <tag> [tests]  -- H2MC rates of the two shipped scenes at 2^20 chains, twice, + a kernel trace of one door step
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
 if [ "${2:-}" = tests ]; then timeout 900 python -m pytest tests/test_gpu_h2mc.py tests/test_gpu_relocate.py -m gpu -q -x > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt; fi

@@ -29,7 +29,10 @@ steps_per_launch = None
 try:
     for ln in open(os.path.join(out, "pass1.log")):
         if ln.startswith("{") and '"roofline"' in ln:
-            steps_per_launch = json.loads(ln)["roofline"]["chain_steps_per_launch"]
+            r = json.loads(ln)["roofline"]
+            # under the counters the window's own figure can come out empty (the per-launch brackets are not collected); the serialised launches
+            # behind the window run the same work lists
+            steps_per_launch = r["chain_steps_per_launch"] or r.get("standalone", {}).get("chain_steps_per_launch")
 except Exception:
     pass
 d = {

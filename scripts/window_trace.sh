@@ -1,4 +1,4 @@
-# usage (GPU box): scripts/debug/window_trace.sh <tag> [step numbers...]  -- kernel trace of the first 30 steps of the headline workload, issued without a
+# usage (GPU box): scripts/window_trace.sh <tag> [step numbers...]  -- kernel trace of the first 30 steps of the headline workload, issued without a
 # per-step wait (as bench.py's timed region does); prints the timelines of the steps asked for (default 12 and 27)
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $O; shift

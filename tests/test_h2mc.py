@@ -57,6 +57,27 @@ def test_h2mc_gaussian_against_numpy(L):
         assert np.allclose(out[dim:dim + dim * dim].reshape(dim, dim), np.eye(dim) * sigma) and np.all(out[:dim] == 0)
 
 
+def test_round_robin_jacobi_order_visits_every_pair_once_per_sweep(L):
+    """The eigen-solve of the H2MC Gaussian (oracle/h2mc_serial.h, device h2gauss.hip) rotates in ROUND-ROBIN order: m - 1 rounds of m / 2 disjoint
+    pairs.  A sweep must visit every pair (p < q) exactly once, and the pairs of a round must not share an index -- that is what makes a round one
+    similarity transform whose rotations can be applied side by side (the device does) or one after the other (the oracle does) with the same result."""
+    L.orc_jacobi_round_pair.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    for m in range(2, 18, 2):
+        seen = set()
+        for r in range(m - 1):
+            used = set()
+            for j in range(m // 2):
+                p, q = ctypes.c_int(), ctypes.c_int()
+                L.orc_jacobi_round_pair(m, r, j, ctypes.byref(p), ctypes.byref(q))
+                assert 0 <= p.value < q.value < m
+                assert p.value not in used and q.value not in used, (m, r, j)
+                used |= {p.value, q.value}
+                assert (p.value, q.value) not in seen, (m, r, j)
+                seen.add((p.value, q.value))
+            assert len(used) == m
+        assert len(seen) == m * (m - 1) // 2
+
+
 def test_hessian_program_matches_reference_h2mc_programs(L):
     """The product's path program differentiated twice (nested duals, pathfunc.h PathFuncHess; host instantiation of the same
     header the kernels compile) against the reference's generated H2MC programs evaluate_path_bidir_<c>_<l>_static_derv
