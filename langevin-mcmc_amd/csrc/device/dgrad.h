@@ -30,9 +30,17 @@ struct StridedOut {
     }
 };
 
+// The serialisers copy scene records into a state's record word by word.  Through references every `o.Put(T.p0[k])` was "load, wait, store" --
+// the store may alias the next load for all the compiler knows, so the next load was not even issued before it: ~450 dependent round trips
+// per serialised state (scripts/isa_load_waits.py on k_h2_perturb_streamed: 36 inlined copies x 46 words, every load waited for on its own).
+// The records are therefore copied by value first, their loads pinned together (dscene.h LMC_PIN), and written out afterwards.
 LMC_D void SerializeTri(const DScene &S, int tri, StridedOut &o) {  // trianglemesh.cpp:145-187
-    const TriData &T = S.tris[tri];
-    const DMesh &M = S.meshes[T.mesh];
+    TriData T = S.tris[tri];
+    LMC_PIN4(T.p0[0], T.e1[1], T.e2[2], T.n0[0]);
+    LMC_PIN4(T.n1[1], T.n2[2], T.st[0], T.st[3]);
+    LMC_PIN2(T.st[5], T.mesh);
+    DMesh M = S.meshes[T.mesh];
+    LMC_PIN2(M.hasST, M.invTotalArea);
     o.Put(0.f);  // ShapeType::TriangleMesh
     o.Put(0.f);  // isMoving
     for (int rep = 0; rep < 2; rep++) {
@@ -52,7 +60,7 @@ LMC_D void SerializeTri(const DScene &S, int tri, StridedOut &o) {  // trianglem
 }
 
 LMC_D void SerializeBSDF(const DScene &S, int tri, V2 st, StridedOut &o) {  // bsdf.cpp:7-11 (10-float slot)
-    const DMaterial &m = MaterialOfTri(S, tri);
+    const DMaterial m = LoadMaterial<true>(S, tri);  // by value, one round of loads (dshade.h)
     int start = o.n;
     o.Put((float)m.type);
     if (m.type == BSDF_LAMBERTIAN) {
@@ -74,7 +82,9 @@ LMC_D void SerializeBSDF(const DScene &S, int tri, V2 st, StridedOut &o) {  // b
 }
 
 LMC_D void SerializeLight(const DScene &S, int light, int lPrimID, StridedOut &o) {  // 56-float slot (light.cpp:7-10)
-    const DLight &L = S.lights[light];
+    DLight L = S.lights[light];
+    LMC_PIN4(L.type, L.pos[0], L.pos[2], L.intensity[1]);
+    LMC_PIN4(L.intensity[2], L.mesh, L.radiance[0], L.radiance[2]);
     int start = o.n;
     o.Put((float)L.type);
     if (L.type == LIGHT_POINT) {  // pointlight.cpp:14-18
@@ -88,15 +98,24 @@ LMC_D void SerializeLight(const DScene &S, int light, int lPrimID, StridedOut &o
         for (int k = 0; k < 30; k++) o.Put(E.xformBlocks[k]);
         int col = lPrimID % E.W, row = lPrimID / E.W;
         const float *cdfCol = E.cdfCols + (long)row * (E.W + 1);
-        o.Put(cdfCol[col]), o.Put(cdfCol[col + 1]);
-        o.Put(E.cdfRows[row]), o.Put(E.cdfRows[row + 1]);
+        // every look-up first, pinned together, then the stores
+        float cc0 = cdfCol[col], cc1 = cdfCol[col + 1], cr0 = E.cdfRows[row], cr1 = E.cdfRows[row + 1];
+        V3 t00 = EnvRepAt(E, col, row), t10 = EnvRepAt(E, col + 1, row), t01 = EnvRepAt(E, col, row + 1), t11 = EnvRepAt(E, col + 1, row + 1);
+        float rw0 = E.rowWeights[Clampi(row, 0, E.H - 1)], rw1 = E.rowWeights[Clampi(row + 1, 0, E.H - 1)];
+        LMC_PIN4(cc0, cc1, cr0, cr1);
+        LMC_PIN3(t00.x, t00.y, t00.z);
+        LMC_PIN3(t10.x, t10.y, t10.z);
+        LMC_PIN3(t01.x, t01.y, t01.z);
+        LMC_PIN3(t11.x, t11.y, t11.z);
+        LMC_PIN2(rw0, rw1);
+        o.Put(cc0), o.Put(cc1);
+        o.Put(cr0), o.Put(cr1);
         o.Put((float)col), o.Put((float)row);
         o.Put(E.pixelSize[0]), o.Put(E.pixelSize[1]);
-        V3 t00 = EnvRepAt(E, col, row), t10 = EnvRepAt(E, col + 1, row), t01 = EnvRepAt(E, col, row + 1), t11 = EnvRepAt(E, col + 1, row + 1);
         o.Put(t00.x), o.Put(t00.y), o.Put(t00.z), o.Put(t10.x), o.Put(t10.y), o.Put(t10.z);
         o.Put(t01.x), o.Put(t01.y), o.Put(t01.z), o.Put(t11.x), o.Put(t11.y), o.Put(t11.z);
-        o.Put(E.rowWeights[Clampi(row, 0, E.H - 1)]);
-        o.Put(E.rowWeights[Clampi(row + 1, 0, E.H - 1)]);
+        o.Put(rw0);
+        o.Put(rw1);
         o.Put(E.normalization);
     }
     o.Skip(56 - (o.n - start));

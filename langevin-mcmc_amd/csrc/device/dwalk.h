@@ -182,12 +182,17 @@ LMC_D unsigned H2SerializeStreamed(const DScene &S, const SoAPathView P, float *
 #endif
     };
     int pi = 0;
-    rec[pi++] = P.HeadF(PW_TIME);
+    // the head words in one round of loads (a store to the record between two loads keeps the second from being issued: dgrad.h)
+    float hTime = P.HeadF(PW_TIME), hLens0 = P.HeadF(PW_LENS0), hLens1 = P.HeadF(PW_LENS1), hScreen0 = P.HeadF(PW_SCREEN0), hScreen1 = P.HeadF(PW_SCREEN1);
+    LMC_PIN5(hTime, hLens0, hLens1, hScreen0, hScreen1);
+    rec[pi++] = hTime;
     rec[H2_REC_C] = __int_as_float(camDepth), rec[H2_REC_L] = __int_as_float(lgtDepth);
-    o.Put(P.HeadF(PW_LENS0)), o.Put(P.HeadF(PW_LENS1)), o.Put(0.f);
+    o.Put(hLens0), o.Put(hLens1), o.Put(0.f);
     if (lgtDepth > 1) {
         const int lgtLight = P.HeadI(PW_LGTLIGHT);
-        rec[pi++] = P.HeadF(PW_LGTPOS0), rec[pi++] = P.HeadF(PW_LGTPOS1), rec[pi++] = P.HeadF(PW_LGTDIR0), rec[pi++] = P.HeadF(PW_LGTDIR1);
+        float lp0 = P.HeadF(PW_LGTPOS0), lp1 = P.HeadF(PW_LGTPOS1), ld0 = P.HeadF(PW_LGTDIR0), ld1 = P.HeadF(PW_LGTDIR1);
+        LMC_PIN4(lp0, lp1, ld0, ld1);
+        rec[pi++] = lp0, rec[pi++] = lp1, rec[pi++] = ld0, rec[pi++] = ld1;
         o.Put(PickLightProb(S, lgtLight));
         SerializeLight(S, lgtLight, P.HeadI(PW_LGTPRIM), o);
         for (int d = 0; d < lgtCount; d++) {
@@ -202,7 +207,7 @@ LMC_D unsigned H2SerializeStreamed(const DScene &S, const SoAPathView P, float *
             o.Put(v.rrWeight);
         }
     }
-    rec[pi++] = P.HeadF(PW_SCREEN0), rec[pi++] = P.HeadF(PW_SCREEN1);
+    rec[pi++] = hScreen0, rec[pi++] = hScreen1;
     for (int d = 0; d < camCount; d++) {
         const DVertex v = P.Vert(false, d);
         Sig(v);
