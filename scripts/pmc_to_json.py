@@ -32,7 +32,9 @@ try:
             r = json.loads(ln)["roofline"]
             # under the counters the window's own figure can come out empty (the per-launch brackets are not collected); the serialised launches
             # behind the window run the same work lists
-            steps_per_launch = r["chain_steps_per_launch"] or r.get("standalone", {}).get("chain_steps_per_launch")
+            # the lean kernel's own work list: the figure of the serialised launches behind the window (under the counters the launches are serialised
+            # and the window's "dominant kernel" can come out as another launch, or empty)
+            steps_per_launch = r.get("standalone", {}).get("chain_steps_per_launch") or r["chain_steps_per_launch"]
 except Exception:
     pass
 d = {
