@@ -4,6 +4,10 @@
 // walking the six passes of its own chain's state over a record in private memory (dgrad.h ComputeGradient, which remains the form of the
 // fall-back kernels).  Forward-mode components never mix and this translation unit keeps the strict arithmetic of the step kernels, so a
 // gradient is bit-identical to ComputeGradient's.  The state's serialised record is staged in LDS once per wave and read by broadcast.
+#ifndef LMC_NO_PF_VEC2
+#define LMC_PF_VEC2  // pathfunc.h: Dual<2> on two-wide vectors (packed FP32 instructions); per component the same operations in the same order, so the
+                     // gradient stays bit-identical to ComputeGradient's (tests/test_gpu_parity.py::test_cache_fill_pipeline_equals_the_single_launch_form)
+#endif
 #include "dh2coop.h"
 #include "pathfunc.h"
 #include "kernels.h"

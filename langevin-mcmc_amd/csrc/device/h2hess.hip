@@ -10,6 +10,9 @@
 #define LMC_PF_CONTRACT  // the dual-number arithmetic of this translation unit may fuse a * b + c (pathfunc.h)
 #define LMC_PF_FASTMATH  // ... and sin / cos / exp / log / pow are the hardware's approximate instructions
 #endif
+#ifndef LMC_NO_PF_VEC2
+#define LMC_PF_VEC2  // the inner Dual<2> of the second-order type on two-wide vectors: packed FP32 instructions without the shuffles (pathfunc.h)
+#endif
 #include "dh2coop.h"
 #include "pathfunc.h"
 #include "kernels.h"

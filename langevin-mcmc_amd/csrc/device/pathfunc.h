@@ -54,6 +54,19 @@ struct DualS {
     S v;
     S d[N];
 };
+#if defined(LMC_PF_VEC2) && defined(__HIP_DEVICE_COMPILE__)
+// LMC_PF_VEC2 (h2hess.hip): the two derivative components of a Dual<2> live in ONE two-wide vector value, and its arithmetic (below, after the
+// generic operators) is written on whole vectors.  gfx950 has packed FP32 instructions (v_pk_mul / v_pk_add / v_pk_fma_f32: two lanes' worth per
+// issue); from the element-wise loops the compiler's SLP pass did form them, but out of whatever scalars happened to pair up, and paid for it in
+// v_mov_b32 that assemble the operand pairs -- 22 k of the Hessian kernel's 80 k instructions (hipcc -S, profiles/r05_ax_*).  Same arithmetic per
+// component, same order of operations.
+typedef float lmc_f2 __attribute__((ext_vector_type(2)));
+template <>
+struct DualS<2, float> {
+    float v;
+    lmc_f2 d;
+};
+#endif
 template <int N>
 using Dual = DualS<N, float>;
 
@@ -130,6 +143,24 @@ template <int N, class S> LMC_HD bool operator>(const DualS<N, S> &a, float b) {
 template <int N, class S> LMC_HD bool operator<(const DualS<N, S> &a, const DualS<N, S> &b) { return Val(a) < Val(b); }
 template <int N, class S> LMC_HD bool operator>(const DualS<N, S> &a, const DualS<N, S> &b) { return Val(a) > Val(b); }
 
+#if defined(LMC_PF_VEC2) && defined(__HIP_DEVICE_COMPILE__)
+// Dual<2> on whole vectors (non-template overloads: preferred over the generic element-wise templates above)
+typedef DualS<2, float> D2v;
+LMC_HD D2v Chain1(const D2v &a, const float &v, const float &dv) { D2v r; r.v = v; r.d = a.d * dv; return r; }
+LMC_HD D2v operator+(const D2v &a, const D2v &b) { D2v r; r.v = a.v + b.v; r.d = a.d + b.d; return r; }
+LMC_HD D2v operator-(const D2v &a, const D2v &b) { D2v r; r.v = a.v - b.v; r.d = a.d - b.d; return r; }
+LMC_HD D2v operator*(const D2v &a, const D2v &b) { D2v r; r.v = a.v * b.v; r.d = a.d * b.v + b.d * a.v; return r; }
+LMC_HD D2v operator/(const D2v &a, const D2v &b) {
+    D2v r;
+    const float inv = 1.0f / b.v;
+    r.v = a.v * inv;
+    r.d = (a.d - b.d * r.v) * inv;
+    return r;
+}
+LMC_HD D2v operator-(const D2v &a) { D2v r; r.v = -a.v; r.d = -a.d; return r; }
+LMC_HD D2v operator*(const D2v &a, float b) { D2v r; r.v = a.v * b; r.d = a.d * b; return r; }
+LMC_HD D2v operator*(float b, const D2v &a) { return a * b; }
+#endif
 LMC_HD float Detach(float x) { return x; }
 template <int N, class S> LMC_HD DualS<N, S> Detach(const DualS<N, S> &x) { return Lift<DualS<N, S>>::Of(Val(x)); }
 // chad's fabs / fmax are conditional expressions that pass their operand through (chad.h:1226-1244), and the code
@@ -191,6 +222,15 @@ LMC_DUAL_T Atan2(const DualS<N, S> &y, const DualS<N, S> &x) {
     for (int i = 0; i < N; i++) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * inv;
     return r;
 }
+#if defined(LMC_PF_VEC2) && defined(__HIP_DEVICE_COMPILE__)
+LMC_HD D2v Atan2(const D2v &y, const D2v &x) {
+    D2v r;
+    r.v = Atan2(y.v, x.v);
+    const float inv = 1.0f / (x.v * x.v + y.v * y.v);
+    r.d = (y.d * x.v - x.d * y.v) * inv;
+    return r;
+}
+#endif
 LMC_DUAL_T Fabs(const DualS<N, S> &a) { return Val(a) >= 0.f ? a : -a; }  // chad.h:1226-1234: x >= 0 ? x : -x
 LMC_DUAL_T Log(const DualS<N, S> &a) { return Chain1(a, S(Log(a.v)), S(1.0f / a.v)); }
 LMC_DUAL_T Exp(const DualS<N, S> &a) { S e = Exp(a.v); return Chain1(a, e, e); }

@@ -38,6 +38,7 @@ __device__ __forceinline__ float *H2GaussRec(const H2Arrays &H, int N, int i, bo
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     StepStats st;
     const int total = *listCount, N = A.N;
@@ -92,6 +93,7 @@ __global__ void __launch_bounds__(64) k_h2_begin(DScene S, ChainArrays A, StepPa
 
 template <bool LDS_STACK>
 __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb(DScene S, ChainArrays A, S
 // stage 1 serialised from that buffer afterwards; offsets and traversal stack in LDS ([word][lane]); no DPath in private memory.  The form for
 // every render whose tree fits the LDS stack and that does not use light-coordinate sampling (LMC_H2_PERTURB=generic selects the kernel above).
 __global__ void __launch_bounds__(64, 2) k_h2_perturb_streamed(DScene S, ChainArrays A, StepParams P, H2Arrays H, const int *list, const int *listCount, int stackWords) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
@@ -246,6 +249,7 @@ __global__ void __launch_bounds__(64, 2) k_h2_perturb_streamed(DScene S, ChainAr
 }
 
 __global__ void __launch_bounds__(64) k_h2_finish(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, H2Arrays H, const int *list, const int *listCount) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     StepStats st;
     const int total = *listCount;

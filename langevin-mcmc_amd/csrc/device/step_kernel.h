@@ -54,6 +54,7 @@ __device__ __forceinline__ void BlockReduceStats(const StepStats &st, unsigned l
 template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, bool GLOSSY, bool LDS_STACK = false, int MUX = 0, bool QUANT = false>
 __global__ void __launch_bounds__(256, (GLOSSY && WITH_LARGE && !WITH_SMALL && LDS_STACK) ? LMC_STEP_WAVES_GLOSSY_LARGE : LMC_STEP_WAVES) k_step(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list, const int *listCount,
                                               NextLists next, float *gradBuf, int gradStride) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];

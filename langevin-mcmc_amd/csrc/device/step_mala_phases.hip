@@ -28,6 +28,7 @@ __device__ __forceinline__ bool WantsGradient(const DCache &cache, const StepPar
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     const DCache &cache = *cachePtr;
     const int total = *listCount, N = A.N;
@@ -71,6 +72,7 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
 #endif
 template <bool LDS_STACK, bool GLOSSY>
 __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);
     extern __shared__ int ldsStack[];
@@ -147,6 +149,7 @@ __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, c
 }
 
 __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cachePtr, ChainArrays A, Film film, StepParams P, MalaPipe M, const int *list, const int *listCount) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     const DCache &cache = *cachePtr;
     StepStats st;

@@ -19,6 +19,7 @@ template <bool GLOSSY>
 #endif
 __global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                       const int *listCount, NextLists next, float *gradBuf, int gradStride, int stackWords) {
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);
     extern __shared__ float lds[];

@@ -32,6 +32,7 @@ template <bool USE_LDS_STACK, bool GLOSSY, bool PROF = false, bool LIGHTLESS = f
 __global__ void __launch_bounds__(256, (GLOSSY && LIGHTLESS) ? LMC_LEAN_WAVES_GLOSSY_LIGHTLESS : LMC_LEAN_WAVES) k_step_small(DScene S, const DCache *cache, ChainArrays A, Film film, StepParams P, const int *list,
                                                     const int *listCount, NextLists next, int stackWords) {
     extern __shared__ float lds[];
+    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
     LMC_MAT_LDS_INIT(S);
     StepStats st;
