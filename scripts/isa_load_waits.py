@@ -17,7 +17,7 @@ src, pat = args[0], args[1]
 maxd = int(args[2]) if len(args) > 2 and args[2].isdigit() else 8
 extra = [a for a in args[2:] if not a.isdigit()]
 out = os.path.join(tempfile.mkdtemp(prefix="isa_"), "k.s")
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result", "-gline-tables-only", "-S",
+cmd = ["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result", "-gline-tables-only", "-S",
        "--cuda-device-only", "-o", out, src] + extra
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 txt = open(out).read().split("\n")
