@@ -592,11 +592,17 @@ LMC_D void EnvSampleDirection(const DScene &S, V2 rnd, int &lPrimID, V3 &dirToLi
     float sinPhi = lsinf(phi), cosPhi = lcosf(phi), sinTheta = lsinf(theta), cosTheta = lcosf(theta);
     dirToLight = XformVector(E.toWorld, V3{sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta});
     float dx1 = tent.x, dx2 = 1.0f - tent.x, dy1 = tent.y, dy2 = 1.0f - tent.y;
-    V3 value1 = EnvAtLinear(E, col, row) * dx2 * dy2 + EnvAtLinear(E, col + 1, row) * dx1 * dy2;
-    V3 value2 = EnvAtLinear(E, col, row + 1) * dx2 * dy1 + EnvAtLinear(E, col + 1, row + 1) * dx1 * dy1;
-    value = value1 + value2;
+    // the four texels and the two row weights in one round of loads (dscene.h LMC_PIN: they were four + two dependent round trips)
+    V3 e00 = EnvAtLinear(E, col, row), e10 = EnvAtLinear(E, col + 1, row), e01 = EnvAtLinear(E, col, row + 1), e11 = EnvAtLinear(E, col + 1, row + 1);
     float rowWeight0 = E.rowWeights[Clampi(row, 0, E.H - 1)];
     float rowWeight1 = E.rowWeights[Clampi(row + 1, 0, E.H - 1)];
+    LMC_PIN4(e00.x, e00.y, e00.z, rowWeight0);
+    LMC_PIN4(e10.x, e10.y, e10.z, rowWeight1);
+    LMC_PIN3(e01.x, e01.y, e01.z);
+    LMC_PIN3(e11.x, e11.y, e11.z);
+    V3 value1 = e00 * dx2 * dy2 + e10 * dx1 * dy2;
+    V3 value2 = e01 * dx2 * dy1 + e11 * dx1 * dy1;
+    value = value1 + value2;
     pdf = (Luminance(value1) * rowWeight0 + Luminance(value2) * rowWeight1) * E.normalization / fmaxf(fabsf(sinTheta), 1e-7f);
 }
 
@@ -657,12 +663,17 @@ LMC_D void LightEmission(const DScene &S, int light, V3 dirToLight, V3 normalOnL
         int col = (int)floorf(uvx), row = (int)floorf(uvy);
         lPrimID = Moduloi(row, E.H) * E.W + Moduloi(col, E.W);
         float dx1 = uvx - col, dx2 = 1.0f - dx1, dy1 = uvy - row, dy2 = 1.0f - dy1;
-        V3 value1 = EnvRepAt(E, col, row) * dx2 * dy2 + EnvRepAt(E, col + 1, row) * dx1 * dy2;
-        V3 value2 = EnvRepAt(E, col, row + 1) * dx2 * dy1 + EnvRepAt(E, col + 1, row + 1) * dx1 * dy1;
-        emission = value1 + value2;
-        float sinTheta = sqrtf(1.0f - square(d.y));
+        V3 e00 = EnvRepAt(E, col, row), e10 = EnvRepAt(E, col + 1, row), e01 = EnvRepAt(E, col, row + 1), e11 = EnvRepAt(E, col + 1, row + 1);
         float rowWeight0 = E.rowWeights[Clampi(row, 0, E.H - 1)];
         float rowWeight1 = E.rowWeights[Clampi(row + 1, 0, E.H - 1)];
+        LMC_PIN4(e00.x, e00.y, e00.z, rowWeight0);  // one round of loads (see EnvSampleDirection)
+        LMC_PIN4(e10.x, e10.y, e10.z, rowWeight1);
+        LMC_PIN3(e01.x, e01.y, e01.z);
+        LMC_PIN3(e11.x, e11.y, e11.z);
+        V3 value1 = e00 * dx2 * dy2 + e10 * dx1 * dy2;
+        V3 value2 = e01 * dx2 * dy1 + e11 * dx1 * dy1;
+        emission = value1 + value2;
+        float sinTheta = sqrtf(1.0f - square(d.y));
         directPdf = (Luminance(value1) * rowWeight0 + Luminance(value2) * rowWeight1) * E.normalization / fmaxf(fabsf(sinTheta), 1e-7f);
         float positionPdf = c_INVPI / square(S.bsRadius);
         emissionPdf = directPdf * positionPdf;

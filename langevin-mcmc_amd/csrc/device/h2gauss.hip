@@ -116,6 +116,31 @@ __device__ __forceinline__ void JacobiSweeps(float *A, float *V, float *rc, floa
         }
     }
 }
+
+// mean, invCov, covL of the dense Gaussian (h2mc.cpp:130-141) for lane k = column k; returns mean[k].  Dimension at compile time: the lane's own row of V
+// and the posterior eigenvalues sit in registers, so a multiply-add of the n x n x n product reads ONE LDS word (V[i][c], the same for the lanes of a
+// group: a broadcast) where the run-time loop read three.  Same operations in the same order.
+template <int NN>
+__device__ __forceinline__ float WriteDense(float *A, const float *V, const float *eb, const float *ob, const float *post, int k, float *G) {
+    float pc[NN], vk[NN], wm[NN];
+#pragma unroll
+    for (int c = 0; c < NN; c++) pc[c] = post[c], vk[c] = V[k * GS + c], wm[c] = (eb[c] / post[c]) * ob[c];
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < NN; c++) m += vk[c] * wm[c];
+    G[k] = m;
+    const float sq1 = sqrtf(1.0f / post[k]);
+#pragma unroll 2
+    for (int i = 0; i < NN; i++) {  // lane k = column k of invCov / covL: a row of the AoS record is written by consecutive lanes
+        float ic = 0.f;
+#pragma unroll
+        for (int c = 0; c < NN; c++) ic += V[i * GS + c] * pc[c] * vk[c];
+        G[H2_GAUSS_INVCOV + i * NN + k] = ic;
+        G[H2_GAUSS_COVL + i * NN + k] = V[i * GS + k] * sq1;
+        A[i * GS + k] = ic;  // kept for px
+    }
+    return m;
+}
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float *__restrict__ hout, H2MCParam param, int expFlags, const int *__restrict__ chainFlags,
@@ -229,17 +254,14 @@ __global__ void __launch_bounds__(64) k_h2_gauss(H2Bins bins, int N, const float
         if (!iso) {
             for (int i = 0; i < n; i++) logDet += tmp[i];
             if (act) {
-                float m = 0.f;
-                for (int c = 0; c < n; c++) m += V[k * GS + c] * ((eb[c] / post[c]) * ob[c]);
-                meanK = m;
-                G[k] = m;
-                const float sq1 = sqrtf(1.0f / post[k]);
-                for (int i = 0; i < n; i++) {  // lane k = column k of invCov / covL: a row of the AoS record is written by consecutive lanes
-                    float ic = 0.f;
-                    for (int c = 0; c < n; c++) ic += V[i * GS + c] * post[c] * V[k * GS + c];
-                    G[H2_GAUSS_INVCOV + i * n + k] = ic;
-                    G[H2_GAUSS_COVL + i * n + k] = V[i * GS + k] * sq1;
-                    A[i * GS + k] = ic;  // kept for px
+                switch (n) {
+                    case 4: meanK = WriteDense<4>(A, V, eb, ob, post, k, G); break;
+                    case 6: meanK = WriteDense<6>(A, V, eb, ob, post, k, G); break;
+                    case 8: meanK = WriteDense<8>(A, V, eb, ob, post, k, G); break;
+                    case 10: meanK = WriteDense<10>(A, V, eb, ob, post, k, G); break;
+                    case 12: meanK = WriteDense<12>(A, V, eb, ob, post, k, G); break;
+                    case 14: meanK = WriteDense<14>(A, V, eb, ob, post, k, G); break;
+                    default: meanK = WriteDense<16>(A, V, eb, ob, post, k, G); break;
                 }
                 if (k == 0) G[H2_GAUSS_LOGDET] = logDet, G[H2_GAUSS_LOGDET + 1] = (float)H2K_DENSE;
             }
