@@ -91,7 +91,7 @@ LMC_D void DirectSample(const DScene &S, Sink &sink, int px, int py, int minDept
         hit.st = V2{0, 0};
         Isect isect;
         const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk);
-        const int light = HitLightOf(S, hitSurface, hit.tri);
+        const int light = HitLightOf(S, hitSurface, hit);
         if (light >= 0 && camDepth + 1 >= minDepth) {  // HandleHitLight (uni)
             int lPrimID = 0;
             V3 emission;

@@ -213,9 +213,10 @@ LMC_D bool ConnectToCamera(const DScene &S, int lgtDepth, const BPS &ps, const D
 // every field of `in` is read before the aliased field of `out` is written.
 // lcJacobian (path.cpp:793-797,825; read by the light-coordinate branch of GeneratePathBidir only): handed out through a pointer so
 // that BPS -- live across every traversal of the hot kernel -- does not carry it
+// (the M form takes the vertex's material record: a caller that has just reconstructed the hit knows the material index -- SurfHit::material --
+// and can have the record on its way before the arithmetic between the hit and the BSDF)
 template <bool adjoint, bool perturb, bool GLOSSY>
-LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib, float *lcJacobian = nullptr) {
-    const DMaterial m = LoadMaterial<GLOSSY>(S, v.tri);
+LMC_D bool BSDFSamplingM(const DScene &S, const DMaterial &m, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib, float *lcJacobian = nullptr) {
     V2 st{v.st0, v.st1};
     float cosWo, bsdfPdf, bsdfRevPdf;
     v.useAbs = (BsdfRoughness<GLOSSY>(S, m, st, v.bsdfDiscrete) > S.opt.roughnessThreshold) ? 1.0f : 0.0f;
@@ -253,6 +254,10 @@ LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3
     out.throughput = cmul(inThr, bsdfContrib);
     return true;
 }
+template <bool adjoint, bool perturb, bool GLOSSY>
+LMC_D bool BSDFSampling(const DScene &S, const BPS &in, DVertex &v, BPS &out, V3 &dir, V3 &bsdfContrib, float *lcJacobian = nullptr) {
+    return BSDFSamplingM<adjoint, perturb, GLOSSY>(S, LoadMaterial<GLOSSY>(S, v.tri), in, v, out, dir, bsdfContrib, lcJacobian);
+}
 
 // path.cpp:902-967 (bidirMIS = true)
 LMC_D bool HandleHitLight(const DScene &S, int camDepth, int light, bool hitSurface, V3 rayDir, V2 screenPos, const BPS &ps, int &envPrim,
@@ -283,8 +288,7 @@ LMC_D bool HandleHitLight(const DScene &S, int camDepth, int light, bool hitSurf
 
 // path.cpp:969-1089 (doOcclusion = true, bidirMIS = true)
 template <class Stk, class Occ>
-LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk, Occ &occ) {
-    const DMaterial m = LoadMaterial<Stk::kGlossy>(S, camVertex.tri);
+LMC_D bool DirectLightingM(const DScene &S, const DMaterial &m, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk, Occ &occ) {  // m: camVertex's material (BSDFSamplingM)
     const int light = camVertex.dirLight;
     V3 dirToLight, lightContrib;
     float dist, cosAtLight, directPdf, emissionPdf;
@@ -312,7 +316,21 @@ LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 scree
     }
     return false;
 }
+template <class Stk, class Occ>
+LMC_D bool DirectLighting(const DScene &S, int camDepth, const BPS &ps, V2 screenPos, float lightPickProb, DVertex &camVertex, Contrib &out, Stk &stk, Occ &occ) {
+    return DirectLightingM(S, LoadMaterial<Stk::kGlossy>(S, camVertex.tri), camDepth, ps, screenPos, lightPickProb, camVertex, out, stk, occ);
+}
 
+// the generators below shade a vertex right behind its hit reconstruction: the material by the index that hit carried (dshade.h LMC_MAT_CARRY)
+#if LMC_MAT_CARRY
+#define MAT_BSDF(adj, pert) BSDFSamplingM<adj, pert, Stk::kGlossy>
+#define MAT_ARG LoadMaterialIdx<Stk::kGlossy>(S, hit.material),
+#define MAT_DIRECT(S, d, ps, sp, pp, sv, c, stk, tr) DirectLightingM(S, LoadMaterialIdx<Stk::kGlossy>(S, hit.material), d, ps, sp, pp, sv, c, stk, tr)
+#else
+#define MAT_BSDF(adj, pert) BSDFSampling<adj, pert, Stk::kGlossy>
+#define MAT_ARG
+#define MAT_DIRECT DirectLighting
+#endif
 // path.cpp:1091-1235 (doOcclusion = true)
 template <class Stk, class Occ>
 LMC_D bool ConnectVertex(const DScene &S, int camDepth, int lgtDepth, const BPS &lps, const DVertex &lgtVertex, const BPS &cps,
@@ -370,6 +388,13 @@ LMC_D bool RussianRoulette(int depth, V3 bsdfContrib, float &rrWeight, V3 &throu
 LMC_D int HitLightOf(const DScene &S, bool hitSurface, int tri) {  // GetHitLight, path.cpp:105-120; -1 = none
     if (!hitSurface) return S.envLight;
     return S.tris[tri].areaLight;
+}
+LMC_D int HitLightOf(const DScene &S, bool hitSurface, const SurfHit &hit) {  // ... of a hit just reconstructed
+#if LMC_MAT_CARRY
+    return hitSurface ? hit.areaLight : S.envLight;
+#else
+    return HitLightOf(S, hitSurface, hit.tri);
+#endif
 }
 
 // GeneratePathBidir, path.cpp:1237-1449 with screenPosi = (-1,-1)
@@ -447,7 +472,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
         if (camDepth + 1 >= minDepth) {
-            int light = HitLightOf(S, hitSurface, hit.tri);
+            int light = HitLightOf(S, hitSurface, hit);
             if (light >= 0) {
                 if (S.opt.useLightCoord && camDepth > 1 && S.lights[light].type == LIGHT_AREA) {  // path.cpp:1339-1360
                     // area light: the BSDF sampling coordinates of the previous vertex become the light's direct sampling coordinates
@@ -475,7 +500,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
             sv.dirRnd0 = r.x, sv.dirRnd1 = r.y;
             sv.dirPrim = LightSampleDiscrete(S, sv.dirLight, rng.Uniform());
             Contrib c;
-            if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk, trace)) sink.Push(c);
+            if (MAT_DIRECT(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk, trace)) sink.Push(c);
         }
         int maxLgtDepth = maxDepth == -1 ? (numLightStates - 1) : min(maxDepth - camDepth - 3, numLightStates - 1);
         for (int lgtDepth = 0; lgtDepth <= maxLgtDepth; lgtDepth++) {
@@ -487,7 +512,7 @@ LMC_D void GeneratePathBidir(const DScene &S, int minDepth, int maxDepth, DPath 
         V2 r = RndVec2(rng);
         sv.rnd0 = r.x, sv.rnd1 = r.y;
         V3 bsdfContrib;
-        if (!BSDFSampling<false, false, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib, &lcJac)) break;
+        if (!MAT_BSDF(false, false)(S, MAT_ARG cps, sv, cps, dir, bsdfContrib, &lcJac)) break;
         if (!RussianRoulette(camDepth, bsdfContrib, sv.rrWeight, cps.throughput, rng)) break;
         org = cps.isect.position;
         tnear = c_IsectEpsilon;
@@ -539,7 +564,7 @@ LMC_D void GenerateSubpath(const DScene &S, int camLength, int lgtLength, DPath 
             V2 r = RndVec2(rng);
             sv.rnd0 = r.x, sv.rnd1 = r.y;
             V3 bsdfContrib;
-            if (!BSDFSampling<true, false, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) return;
+            if (!MAT_BSDF(true, false)(S, MAT_ARG lps, sv, lps, dir, bsdfContrib)) return;
             sv.rrWeight = 1.0f;
             org = lps.isect.position;
         }
@@ -565,7 +590,7 @@ LMC_D void GenerateSubpath(const DScene &S, int camLength, int lgtLength, DPath 
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
         if (camDepth + 2 >= camLength && lgtLength == 0) {
-            const int light = HitLightOf(S, hitSurface, hit.tri);
+            const int light = HitLightOf(S, hitSurface, hit);
             if (light >= 0) {
                 if (camDepth > 1 && S.lights[light].type == LIGHT_AREA) {
                     DVertex &prev = path.cam[camDepth - 1];
@@ -593,7 +618,7 @@ LMC_D void GenerateSubpath(const DScene &S, int camLength, int lgtLength, DPath 
                 V2 r = RndVec2(rng);
                 sv.dirRnd0 = r.x, sv.dirRnd1 = r.y;
                 sv.dirPrim = LightSampleDiscrete(S, sv.dirLight, rng.Uniform());
-                if (DirectLighting(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk, trace)) sink.Push(c);
+                if (MAT_DIRECT(S, camDepth, cps, screenPos, directLightPickProb, sv, c, stk, trace)) sink.Push(c);
             } else {
                 if (ConnectVertex(S, camDepth, lgtLength - 2, lps, path.lgt[lgtLength - 2], cps, sv, screenPos, c, stk, trace)) sink.Push(c);
             }
@@ -602,7 +627,7 @@ LMC_D void GenerateSubpath(const DScene &S, int camLength, int lgtLength, DPath 
         V2 r = RndVec2(rng);
         sv.rnd0 = r.x, sv.rnd1 = r.y;
         V3 bsdfContrib;
-        if (!BSDFSampling<false, false, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib, &lcJac)) return;
+        if (!MAT_BSDF(false, false)(S, MAT_ARG cps, sv, cps, dir, bsdfContrib, &lcJac)) return;
         sv.rrWeight = 1.0f;
         org = cps.isect.position;
         tnear = c_IsectEpsilon;
@@ -716,7 +741,7 @@ LMC_D bool PerturbPathBidir(const DScene &S, const float *offset, DPath &path, C
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, camDepth, -1, org, dir, cps);
         if (camDepth == path.camCount - 1 && path.lgtDepth == 0) {
-            int light = HitLightOf(S, hitSurface, hit.tri);
+            int light = HitLightOf(S, hitSurface, hit);
             if (light >= 0) return HandleHitLight(S, camDepth, light, hitSurface, dir, screenPos, cps, path.envPrim, out);
             return false;
         }

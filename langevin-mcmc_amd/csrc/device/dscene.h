@@ -75,8 +75,15 @@ struct DMesh {
     float areaFuncInt;
 };
 // constant or bitmap texture reference (texture.h, constanttexture.h, bitmaptexture.h)
+// LMC_TEX_INLINE (default): a TEXTURED reference holds what a look-up needs in the words a constant one uses for its value: `bitmap` = the word offset of
+// the bitmap's texels in DScene::texPool, value[0..1] = the bits of its width / height, value[2] = its gamma (filled by host/context.cpp UploadScene).
+// The look-up then goes material record -> texels; through DScene::bitmaps[bitmap] it was material record -> bitmap header -> texels, one more
+// dependent round trip per textured BSDF evaluation.  0: the index form (A/B).
+#ifndef LMC_TEX_INLINE
+#define LMC_TEX_INLINE 1
+#endif
 struct DTexRef {
-    int bitmap;  // index into DScene::bitmaps, -1 = constant
+    int bitmap;  // -1 = constant; else LMC_TEX_INLINE ? word offset into DScene::texPool : index into DScene::bitmaps
     float value[3];
     float sScale, tScale;
 };
@@ -131,6 +138,7 @@ struct DScene {
     const DMesh *meshes;
     const DMaterial *materials;
     const DBitmap *bitmaps;
+    const float *texPool;  // the texels of every bitmap (DTexRef::bitmap)
     const DLight *lights;
     const float *areaFunc, *areaCdf;
     const float *lightFunc, *lightCdf;

@@ -5,6 +5,14 @@
 #pragma once
 #include "dscene.h"
 
+// LMC_MAT_CARRY (default 1): the walks that shade a vertex right behind its hit reconstruction (dsmall.h, dwalk.h, dpath.h) take the vertex's material --
+// and GetHitLight's answer -- from the index the hit record carried (SurfHit::material / areaLight) instead of fetching S.tris[tri].material again: one
+// dependent round trip less per vertex.  With LMC_TEX_INLINE (dscene.h): headline +1.3 %, full-material torus +0.9 %, the others unchanged; same
+// results (profiles/r05_bg_ab_material_index_carried_texture_header_inline.jsonl).  0: the look-up through the triangle record (A/B).
+#ifndef LMC_MAT_CARRY
+#define LMC_MAT_CARRY 1
+#endif
+
 namespace lmcd {
 
 struct Isect {
@@ -13,6 +21,9 @@ struct Isect {
 struct SurfHit {
     int tri;  // global triangle id
     V2 st;
+    int material;  // the triangle's material index (TriData::material): the record is in registers when a hit is reconstructed, so the caller's
+                   // BSDF need not fetch S.tris[tri].material again -- one dependent round trip less per vertex (LoadMaterialIdx below)
+    int areaLight; // ... and TriData::areaLight, what GetHitLight asks of a surface hit (dpath.h HitLightOf)
 };
 
 // path.cpp:91-103 = scene.cpp:106-126 (BVH) + TriangleMesh::Intersect (recompute from primID)
@@ -44,6 +55,7 @@ LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float 
     isect.shadingNormal = Normalize(w * n0 + u * n1 + v * n2);
     if (Dot(isect.geomNormal, isect.shadingNormal) < 0.0f) isect.geomNormal = -isect.geomNormal;
     hit.tri = id;
+    hit.material = T.material, hit.areaLight = T.areaLight;
     if (T.hasST) {
         hit.st.x = (1.0f - u - v) * T.st[0] + u * T.st[2] + v * T.st[4];
         hit.st.y = (1.0f - u - v) * T.st[1] + u * T.st[3] + v * T.st[5];
@@ -98,8 +110,7 @@ __device__ __forceinline__ void MaterialLdsInit(const DScene &S) {
 #define LMC_MAT_LDS_INIT(S) ((void)0)
 #endif
 template <bool GLOSSY>
-LMC_D DMaterial LoadMaterial(const DScene &S, int tri) {
-    const int mi = S.tris[tri].material;
+LMC_D DMaterial LoadMaterialIdx(const DScene &S, int mi) {  // by material index (SurfHit::material of a hit just reconstructed)
 #if defined(LMC_MAT_LDS) && defined(__HIP_DEVICE_COMPILE__)
     if (mi < LMC_MAT_LDS_MAX) return MaterialLds()[mi];
 #endif
@@ -115,6 +126,10 @@ LMC_D DMaterial LoadMaterial(const DScene &S, int tri) {
     }
     return m;
 }
+template <bool GLOSSY>
+LMC_D DMaterial LoadMaterial(const DScene &S, int tri) {
+    return LoadMaterialIdx<GLOSSY>(S, S.tris[tri].material);
+}
 
 // Texture::Eval.  Bitmaps: periodic bilinear lookup standing in for OIIO's TextureSystem::texture() with zero filter
 // width, then fastpow(max(v,0), gamma) (bitmaptexture.h:72-97); the same arithmetic as host/scene.cpp:EvalTexture.
@@ -123,11 +138,17 @@ LMC_D V3 EvalTex(const DScene &S, const DTexRef &t, V2 st) {
     // every load below is pinned where it stands (dscene.h LMC_PIN): hipcc fetched the bitmap's fields and the twelve texel words one by one
     // where each is used -- a chain of up to fourteen dependent round trips per look-up (hipcc -S of the round-5 door kernels: 77 of the 88
     // loads of this function's inlined copies were waited for on their own)
+#if LMC_TEX_INLINE
+    const float *pix = S.texPool + t.bitmap;
+    const int W = __float_as_int(t.value[0]), H = __float_as_int(t.value[1]);
+    const float gamma = t.value[2];
+#else
     const DBitmap *bp = S.bitmaps + t.bitmap;
     const float *pix = bp->pix;
     int W = bp->W, H = bp->H;
     float gamma = bp->gamma;
     LMC_PIN4(pix, W, H, gamma);
+#endif
     const float fs = t.sScale * st.x * W - 0.5f, ft = t.tScale * st.y * H - 0.5f;
     const float x0f = floorf(fs), y0f = floorf(ft);
     const float dx = fs - x0f, dy = ft - y0f;

@@ -572,6 +572,12 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             prof.Mark(PR_VERTEX_LOAD);
 #endif
             const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk, sv.tri);  // sv.tri: the current state's triangle, tried first (dscene.h)
+#if LMC_MAT_CARRY
+            // the vertex's material by the index the hit record carried (dshade.h SurfHit::material), not through S.tris[tri].material again.  (Requesting the
+            // record HERE, so that it travels while ConvertMIS and the draws run, was measured too: -1.4 % -- eight more registers live across that code,
+            // profiles/r05_bg_*)
+            auto HitMaterial = [&]() -> DMaterial { return LoadMaterialIdx<Stk::kGlossy>(S, hit.material); };
+#endif
             prof.Mark(PR_TRAVERSE);
             if (lightPhase) {
                 if (!hitSurface) break;
@@ -596,7 +602,11 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
                 qs.Push(sv.rnd0), qs.Push(sv.rnd1);
                 V3 bsdfContrib;
+#if LMC_MAT_CARRY
+                if (!BSDFSamplingM<true, true, Stk::kGlossy>(S, HitMaterial(), lps, sv, lps, dir, bsdfContrib)) break;
+#else
                 if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) break;
+#endif
                 StoreVertex(prop, N, i, true, depth, sv);
                 lps.throughput = lps.throughput * sv.rrWeight;
                 org = lps.isect.position;
@@ -611,7 +621,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 #ifdef LMC_PROF_FINE  // A/B build: isotropic_offsets = the emitter-hit terminal, vertex_load = the direct-lighting terminal, buffered_reset = PrepareGaussianLean(proposal)
                 prof.Mark(PR_SHADE);
 #endif
-                const int light = HitLightOf(S, hitSurface, hit.tri);
+                const int light = HitLightOf(S, hitSurface, hit);
                 if (light >= 0) ok = HandleHitLight(S, depth, light, hitSurface, dir, screenPos, cps, envPrim, pc);
                 StoreVertex(prop, N, i, false, depth, sv);
 #ifdef LMC_PROF_FINE
@@ -630,7 +640,11 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                     sv.dirRnd0 = Modulo1(sv.dirRnd0 + off.Pop());
                     sv.dirRnd1 = Modulo1(sv.dirRnd1 + off.Pop());
                     qs.Push(sv.dirRnd0), qs.Push(sv.dirRnd1);
+#if LMC_MAT_CARRY
+                    ok = DirectLightingM(S, HitMaterial(), depth, cps, screenPos, directLightPickProb, sv, pc, stk, occ);
+#else
                     ok = DirectLighting(S, depth, cps, screenPos, directLightPickProb, sv, pc, stk, occ);
+#endif
                 } else {
                     ok = ConnectVertex(S, depth, lgtCount - 1, lps, lastLgt, cps, sv, screenPos, pc, stk, occ);
                 }
@@ -644,7 +658,11 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
             qs.Push(sv.rnd0), qs.Push(sv.rnd1);
             V3 bsdfContrib;
+#if LMC_MAT_CARRY
+            if (!BSDFSamplingM<false, true, Stk::kGlossy>(S, HitMaterial(), cps, sv, cps, dir, bsdfContrib)) break;
+#else
             if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
+#endif
             StoreVertex(prop, N, i, false, depth, sv);
             cps.throughput = cps.throughput * sv.rrWeight;
             org = cps.isect.position;

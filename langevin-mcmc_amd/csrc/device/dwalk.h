@@ -112,7 +112,7 @@ LMC_D bool PerturbPathStreamed(const DScene &S, const float *cur, float *prop, s
             sv.rnd0 = Modulo1(sv.rnd0 + off.Pop());
             sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
             V3 bsdfContrib;
-            if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) break;
+            if (!MAT_BSDF(true, true)(S, MAT_ARG lps, sv, lps, dir, bsdfContrib)) break;
             StoreVertex(prop, N, i, true, depth, sv);
             lps.throughput = lps.throughput * sv.rrWeight;
             org = lps.isect.position;
@@ -124,7 +124,7 @@ LMC_D bool PerturbPathStreamed(const DScene &S, const float *cur, float *prop, s
         cps.wi = -dir;
         if (hitSurface) ConvertMIS(S, depth, -1, org, dir, cps);
         if (depth == camCount - 1 && l == 0) {
-            const int light = HitLightOf(S, hitSurface, hit.tri);
+            const int light = HitLightOf(S, hitSurface, hit);
             if (light >= 0) ok = HandleHitLight(S, depth, light, hitSurface, dir, screenPos, cps, envPrim, pc);
             StoreVertex(prop, N, i, false, depth, sv);
             break;
@@ -136,7 +136,7 @@ LMC_D bool PerturbPathStreamed(const DScene &S, const float *cur, float *prop, s
                 const float directLightPickProb = PickLightProb(S, sv.dirLight);
                 sv.dirRnd0 = Modulo1(sv.dirRnd0 + off.Pop());
                 sv.dirRnd1 = Modulo1(sv.dirRnd1 + off.Pop());
-                ok = DirectLighting(S, depth, cps, screenPos, directLightPickProb, sv, pc, stk, occ);
+                ok = MAT_DIRECT(S, depth, cps, screenPos, directLightPickProb, sv, pc, stk, occ);
             } else {
                 ok = ConnectVertex(S, depth, lgtCount - 1, lps, lastLgt, cps, sv, screenPos, pc, stk, occ);
             }
@@ -146,7 +146,7 @@ LMC_D bool PerturbPathStreamed(const DScene &S, const float *cur, float *prop, s
         sv.rnd0 = Modulo1(sv.rnd0 + off.Pop());
         sv.rnd1 = Modulo1(sv.rnd1 + off.Pop());
         V3 bsdfContrib;
-        if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
+        if (!MAT_BSDF(false, true)(S, MAT_ARG cps, sv, cps, dir, bsdfContrib)) break;
         StoreVertex(prop, N, i, false, depth, sv);
         cps.throughput = cps.throughput * sv.rrWeight;
         org = cps.isect.position;

@@ -148,7 +148,7 @@ struct lmc_ctx {
     DevBuf<DMesh> meshes;
     DevBuf<DMaterial> materials;
     DevBuf<DBitmap> bitmaps;
-    std::vector<std::unique_ptr<DevBuf<float>>> bitmapPix;
+    DevBuf<float> texPool;  // the texels of every bitmap, back to back
     DevBuf<DLight> lights;
     DevBuf<float> areaFunc, areaCdf, lightFunc, lightCdf, envImage, envCdfRows, envCdfCols, envRowWeights;
     DScene S;
@@ -328,16 +328,31 @@ static void UploadScene(lmc_ctx *c) {
         if (m.type != lmc::BSDF_LAMBERTIAN) glossy = 1;
         mats.push_back(d);
     }
+    // every bitmap's texels in ONE buffer (DScene::texPool): a textured DTexRef names its bitmap by the word offset of its texels there and carries
+    // width / height / gamma itself (dscene.h LMC_TEX_INLINE), so that a look-up needs no header fetch between the material record and the texels
     std::vector<DBitmap> bitmaps;
-    c->bitmapPix.clear();
-    for (size_t i = 0; i < sc.bitmaps.size(); i++) {
-        const lmc::Bitmap &bm = sc.bitmaps[i];
-        c->bitmapPix.emplace_back(new DevBuf<float>());
-        c->bitmapPix.back()->Upload(bm.img.data);
-        bitmaps.push_back(DBitmap{c->bitmapPix.back()->p, bm.img.width, bm.img.height, bm.gamma});
+    std::vector<float> pool;
+    std::vector<size_t> poolOff;
+    for (const lmc::Bitmap &bm : sc.bitmaps) {
+        poolOff.push_back(pool.size());
+        pool.insert(pool.end(), bm.img.data.begin(), bm.img.data.end());
     }
+    if (pool.size() >= (size_t)1 << 31) throw std::runtime_error("the scene's bitmaps hold more than 2^31 words");
+    if (pool.empty()) pool.push_back(0.f);
+    c->texPool.Upload(pool);
+    for (size_t i = 0; i < sc.bitmaps.size(); i++) bitmaps.push_back(DBitmap{c->texPool.p + poolOff[i], sc.bitmaps[i].img.width, sc.bitmaps[i].img.height, sc.bitmaps[i].gamma});
     if (bitmaps.empty()) bitmaps.push_back(DBitmap{nullptr, 0, 0, 1.f});
     c->bitmaps.Upload(bitmaps);
+#if LMC_TEX_INLINE
+    for (DMaterial &d : mats)
+        for (DTexRef *r : {&d.Kd, &d.Ks, &d.Kt, &d.expOrAlpha})
+            if (r->bitmap >= 0) {
+                const lmc::Bitmap &bm = sc.bitmaps[r->bitmap];
+                const int W = bm.img.width, H = bm.img.height;
+                r->bitmap = (int)poolOff[r->bitmap];
+                memcpy(&r->value[0], &W, 4), memcpy(&r->value[1], &H, 4), r->value[2] = bm.gamma;
+            }
+#endif
     std::vector<DLight> lights;
     for (const lmc::Light &L : sc.lights) {
         DLight d;
@@ -362,7 +377,7 @@ static void UploadScene(lmc_ctx *c) {
     if (quant) c->qnodes.Upload(bvh.qnodes);
     else
         c->qnodes.Free();
-    S.nodes = c->nodes.p, S.qnodes = quant ? c->qnodes.p : nullptr, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.lights = c->lights.p;
+    S.nodes = c->nodes.p, S.qnodes = quant ? c->qnodes.p : nullptr, S.leafTris = c->leafTris.p, S.tris = c->tris.p, S.meshes = c->meshes.p, S.materials = c->materials.p, S.bitmaps = c->bitmaps.p, S.texPool = c->texPool.p, S.lights = c->lights.p;
     S.areaFunc = c->areaFunc.p, S.areaCdf = c->areaCdf.p, S.lightFunc = c->lightFunc.p, S.lightCdf = c->lightCdf.p;
     S.lightFuncInt = sc.lightFuncInt, S.lightWeightSum = sc.lightWeightSum;
     S.numTris = (int)tris.size(), S.numNodes = (int)bvh.nodes.size(), S.numMeshes = (int)meshes.size(), S.numLights = (int)lights.size(), S.numMaterials = (int)mats.size();
