@@ -215,6 +215,10 @@ struct lmc_ctx {
     int *hostCounts = nullptr;               // pinned mirror of cacheCounts
     hipEvent_t countsEvent = nullptr;        // ... is up to date (CacheApplyLaunch / CacheApplyFinish)
     bool countsInFlight = false, appliedEarly = false;
+    // a gradient cache becoming ready (CacheApplyFinish): its rows come down, its existence grid is built and its kd-tree goes up on THIS stream, beside
+    // the step's launches; the device's copy of the cache struct is then refreshed from a pinned copy in stream order behind them
+    hipStream_t cacheStream = nullptr;
+    DCache *cachePinned = nullptr;
     bool earlyApply = true;                  // LMC_EARLY_APPLY=0: a single rank also applies its pushes at the end of the step
     int lastCounts[CACHE_SLOTS] = {0, 0, 0, 0}; // ... as last read back, and the steps run since (CacheApplyLaunch)
     long long stepsSinceCounts = 0;
@@ -255,6 +259,8 @@ struct lmc_ctx {
             }
         }
         if (hostCounts) (void)hipHostFree(hostCounts);
+        if (cachePinned) (void)hipHostFree(cachePinned);
+        if (cacheStream) (void)hipStreamDestroy(cacheStream);
         if (countsEvent) (void)hipEventDestroy(countsEvent);
         for (auto st : partStream)
             if (st) (void)hipStreamDestroy(st);
@@ -434,8 +440,16 @@ static void SyncOptions(lmc_ctx *c) {
     d.leanLightless = (lightlessMode == 2 || (lightlessMode == 1 && c->S.numLights == 1 && c->S.envLight >= 0)) ? 1 : 0;
 }
 
-static void UploadCacheStruct(lmc_ctx *c) {
+static void UploadCacheStruct(lmc_ctx *c, hipStream_t after = nullptr) {
     if (c->cacheDev.n != 1) c->cacheDev.Alloc(1);
+    if (after) {
+        // in stream order behind what `after` holds (the step's launches, which read the struct as it was), from a pinned copy: the host goes on
+        // queueing.  The copy has run long before the pinned words are written again: that happens behind a later step's countsEvent, which the
+        // device reaches after that step's launches, which wait for this stream (StepPhase1's fork).
+        *c->cachePinned = c->cacheHost;
+        HIP_CHECK(hipMemcpyAsync(c->cacheDev.p, c->cachePinned, sizeof(DCache), hipMemcpyHostToDevice, after));
+        return;
+    }
     HIP_CHECK(hipMemcpy(c->cacheDev.p, &c->cacheHost, sizeof(DCache), hipMemcpyHostToDevice));  // in place: the kernels keep the pointer
 }
 
@@ -479,6 +493,8 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
             HIP_CHECK(hipStreamCreateWithPriority(&c->sideStream[k], hipStreamNonBlocking, m > 0 ? hi : m < 0 ? lo : 0));
         }
         for (auto &ps : c->partStream) HIP_CHECK(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
+        HIP_CHECK(hipStreamCreateWithPriority(&c->cacheStream, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
+        HIP_CHECK(hipHostMalloc((void **)&c->cachePinned, sizeof(DCache), hipHostMallocDefault));
     }
     HIP_CHECK(hipEventCreateWithFlags(&c->partFork, hipEventDisableTiming));
     for (auto &e : c->partJoin) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1403,7 +1419,20 @@ static void CacheApplyFinish(lmc_ctx *c) {
     std::vector<lmc::KdTreeResult> treeOf(numReady);
     // a single rank has applied the pushes on the large-step stream and is here while the hot launch still runs: the rows are fetched on that
     // stream (a blocking copy would wait for the step stream), and the kd-trees below are built beside the hot launch instead of after it
-    if (c->appliedEarly && c->overlap) {
+    // ... on the context's cache stream, that is: the large-step stream already holds the step's relocation behind the pushes, and the step stream
+    // the hot launch -- waiting on either put the whole transition (rows down 0.05 ms, two kd-trees 0.5 ms, two grids 0.6 ms, trees up) BEHIND the
+    // hot launch: the step in which dims 10 and 12 become ready took 2.6 ms instead of 1.75 (profiles/r05_final_step_durations_fill_phase.txt).
+    // The pushes of this step are applied (countsEvent above), so nothing on that stream has to wait for anything.
+    const bool beside = c->appliedEarly && c->overlap && c->cacheStream && !c->S.opt.sampleCache && !getenv("LMC_NO_CACHE_STREAM");
+    hipStream_t cs = beside ? c->cacheStream : s;
+    if (beside) {
+        for (int r = 0; r < numReady; r++) {
+            const DevBuf<float> &b = c->cacheDims[readyDims[r]].pss;
+            ptsOf[r].resize(b.n);
+            HIP_CHECK(hipMemcpyAsync(ptsOf[r].data(), b.p, b.n * sizeof(float), hipMemcpyDeviceToHost, cs));
+        }
+        if (numReady) HIP_CHECK(hipStreamSynchronize(cs));
+    } else if (c->appliedEarly && c->overlap) {
         for (int r = 0; r < numReady; r++) {
             const DevBuf<float> &b = c->cacheDims[readyDims[r]].pss;
             ptsOf[r].resize(b.n);
@@ -1417,7 +1446,7 @@ static void CacheApplyFinish(lmc_ctx *c) {
         CacheDimHost &cd = c->cacheDims[readyDims[r]];
         lmc::ChooseGridCoords(ptsOf[r].data(), PSS_MAX_SIZE, readyDims[r], cd.gridM, cd.gridCoord);
         LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, readyDims[r], cd.gridG, cd.gridM, cd.gridCoord, c->gridScratchStart.p, c->gridScratchCursor.p, c->gridScratchWordCount.p, c->gridTileSums.p,
-                             cd.gridWords.p, cd.gridCellStart.p, cd.gridIdx.p, s);
+                             cd.gridWords.p, cd.gridCellStart.p, cd.gridIdx.p, cs);
     }
     {
         std::vector<std::thread> workers;
@@ -1444,9 +1473,9 @@ static void CacheApplyFinish(lmc_ctx *c) {
         CacheDimHost &cd = c->cacheDims[d];
         lmc::KdTreeResult &t = treeOf[r];
         if (t.nodes.size() > KD_MAX_NODES) throw std::runtime_error("kd-tree larger than its preallocated node buffer");
-        HIP_CHECK(hipMemcpyAsync(cd.nodes.p, t.nodes.data(), t.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(cd.vind.p, t.vind.data(), t.vind.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipStreamSynchronize(s));  // the pageable copies above must have left the host before the trees go out of scope
+        HIP_CHECK(hipMemcpyAsync(cd.nodes.p, t.nodes.data(), t.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, cs));
+        HIP_CHECK(hipMemcpyAsync(cd.vind.p, t.vind.data(), t.vind.size() * sizeof(int), hipMemcpyHostToDevice, cs));
+        HIP_CHECK(hipStreamSynchronize(cs));  // the pageable copies above must have left the host before the trees go out of scope (beside: the grids are built by then too)
         DCacheDim &D = c->cacheHost.d[d];
         D.gridWords = c->useOccFilter ? cd.gridWords.p : nullptr, D.gridCellStart = cd.gridCellStart.p, D.gridIdx = cd.gridIdx.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
         for (int k = 0; k < 4; k++) D.gridCoord[k] = cd.gridCoord[k];
@@ -1471,7 +1500,7 @@ static void CacheApplyFinish(lmc_ctx *c) {
         cd.ready = true;
         changed = true;
     }
-    if (changed) UploadCacheStruct(c);
+    if (changed) UploadCacheStruct(c, beside ? s : nullptr);  // beside: the step's launches are still running and read the struct as it was; `s` is behind all of them (StepPhase1's joins)
 }
 
 extern "C++" {
