@@ -43,8 +43,23 @@ struct RecordLayout {
 #ifndef LMC_RELOC_ORDER
 #define LMC_RELOC_ORDER 1
 #endif
-LMC_D int SlotKey(const ChainArrays &A, int i) {
-    const int key = TechniqueKey(__float_as_int(A.curContrib[i]), __float_as_int(A.curContrib[(size_t)A.N + i]));
+// LMC_RELOC_TILES (A/B build): where the technique keys leave room in the 64 bins -- states without a light sub-path up to path length 6: eight
+// techniques -- a technique's chains are sub-ordered by the screen tile (4 x 2) of their camera vertex, so that a wave's camera rays start out
+// through the same part of the tree.  `tiles`: 8 or 0 (LaunchRelocate).
+#ifndef LMC_RELOC_TILES
+#define LMC_RELOC_TILES 0
+#endif
+LMC_D int SlotKey(const ChainArrays &A, int i, int tiles) {
+    const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[(size_t)A.N + i]);
+    int key = TechniqueKey(c, l);
+#if LMC_RELOC_TILES
+    if (tiles && l <= 1 && c + l - 1 <= 6) {
+        const float *path = CurPathBuf(A, A.flags[i]);
+        const float sx = path[(size_t)1 * A.N + i], sy = path[(size_t)2 * A.N + i];  // DPath::screen0, screen1
+        const int tx = min(3, max(0, (int)(sx * 4.f))), ty = min(1, max(0, (int)(sy * 2.f)));
+        key = ((max(c + l - 1, 3) - 3) * 2 + l) * 8 + ty * 4 + tx;
+    }
+#endif
     return LMC_RELOC_ORDER ? 63 - key : key;
 }
 LMC_D bool VectorsMayBeNonZero(int flags) { return (flags & F_BUFFERED) && (flags & F_VDIRTY); }  // dchain.h: the invariant of the seven MALA vectors
@@ -59,9 +74,9 @@ constexpr int RELOC_TILE = 1024;
 // H2MC renders (placedKey's top bit of the launch argument `mode`): a chain that holds a stored Gaussian stays -- the dense Gaussian lives in the
 // pipeline's own per-slot buffers (dh2coop.h H2Arrays::gauss), which are not moved; an accepted large step, the event that changes the
 // technique, has just dropped it (dstep.h), so only chains kept by a REJECTED large step wait for their next one.
-LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i, bool withoutGaussianOnly) {  // -1: not a member
+LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i, bool withoutGaussianOnly, int tiles) {  // -1: not a member
     if (i >= A.N || A.stepKind[i] != NEXT_LARGE) return -1;
-    const int key = SlotKey(A, i);
+    const int key = SlotKey(A, i, tiles);
     if (key == placedKey[i]) return -1;
     if (withoutGaussianOnly && (A.flags[i] & F_GAUSS)) return -1;
     return key;
@@ -70,14 +85,14 @@ LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i,
 // takes the first slot that frees up, a four-wave block waits for four at once (k_reloc_count as 256-thread blocks: 1.0 ms in the queue,
 // profiles/r04_reloc_b_*; the same lesson as kernels.hip k_push_count).  Lane l of a tile's wave looks at slots base + 64 j + l, j = 0 .. 15.
 // tileCount[t] = members of tile t; tileHist[t][k] = ... with key k
-__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned char *placedKey, int *tileCount, int *tileHist, bool noGauss) {
+__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned char *placedKey, int *tileCount, int *tileHist, bool noGauss, int tiles) {
     __shared__ int h[64];
     h[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
     int total = 0;
     for (int j = 0; j < RELOC_TILE / 64; j++) {
-        const int key = MemberKey(A, placedKey, base + 64 * j, noGauss);
+        const int key = MemberKey(A, placedKey, base + 64 * j, noGauss, tiles);
         if (key >= 0) atomicAdd(&h[key], 1), total++;
     }
     __syncthreads();
@@ -117,14 +132,14 @@ __global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount
     }
 }
 // members[m] = slot (ascending); sorted[p] = m for the p-th chain by key (inside a (tile, key) group the order is the LDS atomics')
-__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned char *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted, bool noGauss) {
+__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned char *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted, bool noGauss, int tiles) {
     __shared__ int cursor[64];
     cursor[threadIdx.x] = groupStart[blockIdx.x * 64 + threadIdx.x];
     __syncthreads();
     const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
     int m0 = tileStart[blockIdx.x];
     for (int j = 0; j < RELOC_TILE / 64; j++) {
-        const int key = MemberKey(A, placedKey, base + 64 * j, noGauss);
+        const int key = MemberKey(A, placedKey, base + 64 * j, noGauss, tiles);
         const unsigned long long mask = __ballot(key >= 0);
         const unsigned long long below = (1ull << threadIdx.x) - 1ull;
         if (key >= 0) members[m0 + __popcll(mask & below)] = base + 64 * j;
@@ -150,7 +165,7 @@ LMC_D float *VectorBase(const ChainArrays &A, int v) {
 }
 
 // member m's chain -> staging record m
-__global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, float *staging, int capacity) {
+__global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, float *staging, int capacity, int tiles) {
     const int M = *count;
     if (M > capacity) return;  // more movers than staging records (host/context.cpp sizes the buffer): this step's movers stay where they are, nothing depends on a slot
     const size_t N = A.N;
@@ -164,7 +179,7 @@ __global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout
         r[RW_ADJREJECT] = __int_as_float(A.adjacentReject[i]), r[RW_SPLATCOUNT] = __int_as_float(nSplat), r[RW_CHAINID] = __int_as_float(A.chainId[i]);
         r[RW_SCORESUM] = A.scoreSum[i], r[RW_LASTSCORESUM] = A.lastScoreSum[i], r[RW_LASTSCORE] = A.lastScore[i], r[RW_PATHWEIGHT] = A.pathWeight[i];
         r[RW_NEXTKIND] = __int_as_float((int)A.nextKind[i]), r[RW_RNG_LO] = __int_as_float((int)(uint32_t)rs), r[RW_RNG_HI] = __int_as_float((int)(uint32_t)(rs >> 32));
-        r[RW_KEY] = __int_as_float(SlotKey(A, i));
+        r[RW_KEY] = __int_as_float(SlotKey(A, i, tiles));
         const int ticked = A.rngTicked[i];  // the extension table travels only once the stream has ticked: until then it is a function of the chain's seed (drng.h)
         r[RW_RNG_TICKED] = __int_as_float(ticked);
         if (ticked) {
@@ -284,10 +299,11 @@ size_t RelocTiles(int N) { return (size_t)(N + RELOC_TILE - 1) / RELOC_TILE; }
 void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s) {
     const RecordLayout R = MakeRecordLayout(maxDepth);
     const int N = A.N, nTiles = (N + RELOC_TILE - 1) / RELOC_TILE;
-    hipLaunchKernelGGL(k_reloc_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, withoutGaussianOnly);
+    const int tiles = (LMC_RELOC_TILES && maxDepth <= 6) ? 8 : 0;
+    hipLaunchKernelGGL(k_reloc_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, withoutGaussianOnly, tiles);
     hipLaunchKernelGGL(k_reloc_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.tileHist, B.count);
-    hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted, withoutGaussianOnly);
+    hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted, withoutGaussianOnly, tiles);
     const int moveBlocks = std::min((N + 63) / 64, 4096);
-    hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.capacity);
+    hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.capacity, tiles);
     hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey, B.capacity);
 }
