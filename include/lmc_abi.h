@@ -149,6 +149,9 @@ int lmc_chain_summary(lmc_ctx *ctx, int which, float *out, int stride);
  * lmc_chain_summary reports rows in chain order regardless.
  * out4 = [relocations run, chains moved by the last one, adjacent slot pairs whose chains differ in technique key, slots]; -1 when off */
 int lmc_relocation_stats(lmc_ctx *ctx, long long *out4);
+/* relocations skipped so far because their movers exceeded the staging records (N / 2 after the first full sort): such a step's movers stay where
+ * they are -- a performance event only, visible here and as "chains moved by the last one" = 0; -1 when relocation is off */
+long long lmc_relocation_skipped(lmc_ctx *ctx);
 /* kernel time (ms, HIP events on the launch stream) and launch count of the chain-step kernel since the last call */
 int lmc_step_timing(lmc_ctx *ctx, double *kernel_ms, long long *launches);
 /* split of the interval the last lmc_step_timing call covered: out3[0] = ms inside the lean small-step kernel
@@ -206,7 +209,8 @@ int lmc_kd_probe(int dim, int npts, const float *pts, int nq, const float *q, fl
 int lmc_lower_bound_probe(int n, const float *cdf, int nq, const float *u, int *out);
 /* measurement aid: ms per launch of a kernel that streams `words` state words per chain in batches of `batch` loads; mode 0 = [word][chain], 1 = [tile of 64][word][lane] */
 int lmc_layout_probe(int nChains, int words, int mode, int batch, int reps, double *msPerLaunch);
-/* parity probe: the deterministic float exp (mode 0) / log (1) / pow (2) of the glossy BSDFs (device/dtrans.h) evaluated on the device */
+/* parity probe, evaluated on the device: the deterministic float exp (mode 0) / log (1) / pow (2) of the glossy BSDFs (device/dtrans.h), sin (3) / cos (4) /
+ * acos (5) / atan2(x, y) (6) of the sampling code (device/dtrig.h), and glibc's logf as restated for the normal distribution (7, device/drng.h) */
 int lmc_trans_probe(int n, int mode, const float *x, const float *y, float *out);
 /* measurement hook (LMC_PROF=1): wave cycles per region of the lean small-step kernel since the last call: out16[0 .. LMC_PROF_REGIONS-1]
  * = cycle sums of the regions (dsmall.h PR_*), out16[LMC_PROF_REGIONS] = number of waves */

@@ -58,6 +58,9 @@ def lib():
         L.lmc_chain_summary.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.lmc_step_timing.argtypes = [vp, vp, vp]
         L.lmc_relocation_stats.argtypes = [vp, vp]
+        if hasattr(L, "lmc_relocation_skipped"):  # (an older A/B build selected with LMC_LIB lacks it)
+            L.lmc_relocation_skipped.argtypes = [vp]
+            L.lmc_relocation_skipped.restype = c_ll
         L.lmc_kernel_timing.argtypes = [vp, vp]
         L.lmc_kernel_timing_split.argtypes = [vp, vp]
         L.lmc_get_option.argtypes = [vp, ctypes.c_char_p, vp]
@@ -233,7 +236,7 @@ class Renderer:
             return None
         if r != 0:
             raise RuntimeError(_err())
-        return dict(relocations=o[0], moved=o[1], breaks=o[2], slots=o[3])
+        return dict(relocations=o[0], moved=o[1], breaks=o[2], slots=o[3], skipped=int(lib().lmc_relocation_skipped(self.h)) if hasattr(lib(), "lmc_relocation_skipped") else 0)
 
     def summary(self, which=0):
         n = self.num_chains  # which = 0: current states, 1: init states -- of this rank's chains

@@ -17,6 +17,7 @@
 #include <cstddef>
 
 #include "dtrans.h"
+#include "dtrig.h"
 
 namespace lmcd {
 #if !defined(__HIPCC__)
@@ -136,18 +137,22 @@ LMC_HD V3 Refract(V3 wi, V3 n, float cosThetaT, float eta, float invEta) {
     return n * (Dot(wi, n) * eta_ + cosThetaT) - wi * eta_;
 }
 
-// Trigonometry out of line: the device libm's sinf / cosf carry a large-argument (Payne-Hanek) reduction path of ~150
-// instructions each; inlined at every sampling site they made up a fifth of the lean step kernel's code.  One copy per
-// kernel image, reached by a call, returns the same bits.
-#if defined(__HIPCC__)
+// Trigonometry: the deterministic float routines of dtrig.h (dsinf / dcosf / dacosf / datan2f) -- one implementation on the device, in the CPU oracle
+// and in the host build of the path program, bit-equal by construction, within 1.5 ulp of float64 (the reference calls libm, whose last bit differs
+// between libm builds; until round 6 the device libm was called here and the veach-door chains diverged from the oracle's by it).
+// Out of line on the device: one copy per kernel image, reached by a call (inlined at every sampling site the libm versions made up a fifth of the
+// lean step kernel's code; LMC_TRIG_INLINE=1 for the A/B with these much smaller routines).
+#if defined(__HIPCC__) && !defined(LMC_TRIG_INLINE)
 #define LMC_OUTLINE __host__ __device__ inline __attribute__((noinline))
+#elif defined(__HIPCC__)
+#define LMC_OUTLINE __host__ __device__ inline
 #else
 #define LMC_OUTLINE inline
 #endif
-LMC_OUTLINE float lsinf(float x) { return sinf(x); }
-LMC_OUTLINE float lcosf(float x) { return cosf(x); }
-LMC_OUTLINE float lacosf(float x) { return acosf(x); }
-LMC_OUTLINE float latan2f(float y, float x) { return atan2f(y, x); }
+LMC_OUTLINE float lsinf(float x) { return dsinf(x); }
+LMC_OUTLINE float lcosf(float x) { return dcosf(x); }
+LMC_OUTLINE float lacosf(float x) { return dacosf(x); }
+LMC_OUTLINE float latan2f(float y, float x) { return datan2f(y, x); }
 
 // sampling.h
 LMC_HD V3 SampleSphere(V2 coord, float &jacobian) {

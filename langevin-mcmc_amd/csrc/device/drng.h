@@ -7,6 +7,7 @@
 // table (256 B per chain, AoS in HBM; it only changes on a "tick", once per 2^32 draws -- until then it is synthesised from
 // the seed and never read, see PcgJumpTable below).
 #pragma once
+#include <stdexcept>
 #include "dmath.h"
 
 namespace lmcd {
@@ -102,6 +103,29 @@ struct PcgJumpTable {
 #if defined(__HIPCC__)
 __device__ __constant__ const PcgJumpTable c_pcgJump{};
 #endif
+
+// ---- glibc's logf, restated: the `std::log(r2)` of libstdc++'s normal_distribution<float> (bits/random.tcc; the reference's gaussian.cpp:44,
+// mutation_small.h:35, path.cpp:1958) is glibc's logf -- since 2.27 the table-driven DOUBLE-precision routine of ARM's optimized-routines
+// (sysdeps/ieee754/flt-32/e_logf.c, e_logf_data.c: x = 2^k z, z in [0x1.66p-1, 0x1.66p0) by the top 4 mantissa bits i, r = z invc[i] - 1,
+// log x = k ln2 + logc[i] + r + r^2 (A2 + A1 r + A0 r^2), one rounding to float at the end).  Plain IEEE double arithmetic, so it can be restated
+// bit for bit; the device libm's logf (a float polynomial) agreed with it on 84.6 % of the polar method's arguments only.
+// What is restated is the build of that source the ifunc selects on every x86-64 CPU with FMA (sysdeps/x86_64/fpu/multiarch/e_logf-fma.c = the same
+// C under -mfma -mavx2): WHICH operations gcc fused there was read off this image's libm.so.6 (GLIBC 2.35-0ubuntu3.11, objdump of __logf_fma) and
+// is spelled out below with explicit fma's; the constants are the bytes of its .rodata.  Pinned by tests/test_host.py against the host's logf on
+// EVERY float of (0, 1] -- the polar method's whole domain (1 065 353 216 arguments).
+struct LogfTable {
+    double t[16][2];  // invc, logc
+};
+#define LMC_LOGF_TABLE_INIT                                                                                                                       \
+    {{{0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2}, \
+      {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},    \
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, \
+      {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5}, {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},                                  \
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3}, {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},     \
+      {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}}}
+#if defined(__HIPCC__)
+__device__ __constant__ const LogfTable c_logfTab = LMC_LOGF_TABLE_INIT;
+#endif
 #if defined(LMC_RNG_JUMP_LDS) && defined(__HIP_DEVICE_COMPILE__)
 // A translation unit that defines LMC_RNG_JUMP_LDS (the lean small-step launch) keeps the 1 KB of jump constants in LDS: a draw's look-up then is an LDS
 // read instead of a vector-memory load -- and a vector-memory load's wait (`vmcnt` retires in order) is also a wait for every load issued before
@@ -110,9 +134,22 @@ __device__ __forceinline__ PcgJump *PcgJumpLds() {
     __shared__ PcgJump t[64];
     return t;
 }
+__device__ __forceinline__ double2 *LogfTabLds() {  // ... and so do the 256 bytes of logf's table (one look-up per pair of normal variates)
+    __shared__ double2 t[16];
+    return t;
+}
+// Needs a block of at least 64 threads: every launcher of a kernel that calls it checks its block size on the host (RequireJumpLdsBlock).  (ADVICE r5
+// asked for a strided fill instead, `for (k = threadIdx.x; k < 64; k += blockDim.x)`: with it the veach-door launches faulted at 2^18 chains and more,
+// a run later the same build with this form did not -- gpurun_out r06_d .. r06_f; the loop form is not used.)
 __device__ __forceinline__ void PcgJumpLdsInit() {
     if (threadIdx.x < 64) PcgJumpLds()[threadIdx.x] = c_pcgJump.j[threadIdx.x];
+    if (threadIdx.x < 16) LogfTabLds()[threadIdx.x] = make_double2(c_logfTab.t[threadIdx.x][0], c_logfTab.t[threadIdx.x][1]);
     __syncthreads();
+}
+#endif
+#if defined(__HIPCC__)
+inline void RequireJumpLdsBlock(int blockThreads) {
+    if (blockThreads < 64) throw std::runtime_error("a kernel that keeps the PCG jump constants in LDS needs blocks of at least 64 threads");
 }
 #endif
 #if defined(LMC_RNG_JUMP_LDS) && defined(__HIP_DEVICE_COMPILE__)
@@ -197,6 +234,43 @@ struct Rng {
     }
 };
 
+LMC_HD void LogfTabOf(int i, double &invc, double &logc) {
+#if defined(LMC_RNG_JUMP_LDS) && defined(__HIP_DEVICE_COMPILE__)
+    const double2 e = LogfTabLds()[i];
+    invc = e.x, logc = e.y;
+#elif defined(__HIP_DEVICE_COMPILE__)
+    invc = c_logfTab.t[i][0], logc = c_logfTab.t[i][1];
+#else
+    static const LogfTable T = LMC_LOGF_TABLE_INIT;
+    invc = T.t[i][0], logc = T.t[i][1];
+#endif
+}
+LMC_HD float GlibcLogf(float x) {
+    uint32_t ix = __builtin_bit_cast(uint32_t, x);
+    if (ix == 0x3f800000u) return 0.0f;  // log(1) = +0 in every rounding mode
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {  // x < 0x1p-126 or inf or nan
+        if (ix * 2u == 0u) return -INFINITY;
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
+        ix = __builtin_bit_cast(uint32_t, x * 0x1p23f);  // subnormal: normalised
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    double invc, logc;
+    LogfTabOf(i, invc, logc);
+    const double z = (double)__builtin_bit_cast(float, iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = __builtin_fma((double)k, 0x1.62e42fefa39efp-1, logc);
+    const double r2 = r * r;
+    double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
+    y = __builtin_fma(y, r2, y0 + r);
+    return (float)y;
+}
+
 // one normal_distribution<float> object (the saved variate lives as long as the object)
 struct NormalDist {
     float mean, stddev, saved;
@@ -216,7 +290,7 @@ struct NormalDist {
                 y = 2.0f * u1 - 1.0f;
                 r2 = x * x + y * y;
             } while (r2 > 1.0f || r2 == 0.0f);
-            float mult = sqrtf(-2.0f * logf(r2) / r2);
+            float mult = sqrtf(-2.0f * GlibcLogf(r2) / r2);
             saved = x * mult;
             savedAvailable = true;
             ret = y * mult;

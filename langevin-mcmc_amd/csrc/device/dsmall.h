@@ -707,7 +707,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             float px = dim * (-0.9189385332046727f);
             px += 0.5f * logDet;
             px -= 0.5f * q;
-            a = Clampf(expf(px - py) * pc.ssScore / curSs, 0.0f, 1.0f);
+            a = Clampf(lexpf(px - py) * pc.ssScore / curSs, 0.0f, 1.0f);
         } else {
             a = Clampf(pc.ssScore / curSs, 0.0f, 1.0f);
         }

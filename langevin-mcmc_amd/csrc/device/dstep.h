@@ -386,7 +386,7 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
                 InitGaussianFor<WITH_GRAD>(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st);
                 float py = GaussianLogPdf(dim, offset, false, cg);
                 float px = GaussianLogPdf(dim, offset, true, pg);
-                a = Clampf(expf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+                a = Clampf(lexpf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
             } else {
                 a = Clampf(pc.ssScore / cur.ssScore, 0.0f, 1.0f);
             }

@@ -108,7 +108,7 @@ struct RelocBuffers {
     int *tileCount, *tileHist;  // RelocTiles(N), 64 x RelocTiles(N): members per 1024-slot tile / per (tile, key); then their exclusive prefixes
     int *members;               // N: the slots that take part, ascending
     int *sorted;                // N: member indices by key
-    int *count;                 // 1: number of members
+    int *count;                 // 2: number of members (0: the relocation was skipped, its movers exceeded `capacity`), relocations skipped so far
     float *staging;             // RelocRecordWords(maxDepth) floats per member
     int capacity;               // records the staging buffer holds: a step with more movers leaves them where they are (host/context.cpp)
 };
@@ -117,6 +117,17 @@ size_t RelocRecordWords(int maxDepth);
 void LaunchRelocIota(int n, int *v, hipStream_t s);
 // withoutGaussianOnly (H2MC renders): chains that hold a stored Gaussian stay where they are (the pipeline's Gaussian buffers are per slot)
 void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s);
+void LaunchRelocFineKey(const lmcd::ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, hipStream_t s);
+void LaunchRelocMove(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s);
+// the periodic full re-sort by (technique, screen Morton code): work buffers of the device radix sort
+struct RelocSortBuffers {
+    unsigned *keys[2];  // N each
+    int *vals[2];       // N each
+    int *hist;          // 256 x RelocSortBlocks(N)
+    int *scanSums;      // 256 x RelocSortBlocks(N) / 2048 + 2
+};
+size_t RelocSortBlocks(int N);
+void LaunchRelocFullSort(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
 void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, const int *coord, int *scratchStart, int *scratchCursor, int *scratchWordCount, int *tileSums,
                           uint2 *words, int *cellStart, unsigned short *idx, hipStream_t s);

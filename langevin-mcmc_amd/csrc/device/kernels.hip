@@ -60,7 +60,10 @@ __global__ void k_rng_probe(int nSeeds, const unsigned long long *seeds, int mod
 // counter calibration: the chain state's access pattern (one dword per lane, unit stride) over a known byte count
 // parity probe of the deterministic float transcendentals (dtrans.h): mode 0 exp, 1 log, 2 pow
 __global__ void k_trans_probe(int n, int mode, const float *x, const float *y, float *o) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = mode == 0 ? lexpf(x[i]) : mode == 1 ? llogf(x[i]) : lpowf(x[i], y[i]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float a = x[i], b = y[i];
+        o[i] = mode == 0 ? lexpf(a) : mode == 1 ? llogf(a) : mode == 2 ? lpowf(a, b) : mode == 3 ? lsinf(a) : mode == 4 ? lcosf(a) : mode == 5 ? lacosf(a) : mode == 6 ? latan2f(a, b) : GlibcLogf(a);
+    }
 }
 
 __global__ void k_stream_probe(long long n, const float *in, float *out) {

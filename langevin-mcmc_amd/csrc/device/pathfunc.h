@@ -186,11 +186,21 @@ LMC_HD float Sqrt(float x) { return sqrtf(x); }
 LMC_HD float Sin(float x) { return __sinf(x); }
 LMC_HD float Cos(float x) { return __cosf(x); }
 #else
+#ifdef LMC_PF_LIBM_TRIG  // debugging aid: libm's versions, to tell an ill-conditioned state from a defect of dtrig.h
 LMC_HD float Sin(float x) { return sinf(x); }
 LMC_HD float Cos(float x) { return cosf(x); }
+#else
+LMC_HD float Sin(float x) { return dsinf(x); }  // dtrig.h: the same bits on the device and in the host build
+LMC_HD float Cos(float x) { return dcosf(x); }
 #endif
+#endif
+#ifdef LMC_PF_LIBM_TRIG
 LMC_HD float Acos(float x) { return acosf(x); }
 LMC_HD float Atan2(float y, float x) { return atan2f(y, x); }
+#else
+LMC_HD float Acos(float x) { return dacosf(x); }
+LMC_HD float Atan2(float y, float x) { return datan2f(y, x); }
+#endif
 LMC_HD float Fabs(float x) { return fabsf(x); }
 #if LMC_PF_FAST
 LMC_HD float Log(float x) { return __logf(x); }

@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigne
     if (threadIdx.x == 0) tileCount[blockIdx.x] = total;
 }
 // one wave: tileCount -> first member index of every tile; tileHist -> first sorted position of every (tile, key) group; *count
-__global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount, int *tileHist, int *count) {
+// count[0] = members of this relocation -- 0 when they exceed the staging capacity: the move is skipped as a whole (nothing depends on a slot; the
+// chains are picked up at their next large step) and count[1], the number of relocations skipped so far, goes up (lmc_relocation_skipped)
+__global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount, int *tileHist, int *count, int capacity) {
     const int key = threadIdx.x;
     int total = 0;
 #pragma unroll 8
@@ -111,7 +113,11 @@ __global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount
         const int o = __shfl_up(incl, off);
         if (key >= off) incl += o;
     }
-    if (key == 63) *count = incl;
+    if (key == 63) {
+        if (incl > capacity) count[0] = 0, count[1]++;
+        else
+            count[0] = incl;
+    }
     int run = incl - total;
 #pragma unroll 8
     for (int t = 0; t < nTiles; t++) {
@@ -167,7 +173,7 @@ LMC_D float *VectorBase(const ChainArrays &A, int v) {
 // member m's chain -> staging record m
 __global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, float *staging, int capacity, int tiles) {
     const int M = *count;
-    if (M > capacity) return;  // more movers than staging records (host/context.cpp sizes the buffer): this step's movers stay where they are, nothing depends on a slot
+    if (M > capacity) return;  // (k_reloc_offsets reports 0 members for a relocation that would not fit; the test stays as the guard of the staging buffer)
     const size_t N = A.N;
     for (int m = blockIdx.x * 64 + threadIdx.x; m < M; m += gridDim.x * 64) {
         const int i = members[m];
@@ -276,6 +282,290 @@ __global__ void __launch_bounds__(64) k_reloc_scatter(ChainArrays A, RecordLayou
     }
 }
 
+// ---- the same move, WAVE-COOPERATIVE (round 6).  The lane-per-record kernels above write (read) a staging record word by word from one lane: 64 lanes,
+// 64 records 2.5 KB apart -- every store instruction touches 64 cache lines for 4 bytes each.  Harmless for the ~16 k movers of a step beside the
+// step launches, not for the full re-sort, whose 2^20 records they moved in 3.3 + 1.7 ms (profiles/r06_d_*).  Here a wave owns 64 consecutive
+// members: it reads 64 SoA rows of its chains (lane = chain: coalesced when the members are consecutive slots, as in the full re-sort), turns the
+// 64 x 64 tile in LDS, and writes it to the 64 staging records with lane = word (256 contiguous bytes per record and instruction); the scatter is
+// the mirror image.  Dead words (vertices beyond a chain's counts, splats beyond its count, vectors known to be zero, an isotropic Gaussian) are
+// neither read nor written: per lane by predicate, per wave by the loop bounds (the wave's maxima).  The 16 scalar words of a record stay lane-wise.
+constexpr int XP = 65;  // LDS pitch of a tile row: lane l, column c at [l * XP + c], conflict-free both ways
+LMC_D int WaveMax(int v) {
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+// SoA rows [0, waveRows) of the wave's chains -> record words [recBase, recBase + waveRows) of records m0 .. m0 + nValid - 1.  rowAddr(k): this lane's word of row k
+template <class RowAddr>
+LMC_D void RowsToRecords(float *tile, RowAddr rowAddr, int laneRows, int waveRows, float *staging, size_t recWords, int m0, int nValid, int recBase) {
+    const int lane = threadIdx.x;
+    for (int r0 = 0; r0 < waveRows; r0 += 64) {
+        const int nr = min(64, waveRows - r0);
+#pragma unroll 4
+        for (int w = 0; w < nr; w++) tile[w * XP + lane] = (r0 + w < laneRows) ? *rowAddr(r0 + w) : 0.f;
+        __syncthreads();
+        if (lane < nr) {
+            float *dst = staging + (size_t)m0 * recWords + recBase + r0 + lane;
+#pragma unroll 4
+            for (int c = 0; c < nValid; c++) dst[(size_t)c * recWords] = tile[lane * XP + c];
+        }
+        __syncthreads();
+    }
+}
+// the mirror image: srcRec[c] = the record that goes to the wave's chain c (-1: none)
+template <class RowAddr>
+LMC_D void RecordsToRows(float *tile, const int *srcRec, RowAddr rowAddr, int laneRows, int waveRows, const float *staging, size_t recWords, int nValid, int recBase) {
+    const int lane = threadIdx.x;
+    for (int r0 = 0; r0 < waveRows; r0 += 64) {
+        const int nr = min(64, waveRows - r0);
+        if (lane < nr) {
+#pragma unroll 4
+            for (int c = 0; c < nValid; c++) {
+                const int rec = srcRec[c];
+                if (rec >= 0) tile[lane * XP + c] = staging[(size_t)rec * recWords + recBase + r0 + lane];
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int w = 0; w < nr; w++)
+            if (r0 + w < laneRows) *rowAddr(r0 + w) = tile[w * XP + lane];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64) k_reloc_gather_coop(ChainArrays A, RecordLayout R, const int *members, const int *count, float *staging, int capacity, int tiles) {
+    __shared__ float tile[64 * XP];
+    const int M = *count;
+    if (M > capacity) return;
+    const size_t N = A.N, W = (size_t)R.Words();
+    const int lane = threadIdx.x;
+    for (int m0 = blockIdx.x * 64; m0 < M; m0 += gridDim.x * 64) {
+        const int m = m0 + lane, nValid = min(64, M - m0);
+        const bool valid = m < M;
+        const int i = valid ? members[m] : 0;
+        int flags = 0, camCount = 0, lgtCount = 0, nSplat = 0;
+        const float *path = A.curPath;
+        if (valid) {
+            float *r = staging + (size_t)m * W;
+            flags = A.flags[i];
+            const uint64_t rs = A.rngState[i];
+            nSplat = min(A.curSplatCount[i], R.nS);
+            r[RW_FLAGS] = __int_as_float(flags), r[RW_SAMPLEIDX] = __int_as_float(A.sampleIdx[i]), r[RW_NUMSAMPLES] = __int_as_float(A.numSamples[i]);
+            r[RW_ADJREJECT] = __int_as_float(A.adjacentReject[i]), r[RW_SPLATCOUNT] = __int_as_float(nSplat), r[RW_CHAINID] = __int_as_float(A.chainId[i]);
+            r[RW_SCORESUM] = A.scoreSum[i], r[RW_LASTSCORESUM] = A.lastScoreSum[i], r[RW_LASTSCORE] = A.lastScore[i], r[RW_PATHWEIGHT] = A.pathWeight[i];
+            r[RW_NEXTKIND] = __int_as_float((int)A.nextKind[i]), r[RW_RNG_LO] = __int_as_float((int)(uint32_t)rs), r[RW_RNG_HI] = __int_as_float((int)(uint32_t)(rs >> 32));
+            r[RW_KEY] = __int_as_float(SlotKey(A, i, tiles));
+            const int ticked = A.rngTicked[i];
+            r[RW_RNG_TICKED] = __int_as_float(ticked);
+            if (ticked) {  // once per 2^32 draws of a stream: lane-wise
+                const uint4 *tab = reinterpret_cast<const uint4 *>(A.rngTab + (size_t)i * 64);
+                uint4 *rt = reinterpret_cast<uint4 *>(r + RW_TAB);
+#pragma unroll 4
+                for (int k = 0; k < 16; k++) rt[k] = tab[k];
+            }
+            path = CurPathBuf(A, flags);
+            camCount = min(max(__float_as_int(path[(size_t)12 * N + i]), 0), R.nV), lgtCount = min(max(__float_as_int(path[(size_t)13 * N + i]), 0), R.nV);  // DPath: camCount, lgtCount
+        }
+        const float *pi = path + i;
+        // head + camera vertices are consecutive rows of the path, the light vertices start at row HEAD + MAXD * 12
+        const int camRows = valid ? DPATH_HEAD_WORDS + camCount * DVERTEX_WORDS : 0, lgtRows = lgtCount * DVERTEX_WORDS;
+        RowsToRecords(tile, [&](int k) { return pi + (size_t)k * N; }, camRows, WaveMax(camRows), staging, W, m0, nValid, RW_HEAD);
+        const int wl = WaveMax(lgtRows);
+        if (wl) RowsToRecords(tile, [&](int k) { return pi + (size_t)(DPATH_HEAD_WORDS + MAXD * DVERTEX_WORDS + k) * N; }, lgtRows, wl, staging, W, m0, nValid, RW_VERT + R.nV * DVERTEX_WORDS);
+        // contribution + pending splats: two row ranges written back to back (Splats() = Contrib() + CONTRIB_WORDS)
+        const float *ci = A.curContrib + i, *si = A.curSplat + i;
+        const int csRows = valid ? CONTRIB_WORDS + nSplat * SPLAT_WORDS : 0;
+        RowsToRecords(tile, [&](int k) { return k < CONTRIB_WORDS ? ci + (size_t)k * N : si + (size_t)(k - CONTRIB_WORDS) * N; }, csRows, WaveMax(csRows), staging, W, m0, nValid, R.Contrib());
+        const int vecRows = valid && VectorsMayBeNonZero(flags) ? 7 * MAXPSS : 0, wv = WaveMax(vecRows);
+        if (wv) RowsToRecords(tile, [&](int k) { return VectorBase(A, k / MAXPSS) + (size_t)(k % MAXPSS) * N + i; }, vecRows, wv, staging, W, m0, nValid, R.Vectors());
+        const int gRows = valid && HasStoredGaussian(flags) ? GAUSS_WORDS : 0, wg = WaveMax(gRows);
+        if (wg) {
+            const float *gi = CurGaussBuf(A, flags) + i;
+            RowsToRecords(tile, [&](int k) { return gi + (size_t)k * N; }, gRows, wg, staging, W, m0, nValid, R.Gauss());
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_reloc_scatter_coop(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, const float *staging,
+                                                            unsigned char *placedKey, int capacity) {
+    __shared__ float tile[64 * XP];
+    __shared__ int srcRec[64];
+    const int M = *count;
+    if (M > capacity) return;
+    const size_t N = A.N, W = (size_t)R.Words();
+    const int lane = threadIdx.x;
+    for (int d0 = blockIdx.x * 64; d0 < M; d0 += gridDim.x * 64) {
+        const int d = d0 + lane, nValid = min(64, M - d0);
+        const bool valid = d < M;
+        const int i = valid ? members[d] : 0, m = valid ? sorted[d] : -1;
+        const bool moves = valid && m != d;  // m == d: the chain stays where it is
+        const float *r = staging + (size_t)(valid ? m : 0) * W;
+        int flags = 0, oldFlags = 0, camCount = 0, lgtCount = 0, nSplat = 0;
+        if (valid) placedKey[i] = (unsigned char)__float_as_int(r[RW_KEY]);
+        if (moves) {
+            flags = __float_as_int(r[RW_FLAGS]), oldFlags = __float_as_int(staging[(size_t)d * W + RW_FLAGS]);
+            nSplat = __float_as_int(r[RW_SPLATCOUNT]);
+            A.flags[i] = flags, A.sampleIdx[i] = __float_as_int(r[RW_SAMPLEIDX]), A.numSamples[i] = __float_as_int(r[RW_NUMSAMPLES]);
+            A.adjacentReject[i] = __float_as_int(r[RW_ADJREJECT]), A.curSplatCount[i] = nSplat, A.chainId[i] = __float_as_int(r[RW_CHAINID]), A.slotOf[__float_as_int(r[RW_CHAINID])] = i;
+            A.scoreSum[i] = r[RW_SCORESUM], A.lastScoreSum[i] = r[RW_LASTSCORESUM], A.lastScore[i] = r[RW_LASTSCORE], A.pathWeight[i] = r[RW_PATHWEIGHT];
+            A.nextKind[i] = (unsigned char)__float_as_int(r[RW_NEXTKIND]);
+            A.rngState[i] = (uint64_t)(uint32_t)__float_as_int(r[RW_RNG_LO]) | ((uint64_t)(uint32_t)__float_as_int(r[RW_RNG_HI]) << 32);
+            const int ticked = __float_as_int(r[RW_RNG_TICKED]);
+            A.rngTicked[i] = (unsigned char)ticked;
+            if (ticked) {
+                uint4 *tab = reinterpret_cast<uint4 *>(A.rngTab + (size_t)i * 64);
+                const uint4 *rt = reinterpret_cast<const uint4 *>(r + RW_TAB);
+#pragma unroll 4
+                for (int k = 0; k < 16; k++) tab[k] = rt[k];
+            }
+            camCount = min(max(__float_as_int(r[RW_HEAD + 12]), 0), R.nV), lgtCount = min(max(__float_as_int(r[RW_HEAD + 13]), 0), R.nV);
+        }
+        __syncthreads();  // (the previous group's tile and srcRec are no longer read)
+        srcRec[lane] = moves ? m : -1;
+        __syncthreads();
+        float *pi = CurPathBuf(A, flags) + i;
+        const int camRows = moves ? DPATH_HEAD_WORDS + camCount * DVERTEX_WORDS : 0, lgtRows = lgtCount * DVERTEX_WORDS;
+        RecordsToRows(tile, srcRec, [&](int k) { return pi + (size_t)k * N; }, camRows, WaveMax(camRows), staging, W, nValid, RW_HEAD);
+        const int wl = WaveMax(lgtRows);
+        if (wl) RecordsToRows(tile, srcRec, [&](int k) { return pi + (size_t)(DPATH_HEAD_WORDS + MAXD * DVERTEX_WORDS + k) * N; }, lgtRows, wl, staging, W, nValid, RW_VERT + R.nV * DVERTEX_WORDS);
+        float *ci = A.curContrib + i, *si = A.curSplat + i;
+        const int csRows = moves ? CONTRIB_WORDS + nSplat * SPLAT_WORDS : 0;
+        RecordsToRows(tile, srcRec, [&](int k) { return k < CONTRIB_WORDS ? ci + (size_t)k * N : si + (size_t)(k - CONTRIB_WORDS) * N; }, csRows, WaveMax(csRows), staging, W, nValid, R.Contrib());
+        // the seven MALA vectors: the incoming chain's, or zeros over a slot whose previous chain had any (the gather wrote zeros into the record of a
+        // chain whose vectors are zero by the invariant, so "copy the record" covers both)
+        const bool vecIn = moves && VectorsMayBeNonZero(flags);
+        const int vecRows = (vecIn || (moves && VectorsMayBeNonZero(oldFlags))) ? 7 * MAXPSS : 0, wv = WaveMax(vecRows);
+        if (wv) {
+            // a record whose vector words were not written by the gather (its chain's vectors are zero and no chain of its gather wave had any): write zeros
+            __syncthreads();
+            const int keep = srcRec[lane];
+            __syncthreads();
+            if (!vecIn) srcRec[lane] = -1;
+            __syncthreads();
+            for (int w = 0; w < 64; w++) tile[w * XP + lane] = 0.f;  // a lane without a source record stores zeros
+            __syncthreads();
+            RecordsToRows(tile, srcRec, [&](int k) { return VectorBase(A, k / MAXPSS) + (size_t)(k % MAXPSS) * N + i; }, vecRows, wv, staging, W, nValid, R.Vectors());
+            srcRec[lane] = keep;
+            __syncthreads();
+        }
+        const int gRows = moves && HasStoredGaussian(flags) ? GAUSS_WORDS : 0, wg = WaveMax(gRows);
+        if (wg) {
+            float *gi = CurGaussBuf(A, flags) + i;
+            RecordsToRows(tile, srcRec, [&](int k) { return gi + (size_t)k * N; }, gRows, wg, staging, W, nValid, R.Gauss());
+        }
+    }
+}
+
+// ---- experiment (LMC_EXP / lmc_set_option "exp_resort"): a FULL re-sort of the resident chains by a key finer than the technique, the order worked out
+// on the host -- the upper bound of what any finer slot order can buy the step launches (profiles/r06_a_*).  key = [63 - technique | sub-key]:
+//   mode 1: Morton code of the camera vertex's screen position (12 + 12 bits)
+//   mode 2: leaf-order position of the first walked vertex's triangle (the tree's depth-first order is a space-filling order), then the second's
+//   mode 3: first triangle's leaf position, then the screen Morton code
+LMC_D unsigned Part1By1(unsigned x) {
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+__global__ void __launch_bounds__(256) k_reloc_finekey(ChainArrays A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.N) return;
+    const size_t N = A.N;
+    const int c = __float_as_int(A.curContrib[i]), l = __float_as_int(A.curContrib[N + i]);
+    const float *path = CurPathBuf(A, A.flags[i]);
+    const float sx = path[(size_t)1 * N + i], sy = path[(size_t)2 * N + i];
+    const unsigned mx = (unsigned)min(4095, max(0, (int)(sx * 4096.f))), my = (unsigned)min(4095, max(0, (int)(sy * 4096.f)));
+    const unsigned morton = Part1By1(mx) | (Part1By1(my) << 1);
+    const int camCount = max(c - 1, 0), lgtCount = max(l - 1, 0);
+    auto posOf = [&](int walkIdx) -> unsigned {  // the walk's vertices: light sub-path first (dsmall.h)
+        int word = -1;
+        if (walkIdx < lgtCount) word = DPATH_HEAD_WORDS + (MAXD + walkIdx) * DVERTEX_WORDS;
+        else if (walkIdx - lgtCount < camCount) word = DPATH_HEAD_WORDS + (walkIdx - lgtCount) * DVERTEX_WORDS;
+        if (word < 0) return 0xffffu;
+        const int tri = __float_as_int(path[(size_t)word * N + i]);
+        return tri >= 0 && tri < numTris ? (unsigned)leafPosOfTri[tri] : 0xffffu;
+    };
+    unsigned long long sub = 0;
+    if (mode == 1) sub = morton;
+    else if (mode == 2) sub = ((unsigned long long)posOf(0) << 16) | posOf(1);
+    else if (mode == 3) sub = ((unsigned long long)posOf(0) << 24) | morton;
+    else if (mode == 5) sub = morton >> 18;  // 8 x 8 screen tiles
+    else if (mode == 6) sub = morton >> 14;  // 32 x 32
+    // mode 4: the technique alone (what a relocation without misplaced chains would give)
+    keys[i] = ((unsigned long long)SlotKey(A, i, 0) << 48) | sub;
+}
+
+// ---- the full re-sort (round 6): every K steps ALL resident chains are re-placed in the order of a 24-bit key
+//   [63 - technique (6 bits) | Morton code of the camera vertex's screen position (9 + 9 bits)]
+// Why: (1) the per-step relocation above places a mover at the slot QUANTILE of its key quantile, which is exact only for a stationary technique
+// histogram -- while the histogram drifts (start-up, the change of the large-step probability at 10 % of a chain's samples, mlt.cpp:96-97) the surplus
+// of a growing technique lands scattered inside its neighbour's region and stays there: 100-200 k technique breaks along 2^20 slots, a dozen foreign
+// chains per wave, each stretching its wave to the longer technique (profiles/r06_b_*: a pure order alone = lean kernel -7.6 %); (2) inside a
+// technique, chains whose camera vertices are neighbours on the screen start their walks through the same nodes and leaves: the lanes of a wave
+// leave the traversal loops together (a further -9 %, decaying as small steps drift and accepted large steps jump: half of it is gone after ~16 steps).
+// The order is computed on the device: key kernel, three stable 8-bit counting passes over (key, slot) pairs (one-wave blocks of RS_TILE keys: digit
+// histogram -> scan over [digit][block] -> ranked scatter, ranks by ballot match), then the move of the relocation with every slot a member.
+constexpr int RS_TILE = 4096;
+__global__ void __launch_bounds__(256) k_rs_key(ChainArrays A, unsigned *keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.N) return;
+    const size_t N = A.N;
+    const float *path = CurPathBuf(A, A.flags[i]);
+    const float sx = path[(size_t)1 * N + i], sy = path[(size_t)2 * N + i];  // DPath::screen0, screen1
+    const unsigned mx = (unsigned)min(511, max(0, (int)(sx * 512.f))), my = (unsigned)min(511, max(0, (int)(sy * 512.f)));
+    keys[i] = ((unsigned)SlotKey(A, i, 0) << 18) | Part1By1(mx) | (Part1By1(my) << 1);
+}
+// hist[digit * nBlocks + block] = keys of the block's tile with that digit
+__global__ void __launch_bounds__(64) k_rs_hist(const unsigned *keys, int n, int shift, int *hist, int nBlocks) {
+    __shared__ int h[256];
+    for (int k = threadIdx.x; k < 256; k += 64) h[k] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE + threadIdx.x;
+    for (int j = 0; j < RS_TILE / 64; j++) {
+        const int i = base + 64 * j;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 256; k += 64) hist[k * nBlocks + blockIdx.x] = h[k];
+}
+// histIncl: the inclusive scan of hist.  Stable: inside a (block, digit) group the entries keep their order (rank by ballot match, rounds in order).
+__global__ void __launch_bounds__(64) k_rs_scatter(const unsigned *keysIn, const int *valsIn, unsigned *keysOut, int *valsOut, int n, int shift, const int *histIncl, int nBlocks) {
+    __shared__ int cursor[256];
+    for (int k = threadIdx.x; k < 256; k += 64) {
+        const int idx = k * nBlocks + blockIdx.x;
+        cursor[k] = idx ? histIncl[idx - 1] : 0;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+    const int base = blockIdx.x * RS_TILE + threadIdx.x;
+    for (int j = 0; j < RS_TILE / 64; j++) {
+        const int i = base + 64 * j;
+        const bool valid = i < n;
+        const unsigned key = valid ? keysIn[i] : 0u;
+        const unsigned d = (key >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);  // the valid lanes with my digit
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        const int rank = __popcll(peers & below);
+        if (valid) {
+            const int pos = cursor[d] + rank;
+            keysOut[pos] = key;
+            valsOut[pos] = valsIn ? valsIn[i] : i;
+        }
+        __syncthreads();
+        if (valid && rank == 0) cursor[d] += __popcll(peers);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(64) k_rs_set_count(int *count, int n) {
+    if (threadIdx.x == 0) count[0] = n;
+}
+
 __global__ void __launch_bounds__(256) k_reloc_iota(int n, int *v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) v[i] = i;
@@ -296,14 +586,54 @@ size_t RelocRecordWords(int maxDepth) { return (size_t)MakeRecordLayout(maxDepth
 void LaunchRelocIota(int n, int *v, hipStream_t s) { hipLaunchKernelGGL(k_reloc_iota, dim3((n + 255) / 256), dim3(256), 0, s, n, v); }
 size_t RelocTiles(int N) { return (size_t)(N + RELOC_TILE - 1) / RELOC_TILE; }
 
+// gather + scatter of a relocation whose members / sorted / count are in place: the wave-cooperative kernels (LMC_RELOC_COOP=0: the lane-per-record ones, A/B)
+static void LaunchMoveKernels(const ChainArrays &A, const RecordLayout &R, const RelocBuffers &B, int tiles, int moveBlocks, hipStream_t s) {
+    static const bool coop = !(getenv("LMC_RELOC_COOP") && atoi(getenv("LMC_RELOC_COOP")) == 0);
+    if (coop) {
+        hipLaunchKernelGGL(k_reloc_gather_coop, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.count, B.staging, B.capacity, tiles);
+        hipLaunchKernelGGL(k_reloc_scatter_coop, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey, B.capacity);
+    } else {
+        hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.capacity, tiles);
+        hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey, B.capacity);
+    }
+}
+void LaunchRelocFineKey(const ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_reloc_finekey, dim3((A.N + 255) / 256), dim3(256), 0, s, A, leafPosOfTri, numTris, mode, keys);
+}
+// the move of a relocation whose members / sorted / count the caller has filled in
+void LaunchRelocMove(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s) {
+    const RecordLayout R = MakeRecordLayout(maxDepth);
+    const int moveBlocks = std::min((A.N + 63) / 64, 4096);
+    LaunchMoveKernels(A, R, B, 0, moveBlocks, s);
+}
+
+size_t RelocSortBlocks(int N) { return (size_t)(N + RS_TILE - 1) / RS_TILE; }
+// every chain re-placed by (technique, screen Morton code); B.capacity must be N (the caller checks).  W: keys[2][N], vals[2][N], hist[256 x RelocSortBlocks(N)], scan tile sums
+void LaunchRelocFullSort(const ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, hipStream_t s) {
+    const int N = A.N, nBlocks = (int)RelocSortBlocks(N);
+    hipLaunchKernelGGL(k_rs_key, dim3((N + 255) / 256), dim3(256), 0, s, A, W.keys[0]);
+    // three passes: keys 0 -> 1 -> 0 -> 1; values iota -> vals[0] -> vals[1] -> B.sorted
+    const unsigned *kin[3] = {W.keys[0], W.keys[1], W.keys[0]};
+    unsigned *kout[3] = {W.keys[1], W.keys[0], W.keys[1]};
+    const int *vin[3] = {nullptr, W.vals[0], W.vals[1]};
+    int *vout[3] = {W.vals[0], W.vals[1], B.sorted};
+    for (int pass = 0; pass < 3; pass++) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(nBlocks), dim3(64), 0, s, kin[pass], N, 8 * pass, W.hist, nBlocks);
+        LaunchInclusiveScan(W.hist, 256 * nBlocks, W.scanSums, s);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nBlocks), dim3(64), 0, s, kin[pass], vin[pass], kout[pass], vout[pass], N, 8 * pass, W.hist, nBlocks);
+    }
+    hipLaunchKernelGGL(k_reloc_iota, dim3((N + 255) / 256), dim3(256), 0, s, N, B.members);
+    hipLaunchKernelGGL(k_rs_set_count, dim3(1), dim3(64), 0, s, B.count, N);
+    LaunchRelocMove(A, maxDepth, B, s);
+}
+
 void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s) {
     const RecordLayout R = MakeRecordLayout(maxDepth);
     const int N = A.N, nTiles = (N + RELOC_TILE - 1) / RELOC_TILE;
     const int tiles = (LMC_RELOC_TILES && maxDepth <= 6) ? 8 : 0;
     hipLaunchKernelGGL(k_reloc_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, withoutGaussianOnly, tiles);
-    hipLaunchKernelGGL(k_reloc_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.tileHist, B.count);
+    hipLaunchKernelGGL(k_reloc_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.tileHist, B.count, B.capacity);
     hipLaunchKernelGGL(k_reloc_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.tileHist, B.members, B.sorted, withoutGaussianOnly, tiles);
     const int moveBlocks = std::min((N + 63) / 64, 4096);
-    hipLaunchKernelGGL(k_reloc_gather, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.capacity, tiles);
-    hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey, B.capacity);
+    LaunchMoveKernels(A, R, B, tiles, moveBlocks, s);
 }

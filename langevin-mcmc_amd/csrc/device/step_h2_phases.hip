@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(64) k_h2_finish(DScene S, const DCache *cache,
             if (h2) {
                 // states of more than 16 dimensions: both Gaussians are the same isotropic one, px == py (mutation_h2mc.h:62,104-105)
                 const float px = useDense ? H.px[i] : 0.0f, py = useDense ? H.py[i] : 0.0f;
-                a = Clampf(expf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+                a = Clampf(lexpf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
             } else {
                 a = Clampf(pc.ssScore / cur.ssScore, 0.0f, 1.0f);
             }

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cach
                 for (int k = 0; k < dim; k++) offset[k] = M.offset[(size_t)k * N + i];
                 const float py = M.py[i];
                 const float px = GaussianLogPdf(dim, offset, true, pg);
-                a = Clampf(expf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
+                a = Clampf(lexpf(px - py) * pc.ssScore / cur.ssScore, 0.0f, 1.0f);
             } else {
                 a = Clampf(pc.ssScore / cur.ssScore, 0.0f, 1.0f);
             }

@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256, LMC_LEANGRAD_WAVES) k_step_small_grad(DSc
 // gridBlocks * blockThreads must not exceed gradStride (one serialisation slot per thread)
 void LaunchStepSmallLeanGrad(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
                              const NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int blockThreads, int bvhStackNeed, hipStream_t s) {
+    RequireJumpLdsBlock(blockThreads);
     const int stackWords = LeanStackWords(bvhStackNeed);
     const size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float);
     if (glossy) hipLaunchKernelGGL((k_step_small_grad<true>), dim3(gridBlocks), dim3(blockThreads), ldsBytes, s, S, cache, A, film, P, list, listCount, next, gradBuf, gradStride, stackWords);

@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(256, (GLOSSY && LIGHTLESS) ? LMC_LEAN_WAVES_GL
 
 void LaunchStepSmallPlain(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const int *list, const int *listCount,
                           const NextLists &next, int bvhDepth, bool glossy, int gridBlocks, int blockThreads, bool profile, hipStream_t s) {
+    RequireJumpLdsBlock(blockThreads);
     const int stackWords = LeanStackWords(bvhDepth);  // bvhDepth: the tree's stack need (host/accel.cpp)
     size_t ldsBytes = (size_t)blockThreads * LeanLdsWordsPerThread(stackWords) * sizeof(float);
     if (const char *e = getenv("LMC_EXP_LDS_EXTRA")) ldsBytes += (size_t)atoi(e);  // measurement aid: lowers the occupancy without touching the code

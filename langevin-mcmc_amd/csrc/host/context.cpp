@@ -144,6 +144,7 @@ struct lmc_ctx {
     DevBuf<BvhNode4Q> qnodes;
     double thickFlatShare = 0;  // accel.h ThickenedFlatLeafShare of the scene's tree: decides the node format of the hot launches (UploadScene)
     DevBuf<LeafTri> leafTris;
+    DevBuf<int> leafPosOfTri;
     DevBuf<TriData> tris;
     DevBuf<DMesh> meshes;
     DevBuf<DMaterial> materials;
@@ -197,6 +198,13 @@ struct lmc_ctx {
     DevBuf<float> relocStaging;
     RelocBuffers RB{};
     long long relocations = 0;
+    int pendingResort = 0;
+    // the periodic full re-sort by (technique, screen Morton code) (relocate.hip): every resortEvery-th step ends with it; 0 = off
+    int resortEvery = 0;
+    long long stepsSinceInit = 0, resorts = 0;
+    DevBuf<unsigned> sortKeys[2];
+    DevBuf<int> sortVals[2], sortHist, sortScanSums;
+    RelocSortBuffers RS{};
     // work lists (double buffered): [parity][large | smallGrad | smallPlain]
     DevBuf<int> lists[2][3], listCounts[2];
     int parity = 0;
@@ -370,6 +378,14 @@ static void UploadScene(lmc_ctx *c) {
     c->nodes.Upload(bvh.nodes), c->leafTris.Upload(bvh.leafTris), c->tris.Upload(tris), c->meshes.Upload(meshes), c->materials.Upload(mats),
         c->lights.Upload(lights);
     c->areaFunc.Upload(areaFunc), c->areaCdf.Upload(areaCdf), c->lightFunc.Upload(sc.lightFunc), c->lightCdf.Upload(sc.lightCdf);
+    {   // triangle id -> its position in the tree's leaf order (a space-filling order of the scene): the spatial part of the relocation's fine key (relocate.hip)
+        std::vector<int> pos(tris.size(), 0);
+        for (size_t q = bvh.leafTris.size(); q-- > 0;) {
+            const int id = bvh.leafTris[q].id;
+            if (id >= 0 && (size_t)id < pos.size()) pos[id] = (int)q;
+        }
+        c->leafPosOfTri.Upload(pos);
+    }
     DScene &S = c->S;
     memset(&S, 0, sizeof(S));
     // Node format of the scene's hot launches (lean small steps, large steps; dscene.h LdsStackT::kQuant): the 64-byte quantised nodes unless the tree
@@ -379,7 +395,10 @@ static void UploadScene(lmc_ctx *c) {
     c->thickFlatShare = lmc::ThickenedFlatLeafShare(bvh);
     bool quant = !bvh.qnodes.empty() && c->thickFlatShare < 0.05;
     if (const char *e = getenv("LMC_BVH_NODES")) quant = !bvh.qnodes.empty() && std::string(e) == "quant" ? true : std::string(e) == "exact" ? false : quant;
-    if (LMC_BVH_QUANT) quant = true;
+    if (LMC_BVH_QUANT) {  // a build whose every kernel walks the quantised nodes must not run on a tree the format cannot hold (QuantizeBvh4 left qnodes empty)
+        if (bvh.qnodes.empty()) throw std::runtime_error("LMC_BVH_QUANT build: this scene's tree cannot be represented by the quantised nodes");
+        quant = true;
+    }
     if (quant) c->qnodes.Upload(bvh.qnodes);
     else
         c->qnodes.Free();
@@ -584,6 +603,12 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "samplecache") o.sampleFromGlobalCache = v != 0;
     else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
+    else if (n == "exp_resort") c->pendingResort = (int)v;
+    else if (n == "resort_every") {  // takes effect at the next lmc_chains_init (the sort's buffers are allocated there); LMC_RESORT_EVERY is the environment form
+        char b[32];
+        snprintf(b, sizeof b, "%d", (int)v);
+        setenv("LMC_RESORT_EVERY", b, 1);
+    }  // experiment: the next step ends with a full re-sort of the chains by fine key `v` (relocate.hip k_reloc_finekey)
     else throw std::runtime_error("Unknown dpt option:" + n);
     SyncOptions(c);
     return 0;
@@ -1020,11 +1045,21 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->relocations = 0;
     if (c->relocate) {
         c->chainId.Alloc(N, false), c->slotOf.Alloc(N, false), c->relocTileCount.Alloc(RelocTiles((int)N) + 1, false), c->relocTileHist.Alloc(RelocTiles((int)N) * 64, false), c->relocMembers.Alloc(N, false);
-        c->relocSorted.Alloc(N, false), c->relocCount.Alloc(1), c->relocPlacedKey.Alloc(N, false), c->stepKind.Alloc(N + 4, false);
+        c->relocSorted.Alloc(N, false), c->relocCount.Alloc(2), c->relocPlacedKey.Alloc(N, false), c->stepKind.Alloc(N + 4, false);
         c->relocStaging.Alloc(N * RelocRecordWords(c->S.opt.maxDepth), false);  // the first step is a large step of every chain: N records, cut to N / 2 after it (StepPhase1)
         HIP_CHECK(hipMemsetAsync(c->relocPlacedKey.p, 0xff, N, s));
         HIP_CHECK(hipMemsetAsync(c->stepKind.p, NEXT_LARGE, N, s));  // k_init_lists: every chain starts with a large step
         LaunchRelocIota((int)N, c->chainId.p, s), LaunchRelocIota((int)N, c->slotOf.p, s);
+        c->resortEvery = 0;
+        if (const char *e = getenv("LMC_RESORT_EVERY")) c->resortEvery = std::max(0, atoi(e));
+        if (c->S.opt.h2mc) c->resortEvery = 0;  // the dense Gaussians of an H2MC render live in per-slot buffers that do not move (relocate.hip MemberKey)
+        c->stepsSinceInit = 0, c->resorts = 0;
+        if (c->resortEvery > 0) {
+            const size_t nb = RelocSortBlocks((int)N);
+            for (int k = 0; k < 2; k++) c->sortKeys[k].Alloc(N, false), c->sortVals[k].Alloc(N, false);
+            c->sortHist.Alloc(256 * nb, false), c->sortScanSums.Alloc(256 * nb / 2048 + 2, false);
+            c->RS = RelocSortBuffers{{c->sortKeys[0].p, c->sortKeys[1].p}, {c->sortVals[0].p, c->sortVals[1].p}, c->sortHist.p, c->sortScanSums.p};
+        }
         c->RB = RelocBuffers{c->relocPlacedKey.p, c->relocTileCount.p, c->relocTileHist.p, c->relocMembers.p, c->relocSorted.p, c->relocCount.p, c->relocStaging.p, (int)N};
         A.chainId = c->chainId.p, A.slotOf = c->slotOf.p, A.stepKind = c->stepKind.p;
     } else {
@@ -1116,6 +1151,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         c->h2PartStride = (int)(((N + 127) / 128) * 64 + 64);  // the most entries the interleaved split gives one of two (or more) parts
         c->h2Items.Alloc((size_t)MP * 2 * N, false), c->h2BinOf.Alloc(2 * N, false), c->h2Counts.Alloc((size_t)MP * 2 * 3 * H2_COUNT_WORDS);
         c->h2SubList.Alloc(MP * (size_t)c->h2PartStride, false), c->h2SubCount.Alloc(MP);
+        c->h2SplitOf = nullptr;  // the lists were re-allocated; an address that happens to repeat must not pass for "already cut"
         H2Arrays &H = c->H2;
         H.rec = c->h2Rec.p, H.hout = c->h2Out.p, H.gauss = c->h2Gauss.p, H.offset = c->h2Offset.p, H.py = c->h2Py.p, H.px = c->h2Px.p, H.propContrib = c->h2PropContrib.p;
         H.step = c->h2Step.p, H.kind = c->h2Kind.p;
@@ -1639,9 +1675,15 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
             // the staging buffer is 3-4 KB per record.  Only the first relocation (every chain took a large step: the full sort) can
             // need N records; from the third step on it holds N / 2 (the most movers seen in a later step: 0.3 N, step 1 of a fresh population);
             // the move kernels skip a step that would need more (relocate.hip).  The free is a device-wide wait, once, in the second step.
-            if (c->relocations == 2 && c->RB.capacity == (int)c->N && c->N >= 65536 && !getenv("LMC_RELOC_STAGING_FULL")) {
+            if (c->relocations == 2 && c->RB.capacity == (int)c->N && c->N >= 65536 && c->resortEvery == 0 && !getenv("LMC_RELOC_STAGING_FULL")) {  // (the full re-sort moves every chain: N records stay)
+                // the members of an in-process group reach this point in the same step, each on its own host thread; concurrent hipFree /
+                // hipMalloc is the pattern that aborted the group's threaded init one run in eight (RunInit), so the re-allocation is serialised
+                // process-wide, and RB never points at a freed buffer: it is cleared first and set only after a successful Alloc
+                static std::mutex stagingMutex;
+                std::lock_guard<std::mutex> lock(stagingMutex);
                 HIP_CHECK(hipStreamSynchronize(sL));
                 const size_t cap = c->N / 2;
+                c->RB.staging = nullptr, c->RB.capacity = 0;
                 c->relocStaging.Alloc(cap * RelocRecordWords(c->S.opt.maxDepth), false);
                 c->RB.staging = c->relocStaging.p, c->RB.capacity = (int)cap;
             }
@@ -1670,6 +1712,33 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     }
     return exchange;
 }
+// Experiment (lmc_set_option "exp_resort"): every chain re-placed in the order of a fine key, worked out on the host.  Stream s is behind all of the
+// step's launches here (StepPhase1's joins) and the next step's lists are not built yet.
+void DebugResort(lmc_ctx *c) {
+    hipStream_t s = c->stream;
+    const int mode = c->pendingResort;
+    c->pendingResort = 0;
+    const size_t N = c->N;
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (c->RB.capacity < (int)N) {
+        c->relocStaging.Alloc(N * RelocRecordWords(c->S.opt.maxDepth), false);
+        c->RB.staging = c->relocStaging.p, c->RB.capacity = (int)N;
+    }
+    DevBuf<unsigned long long> keys;
+    keys.Alloc(N, false);
+    LaunchRelocFineKey(c->A, c->leafPosOfTri.p, c->S.numTris, mode, keys.p, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    const std::vector<unsigned long long> k = keys.Download();
+    std::vector<int> perm(N);
+    for (size_t i = 0; i < N; i++) perm[i] = (int)i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return k[a] < k[b]; });
+    LaunchRelocIota((int)N, c->relocMembers.p, s);
+    HIP_CHECK(hipMemcpyAsync(c->relocSorted.p, perm.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+    const int cnt = (int)N;
+    HIP_CHECK(hipMemcpyAsync(c->relocCount.p, &cnt, sizeof(int), hipMemcpyHostToDevice, s));
+    LaunchRelocMove(c->A, c->S.opt.maxDepth, c->RB, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
 // second half: the gathered pushes applied (a cache that becomes ready at the end of this step -- mlt.cpp: push() flips is_ready
 // inside the step -- is seen by the list build: chains whose next step no longer needs a gradient go to the lean launch right
 // away), then the work lists of the next step
@@ -1682,6 +1751,23 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
         if (!c->appliedEarly) CacheApplyLaunch(c, s);
         CacheApplyFinish(c);
     }
+    if (c->pendingResort && c->relocate) DebugResort(c);
+    // the periodic full re-sort (relocate.hip): stream s is behind all of the step's launches here (StepPhase1's joins) and the next step's lists are not built yet
+    if (c->relocate && c->resortEvery > 0 && c->RB.capacity >= (int)c->N && c->stepsSinceInit % c->resortEvery == 0) {
+        static const bool log = getenv("LMC_RESORT_LOG") != nullptr;
+        std::chrono::steady_clock::time_point t0;
+        if (log) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            t0 = std::chrono::steady_clock::now();
+        }
+        LaunchRelocFullSort(c->A, c->S.opt.maxDepth, c->RB, c->RS, s);
+        c->resorts++;
+        if (log) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            fprintf(stderr, "[lmc] full re-sort after step %lld: %.3f ms\n", c->stepsSinceInit, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
+    c->stepsSinceInit++;
     const int sortPlain = c->relocate ? 0 : c->sortPlain;  // relocated chains are grouped already, and in place
     LaunchBuildLists(c->A, next, sortPlain == 4 ? 0 : sortPlain, LeanDims(c) | (c->S.opt.leanLightless ? 1u << 31 : 0u), s);
     if (sortPlain == 4) {  // A/B: the lean list grouped by technique over the WHOLE list (a wave then retraces one technique; its lanes' state lines are anywhere)
@@ -2136,6 +2222,14 @@ int lmc_relocation_stats(lmc_ctx *c, long long *out4) {
     }
     out4[0] = c->relocations, out4[1] = c->relocations ? c->relocCount.Download()[0] : 0, out4[2] = breaks, out4[3] = (long long)N;
     return 0;
+    LMC_CATCH(-2)
+}
+
+long long lmc_relocation_skipped(lmc_ctx *c) {
+    LMC_TRY
+    if (!c->relocate || c->N <= 0) return -1;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return c->relocations ? c->relocCount.Download()[1] : 0;
     LMC_CATCH(-2)
 }
 

@@ -12,6 +12,8 @@
 #include <limits>
 #include <vector>
 
+#include "../langevin-mcmc_amd/csrc/device/dtrig.h"  // the deterministic sin / cos / acos / atan2 shared with the device build (like dtrans.h: same source, same bits)
+
 namespace orc {
 
 typedef float Float;
@@ -133,22 +135,22 @@ inline float fastlog(float x) { return 0.69314718f * fastlog2(x); }
 inline Vector3 SampleSphere(const Vector2 coord, Float &jacobian) {
     const Float scaledTheta = c_TWOPI * coord[0];
     const Float scaledPhi = c_PI * coord[1];
-    const Float sinPhi = std::sin(scaledPhi);
-    const Float cosPhi = std::cos(scaledPhi);
-    Vector3 dir(sinPhi * std::cos(scaledTheta), sinPhi * std::sin(scaledTheta), cosPhi);
+    const Float sinPhi = lmcd::dsinf(scaledPhi);
+    const Float cosPhi = lmcd::dcosf(scaledPhi);
+    Vector3 dir(sinPhi * lmcd::dcosf(scaledTheta), sinPhi * lmcd::dsinf(scaledTheta), cosPhi);
     jacobian = std::fabs(sinPhi) * c_TWOPI * c_PI;
     return dir;
 }
 inline Float patan2(Float y, Float x) {
     if (y == Float(0.0) && x == Float(0.0)) return Float(0.0);
-    Float result = std::atan2(y, x);
+    Float result = lmcd::datan2f(y, x);
     if (result < 0.0) result += c_TWOPI;
     return result;
 }
 inline Vector2 ToSphericalCoord(const Vector3 &dir, Float &jacobian) {
     Float theta = patan2(dir[1], dir[0]) * c_INVTWOPI;
-    Float phi = std::acos(dir[2]);
-    jacobian = std::fabs(std::sin(phi)) * c_TWOPI * c_PI;
+    Float phi = lmcd::dacosf(dir[2]);
+    jacobian = std::fabs(lmcd::dsinf(phi)) * c_TWOPI * c_PI;
     phi *= c_INVPI;
     return Vector2(theta, phi);
 }
@@ -165,12 +167,12 @@ inline Vector2 SampleConcentricDisc(const Vector2 rndParam) {
         r = r2;
         phi = c_PIOVERTWO - (r1 / r2) * c_PIOVERFOUR;
     }
-    return Vector2(r * std::cos(phi), r * std::sin(phi));
+    return Vector2(r * lmcd::dcosf(phi), r * lmcd::dsinf(phi));
 }
 inline Vector3 SampleCosHemisphere(const Vector2 rndParam) {  // ADEpsilon<Float>() == 0 (utils.h:440-443)
     Float phi = c_TWOPI * rndParam[0];
     Float tmp = std::sqrt(std::fmax(Float(1.0) - rndParam[1], Float(0.0)));
-    return Vector3(std::cos(phi) * tmp, std::sin(phi) * tmp, std::sqrt(std::fmax(rndParam[1], Float(0.0))));
+    return Vector3(lmcd::dcosf(phi) * tmp, lmcd::dsinf(phi) * tmp, std::sqrt(std::fmax(rndParam[1], Float(0.0))));
 }
 
 }  // namespace orc

@@ -798,7 +798,7 @@ Float MLT::MALAMutate(ChainCtx &c) {  // mutation_mala.h:35-278
         InitGaussianFor(c, proposalState, true);
         Float py = GaussianLogPdf(offset, currentState.gaussian, false);
         Float px = GaussianLogPdf(offset, proposalState.gaussian, true);
-        a = Clamp(std::exp(px - py) * proposalState.spContrib.ssScore / currentState.spContrib.ssScore, Float(0.0), Float(1.0));
+        a = Clamp(lmcd::lexpf(px - py) * proposalState.spContrib.ssScore / currentState.spContrib.ssScore, Float(0.0), Float(1.0));
         proposalState.toSplat.clear();
         for (const auto &spContrib : spContribs)
             proposalState.toSplat.push_back(SplatSample{spContrib.screenPos, spContrib.contrib * normalization / spContrib.lsScore});
@@ -861,7 +861,7 @@ Float MLT::H2MCMutate(ChainCtx &c) {  // mutation_h2mc.h:38-128
         initGaussian(proposalState);
         Float py = GaussianLogPdf(offset, currentState.gaussian, false);
         Float px = GaussianLogPdf(offset, proposalState.gaussian, true);
-        a = Clamp(std::exp(px - py) * proposalState.spContrib.ssScore / currentState.spContrib.ssScore, Float(0.0), Float(1.0));
+        a = Clamp(lmcd::lexpf(px - py) * proposalState.spContrib.ssScore / currentState.spContrib.ssScore, Float(0.0), Float(1.0));
         proposalState.toSplat.clear();
         for (const auto &spContrib : spContribs)
             proposalState.toSplat.push_back(SplatSample{spContrib.screenPos, spContrib.contrib * (normalization / spContrib.lsScore)});

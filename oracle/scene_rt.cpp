@@ -399,7 +399,7 @@ static Float FresnelDielectricExt(Float cosThetaI_, Float eta, Float invEta) {
 }
 static Vector3 SampleMicronormal(const Vector2 rndParam, Float alpha, Float &pdfW) {
     Float phiM = c_TWOPI * rndParam[1];
-    Float sinPhiM = std::sin(phiM), cosPhiM = std::cos(phiM);
+    Float sinPhiM = lmcd::dsinf(phiM), cosPhiM = lmcd::dcosf(phiM);
     Float alphaSqr = square(alpha);
     Float tanThetaMSqr = alphaSqr * (-logd(std::fmax(Float(1.0) - rndParam[0], Float(1e-6))));
     Float cosThetaM = Float(1.0) / std::sqrt(Float(1.0) + tanThetaMSqr);
@@ -496,7 +496,7 @@ struct Phong : TexturedBSDF {  // phong.cpp:14-157
         const Float cosAlpha = powd(rndParam[1], power);
         const Float sinAlpha = std::sqrt(Float(1.0) - square(cosAlpha));
         const Float phi = c_TWOPI * rndParam0;
-        const Vector3 localDir = Vector3(sinAlpha * std::cos(phi), sinAlpha * std::sin(phi), cosAlpha);
+        const Vector3 localDir = Vector3(sinAlpha * lmcd::dcosf(phi), sinAlpha * lmcd::dsinf(phi), cosAlpha);
         Vector3 b0, b1;
         CoordinateSystem(n, b0, b1);
         wo = localDir[0] * b0 + localDir[1] * b1 + localDir[2] * n;
@@ -856,7 +856,7 @@ struct EnvLight : Light {  // envlight.cpp:65-248
         Vector2 pl((Float)col + tent[0], (Float)row + tent[1]);
         Float phi = (pl[0] + Float(0.5)) * si.pixelSize[0];
         Float theta = (pl[1] + Float(0.5)) * si.pixelSize[1];
-        Float sinPhi = std::sin(phi), cosPhi = std::cos(phi), sinTheta = std::sin(theta), cosTheta = std::cos(theta);
+        Float sinPhi = lmcd::dsinf(phi), cosPhi = lmcd::dcosf(phi), sinTheta = lmcd::dsinf(theta), cosTheta = lmcd::dcosf(theta);
         dirToLight = XformVector(toWorld, Vector3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
         Float dx1 = tent[0], dx2 = Float(1.0) - tent[0], dy1 = tent[1], dy2 = Float(1.0) - tent[1];
         // NB: the reference uses At() (no wrap) here, envlight.cpp:164-165: col+1 == W reads the first texel of the next row and
@@ -891,7 +891,7 @@ struct EnvLight : Light {  // envlight.cpp:65-248
                   Float &directPdf, Float &emissionPdf) const override {
         const lmc::EnvmapSampleInfo &si = L->sampleInfo;
         Vector3 d = XformVector(toLight, dirToLight);
-        Vector2 uv(std::atan2(d[0], -d[2]) * c_INVTWOPI * (Float)W - Float(0.5), std::acos(d[1]) * c_INVPI * (Float)H - Float(0.5));
+        Vector2 uv(lmcd::datan2f(d[0], -d[2]) * c_INVTWOPI * (Float)W - Float(0.5), lmcd::dacosf(d[1]) * c_INVPI * (Float)H - Float(0.5));
         int col = int(std::floor(uv[0]));
         int row = int(std::floor(uv[1]));
         lPrimID = Modulo(row, H) * W + Modulo(col, W);

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""The figures behind the veach-door parity bars (tests/test_gpu_door.py): oracle vs device on the shipped door scene, LMC without / with gradients
+and H2MC -- after round 6's deterministic trigonometry (device/dtrig.h) and restated glibc logf (drng.h) the chains can be compared one by one.
+usage: python scripts/debug/door_parity_figures.py > out.jsonl   (GPU)"""
+import json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import gpu_checks as gc
+
+DOOR = os.path.join(gc.ROOT, "scenes", "veachdoor", "lmc.xml")
+DOOR_H2 = os.path.join(gc.ROOT, "scenes", "veachdoor", "h2mc.xml")
+keep = ("contribs_gpu", "contribs_oracle", "norm_gpu", "norm_oracle", "init_cl_match", "init_ls_relerr_max", "init_pss_maxdiff", "stats_oracle", "stats_gpu", "film_rel_l2", "final_state_match",
+        "film_sum_gpu", "film_sum_oracle", "energy_gpu", "energy_oracle", "nonfinite_gpu")
+for name, scene, grad, og in (("lmc_nograd", DOOR, 0, "reference"), ("lmc_grad_reference", DOOR, 1, "reference"), ("lmc_grad_product", DOOR, 1, "product"), ("h2mc_product", DOOR_H2, 1, "product")):
+    try:
+        r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=grad, max_depth=8, scene=scene, force_diffuse=0, oracle_grad=og)
+        print(json.dumps({"case": name, **{k: r[k] for k in keep if k in r}}), flush=True)
+    except Exception as e:
+        print(json.dumps({"case": name, "error": repr(e)}), flush=True)

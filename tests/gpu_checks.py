@@ -183,14 +183,16 @@ def host_pathfunc_lib():
 
 
 def host_trans_lib():
-    """Test helper: device/dtrans.h compiled for the host (same flags as the oracle: no contraction)."""
+    """Test helper: device/dtrans.h, dtrig.h and drng.h's GlibcLogf compiled for the host (same flags as the oracle: no contraction; -mfma so that the
+    EXPLICIT fused multiply-adds are the instruction -- without it they are libm calls with the same result)."""
     import subprocess
 
     so = os.path.join(ROOT, "tests", "helpers", "libdtrans_host.so")
     src = os.path.join(ROOT, "tests", "helpers", "dtrans_host.cpp")
-    hdr = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "device", "dtrans.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], cwd=ROOT)
+    dev = os.path.join(ROOT, "langevin-mcmc_amd", "csrc", "device")
+    hdrs = [os.path.join(dev, h) for h in ("dtrans.h", "dtrig.h", "drng.h", "dmath.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-pthread", src, "-o", so], cwd=ROOT)
     return so
 
 
@@ -205,6 +207,26 @@ def trans_cases(seed=1, n=1 << 20):
         (1, rng.uniform(1e-6, 1.0, n).astype(f), np.zeros(n, f)),  # -log(1 - u)
         (2, rng.uniform(0, 1, n).astype(f), rng.choice([20.0, 100.0, 200.0, 1 / 21.0, 1 / 101.0, 1 / 201.0, 37.5], n).astype(f)),  # Phong lobes
         (2, np.exp(rng.uniform(-20, 20, n)).astype(f), rng.uniform(-4, 4, n).astype(f)),
+    ]
+
+
+def trig_cases(seed=2, n=1 << 20):
+    """(mode, x, y) of the sin / cos / acos / atan2 / logf checks (host helper modes 3 .. 7): the arguments the sampling code produces -- angles in
+    [-pi, 2 pi], direction cosines, quotients of direction components, r2 of the polar method in (0, 1] -- and wider ranges"""
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    z = np.zeros(n, f)
+    u = rng.uniform(0, 1, n).astype(f)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f)
+    return [
+        (3, (f(2 * np.pi) * u).astype(f), z), (4, (f(2 * np.pi) * u).astype(f), z), (3, (f(np.pi) * u).astype(f), z), (4, (f(np.pi) * u).astype(f), z),
+        (3, rng.uniform(-400, 400, n).astype(f), z), (4, rng.uniform(-400, 400, n).astype(f), z), (3, rng.uniform(-3e9, 3e9, n).astype(f), z), (4, rng.uniform(-1e6, 1e6, n).astype(f), z),
+        (3, (rng.uniform(-1, 1, n) * np.exp(rng.uniform(-60, 0, n))).astype(f), z),
+        (5, d[:, 2].copy(), z), (5, rng.uniform(-1, 1, n).astype(f), z), (5, (1 - np.exp(rng.uniform(-17, 0, n))).astype(f), z), (5, (-1 + np.exp(rng.uniform(-17, 0, n))).astype(f), z),
+        (6, d[:, 1].copy(), d[:, 0].copy()), (6, rng.uniform(-1, 1, n).astype(f), rng.uniform(-1, 1, n).astype(f)),
+        (6, (rng.uniform(-1, 1, n) * np.exp(rng.uniform(-40, 40, n))).astype(f), (rng.uniform(-1, 1, n) * np.exp(rng.uniform(-40, 40, n))).astype(f)),
+        (7, (1.0 - u).astype(f) + f(1e-38), z), (7, np.exp(rng.uniform(np.log(1e-38), 0, n)).astype(f), z), (7, np.exp(rng.uniform(np.log(1e-44), np.log(3e38), n)).astype(f), z),
     ]
 
 

@@ -703,6 +703,21 @@ def test_deterministic_transcendentals_bit_equal_on_device():
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mode, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
 
 
+def test_deterministic_trigonometry_and_logf_bit_equal_on_device():
+    """device/dtrig.h and drng.h GlibcLogf: the same source under hipcc (device: v_fma_f32 / v_fma_f64) and g++ (the oracle's build flags) gives the
+    same BITS for sin, cos, acos, atan2 and the normal distribution's logf on 19 x 2^20 arguments -- sampling ranges, the whole float range, the
+    polar method's (0, 1].  With it the device's proposal normals are libstdc++'s bit for bit (smoke: normal_exact_frac == 1) and the veach-door
+    chains follow the oracle's (tests/test_gpu_door.py)."""
+    lib = gc.pkg().lib()
+    host = ctypes.CDLL(gc.host_trans_lib())
+    for mode, x, y in gc.trig_cases():
+        a, b = np.zeros(len(x), np.float32), np.zeros(len(x), np.float32)
+        assert lib.lmc_trans_probe(len(x), mode, P(x), P(y), P(a)) == 0
+        host.lmc_test_trans_host(len(x), mode, P(x), P(y), P(b))
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), (mode, int((~same).sum()), float(x[~same][0]), float(y[~same][0]))
+
+
 def test_plugin_symbol_call_cost_and_threads(pair_full):
     """the drop-in symbols must not cost 100-200 us per call.  Each calling thread owns a stream and two
     host-mapped pinned buffers (context.cpp PluginSlot); a call = host memcpy of the arguments + ONE single-wave launch + one

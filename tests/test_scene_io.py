@@ -386,3 +386,70 @@ def test_front_end_against_independent_parsers(which):
         if name in d["options"]:
             got = d["options"][name]
             assert (got == (val == "true")) if isinstance(got, bool) else abs(float(got) - float(val)) < 1e-6, name
+
+
+# ---------------------------------------------------------------------------------------------- EXR decoder, pinned independently
+import sys
+
+ROOT = gc.ROOT
+SHIPPED_RENDERS = [
+    "/root/reference/scenes/torus/lmc_timeuse_44.689152s.exr",
+    "/root/reference/scenes/torus/h2mc_timeuse_45.381592s.exr",
+    "/root/reference/scenes/veachdoor/lmc_timeuse_30.236183s.exr",
+    "/root/reference/scenes/veachdoor/h2mc_timeuse_32.686382s.exr",
+]
+
+
+def _exr_py():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    import exr_py
+
+    return exr_py
+
+
+def test_exr_reader_bit_equal_to_an_independent_python_reader():
+    """`lmc_image_read` (host/imageio.cpp ReadEXR; reference image.cpp:6-60 through OpenImageIO) decodes the env-map light, the four golden renders and --
+    linked into the oracle -- the oracle's env map too.  tests/helpers/exr_py.py is a reader that shares no code with it (struct + zlib + numpy:
+    ZIP chunks, predictor, interleave, channels by NAME in file order); every float of every file must come out bit-equal."""
+    exr_py = _exr_py()
+    p = importlib.import_module("langevin-mcmc_amd")
+    files = [os.path.join(ROOT, "scenes", "torus", "data", "sunsky.exr")] + [f for f in SHIPPED_RENDERS if os.path.exists(f)]
+    for fn in files:
+        names, _ = exr_py.read_exr(fn)
+        assert names == ["B", "G", "R"], names  # OpenEXR stores channels alphabetically: a reader that took file order for RGB would swap red and blue
+        a, b = exr_py.read_exr_rgb(fn), p.read_image(fn)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), fn
+    # the env map is FLOAT, the renders HALF: both sample types went through
+    assert exr_py.read_exr_rgb(files[0]).shape == (256, 512, 3)
+
+
+@pytest.mark.skipif(not os.path.exists(SHIPPED_RENDERS[0]), reason="the reference's shipped renders live in /root/reference (build container only)")
+def test_exr_channel_order_against_the_shipped_png():
+    """Both readers name channels from the file's own channel list; this ties the NAMES to colours with a third decoder: the tone-mapped PNG the reference
+    ships next to each render (Pillow).  Each EXR channel must correlate best with the PNG channel of the same name (the torus scene's blue sky / warm
+    ground and the door scene's wood make R, G and B differ enough)."""
+    from PIL import Image
+
+    exr_py = _exr_py()
+    for fn in SHIPPED_RENDERS:
+        exr = exr_py.read_exr_rgb(fn)
+        png = np.asarray(Image.open(fn[:-4] + ".png").convert("RGB")).astype(np.float64)
+        assert png.shape == exr.shape
+        # colour differences cancel the common luminance: R - B of the EXR must follow R - B of the PNG, not B - R
+        e = np.log1p(exr.astype(np.float64))
+        d_exr, d_png = (e[..., 0] - e[..., 2]).ravel(), (png[..., 0] - png[..., 2]).ravel()
+        assert np.corrcoef(d_exr, d_png)[0, 1] > 0.5, (fn, np.corrcoef(d_exr, d_png)[0, 1])
+
+
+def test_golden_image_fixtures_follow_from_the_independent_reader():
+    """tests/golden/*_ref_images_*.npz were made with the product's reader (make_golden_images.py); the same 4x box filter over the independent reader's
+    output reproduces them -- the fixtures do not depend on the decoder under test."""
+    if not os.path.exists(SHIPPED_RENDERS[0]):
+        pytest.skip("needs /root/reference")
+    exr_py = _exr_py()
+    for npz, keys in (("torus_ref_images_256x192.npz", {"lmc": SHIPPED_RENDERS[0], "h2mc": SHIPPED_RENDERS[1]}), ("veachdoor_ref_images_320x180.npz", {"lmc": SHIPPED_RENDERS[2], "h2mc": SHIPPED_RENDERS[3]})):
+        g = np.load(os.path.join(ROOT, "tests", "golden", npz))
+        for k, fn in keys.items():
+            img = exr_py.read_exr_rgb(fn)
+            h, w, _ = img.shape
+            assert np.array_equal(img.reshape(h // 4, 4, w // 4, 4, 3).mean(axis=(1, 3)).astype(np.float32), g[k]), (npz, k)
