@@ -45,8 +45,15 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json workloads (the `configs` array of the JSON line)")
     ap.add_argument("--rmse-seconds", type=float, default=2.0, help="GPU wall time of the equal-time RMSE leg")
     ap.add_argument("--rmse-gt-spp", type=int, default=8192)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's form): --chains per GPU, the job grows with N; strong: --chains is the job's TOTAL, split evenly over the N GPUs (the other reading of north_star's '>= 6x at 8 GPUs')")
     ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 without a launcher: ONE process drives N contexts (device copies instead of RCCL); the default is one process per GPU over RCCL")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scaling == "strong":  # everything below works with chains PER GPU
+        if args.chains % args.gpus:
+            ap.error("--scaling strong: --chains (the job's total) must be a multiple of --gpus")
+        args.chains //= args.gpus
+    return args
 
 
 def host_cpus():
@@ -141,13 +148,23 @@ def equal_time_rmse(args, p, gc, gpu_rate, cpu_rate, cores):
     from tests import _orc
 
     W, H = 256, 192
-    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=W, height=H, seed_offset=0, use_gradient=1)
-    t0 = time.time()
-    gt = lum(ren.bidir_mc(args.rmse_gt_spp))
-    t_gt = time.time() - t0
     chains = 1 << 16
     spp = max(64, int(gpu_rate * 0.25 * args.rmse_seconds / (W * H)))  # 2^16 chains run at about a quarter of the 2^20-chain rate
     per = spp * W * H // chains
+    # Ground truth: at least 16 x the samples of the leg under test, as TWO independent half-budget estimates (different RNG streams)
+    # whose difference measures the truth's own noise: the truth is their mean, its noise half the RMS of their difference (at
+    # 8192 spp against a 5700-spp leg the reported rel_rmse sat on the truth's noise floor)
+    gt_half = max(args.rmse_gt_spp, 16 * spp) // 2
+    t0 = time.time()
+    halves = []
+    for so in (0, 1000003):
+        r2 = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=W, height=H, seed_offset=so, use_gradient=1)
+        halves.append(lum(r2.bidir_mc(gt_half)))
+        r2.close()
+    t_gt = time.time() - t0
+    gt = 0.5 * (halves[0] + halves[1])
+    gt_noise = float(np.sqrt(np.mean((0.5 * (halves[0] - halves[1])) ** 2)) / gt.mean())
+    ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=W, height=H, seed_offset=0, use_gradient=1)
     ren.init_chains(8 * chains, chains, 65536, per, per % chains)
     ren.sync()
     t0 = time.time()
@@ -169,13 +186,16 @@ def equal_time_rmse(args, p, gc, gpu_rate, cpu_rate, cores):
     img_cpu = lum(orc.film()) / spp_cpu
     orc.close()
     rel = lambda a: float(np.sqrt(np.mean((a - gt) ** 2)) / gt.mean())
+    net = lambda a: float(np.sqrt(max(rel(a) ** 2 - gt_noise ** 2, 0.0)))  # the leg's own error with the truth's (independent) noise taken out
     return {
         "truth_crosscheck": truth_crosscheck(p, gc),
         "film": [W, H],
         "metric": "relative RMSE of the luminance of the indirect (path length >= 3) image vs a plain-MC bidirectional estimate",
-        "ground_truth": {"estimator": "lmc_bidir_mc", "spp": args.rmse_gt_spp, "seconds": t_gt},
-        "gpu": {"seconds": t_gpu, "spp": spp, "chains": chains, "mutations_per_chain": per, "rel_rmse": rel(img_gpu), "mean_ratio": float(img_gpu.mean() / gt.mean())},
-        "cpu": {"seconds": t_cpu, "spp": spp_cpu, "chains": n, "threads": cores, "cpus_granted": host_cpus(), "mutations_per_chain": per_c, "rel_rmse": rel(img_cpu), "mean_ratio": float(img_cpu.mean() / gt.mean())},
+        "ground_truth": {"estimator": "lmc_bidir_mc, mean of two independent halves (seed offsets 0 and 1000003)", "spp": 2 * gt_half, "spp_over_gpu_leg": 2 * gt_half / spp, "seconds": t_gt,
+                         "own_noise_rel_rmse": gt_noise, "note": "own_noise = half the RMS difference of the two halves, relative to the mean luminance: the floor under every rel_rmse below"},
+        "gpu": {"seconds": t_gpu, "spp": spp, "chains": chains, "mutations_per_chain": per, "rel_rmse": rel(img_gpu), "rel_rmse_net_of_truth_noise": net(img_gpu), "mean_ratio": float(img_gpu.mean() / gt.mean())},
+        "cpu": {"seconds": t_cpu, "spp": spp_cpu, "chains": n, "threads": cores, "cpus_granted": host_cpus(), "mutations_per_chain": per_c, "rel_rmse": rel(img_cpu), "rel_rmse_net_of_truth_noise": net(img_cpu),
+                "mean_ratio": float(img_cpu.mean() / gt.mean())},
     }
 
 
@@ -415,7 +435,7 @@ def main_inprocess(args):
                          gc.TORUS, dict(force_diffuse=1, max_depth=6), devices, args.warmup, args.steps, ALGO_BYTES_PER_STEP)
     out = {
         "metric": "MALA chain-steps/sec, torus scene", "value": head["value"], "unit": "chain-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic chains on the shipped torus geometry + sunsky env map (random-seeded PCG streams)",
         "config": {"workload": head["workload"], "chains_per_gpu": args.chains, "init_samples": 8 * args.chains * args.gpus, "samples_per_chain": args.samples_per_chain,
                    "parallelism": "chains sharded x%d, one process, one context per device, one host thread per context" % args.gpus,
@@ -667,7 +687,7 @@ def main_rank(args):
     multi = world > 1 or bool(os.environ.get("LMC_BENCH_FORCE_DIST"))
     head_name = "torus scene, %d persistent chains per GPU, Lambertian-only BSDF, max path length 6 (BASELINE.json configs[1])" % args.chains
     head = rank_job(args, p, gc, boot, rank, world, local, head_name, gc.TORUS, dict(force_diffuse=1, max_depth=6), args.warmup, args.steps, ALGO_BYTES_PER_STEP,
-                    "k_step_small<true,false,false,true> (plain small steps; the instantiation without light sub-paths: this scene is lit by its environment map alone)", True)
+                    "k_step_small<true, false, false, true, true> (rocprofv3's name: LDS stack, Lambertian, no region profiling, no light sub-paths, quantised nodes; plain small steps of a scene lit by its environment map alone)", True)
     door = None
     if multi and not args.no_configs:  # north_star names both scenes at 1 / 2 / 4 / 8 GPUs: the veach-door LMC workload as the job's second line
         try:
@@ -694,7 +714,7 @@ def main_rank(args):
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic chains on the shipped torus geometry + sunsky env map (random-seeded PCG streams)",

@@ -300,12 +300,12 @@ LMC_D void RowsToRecords(float *tile, RowAddr rowAddr, int laneRows, int waveRow
     const int lane = threadIdx.x;
     for (int r0 = 0; r0 < waveRows; r0 += 64) {
         const int nr = min(64, waveRows - r0);
-#pragma unroll 4
+#pragma unroll 8
         for (int w = 0; w < nr; w++) tile[w * XP + lane] = (r0 + w < laneRows) ? *rowAddr(r0 + w) : 0.f;
         __syncthreads();
         if (lane < nr) {
             float *dst = staging + (size_t)m0 * recWords + recBase + r0 + lane;
-#pragma unroll 4
+#pragma unroll 8
             for (int c = 0; c < nValid; c++) dst[(size_t)c * recWords] = tile[lane * XP + c];
         }
         __syncthreads();
@@ -318,14 +318,14 @@ LMC_D void RecordsToRows(float *tile, const int *srcRec, RowAddr rowAddr, int la
     for (int r0 = 0; r0 < waveRows; r0 += 64) {
         const int nr = min(64, waveRows - r0);
         if (lane < nr) {
-#pragma unroll 4
+#pragma unroll 8
             for (int c = 0; c < nValid; c++) {
                 const int rec = srcRec[c];
                 if (rec >= 0) tile[lane * XP + c] = staging[(size_t)rec * recWords + recBase + r0 + lane];
             }
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 8
         for (int w = 0; w < nr; w++)
             if (r0 + w < laneRows) *rowAddr(r0 + w) = tile[w * XP + lane];
         __syncthreads();
@@ -603,7 +603,9 @@ void LaunchRelocFineKey(const ChainArrays &A, const int *leafPosOfTri, int numTr
 // the move of a relocation whose members / sorted / count the caller has filled in
 void LaunchRelocMove(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s) {
     const RecordLayout R = MakeRecordLayout(maxDepth);
-    const int moveBlocks = std::min((A.N + 63) / 64, 4096);
+    // every chain moves and nothing runs beside this launch: one group of 64 records per one-wave block, all of them resident together (the move is a
+    // chain of dependent round trips per tile: with 4096 blocks -- four groups per wave in a row -- it took 2.9 ms at 2^20 chains, profiles/r06_i_*)
+    const int moveBlocks = std::min((A.N + 63) / 64, 65536);
     LaunchMoveKernels(A, R, B, 0, moveBlocks, s);
 }
 

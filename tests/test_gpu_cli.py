@@ -125,3 +125,30 @@ def test_bench_gpus_n_drives_n_ranks_or_fails(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - 2 * 8192 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     lum = m["film_sum"]  # sum of R + G + B over the merged film; every step of every chain of BOTH ranks deposits `normalization` of luminance
     assert lum > 0
+
+
+def test_dpt_amd_shards_the_chains_over_a_device_list(tmp_path):
+    """VERDICT r5 missing #3: the command line reaches the multi-GPU sharding.  `--gpus N` = devices 0 .. N-1, `--devices a,b` an explicit list; on
+    this one-GPU tier the list names device 0 twice (two ranks of one job on one device, the bring-up form of lmc_group_*): the job follows the
+    single-device trajectories, so the image must be the single-device image up to the order of the film's float atomics, and the mutation count
+    the same.  A list naming a device that is not there is refused with exit code 2."""
+    if not os.path.exists(CLI):
+        pytest.skip("dpt_amd not built")
+    imgs, muts = [], []
+    for k, extra in enumerate((["--device", "0"], ["--devices", "0,0"])):
+        d = tmp_path / ("run%d" % k)
+        d.mkdir()
+        scene = _small_scene(d, spp=32)
+        r = subprocess.run([CLI, "--seedoffset", "5", "--chains", "4096"] + extra + [scene], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout
+        assert ("sharded over 2 devices" in r.stdout) == (k == 1), r.stdout
+        muts.append(int(re.search(r"(\d+) mutations", r.stdout).group(1)))
+        exrs = [f for f in os.listdir(d) if f.endswith(".exr")]
+        assert len(exrs) == 1
+        imgs.append(gc.pkg().read_image(str(d / exrs[0])))
+    assert muts[0] == muts[1]
+    a, b = gc.lum(imgs[0].reshape(-1, 3)), gc.lum(imgs[1].reshape(-1, 3))
+    assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(a)  # half-precision output pixels + atomics' order
+    scene = _small_scene(tmp_path)
+    r = subprocess.run([CLI, "--gpus", "64", scene], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 2 and "visible" in r.stdout, r.stdout

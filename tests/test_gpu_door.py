@@ -48,46 +48,57 @@ def _hist_l1(r):
     return sum(abs(r["hist_oracle"].get(k, 0.0) - r["hist_gpu"].get(k, 0.0)) for k in keys)
 
 
-@pytest.mark.parametrize("use_gradient", [0, 1])
-def test_door_chain_parity(use_gradient):
-    """MLTInit + 60 lock-step mutations of 2048 chains on the door scene, GPU vs oracle: area-light sampling in every large
-    step (EmitFromLight, DirectLighting, hitting the emitter), twosided Lambertian / Phong, textured reflectances.
+@pytest.mark.parametrize("use_gradient,oracle_grad", [(0, "reference"), (1, "product"), (1, "reference")])
+def test_door_chain_parity(use_gradient, oracle_grad):
+    """MLTInit + 60 lock-step mutations of 2048 chains on the door scene, GPU vs oracle: area-light sampling in every large step (EmitFromLight,
+    DirectLighting, hitting the emitter), twosided Lambertian / Phong, textured reflectances.
 
-    What can be compared here is statistical, for a measured reason (scripts/init_diff.py, profiles/r02_d_door_init_diff.txt): the
-    room is ~400 units across with centimetre-scale features, so a one-ulp difference between the device libm and glibc in a
-    sampled direction (sinf / cosf) moves a hit point by ~3e-5 absolute and the SHORT distances between path vertices by ~1e-5
-    relative -- 100x the torus figure (2e-7).  lsScores of the same init sample then differ by 1e-5 .. 1e-4 relative and about one
-    sample in 400 takes a different Russian-roulette / rejection branch; MLTInit seeds its resampling stream with the NUMBER of
-    contributions (mlt.h:115), so a single flipped sample re-seeds every chain.  Chain-by-chain comparison is therefore
-    meaningless on this scene; counts, rates, the technique mix of the final states and the energy identity are not."""
-    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=use_gradient, max_depth=8, scene=DOOR, force_diffuse=0, oracle_grad="reference")
-    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 0.01 * r["contribs_oracle"]
-    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 2e-3 * r["norm_oracle"]
+    Until round 6 this comparison was statistical (counts within 1-3 %, histogram L1 < 0.08): the room is ~400 units across with centimetre-scale
+    features, one ulp between the device libm's sinf / cosf and glibc's moved a hit point by ~3e-5, about one init sample in 400 took another
+    Russian-roulette branch, and MLTInit seeds its resampling stream with the NUMBER of contributions (mlt.h:115), so a single flipped sample re-seeded
+    every chain (profiles/r02_d_door_init_diff.txt).  With one deterministic sin / cos / acos / atan2 on both sides (device/dtrig.h) and glibc's logf
+    restated for the normal variates (drng.h) the chains are the oracle's, one by one -- what test_chain_loop_parity asserts on the torus holds here:
+      * without gradients, and with the oracle drawing its gradients from the product's path program compiled for the host: EXACT -- contributions,
+        normalization, every init state, large steps, accepted steps, gradient calls, every final state; film 1e-6 (atomics' order);
+      * with the oracle on the reference's generated derivative programs (1e-2 from the product's, test_full_material_gradient_kernel_*): a chain whose
+        accept decision the gradients flip diverges; measured 2037 / 2048 final states equal, large steps 27722 / 27715 (profiles/r06_h_door_parity.jsonl)."""
+    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=use_gradient, max_depth=8, scene=DOOR, force_diffuse=0, oracle_grad=oracle_grad)
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["norm_gpu"] == r["norm_oracle"]
+    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] == 0.0 and r["init_pss_maxdiff"] == 0.0
     so, sg = r["stats_oracle"], r["stats_gpu"]
     assert sg["steps"] == so["steps"] == 2048 * 60
-    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.03 * so["largeSteps"]
-    assert abs(sg["accepted"] - so["accepted"]) <= 0.02 * so["accepted"]
+    if use_gradient == 0 or oracle_grad == "product":
+        for k in ("largeSteps", "accepted", "gradCalls"):
+            assert sg[k] == so[k], (k, sg[k], so[k])
+        assert r["final_state_match"] == 1.0 and r["film_rel_l2"] < 1e-6
+        assert r["hist_gpu"] == r["hist_oracle"]
+    else:
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 30 and abs(sg["accepted"] - so["accepted"]) <= 40 and abs(sg["gradCalls"] - so["gradCalls"]) <= 60
+        assert r["final_state_match"] > 0.985 and r["film_rel_l2"] < 0.1 and _hist_l1(r) < 0.02
     if use_gradient:
-        assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.03 * max(so["gradCalls"], 100) and sg["gradCalls"] > 0
-    assert _hist_l1(r) < 0.08, (r["hist_oracle"], r["hist_gpu"])
-    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 0.01
+        assert sg["gradCalls"] > 10000
+    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 1e-6
     assert r["nonfinite_gpu"] == 0
     # film luminance / (normalization x splat weights): below 1 by the splats both sides DROP as non-finite (image.h:72): states with a
     # denormal lsScore (3e-39 occurs in this scene) give normalization / lsScore = inf.  Same deficit on both sides.
-    assert 0.99 < r["energy_gpu"] <= 1.0001 and abs(r["energy_gpu"] - r["energy_oracle"]) < 2e-3
+    assert 0.99 < r["energy_gpu"] <= 1.0001 and abs(r["energy_gpu"] - r["energy_oracle"]) < 1e-6
 
 
 def test_door_diffuse_chain_parity():
-    """every BSDF forced to `diffuse`: same statistical comparison, tighter (no glossy amplification on top of the scale)"""
-    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=1 if gc.pathref() else 0, max_depth=6, scene=DOOR, force_diffuse=1)
-    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 0.005 * r["contribs_oracle"]
-    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-3 * r["norm_oracle"]
+    """every BSDF forced to `diffuse`, gradients on (the oracle's from the reference's programs): the init is exact, the chains diverge only where the two
+    gradient implementations flip an accept decision (see test_door_chain_parity)"""
+    grad = 1 if gc.pathref() else 0
+    r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=grad, max_depth=6, scene=DOOR, force_diffuse=1)
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["norm_gpu"] == r["norm_oracle"]
+    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] == 0.0 and r["init_pss_maxdiff"] == 0.0
     so, sg = r["stats_oracle"], r["stats_gpu"]
-    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 0.02 * so["largeSteps"]
-    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
-    assert _hist_l1(r) < 0.06, (r["hist_oracle"], r["hist_gpu"])
-    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 0.01
-    assert 0.99 < r["energy_gpu"] <= 1.0001 and abs(r["energy_gpu"] - r["energy_oracle"]) < 2e-3
+    if grad:
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 30 and abs(sg["accepted"] - so["accepted"]) <= 40
+        assert r["final_state_match"] > 0.985 and _hist_l1(r) < 0.02, (r["final_state_match"], r["hist_oracle"], r["hist_gpu"])
+    else:
+        assert sg["largeSteps"] == so["largeSteps"] and sg["accepted"] == so["accepted"] and r["final_state_match"] == 1.0
+    assert abs(r["film_sum_gpu"] / r["film_sum_oracle"] - 1) < 1e-6
+    assert 0.99 < r["energy_gpu"] <= 1.0001 and abs(r["energy_gpu"] - r["energy_oracle"]) < 1e-6
 
 
 def test_door_render_matches_reference_image():

@@ -50,8 +50,8 @@ def test_native_library_is_loaded():
 
 
 def test_rng_streams_bit_exact(L):
-    r = gc.check_rng(L)  # raw u32, table tick, uniform01: asserted bit-exact inside; normals within 5e-6 rel
-    assert r["normal_exact_frac"] > 0.5
+    r = gc.check_rng(L)  # raw u32, table tick, uniform01, normal variates, the mixed stream: all asserted bit-exact inside
+    assert r["normal_exact_frac"] == 1.0
 
 
 def test_scene_block_and_bvh(L, pair):
@@ -155,47 +155,45 @@ def test_plugin_symbol_single_call(pair):
 
 @pytest.mark.parametrize("use_gradient", [0, 1])
 def test_chain_loop_parity(use_gradient):
-    """MLTInit + 40 lock-step mutations of 256 chains: identical PCG streams on both sides, so the discrete history
-    (technique of every init state, number of large steps, number of accepted proposals) must agree exactly on a run
-    this short, and the film within 1e-3 relative L2 (float add order of the splats + libm rounding)."""
+    """MLTInit + 40 lock-step mutations of 256 chains: identical PCG streams, identical normal variates (drng.h GlibcLogf), identical trigonometry
+    (dtrig.h) and exp / log / pow (dtrans.h) on both sides -- since round 6 EVERYTHING discrete and every state agrees exactly: contributions,
+    normalization and init states bit for bit, large steps, accepted proposals, gradient calls, every chain's final state; the film within 1e-4
+    relative L2 (float add order of the splats; with gradients the oracle's come from the reference's generated programs, measured 1.6e-5)."""
     if use_gradient and not gc.pathref():
         pytest.skip("oracle/_ref not built")
     r = gc.run_pair(160, 120, 40000, 256, 8, 400, 40, use_gradient=use_gradient)
-    assert r["contribs_gpu"] == r["contribs_oracle"]
-    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-5 * r["norm_oracle"]
-    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] < 1e-4 and r["init_pss_maxdiff"] < 1e-5
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["norm_gpu"] == r["norm_oracle"]
+    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] == 0.0 and r["init_pss_maxdiff"] == 0.0
     so, sg = r["stats_oracle"], r["stats_gpu"]
     assert sg["steps"] == so["steps"] == 256 * 40
-    assert sg["largeSteps"] == so["largeSteps"]
-    assert abs(sg["accepted"] - so["accepted"]) <= 2
-    assert sg["gradCalls"] == so["gradCalls"] or abs(sg["gradCalls"] - so["gradCalls"]) <= 4
-    assert r["film_rel_l2"] < 1e-3
-    assert r["final_state_match"] > 0.98
+    assert sg["largeSteps"] == so["largeSteps"] and sg["accepted"] == so["accepted"] and sg["gradCalls"] == so["gradCalls"]
+    assert r["film_rel_l2"] < 1e-4
+    assert r["final_state_match"] == 1.0
     assert r["nonfinite_gpu"] == 0
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
 
-@pytest.mark.parametrize("use_gradient", [0, 1])
-def test_full_material_scene_chain_parity(use_gradient):
-    """The shipped torus scene as is (Phong floor with a bitmap texture, Phong metal, rough-dielectric glass, diffuse
-    donut; BASELINE.json configs[2] materials) at maxdepth 8: same checks as test_chain_loop_parity.  With gradients the
-    oracle evaluates them through the REFERENCE's generated derivative programs (oracle/_ref), the GPU through its own path
-    program: no self-comparison."""
-    # one init stream per sample (init_threads == num_init): a Russian-roulette decision that flips on a last-bit difference
-    # of a glossy BSDF value (exp(-tan^2/alpha^2) with alpha = 0.04 amplifies rounding ~600x) then stays local to its sample
-    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=use_gradient, max_depth=8, force_diffuse=0, oracle_grad="reference")
-    assert abs(r["contribs_gpu"] - r["contribs_oracle"]) <= 2
-    assert abs(r["norm_gpu"] - r["norm_oracle"]) <= 1e-4 * r["norm_oracle"]
-    assert r["init_cl_match"] > 0.97
+@pytest.mark.parametrize("use_gradient,oracle_grad", [(0, "reference"), (1, "product"), (1, "reference")])
+def test_full_material_scene_chain_parity(use_gradient, oracle_grad):
+    """The shipped torus scene as is (Phong floor with a bitmap texture, Phong metal, rough-dielectric glass, diffuse donut; BASELINE.json configs[2]
+    materials) at maxdepth 8.  Without gradients, and with the oracle drawing its gradients from the product's path program compiled for the host:
+    exact, like test_chain_loop_parity.  With the oracle on the REFERENCE's generated derivative programs (oracle/_ref; the GPU on its own path program:
+    no self-comparison) the init is still exact and the chains diverge only where the two gradient implementations (1e-2 apart on ill-conditioned
+    glossy states) flip an accept decision: measured 252 / 256 final states equal, large steps 1346 / 1348 (profiles/r06_i_torus_parity.jsonl)."""
+    if use_gradient and oracle_grad == "reference" and not gc.pathref():
+        pytest.skip("oracle/_ref not built")
+    # one init stream per sample (init_threads == num_init)
+    r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, use_gradient=use_gradient, max_depth=8, force_diffuse=0, oracle_grad=oracle_grad)
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["norm_gpu"] == r["norm_oracle"]
+    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] == 0.0 and r["init_pss_maxdiff"] == 0.0
     so, sg = r["stats_oracle"], r["stats_gpu"]
     assert sg["steps"] == so["steps"] == 256 * 40
-    assert abs(sg["largeSteps"] - so["largeSteps"]) <= 3
-    assert abs(sg["accepted"] - so["accepted"]) <= 0.01 * so["accepted"]
-    assert abs(sg["gradCalls"] - so["gradCalls"]) <= 0.01 * max(so["gradCalls"], 100)
-    # measured (scripts/debug/parity_bars.py, round 4): film 0.048 / 0.103 (use_gradient 0 / 1), final_state_match 0.988 / 0.984; bars at twice
-    # the measured deviation (256 chains x 40 steps: one diverged chain moves a few percent of the film energy)
-    assert r["film_rel_l2"] < (0.2 if use_gradient else 0.1)
-    assert r["final_state_match"] > (0.968 if use_gradient else 0.976)
+    if use_gradient == 0 or oracle_grad == "product":
+        assert sg["largeSteps"] == so["largeSteps"] and sg["accepted"] == so["accepted"] and sg["gradCalls"] == so["gradCalls"]
+        assert r["final_state_match"] == 1.0 and r["film_rel_l2"] < 1e-6
+    else:
+        assert abs(sg["largeSteps"] - so["largeSteps"]) <= 6 and abs(sg["accepted"] - so["accepted"]) <= 12 and abs(sg["gradCalls"] - so["gradCalls"]) <= 12
+        assert r["film_rel_l2"] < 0.2 and r["final_state_match"] > 0.968
     assert r["nonfinite_gpu"] == 0
     assert abs(r["energy_gpu"] - 1.0) < 1e-4
 
@@ -208,7 +206,7 @@ def test_full_material_gradient_kernel_vs_reference_programs(pair_full):
     agree within 1e-2 relative L2 (host twin: 859 / 859)."""
     orc, ren = pair_full
     inputs = gc.collect_grad_inputs(orc, 1024)
-    ok = tot = 0
+    ok = tot = ill = 0
     p = gc.pkg()
     sp = ren.scene_params()
     for (c, l), (prim, vert) in sorted(inputs.items()):
@@ -217,10 +215,17 @@ def test_full_material_gradient_kernel_vs_reference_programs(pair_full):
             r = orc.ref_eval(c, l, prim[i], vert[i])
             if r is None or not np.isfinite(r[0]) or not np.isfinite(r[1]).all():
                 continue
-            assert abs(r[0] - ll[i]) < 5e-3
+            if abs(r[0] - ll[i]) >= 5e-3:
+                # only an ill-conditioned state may exceed the bar: the reference's OWN program must move by more than the deviation when its primary
+                # sample moves by 1e-6 (tests/test_host.py has the state this was written for: five rough-dielectric interfaces, d logLum / d pss ~ 1e5)
+                prng = np.random.default_rng(i)
+                spread = max(abs(orc.ref_eval(c, l, prim[i] + (prng.uniform(-1, 1, len(prim[i])) * 1e-6).astype(np.float32), vert[i])[0] - r[0]) for _ in range(4))
+                assert spread > abs(r[0] - ll[i]), (c, l, i, float(r[0]), float(ll[i]), float(spread))
+                ill += 1
+                continue
             tot += 1
             ok += np.linalg.norm(r[1] - g[:, i]) <= 1e-2 * max(np.linalg.norm(r[1]), 1e-2)
-    assert tot > 500 and tot - ok <= tot // 200, (ok, tot)
+    assert tot > 500 and tot - ok <= tot // 200 and ill <= 3, (ok, tot, ill)
 
 
 @pytest.mark.parametrize("force_diffuse", [1, 0])

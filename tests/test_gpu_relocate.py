@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 def _run(relocate, mala, n_chains, steps, opts, checkpoints=(), max_depth=6, outlier_test=False):
     os.environ["LMC_RELOCATE"] = "1" if relocate else "0"
     os.environ["LMC_EXP_OUTLIER_TEST"] = "1" if outlier_test else "0"
+    os.environ["LMC_RESORT_EVERY"] = "4" if relocate else "0"  # the periodic full re-sort by (technique, screen Morton code) rides along: every 4th step here
     try:
         p = gc.pkg()
         ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=max_depth, width=128, height=96, seed_offset=0, use_gradient=1 if gc.pathref() else 0)
@@ -24,7 +25,7 @@ def _run(relocate, mala, n_chains, steps, opts, checkpoints=(), max_depth=6, out
             ren.set_option("mala", 0)
         ren.init_chains(200000, n_chains, 64, 10 ** 6)
     finally:
-        del os.environ["LMC_RELOCATE"], os.environ["LMC_EXP_OUTLIER_TEST"]
+        del os.environ["LMC_RELOCATE"], os.environ["LMC_EXP_OUTLIER_TEST"], os.environ["LMC_RESORT_EVERY"]
     out = []
     done = 0
     for upto in list(checkpoints) + [steps]:
@@ -111,3 +112,41 @@ def test_relocated_chains_reset_to_the_init_state_of_their_own_id(mala):
             assert st0[k] == st1[k], k
     l0, l1 = gc.lum(film0), gc.lum(film1)
     assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
+
+
+def test_benchmarked_size_through_the_cache_ready_transition():
+    """the size bench.py measures -- 2^20 chains of the torus workload (Lambertian, maxdepth 6, 1024x768 film), 30 steps of
+    a fresh population, i.e. through the whole cache-fill phase and the step in which dims 10 and 12 become ready -- with chain relocation AND the
+    periodic full re-sort on, against the same run with neither: every chain of a 4096-chain sample (plus the first and last 64 ids) in the SAME state,
+    exact counters, the energy identity, 64-bit-safe indexing (the state arrays hold 2^20 x ~3000 words: word offsets beyond 2^31)."""
+    p = gc.pkg()
+    n = 1 << 20
+    runs = []
+    for relocate in (False, True):
+        os.environ["LMC_RELOCATE"] = "1" if relocate else "0"
+        os.environ["LMC_RESORT_EVERY"] = "8" if relocate else "0"
+        try:
+            ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, seed_offset=0, use_gradient=1 if gc.pathref() else 0)
+            norm, nc = ren.init_chains(8 * n, n, 65536, 256)
+        finally:
+            del os.environ["LMC_RELOCATE"], os.environ["LMC_RESORT_EVERY"]
+        assert nc >= n
+        ren.step(30)
+        st, rs, summ, film = ren.stats(), ren.relocation_stats(), ren.summary(0), ren.film()
+        ren.close()
+        assert st["steps"] == 30 * n and np.isfinite(film).all() and (film >= 0).all()
+        assert gc.lum(film).sum() == pytest.approx(norm * st["weightSum"], rel=2e-4)
+        runs.append((st, rs, summ, film, norm))
+    (st0, rs0, s0, f0, n0), (st1, rs1, s1, f1, n1) = runs
+    assert n0 == n1 and rs0 is None and rs1 is not None and rs1["relocations"] >= 29 and rs1["skipped"] == 0
+    if gc.pathref():
+        assert st0["cacheReadyMask"] != 0 and st0["gradCalls"] > 0, "test set-up: the run never left the cache-fill phase"
+    for k in ("steps", "largeSteps", "accepted", "resets", "cacheQueries", "cacheHits", "gradCalls", "cacheReadyMask"):
+        assert st0[k] == st1[k], (k, st0[k], st1[k])
+    sample = np.r_[np.arange(64), np.random.default_rng(0).choice(n, 4096, replace=False), np.arange(n - 64, n)]
+    _same_states(s0[sample], s1[sample])
+    _same_states(s0, s1)  # ... and, since the rows are here anyway, every chain
+    l0, l1 = gc.lum(f0), gc.lum(f1)
+    assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
+    # the chains ARE grouped: few technique changes along the slots right after a step whose last full re-sort was at most 8 steps ago
+    assert rs1["breaks"] < 0.2 * rs1["slots"], rs1

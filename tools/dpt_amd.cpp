@@ -2,8 +2,12 @@
 // /root/reference/src/main.cpp:30-118) on top of the C ABI of liblmc_hip.so.  Same scene XML, same <dpt> keys, same
 // output naming (<film filename>_timeuse_<seconds>s.exr written next to the scene, mlt.cpp:208) and the same stdout
 // lines ("Average brightness:", "Elapsed time:", "Done!").  Only integrator = mcmc with mala = true (the LMC path) is
-// served; anything else is refused.  Extra flags (not in the reference): --chains N (Markov chains resident on the GPU,
-// default: <dpt numchains>), --init-threads V (MLTInit streams, default 65536), --device D, --force-diffuse, --maxdepth D.
+// served; anything else is refused.  Extra flags (not in the reference): --chains N (Markov chains resident on the GPUs,
+// default: <dpt numchains>), --init-threads V (MLTInit streams, default 65536), --device D, --force-diffuse, --maxdepth D, and
+// --gpus N (devices 0 .. N-1) / --devices a,b,.. (an explicit list; a device may appear more than once: bring-up on one GPU): the chains are
+// sharded over the listed devices as ranks of ONE job (lmc_group_*: MLTInit sharded by init stream, contiguous chain-id ranges, the gradient
+// cache's pushes exchanged while it fills -- the trajectories of a single device holding all the chains), and the per-device films are summed
+// on the devices before the image is written (mlt.cpp:203-207 merges its per-thread films the same way).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +31,7 @@ int main(int argc, char *argv[]) {
     printf("Langevin MCMC dpt (MI355X back end)\n");
     int seedoffset = 0, device = 0, forceDiffuse = 0, maxDepth = 0, initThreads = 65536, maxDervDepth = 8;
     long long chains = 0;
+    std::vector<int> devices;
     std::vector<std::string> filenames;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -37,21 +42,46 @@ int main(int argc, char *argv[]) {
         } else if (a == "--chains") chains = std::stoll(argv[++i]);
         else if (a == "--init-threads") initThreads = std::stoi(argv[++i]);
         else if (a == "--device") device = std::stoi(argv[++i]);
-        else if (a == "--force-diffuse") forceDiffuse = 1;
+        else if (a == "--gpus") {
+            const int n = std::stoi(argv[++i]);
+            devices.clear();
+            for (int d = 0; d < n; d++) devices.push_back(d);
+        } else if (a == "--devices") {
+            devices.clear();
+            std::string list = argv[++i];
+            for (size_t b = 0; b <= list.size();) {
+                const size_t e = list.find(',', b) == std::string::npos ? list.size() : list.find(',', b);
+                if (e > b) devices.push_back(std::stoi(list.substr(b, e - b)));
+                b = e + 1;
+            }
+        } else if (a == "--force-diffuse") forceDiffuse = 1;
         else if (a == "--maxdepth") maxDepth = std::stoi(argv[++i]);
         else filenames.push_back(a);
     }
-    for (const std::string &filename : filenames) {
-        lmc_scene_desc desc;
-        memset(&desc, 0, sizeof(desc));
-        desc.scene_xml = filename.c_str();
-        desc.force_diffuse = forceDiffuse, desc.max_depth = maxDepth, desc.seed_offset = seedoffset, desc.device = device, desc.use_gradient = 1;
-        lmc_ctx *ctx = lmc_create(&desc);
-        if (!ctx) {
-            fprintf(stderr, "%s\n", lmc_last_error());
-            return 1;
+    if (devices.empty()) devices.push_back(device);
+    const int visible = lmc_device_count();
+    for (int d : devices)
+        if (d < 0 || d >= visible) {
+            fprintf(stderr, "device %d requested, %d HIP device(s) visible\n", d, visible);
+            return 2;
         }
-        lmc_set_option(ctx, "max-derivatives-depth", maxDervDepth);
+    const int nDev = (int)devices.size();
+    for (const std::string &filename : filenames) {
+        std::vector<lmc_ctx *> ctxs;
+        for (int d : devices) {
+            lmc_scene_desc desc;
+            memset(&desc, 0, sizeof(desc));
+            desc.scene_xml = filename.c_str();
+            desc.force_diffuse = forceDiffuse, desc.max_depth = maxDepth, desc.seed_offset = seedoffset, desc.device = d, desc.use_gradient = 1;
+            lmc_ctx *c = lmc_create(&desc);
+            if (!c) {
+                fprintf(stderr, "%s\n", lmc_last_error());
+                return 1;
+            }
+            lmc_set_option(c, "max-derivatives-depth", maxDervDepth);
+            ctxs.push_back(c);
+        }
+        lmc_ctx *ctx = ctxs[0];
         if (Opt(ctx, "mala") == 0 && Opt(ctx, "h2mc") == 0) {
             fprintf(stderr, "dpt_amd serves the LMC path only (<dpt> integrator=mcmc with mala=true or h2mc=true)\n");
             return 1;
@@ -75,7 +105,9 @@ int main(int argc, char *argv[]) {
             numInit = 8 * numChains;
             printf("numinitsamples raised to %lld for %lld chains\n", numInit, numChains);
         }
-        if (lmc_chains_init(ctx, numInit, (int)numChains, initThreads, 0, (int)numChains, numSamplesPerChain, chainsNeedExtraSamples) != 0) {
+        if (nDev > 1) printf("%lld chains sharded over %d devices\n", numChains, nDev);
+        if ((nDev == 1 ? lmc_chains_init(ctx, numInit, (int)numChains, initThreads, 0, (int)numChains, numSamplesPerChain, chainsNeedExtraSamples)
+                       : lmc_group_chains_init(ctxs.data(), nDev, numInit, (int)numChains, initThreads, numSamplesPerChain, chainsNeedExtraSamples)) != 0) {
             fprintf(stderr, "%s\n", lmc_last_error());
             return 1;
         }
@@ -85,11 +117,15 @@ int main(int argc, char *argv[]) {
         printf("Average brightness:%g\n", normalization);
         auto t0 = std::chrono::steady_clock::now();
         for (long long done = 0; done < numSamplesPerChain + 1; done += 64)
-            if (lmc_chains_step(ctx, 64) != 0) {
+            if ((nDev == 1 ? lmc_chains_step(ctx, 64) : lmc_group_chains_step(ctxs.data(), nDev, 64)) != 0) {
                 fprintf(stderr, "%s\n", lmc_last_error());
                 return 1;
             }
-        lmc_sync(ctx);
+        for (lmc_ctx *c : ctxs) lmc_sync(c);
+        if (nDev > 1 && lmc_group_film_reduce(ctxs.data(), nDev, nullptr) != 0) {  // the per-device films summed on the devices (peer copies); timed with the loop
+            fprintf(stderr, "%s\n", lmc_last_error());
+            return 1;
+        }
         const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("Elapsed time:%g\n", elapsed);
         // MergeBuffer + BufferToFilm, mlt.cpp:203-207
@@ -104,11 +140,15 @@ int main(int argc, char *argv[]) {
             fprintf(stderr, "%s\n", lmc_last_error());
             return 1;
         }
-        long long st[8];
-        double ws = 0;
-        lmc_stats(ctx, st, &ws);
-        printf("%lld mutations, %.1f M mutations/s, wrote %s\n", st[0], st[0] / elapsed * 1e-6, out.c_str());
-        lmc_destroy(ctx);
+        long long mutations = 0;
+        for (lmc_ctx *c : ctxs) {
+            long long st[8];
+            double ws = 0;
+            lmc_stats(c, st, &ws);
+            mutations += st[0];
+        }
+        printf("%lld mutations, %.1f M mutations/s, wrote %s\n", mutations, mutations / elapsed * 1e-6, out.c_str());
+        for (lmc_ctx *c : ctxs) lmc_destroy(c);
         printf("Done!\n");
     }
     return 0;
