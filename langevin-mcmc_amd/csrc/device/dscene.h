@@ -395,6 +395,45 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
     }
 #endif
     int cur = 0;  // root is an inner node
+#if defined(LMC_TRAV_SPEC) && defined(__HIP_DEVICE_COMPILE__)
+    // A/B build ("speculative" while-while): the wave leaves the inner-node loop as soon as fewer than LMC_TRAV_SPEC of its lanes
+    // still hold an inner node -- the lanes waiting at their leaves test them while the stragglers keep their node for the next round -- instead of
+    // when none does.  Same visits per ray, same answer; what changes is how many lanes idle in which loop.  cur == BVH4_EMPTY: this lane's walk is over.
+    for (;;) {
+        for (;;) {
+            if (cur >= 0 && cur != BVH4_EMPTY) {
+                cur = VisitInner<true>(S, cur, org, invd, tnear, bestT, stk);
+                if (cur == BVH4_EMPTY && !stk.Empty()) cur = stk.Pop();
+            }
+            if (__popcll(__ballot(cur >= 0 && cur != BVH4_EMPTY)) < LMC_TRAV_SPEC) break;
+        }
+        if (cur < 0) {
+            const unsigned code = (unsigned)~cur;
+            const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int base = 0; base < cnt; base += 4) {
+                LeafTri tr[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) tr[i] = S.leafTris[first + min(base + i, cnt - 1)];
+#pragma unroll
+                for (int i = 0; i < 4; i++) LMC_PIN3(tr[i].p0[0], tr[i].p0[1], tr[i].p0[2]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float t;
+                    if (base + i < cnt && TriTest(tr[i].p0, tr[i].e1, tr[i].e2, org, dir, tnear, bestT, t)) {
+                        if (best < 0 || t < bestT || (t == bestT && tr[i].id < best)) {
+                            bestT = t;
+                            best = tr[i].id;
+                        }
+                    }
+                }
+            }
+            cur = stk.Empty() ? BVH4_EMPTY : stk.Pop();
+        }
+        if (__ballot(cur != BVH4_EMPTY) == 0ull) break;
+    }
+    tHit = bestT;
+    return best;
+#endif
     for (;;) {
         while (cur >= 0) {
             cur = VisitInner<true>(S, cur, org, invd, tnear, bestT, stk);

@@ -294,21 +294,31 @@ LMC_D int WaveMax(int v) {
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
     return v;
 }
-// SoA rows [0, waveRows) of the wave's chains -> record words [recBase, recBase + waveRows) of records m0 .. m0 + nValid - 1.  rowAddr(k): this lane's word of row k
+// One-wave blocks: the LDS operations of a wave execute in order, so a tile written by all lanes can be read back transposed without a barrier --
+// WaveSync is a compiler-level fence only.  (__syncthreads() also drains the wave's outstanding global stores at every tile: with it, and with the
+// loads of a tile issued eight at a time, a re-sort's two launches took 1.3 + 1.3 ms at 2^20 chains against 0.2 ms of traffic, profiles/r06_j_*.)
+LMC_D void WaveSync() { __builtin_amdgcn_wave_barrier(); }
+// SoA rows [0, waveRows) of the wave's chains -> record words [recBase, recBase + waveRows) of records m0 .. m0 + nValid - 1.  rowAddr(k): this lane's word of row k.
+// All 64 loads of a tile are in flight together (fixed trip count, predicated).
 template <class RowAddr>
 LMC_D void RowsToRecords(float *tile, RowAddr rowAddr, int laneRows, int waveRows, float *staging, size_t recWords, int m0, int nValid, int recBase) {
     const int lane = threadIdx.x;
+    const unsigned long long live = __ballot(laneRows > 0);
     for (int r0 = 0; r0 < waveRows; r0 += 64) {
         const int nr = min(64, waveRows - r0);
-#pragma unroll 8
-        for (int w = 0; w < nr; w++) tile[w * XP + lane] = (r0 + w < laneRows) ? *rowAddr(r0 + w) : 0.f;
-        __syncthreads();
+        float v[64];
+#pragma unroll
+        for (int w = 0; w < 64; w++) v[w] = (r0 + w < laneRows) ? *rowAddr(r0 + w) : 0.f;
+#pragma unroll
+        for (int w = 0; w < 64; w++) tile[w * XP + lane] = v[w];
+        WaveSync();
         if (lane < nr) {
             float *dst = staging + (size_t)m0 * recWords + recBase + r0 + lane;
-#pragma unroll 8
-            for (int c = 0; c < nValid; c++) dst[(size_t)c * recWords] = tile[lane * XP + c];
+#pragma unroll 16
+            for (int c = 0; c < nValid; c++)
+                if ((live >> c) & 1ull) dst[(size_t)c * recWords] = tile[lane * XP + c];  // a record whose chain has none of these rows is not written (nor read by the scatter)
         }
-        __syncthreads();
+        WaveSync();
     }
 }
 // the mirror image: srcRec[c] = the record that goes to the wave's chain c (-1: none)
@@ -318,17 +328,21 @@ LMC_D void RecordsToRows(float *tile, const int *srcRec, RowAddr rowAddr, int la
     for (int r0 = 0; r0 < waveRows; r0 += 64) {
         const int nr = min(64, waveRows - r0);
         if (lane < nr) {
-#pragma unroll 8
-            for (int c = 0; c < nValid; c++) {
-                const int rec = srcRec[c];
-                if (rec >= 0) tile[lane * XP + c] = staging[(size_t)rec * recWords + recBase + r0 + lane];
+            float v[64];
+#pragma unroll
+            for (int c = 0; c < 64; c++) {
+                const int rec = c < nValid ? srcRec[c] : -1;
+                v[c] = rec >= 0 ? staging[(size_t)rec * recWords + recBase + r0 + lane] : 0.f;
             }
+#pragma unroll
+            for (int c = 0; c < 64; c++)
+                if (c < nValid && srcRec[c] >= 0) tile[lane * XP + c] = v[c];
         }
-        __syncthreads();
-#pragma unroll 8
+        WaveSync();
+#pragma unroll 16
         for (int w = 0; w < nr; w++)
             if (r0 + w < laneRows) *rowAddr(r0 + w) = tile[w * XP + lane];
-        __syncthreads();
+        WaveSync();
     }
 }
 
@@ -419,9 +433,9 @@ __global__ void __launch_bounds__(64) k_reloc_scatter_coop(ChainArrays A, Record
             }
             camCount = min(max(__float_as_int(r[RW_HEAD + 12]), 0), R.nV), lgtCount = min(max(__float_as_int(r[RW_HEAD + 13]), 0), R.nV);
         }
-        __syncthreads();  // (the previous group's tile and srcRec are no longer read)
+        WaveSync();  // (the previous group's tile and srcRec are no longer read)
         srcRec[lane] = moves ? m : -1;
-        __syncthreads();
+        WaveSync();
         float *pi = CurPathBuf(A, flags) + i;
         const int camRows = moves ? DPATH_HEAD_WORDS + camCount * DVERTEX_WORDS : 0, lgtRows = lgtCount * DVERTEX_WORDS;
         RecordsToRows(tile, srcRec, [&](int k) { return pi + (size_t)k * N; }, camRows, WaveMax(camRows), staging, W, nValid, RW_HEAD);
@@ -430,22 +444,22 @@ __global__ void __launch_bounds__(64) k_reloc_scatter_coop(ChainArrays A, Record
         float *ci = A.curContrib + i, *si = A.curSplat + i;
         const int csRows = moves ? CONTRIB_WORDS + nSplat * SPLAT_WORDS : 0;
         RecordsToRows(tile, srcRec, [&](int k) { return k < CONTRIB_WORDS ? ci + (size_t)k * N : si + (size_t)(k - CONTRIB_WORDS) * N; }, csRows, WaveMax(csRows), staging, W, nValid, R.Contrib());
-        // the seven MALA vectors: the incoming chain's, or zeros over a slot whose previous chain had any (the gather wrote zeros into the record of a
-        // chain whose vectors are zero by the invariant, so "copy the record" covers both)
+        // the seven MALA vectors: the incoming chain's, or zeros over a slot whose previous chain had any (the record of a chain whose vectors are zero by
+        // the invariant holds nothing there: such a lane has no source record and stores the zeros the tile is filled with)
         const bool vecIn = moves && VectorsMayBeNonZero(flags);
         const int vecRows = (vecIn || (moves && VectorsMayBeNonZero(oldFlags))) ? 7 * MAXPSS : 0, wv = WaveMax(vecRows);
         if (wv) {
             // a record whose vector words were not written by the gather (its chain's vectors are zero and no chain of its gather wave had any): write zeros
-            __syncthreads();
+            WaveSync();
             const int keep = srcRec[lane];
-            __syncthreads();
+            WaveSync();
             if (!vecIn) srcRec[lane] = -1;
-            __syncthreads();
+            WaveSync();
             for (int w = 0; w < 64; w++) tile[w * XP + lane] = 0.f;  // a lane without a source record stores zeros
-            __syncthreads();
+            WaveSync();
             RecordsToRows(tile, srcRec, [&](int k) { return VectorBase(A, k / MAXPSS) + (size_t)(k % MAXPSS) * N + i; }, vecRows, wv, staging, W, nValid, R.Vectors());
             srcRec[lane] = keep;
-            __syncthreads();
+            WaveSync();
         }
         const int gRows = moves && HasStoredGaussian(flags) ? GAUSS_WORDS : 0, wg = WaveMax(gRows);
         if (wg) {
