@@ -117,7 +117,7 @@ size_t RelocRecordWords(int maxDepth);
 void LaunchRelocIota(int n, int *v, hipStream_t s);
 // withoutGaussianOnly (H2MC renders): chains that hold a stored Gaussian stay where they are (the pipeline's Gaussian buffers are per slot)
 void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s);
-void LaunchRelocFineKey(const lmcd::ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, hipStream_t s);
+void LaunchRelocFineKey(const lmcd::ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, const lmcd::TriData *tris, const lmcd::DMaterial *materials, hipStream_t s);
 void LaunchRelocMove(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s);
 // the periodic full re-sort by (technique, screen Morton code): work buffers of the device radix sort
 struct RelocSortBuffers {

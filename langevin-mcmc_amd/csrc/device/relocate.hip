@@ -482,7 +482,7 @@ LMC_D unsigned Part1By1(unsigned x) {
     x = (x ^ (x << 1)) & 0x55555555u;
     return x;
 }
-__global__ void __launch_bounds__(256) k_reloc_finekey(ChainArrays A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys) {
+__global__ void __launch_bounds__(256) k_reloc_finekey(ChainArrays A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, const TriData *tris, const DMaterial *materials) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.N) return;
     const size_t N = A.N;
@@ -504,6 +504,17 @@ __global__ void __launch_bounds__(256) k_reloc_finekey(ChainArrays A, const int 
     if (mode == 1) sub = morton;
     else if (mode == 2) sub = ((unsigned long long)posOf(0) << 16) | posOf(1);
     else if (mode == 3) sub = ((unsigned long long)posOf(0) << 24) | morton;
+    else if (mode == 7 || mode == 8) {  // the BSDF type of the first two walked vertices (the branches a glossy wave diverges on), then the screen position
+        auto matOf = [&](int walkIdx) -> unsigned {
+            int word = -1;
+            if (walkIdx < lgtCount) word = DPATH_HEAD_WORDS + (MAXD + walkIdx) * DVERTEX_WORDS;
+            else if (walkIdx - lgtCount < camCount) word = DPATH_HEAD_WORDS + (walkIdx - lgtCount) * DVERTEX_WORDS;
+            if (word < 0) return 3u;
+            const int tri = __float_as_int(path[(size_t)word * N + i]);
+            return tri >= 0 && tri < numTris ? (unsigned)materials[tris[tri].material].type & 3u : 3u;
+        };
+        sub = mode == 7 ? ((unsigned long long)matOf(0) << 26) | ((unsigned long long)matOf(1) << 24) | morton : ((unsigned long long)matOf(1) << 24) | morton;
+    }
     else if (mode == 5) sub = morton >> 18;  // 8 x 8 screen tiles
     else if (mode == 6) sub = morton >> 14;  // 32 x 32
     // mode 4: the technique alone (what a relocation without misplaced chains would give)
@@ -611,8 +622,8 @@ static void LaunchMoveKernels(const ChainArrays &A, const RecordLayout &R, const
         hipLaunchKernelGGL(k_reloc_scatter, dim3(moveBlocks), dim3(64), 0, s, A, R, B.members, B.sorted, B.count, B.staging, B.placedKey, B.capacity);
     }
 }
-void LaunchRelocFineKey(const ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, hipStream_t s) {
-    hipLaunchKernelGGL(k_reloc_finekey, dim3((A.N + 255) / 256), dim3(256), 0, s, A, leafPosOfTri, numTris, mode, keys);
+void LaunchRelocFineKey(const ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, const TriData *tris, const DMaterial *materials, hipStream_t s) {
+    hipLaunchKernelGGL(k_reloc_finekey, dim3((A.N + 255) / 256), dim3(256), 0, s, A, leafPosOfTri, numTris, mode, keys, tris, materials);
 }
 // the move of a relocation whose members / sorted / count the caller has filled in
 void LaunchRelocMove(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s) {

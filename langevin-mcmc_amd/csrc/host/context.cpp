@@ -200,7 +200,7 @@ struct lmc_ctx {
     long long relocations = 0;
     int pendingResort = 0;
     // the periodic full re-sort by (technique, screen Morton code) (relocate.hip): every resortEvery-th step ends with it; 0 = off
-    int resortEvery = 0;
+    int resortEvery = 0, resortFirst = 0;
     long long stepsSinceInit = 0, resorts = 0;
     DevBuf<unsigned> sortKeys[2];
     DevBuf<int> sortVals[2], sortHist, sortScanSums;
@@ -1054,6 +1054,13 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         // a re-sort costs 1.3 ms at 2^20 chains, 1.7 ms while the fill phase's MALA vectors are alive); LMC_RESORT_EVERY=0 switches it off (A/B)
         c->resortEvery = 32;
         if (const char *e = getenv("LMC_RESORT_EVERY")) c->resortEvery = std::max(0, atoi(e));
+        // the first one after step resortFirst, then every resortEvery steps.  Every chain's first step is a large step, and so are most of the next few
+        // (2^20 chains: 1.05 M, 845 k, 682 k, 553 k, 451 k, 369 k ... large steps in steps 0, 1, 2 ...): an order made before that storm has died down is
+        // gone within a step or two.  After it, while a chain's large-step probability is still the unscaled 0.05 (mlt.cpp:96-97: the first 10 % of
+        // its samples), an order lasts long: the lean launch of the steps behind a sort ran 1.46 ms instead of 1.71 for the next six steps of the fill
+        // phase (profiles/r06_l_step_durations_fill_phase_resort16.txt).  LMC_RESORT_FIRST overrides (A/B).
+        c->resortFirst = 4;
+        if (const char *e = getenv("LMC_RESORT_FIRST")) c->resortFirst = std::max(0, atoi(e));
         if (c->S.opt.h2mc) c->resortEvery = 0;  // the dense Gaussians of an H2MC render live in per-slot buffers that do not move (relocate.hip MemberKey)
         c->stepsSinceInit = 0, c->resorts = 0;
         if (c->resortEvery > 0) {
@@ -1728,7 +1735,7 @@ void DebugResort(lmc_ctx *c) {
     }
     DevBuf<unsigned long long> keys;
     keys.Alloc(N, false);
-    LaunchRelocFineKey(c->A, c->leafPosOfTri.p, c->S.numTris, mode, keys.p, s);
+    LaunchRelocFineKey(c->A, c->leafPosOfTri.p, c->S.numTris, mode, keys.p, c->S.tris, c->S.materials, s);
     HIP_CHECK(hipStreamSynchronize(s));
     const std::vector<unsigned long long> k = keys.Download();
     std::vector<int> perm(N);
@@ -1755,7 +1762,7 @@ void StepPhase2(lmc_ctx *c, lmc_ctx::StepEvents &ev, bool exchanged) {
     }
     if (c->pendingResort && c->relocate) DebugResort(c);
     // the periodic full re-sort (relocate.hip): stream s is behind all of the step's launches here (StepPhase1's joins) and the next step's lists are not built yet
-    if (c->relocate && c->resortEvery > 0 && c->RB.capacity >= (int)c->N && c->stepsSinceInit % c->resortEvery == 0) {
+    if (c->relocate && c->resortEvery > 0 && c->RB.capacity >= (int)c->N && c->stepsSinceInit >= c->resortFirst && (c->stepsSinceInit - c->resortFirst) % c->resortEvery == 0) {
         static const bool log = getenv("LMC_RESORT_LOG") != nullptr;
         std::chrono::steady_clock::time_point t0;
         if (log) {
