@@ -304,6 +304,16 @@ def other_configs(args, p, gc):
                              "concurrent_launches": "the three step launches share the GPU inside each bracket"},
                 "accept_rate": (s1["accepted"] - s0["accepted"]) / max(steps_total, 1), "large_step_frac": large_steps / max(steps_total, 1),
             })
+            if c["h2mc"]:
+                # the pipeline's dominant launch (k_h2_hess) is ARITHMETIC-bound: the HBM fraction above says nothing about it.  Its governing figure -- the share
+                # of a SIMD's cycles in which the vector ALU issues -- needs counters, i.e. its own rocprofv3 --pmc passes: replayed from the committed summary
+                vr = os.path.join(ROOT, "profiles", "h2mc_valu_roofline.json")
+                if os.path.exists(vr):
+                    v = json.load(open(vr))
+                    hk = v["kernels"].get("k_h2_hess", {})
+                    out[-1]["roofline"]["governing"] = {"bound": "valu", "kernel": "k_h2_hess (two launches per step, the largest part of the pipeline)", "valu_busy": hk.get("valu_busy"),
+                                                         "lanes_active": hk.get("lanes_active"), "all_pipeline_kernels": {k: {"valu_busy": x["valu_busy"], "lanes_active": x["lanes_active"]} for k, x in v["kernels"].items()},
+                                                         "source": "REPLAYED from profiles/h2mc_valu_roofline.json (%s; %s): not counted during this run" % (v.get("scene"), v.get("source"))}
         except Exception as e:  # noqa: BLE001 -- the headline line must still come out
             out.append({"workload": c["name"], "failed": str(e)[:300]})
     return out
@@ -723,6 +733,11 @@ def main_rank(args):
                 "chains_per_gpu": args.chains,
                 "init_samples": head["init_samples"],
                 "samples_per_chain": args.samples_per_chain,
+                "timed_steps_of_the_population": "steps %d..%d of a fresh population.  What those are: steps 0-4 nearly every chain takes a large step; the gradient caches of dims 6 / 8 "
+                                                 "are ready after step 5, those of dims 10 / 12 after step 22 -- until then ~15 k chains per step evaluate gradients (the fill pipeline "
+                                                 "beside the hot launch); from step 23 on >= 99.99 %% of the proposals are the isotropic ones of mutation_mala.h:131-164 (cache misses), and "
+                                                 "from 10 %% of a chain's samples on (step %d here) its large-step probability is 0.2 instead of 0.05 (mlt.cpp:96-97).  The driver's "
+                                                 "--steps 20 --warmup 5 window is the fill phase; --steps 64 --warmup 40 is the steady state" % (args.warmup, args.warmup + args.steps - 1, int(0.1 * args.samples_per_chain) + 1),
                 "film": head["film"],
                 "bvh_nodes": head["bvh_nodes"],
                 "parallelism": "chains sharded x%d, one process per GPU" % world,
