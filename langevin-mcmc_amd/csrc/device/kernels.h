@@ -104,13 +104,14 @@ void LaunchSortByTechnique(const unsigned char *nextKind, const int *in, int *ou
 void LaunchInclusiveScan(int *v, int n, int *tileSums, hipStream_t s);
 // chain relocation (relocate.hip): the chains of the step's large-step launch whose technique changed since they were placed are sorted by technique into the slots they occupy
 struct RelocBuffers {
-    unsigned char *placedKey;   // N: the key a slot's chain was placed under (0xff: never placed)
+    unsigned *placedKey;        // N: the key a slot's chain was placed under (all ones: never placed): the technique key, or with `fine` the 24-bit [technique | screen Morton] key
     int *tileCount, *tileHist;  // RelocTiles(N), 64 x RelocTiles(N): members per 1024-slot tile / per (tile, key); then their exclusive prefixes
     int *members;               // N: the slots that take part, ascending
     int *sorted;                // N: member indices by key
     int *count;                 // 2: number of members (0: the relocation was skipped, its movers exceeded `capacity`), relocations skipped so far
     float *staging;             // RelocRecordWords(maxDepth) floats per member
     int capacity;               // records the staging buffer holds: a step with more movers leaves them where they are (host/context.cpp)
+    bool fine;                  // the per-step relocation and the full re-sort place by the fine key (LMC_RELOC_FINE=0: the technique alone, round 4's rule)
 };
 size_t RelocTiles(int N);
 size_t RelocRecordWords(int maxDepth);
@@ -118,7 +119,7 @@ void LaunchRelocIota(int n, int *v, hipStream_t s);
 // withoutGaussianOnly (H2MC renders): chains that hold a stored Gaussian stay where they are (the pipeline's Gaussian buffers are per slot)
 void LaunchRelocate(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s);
 void LaunchRelocFineKey(const lmcd::ChainArrays &A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, const lmcd::TriData *tris, const lmcd::DMaterial *materials, hipStream_t s);
-void LaunchRelocMove(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s);
+void LaunchRelocMove(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s, int keyMode = 0);
 // the periodic full re-sort by (technique, screen Morton code): work buffers of the device radix sort
 struct RelocSortBuffers {
     unsigned *keys[2];  // N each
@@ -128,6 +129,7 @@ struct RelocSortBuffers {
 };
 size_t RelocSortBlocks(int N);
 void LaunchRelocFullSort(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, hipStream_t s);
+void LaunchRelocateFine(const lmcd::ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, bool withoutGaussianOnly, hipStream_t s);
 // dilated grid of one cache dim on the device (DCacheDim::gridStart / gridRows); buffer sizes in kernels.hip
 void LaunchBuildCacheGrid(const float *pts, int n, int dim, int G, int m, const int *coord, int *scratchStart, int *scratchCursor, int *scratchWordCount, int *tileSums,
                           uint2 *words, int *cellStart, unsigned short *idx, hipStream_t s);

@@ -62,6 +62,24 @@ LMC_D int SlotKey(const ChainArrays &A, int i, int tiles) {
 #endif
     return LMC_RELOC_ORDER ? 63 - key : key;
 }
+LMC_D unsigned Part1By1(unsigned x) {
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+// the fine key of a slot's chain: [63 - technique (6 bits) | Morton code of the camera vertex's screen position (9 + 9 bits)] -- the order of the full
+// re-sort and, since round 6, of the per-step relocation too (key mode -1 of the move kernels)
+LMC_D unsigned FineKey(const ChainArrays &A, int i) {
+    const size_t N = A.N;
+    const float *path = CurPathBuf(A, A.flags[i]);
+    const float sx = path[(size_t)1 * N + i], sy = path[(size_t)2 * N + i];  // DPath::screen0, screen1
+    const unsigned mx = (unsigned)min(511, max(0, (int)(sx * 512.f))), my = (unsigned)min(511, max(0, (int)(sy * 512.f)));
+    return ((unsigned)SlotKey(A, i, 0) << 18) | Part1By1(mx) | (Part1By1(my) << 1);
+}
+LMC_D int SlotKeyMode(const ChainArrays &A, int i, int mode) { return mode < 0 ? (int)FineKey(A, i) : SlotKey(A, i, mode); }
 LMC_D bool VectorsMayBeNonZero(int flags) { return (flags & F_BUFFERED) && (flags & F_VDIRTY); }  // dchain.h: the invariant of the seven MALA vectors
 LMC_D bool HasStoredGaussian(int flags) { return (flags & F_GAUSS) && !(flags & F_GAUSS_ISO); }
 
@@ -74,10 +92,10 @@ constexpr int RELOC_TILE = 1024;
 // H2MC renders (placedKey's top bit of the launch argument `mode`): a chain that holds a stored Gaussian stays -- the dense Gaussian lives in the
 // pipeline's own per-slot buffers (dh2coop.h H2Arrays::gauss), which are not moved; an accepted large step, the event that changes the
 // technique, has just dropped it (dstep.h), so only chains kept by a REJECTED large step wait for their next one.
-LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i, bool withoutGaussianOnly, int tiles) {  // -1: not a member
+LMC_D int MemberKey(const ChainArrays &A, const unsigned *placedKey, int i, bool withoutGaussianOnly, int tiles) {  // -1: not a member
     if (i >= A.N || A.stepKind[i] != NEXT_LARGE) return -1;
     const int key = SlotKey(A, i, tiles);
-    if (key == placedKey[i]) return -1;
+    if ((unsigned)key == placedKey[i]) return -1;
     if (withoutGaussianOnly && (A.flags[i] & F_GAUSS)) return -1;
     return key;
 }
@@ -85,7 +103,7 @@ LMC_D int MemberKey(const ChainArrays &A, const unsigned char *placedKey, int i,
 // takes the first slot that frees up, a four-wave block waits for four at once (k_reloc_count as 256-thread blocks: 1.0 ms in the queue,
 // profiles/r04_reloc_b_*; the same lesson as kernels.hip k_push_count).  Lane l of a tile's wave looks at slots base + 64 j + l, j = 0 .. 15.
 // tileCount[t] = members of tile t; tileHist[t][k] = ... with key k
-__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned char *placedKey, int *tileCount, int *tileHist, bool noGauss, int tiles) {
+__global__ void __launch_bounds__(64) k_reloc_count(ChainArrays A, const unsigned *placedKey, int *tileCount, int *tileHist, bool noGauss, int tiles) {
     __shared__ int h[64];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -138,7 +156,7 @@ __global__ void __launch_bounds__(64) k_reloc_offsets(int nTiles, int *tileCount
     }
 }
 // members[m] = slot (ascending); sorted[p] = m for the p-th chain by key (inside a (tile, key) group the order is the LDS atomics')
-__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned char *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted, bool noGauss, int tiles) {
+__global__ void __launch_bounds__(64) k_reloc_assign(ChainArrays A, const unsigned *placedKey, const int *tileStart, const int *groupStart, int *members, int *sorted, bool noGauss, int tiles) {
     __shared__ int cursor[64];
     cursor[threadIdx.x] = groupStart[blockIdx.x * 64 + threadIdx.x];
     __syncthreads();
@@ -185,7 +203,7 @@ __global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout
         r[RW_ADJREJECT] = __int_as_float(A.adjacentReject[i]), r[RW_SPLATCOUNT] = __int_as_float(nSplat), r[RW_CHAINID] = __int_as_float(A.chainId[i]);
         r[RW_SCORESUM] = A.scoreSum[i], r[RW_LASTSCORESUM] = A.lastScoreSum[i], r[RW_LASTSCORE] = A.lastScore[i], r[RW_PATHWEIGHT] = A.pathWeight[i];
         r[RW_NEXTKIND] = __int_as_float((int)A.nextKind[i]), r[RW_RNG_LO] = __int_as_float((int)(uint32_t)rs), r[RW_RNG_HI] = __int_as_float((int)(uint32_t)(rs >> 32));
-        r[RW_KEY] = __int_as_float(SlotKey(A, i, tiles));
+        r[RW_KEY] = __int_as_float(SlotKeyMode(A, i, tiles));
         const int ticked = A.rngTicked[i];  // the extension table travels only once the stream has ticked: until then it is a function of the chain's seed (drng.h)
         r[RW_RNG_TICKED] = __int_as_float(ticked);
         if (ticked) {
@@ -224,14 +242,14 @@ __global__ void __launch_bounds__(64) k_reloc_gather(ChainArrays A, RecordLayout
 // staging record sorted[d] -> member slot d.  Record d still holds what the slot contained: its flags say whether the slot's MALA
 // vectors have to be zeroed for an incoming chain whose vectors are zero by the invariant.
 __global__ void __launch_bounds__(64) k_reloc_scatter(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, const float *staging,
-                                                       unsigned char *placedKey, int capacity) {
+                                                       unsigned *placedKey, int capacity) {
     const int M = *count;
     if (M > capacity) return;
     const size_t N = A.N;
     for (int d = blockIdx.x * 64 + threadIdx.x; d < M; d += gridDim.x * 64) {
         const int i = members[d], m = sorted[d];
         const float *r = staging + (size_t)m * R.Words();
-        placedKey[i] = (unsigned char)__float_as_int(r[RW_KEY]);
+        placedKey[i] = (unsigned)__float_as_int(r[RW_KEY]);
         if (m == d) continue;  // the chain stays where it is
         const int flags = __float_as_int(r[RW_FLAGS]), oldFlags = __float_as_int(staging[(size_t)d * R.Words() + RW_FLAGS]);
         const int nSplat = __float_as_int(r[RW_SPLATCOUNT]);
@@ -367,7 +385,7 @@ __global__ void __launch_bounds__(64) k_reloc_gather_coop(ChainArrays A, RecordL
             r[RW_ADJREJECT] = __int_as_float(A.adjacentReject[i]), r[RW_SPLATCOUNT] = __int_as_float(nSplat), r[RW_CHAINID] = __int_as_float(A.chainId[i]);
             r[RW_SCORESUM] = A.scoreSum[i], r[RW_LASTSCORESUM] = A.lastScoreSum[i], r[RW_LASTSCORE] = A.lastScore[i], r[RW_PATHWEIGHT] = A.pathWeight[i];
             r[RW_NEXTKIND] = __int_as_float((int)A.nextKind[i]), r[RW_RNG_LO] = __int_as_float((int)(uint32_t)rs), r[RW_RNG_HI] = __int_as_float((int)(uint32_t)(rs >> 32));
-            r[RW_KEY] = __int_as_float(SlotKey(A, i, tiles));
+            r[RW_KEY] = __int_as_float(SlotKeyMode(A, i, tiles));
             const int ticked = A.rngTicked[i];
             r[RW_RNG_TICKED] = __int_as_float(ticked);
             if (ticked) {  // once per 2^32 draws of a stream: lane-wise
@@ -400,7 +418,7 @@ __global__ void __launch_bounds__(64) k_reloc_gather_coop(ChainArrays A, RecordL
 }
 
 __global__ void __launch_bounds__(64) k_reloc_scatter_coop(ChainArrays A, RecordLayout R, const int *members, const int *sorted, const int *count, const float *staging,
-                                                            unsigned char *placedKey, int capacity) {
+                                                            unsigned *placedKey, int capacity) {
     __shared__ float tile[64 * XP];
     __shared__ int srcRec[64];
     const int M = *count;
@@ -414,7 +432,7 @@ __global__ void __launch_bounds__(64) k_reloc_scatter_coop(ChainArrays A, Record
         const bool moves = valid && m != d;  // m == d: the chain stays where it is
         const float *r = staging + (size_t)(valid ? m : 0) * W;
         int flags = 0, oldFlags = 0, camCount = 0, lgtCount = 0, nSplat = 0;
-        if (valid) placedKey[i] = (unsigned char)__float_as_int(r[RW_KEY]);
+        if (valid) placedKey[i] = (unsigned)__float_as_int(r[RW_KEY]);
         if (moves) {
             flags = __float_as_int(r[RW_FLAGS]), oldFlags = __float_as_int(staging[(size_t)d * W + RW_FLAGS]);
             nSplat = __float_as_int(r[RW_SPLATCOUNT]);
@@ -474,14 +492,6 @@ __global__ void __launch_bounds__(64) k_reloc_scatter_coop(ChainArrays A, Record
 //   mode 1: Morton code of the camera vertex's screen position (12 + 12 bits)
 //   mode 2: leaf-order position of the first walked vertex's triangle (the tree's depth-first order is a space-filling order), then the second's
 //   mode 3: first triangle's leaf position, then the screen Morton code
-LMC_D unsigned Part1By1(unsigned x) {
-    x &= 0x0000ffffu;
-    x = (x ^ (x << 8)) & 0x00ff00ffu;
-    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
-    x = (x ^ (x << 2)) & 0x33333333u;
-    x = (x ^ (x << 1)) & 0x55555555u;
-    return x;
-}
 __global__ void __launch_bounds__(256) k_reloc_finekey(ChainArrays A, const int *leafPosOfTri, int numTris, int mode, unsigned long long *keys, const TriData *tris, const DMaterial *materials) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.N) return;
@@ -534,16 +544,12 @@ __global__ void __launch_bounds__(256) k_reloc_finekey(ChainArrays A, const int 
 constexpr int RS_TILE = 4096;
 __global__ void __launch_bounds__(256) k_rs_key(ChainArrays A, unsigned *keys) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.N) return;
-    const size_t N = A.N;
-    const float *path = CurPathBuf(A, A.flags[i]);
-    const float sx = path[(size_t)1 * N + i], sy = path[(size_t)2 * N + i];  // DPath::screen0, screen1
-    const unsigned mx = (unsigned)min(511, max(0, (int)(sx * 512.f))), my = (unsigned)min(511, max(0, (int)(sy * 512.f)));
-    keys[i] = ((unsigned)SlotKey(A, i, 0) << 18) | Part1By1(mx) | (Part1By1(my) << 1);
+    if (i < A.N) keys[i] = FineKey(A, i);
 }
 // hist[digit * nBlocks + block] = keys of the block's tile with that digit
-__global__ void __launch_bounds__(64) k_rs_hist(const unsigned *keys, int n, int shift, int *hist, int nBlocks) {
+__global__ void __launch_bounds__(64) k_rs_hist(const unsigned *keys, const int *nPtr, int nMax, int shift, int *hist, int nBlocks) {
     __shared__ int h[256];
+    const int n = min(*nPtr, nMax);  // the number of keys lives on the device (the per-step relocation's member count)
     for (int k = threadIdx.x; k < 256; k += 64) h[k] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE + threadIdx.x;
@@ -555,8 +561,10 @@ __global__ void __launch_bounds__(64) k_rs_hist(const unsigned *keys, int n, int
     for (int k = threadIdx.x; k < 256; k += 64) hist[k * nBlocks + blockIdx.x] = h[k];
 }
 // histIncl: the inclusive scan of hist.  Stable: inside a (block, digit) group the entries keep their order (rank by ballot match, rounds in order).
-__global__ void __launch_bounds__(64) k_rs_scatter(const unsigned *keysIn, const int *valsIn, unsigned *keysOut, int *valsOut, int n, int shift, const int *histIncl, int nBlocks) {
+__global__ void __launch_bounds__(64) k_rs_scatter(const unsigned *keysIn, const int *valsIn, unsigned *keysOut, int *valsOut, const int *nPtr, int nMax, int shift, const int *histIncl, int nBlocks) {
     __shared__ int cursor[256];
+    const int n = min(*nPtr, nMax);
+    if (blockIdx.x * RS_TILE >= n) return;
     for (int k = threadIdx.x; k < 256; k += 64) {
         const int idx = k * nBlocks + blockIdx.x;
         cursor[k] = idx ? histIncl[idx - 1] : 0;
@@ -589,6 +597,65 @@ __global__ void __launch_bounds__(64) k_rs_scatter(const unsigned *keysIn, const
 }
 __global__ void __launch_bounds__(64) k_rs_set_count(int *count, int n) {
     if (threadIdx.x == 0) count[0] = n;
+}
+
+// ---- the per-step relocation by the FINE key (round 6; LMC_RELOC_FINE=1 -- measured and NOT the default, host/context.cpp): the movers of a step -- the chains of its large-step launch whose technique or 32 x 32 screen
+// tile is no longer the one they were placed under (an accepted large step jumps, a rejected one still finds the drift of the small steps since the
+// placement) -- are sorted by the full 24-bit key with the radix sort above and land, as before, in the member slots in ascending order: the quantile
+// rule now also holds the Morton order inside a technique between two full re-sorts instead of letting it decay.
+constexpr int RELOC_MEMBER_SHIFT = 8;  // membership compares technique + the top 5 + 5 Morton bits
+LMC_D bool FineMember(const ChainArrays &A, const unsigned *placedKey, int i, bool withoutGaussianOnly, unsigned &key) {
+    if (i >= A.N || A.stepKind[i] != NEXT_LARGE) return false;
+    key = FineKey(A, i);
+    if ((key >> RELOC_MEMBER_SHIFT) == (placedKey[i] >> RELOC_MEMBER_SHIFT)) return false;
+    if (withoutGaussianOnly && (A.flags[i] & F_GAUSS)) return false;
+    return true;
+}
+__global__ void __launch_bounds__(64) k_relf_count(ChainArrays A, const unsigned *placedKey, int *tileCount, bool noGauss) {
+    const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
+    int total = 0;
+    for (int j = 0; j < RELOC_TILE / 64; j++) {
+        unsigned key;
+        total += FineMember(A, placedKey, base + 64 * j, noGauss, key) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (threadIdx.x == 0) tileCount[blockIdx.x] = total;
+}
+// one wave: tileCount -> first member index of every tile; count[0] = members (0 and count[1]++ when they exceed the staging capacity)
+__global__ void __launch_bounds__(64) k_relf_offsets(int nTiles, int *tileCount, int *count, int capacity) {
+    int carry = 0;
+    for (int b = 0; b < nTiles; b += 64) {
+        const int t = b + threadIdx.x, v = t < nTiles ? tileCount[t] : 0;
+        int in = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(in, off);
+            if ((int)threadIdx.x >= off) in += o;
+        }
+        if (t < nTiles) tileCount[t] = carry + in - v;
+        carry += __shfl(in, 63);
+    }
+    if (threadIdx.x == 0) {
+        if (carry > capacity) count[0] = 0, count[1]++;
+        else
+            count[0] = carry;
+    }
+}
+// members[m] = slot (ascending), mkeys[m] = its chain's fine key
+__global__ void __launch_bounds__(64) k_relf_assign(ChainArrays A, const unsigned *placedKey, const int *tileStart, const int *count, int *members, unsigned *mkeys, bool noGauss) {
+    if (count[0] == 0) return;  // nothing to do, or skipped
+    const int base = blockIdx.x * RELOC_TILE + threadIdx.x;
+    const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+    int m0 = tileStart[blockIdx.x];
+    for (int j = 0; j < RELOC_TILE / 64; j++) {
+        unsigned key = 0;
+        const bool mem = FineMember(A, placedKey, base + 64 * j, noGauss, key);
+        const unsigned long long mask = __ballot(mem);
+        if (mem) {
+            const int m = m0 + __popcll(mask & below);
+            members[m] = base + 64 * j, mkeys[m] = key;
+        }
+        m0 += __popcll(mask);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_reloc_iota(int n, int *v) {
@@ -626,32 +693,48 @@ void LaunchRelocFineKey(const ChainArrays &A, const int *leafPosOfTri, int numTr
     hipLaunchKernelGGL(k_reloc_finekey, dim3((A.N + 255) / 256), dim3(256), 0, s, A, leafPosOfTri, numTris, mode, keys, tris, materials);
 }
 // the move of a relocation whose members / sorted / count the caller has filled in
-void LaunchRelocMove(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s) {
+void LaunchRelocMove(const ChainArrays &A, int maxDepth, const RelocBuffers &B, hipStream_t s, int keyMode) {
     const RecordLayout R = MakeRecordLayout(maxDepth);
     // every chain moves and nothing runs beside this launch: one group of 64 records per one-wave block, all of them resident together (the move is a
     // chain of dependent round trips per tile: with 4096 blocks -- four groups per wave in a row -- it took 2.9 ms at 2^20 chains, profiles/r06_i_*)
     const int moveBlocks = std::min((A.N + 63) / 64, 65536);
-    LaunchMoveKernels(A, R, B, 0, moveBlocks, s);
+    LaunchMoveKernels(A, R, B, keyMode, moveBlocks, s);
 }
 
 size_t RelocSortBlocks(int N) { return (size_t)(N + RS_TILE - 1) / RS_TILE; }
 // every chain re-placed by (technique, screen Morton code); B.capacity must be N (the caller checks).  W: keys[2][N], vals[2][N], hist[256 x RelocSortBlocks(N)], scan tile sums
-void LaunchRelocFullSort(const ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, hipStream_t s) {
-    const int N = A.N, nBlocks = (int)RelocSortBlocks(N);
-    hipLaunchKernelGGL(k_rs_key, dim3((N + 255) / 256), dim3(256), 0, s, A, W.keys[0]);
-    // three passes: keys 0 -> 1 -> 0 -> 1; values iota -> vals[0] -> vals[1] -> B.sorted
+// the three stable 8-bit passes over (key, value) pairs: keys W.keys[0] -> [1] -> [0] -> [1], values iota -> W.vals[0] -> W.vals[1] -> out; *nPtr pairs (at most nMax)
+static void LaunchRadixSort24(const RelocSortBuffers &W, const int *nPtr, int nMax, int *out, hipStream_t s) {
+    const int nBlocks = (int)RelocSortBlocks(nMax);
     const unsigned *kin[3] = {W.keys[0], W.keys[1], W.keys[0]};
     unsigned *kout[3] = {W.keys[1], W.keys[0], W.keys[1]};
     const int *vin[3] = {nullptr, W.vals[0], W.vals[1]};
-    int *vout[3] = {W.vals[0], W.vals[1], B.sorted};
+    int *vout[3] = {W.vals[0], W.vals[1], out};
     for (int pass = 0; pass < 3; pass++) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(nBlocks), dim3(64), 0, s, kin[pass], N, 8 * pass, W.hist, nBlocks);
+        hipLaunchKernelGGL(k_rs_hist, dim3(nBlocks), dim3(64), 0, s, kin[pass], nPtr, nMax, 8 * pass, W.hist, nBlocks);
         LaunchInclusiveScan(W.hist, 256 * nBlocks, W.scanSums, s);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nBlocks), dim3(64), 0, s, kin[pass], vin[pass], kout[pass], vout[pass], N, 8 * pass, W.hist, nBlocks);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nBlocks), dim3(64), 0, s, kin[pass], vin[pass], kout[pass], vout[pass], nPtr, nMax, 8 * pass, W.hist, nBlocks);
     }
-    hipLaunchKernelGGL(k_reloc_iota, dim3((N + 255) / 256), dim3(256), 0, s, N, B.members);
+}
+// every chain re-placed by (technique, screen Morton code); B.capacity must be N (the caller checks).  W: keys[2][N], vals[2][N], hist[256 x RelocSortBlocks(N)], scan tile sums
+void LaunchRelocFullSort(const ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, hipStream_t s) {
+    const int N = A.N;
     hipLaunchKernelGGL(k_rs_set_count, dim3(1), dim3(64), 0, s, B.count, N);
-    LaunchRelocMove(A, maxDepth, B, s);
+    hipLaunchKernelGGL(k_rs_key, dim3((N + 255) / 256), dim3(256), 0, s, A, W.keys[0]);
+    LaunchRadixSort24(W, B.count, N, B.sorted, s);
+    hipLaunchKernelGGL(k_reloc_iota, dim3((N + 255) / 256), dim3(256), 0, s, N, B.members);
+    LaunchRelocMove(A, maxDepth, B, s, B.fine ? -1 : 0);
+}
+// the per-step relocation by the fine key (k_relf_*): members -> radix sort of their keys -> move
+void LaunchRelocateFine(const ChainArrays &A, int maxDepth, const RelocBuffers &B, const RelocSortBuffers &W, bool withoutGaussianOnly, hipStream_t s) {
+    const RecordLayout R = MakeRecordLayout(maxDepth);
+    const int N = A.N, nTiles = (N + RELOC_TILE - 1) / RELOC_TILE;
+    hipLaunchKernelGGL(k_relf_count, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, withoutGaussianOnly);
+    hipLaunchKernelGGL(k_relf_offsets, dim3(1), dim3(64), 0, s, nTiles, B.tileCount, B.count, B.capacity);
+    hipLaunchKernelGGL(k_relf_assign, dim3(nTiles), dim3(64), 0, s, A, B.placedKey, B.tileCount, B.count, B.members, W.keys[0], withoutGaussianOnly);
+    LaunchRadixSort24(W, B.count, B.capacity, B.sorted, s);
+    const int moveBlocks = std::min((N + 63) / 64, 4096);  // beside the step launches: few blocks (relocate.hip header)
+    LaunchMoveKernels(A, R, B, -1, moveBlocks, s);
 }
 
 void LaunchRelocate(const ChainArrays &A, int maxDepth, const RelocBuffers &B, bool withoutGaussianOnly, hipStream_t s) {

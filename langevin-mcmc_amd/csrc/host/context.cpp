@@ -194,7 +194,9 @@ struct lmc_ctx {
     // chain relocation (device/relocate.hip): the chains kept physically grouped by technique from the first step on (fill phase included: the safety argument is at the launch site, StepPhase1); LMC_RELOCATE overrides
     bool relocate = false;
     DevBuf<int> chainId, slotOf, relocTileCount, relocTileHist, relocMembers, relocSorted, relocCount;
-    DevBuf<unsigned char> relocPlacedKey, stepKind;
+    DevBuf<unsigned> relocPlacedKey;
+    DevBuf<unsigned char> stepKind;
+    bool relocFine = false;  // LMC_RELOC_FINE=1 (A/B, rejected: profiles/r06_r_*): the per-step relocation sorts its movers by the fine key (relocate.hip k_relf_*)
     DevBuf<float> relocStaging;
     RelocBuffers RB{};
     long long relocations = 0;
@@ -1047,7 +1049,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         c->chainId.Alloc(N, false), c->slotOf.Alloc(N, false), c->relocTileCount.Alloc(RelocTiles((int)N) + 1, false), c->relocTileHist.Alloc(RelocTiles((int)N) * 64, false), c->relocMembers.Alloc(N, false);
         c->relocSorted.Alloc(N, false), c->relocCount.Alloc(2), c->relocPlacedKey.Alloc(N, false), c->stepKind.Alloc(N + 4, false);
         c->relocStaging.Alloc(N * RelocRecordWords(c->S.opt.maxDepth), false);  // the first step is a large step of every chain: N records, cut to N / 2 after it (StepPhase1)
-        HIP_CHECK(hipMemsetAsync(c->relocPlacedKey.p, 0xff, N, s));
+        HIP_CHECK(hipMemsetAsync(c->relocPlacedKey.p, 0xff, N * sizeof(unsigned), s));
         HIP_CHECK(hipMemsetAsync(c->stepKind.p, NEXT_LARGE, N, s));  // k_init_lists: every chain starts with a large step
         LaunchRelocIota((int)N, c->chainId.p, s), LaunchRelocIota((int)N, c->slotOf.p, s);
         // default: every 32nd step (profiles/r06_l_*, r06_m_*: headline steady state +3 % at 32 and at 16, -2 % at 8 -- the lean kernel alone gains 6 / 10 / 11 %,
@@ -1063,13 +1065,17 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         if (const char *e = getenv("LMC_RESORT_FIRST")) c->resortFirst = std::max(0, atoi(e));
         if (c->S.opt.h2mc) c->resortEvery = 0;  // the dense Gaussians of an H2MC render live in per-slot buffers that do not move (relocate.hip MemberKey)
         c->stepsSinceInit = 0, c->resorts = 0;
-        if (c->resortEvery > 0) {
+        // per-step relocation by the fine key: measured and not taken -- the lean launch gains 2.5 % (1.12 against 1.15 ms alone), but the radix sort of the step's
+        // movers is fifteen more launches on the large-step stream, which then outlasts the hot launch: 2.19 against 1.69 ms per step (profiles/r06_r_*)
+        c->relocFine = false;
+        if (const char *e = getenv("LMC_RELOC_FINE")) c->relocFine = atoi(e) != 0;
+        if (c->resortEvery > 0 || c->relocFine) {
             const size_t nb = RelocSortBlocks((int)N);
             for (int k = 0; k < 2; k++) c->sortKeys[k].Alloc(N, false), c->sortVals[k].Alloc(N, false);
             c->sortHist.Alloc(256 * nb, false), c->sortScanSums.Alloc(256 * nb / 2048 + 2, false);
             c->RS = RelocSortBuffers{{c->sortKeys[0].p, c->sortKeys[1].p}, {c->sortVals[0].p, c->sortVals[1].p}, c->sortHist.p, c->sortScanSums.p};
         }
-        c->RB = RelocBuffers{c->relocPlacedKey.p, c->relocTileCount.p, c->relocTileHist.p, c->relocMembers.p, c->relocSorted.p, c->relocCount.p, c->relocStaging.p, (int)N};
+        c->RB = RelocBuffers{c->relocPlacedKey.p, c->relocTileCount.p, c->relocTileHist.p, c->relocMembers.p, c->relocSorted.p, c->relocCount.p, c->relocStaging.p, (int)N, c->relocFine};
         A.chainId = c->chainId.p, A.slotOf = c->slotOf.p, A.stepKind = c->stepKind.p;
     } else {
         A.chainId = nullptr, A.slotOf = nullptr, A.stepKind = nullptr;
@@ -1696,7 +1702,10 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
                 c->relocStaging.Alloc(cap * RelocRecordWords(c->S.opt.maxDepth), false);
                 c->RB.staging = c->relocStaging.p, c->RB.capacity = (int)cap;
             }
-            LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, c->S.opt.h2mc != 0, sL), c->relocations++;
+            if (c->relocFine) LaunchRelocateFine(c->A, c->S.opt.maxDepth, c->RB, c->RS, c->S.opt.h2mc != 0, sL);
+            else
+                LaunchRelocate(c->A, c->S.opt.maxDepth, c->RB, c->S.opt.h2mc != 0, sL);
+            c->relocations++;
         }
     };
     if (!genericFirst) large();
