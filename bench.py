@@ -682,7 +682,9 @@ def main_rank(args):
         import hashlib
 
         ids = [boot.share_id(lambda: os.urandom(128)) for _ in range(2)]
-        rep = {"rank": rank, "world": world, "local": local, "ids": [hashlib.sha256(i).hexdigest() for i in ids], "lens": [len(i) for i in ids]}
+        sharding = importlib.import_module("langevin-mcmc_amd.sharding")
+        rep = {"rank": rank, "world": world, "local": local, "ids": [hashlib.sha256(i).hexdigest() for i in ids], "lens": [len(i) for i in ids],
+               "scaling": args.scaling, "chains_per_gpu": args.chains, "chain_range": list(sharding.chain_range(rank, world, args.chains)), "chains_total": args.chains * world}
         reps = boot.gather_reports(rep)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "boot": boot.kind, "ranks": reps, "ids_equal": all(r["ids"] == reps[0]["ids"] for r in reps),

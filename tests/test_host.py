@@ -99,6 +99,14 @@ def test_bench_starts_one_process_per_gpu_and_hands_the_rccl_id_over():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["dry_run"] and d["n_gpus"] == 4 and d["boot"] == "file" and d["ids_equal"] and d["ids_distinct_per_job"]
     assert [x["rank"] for x in d["ranks"]] == [0, 1, 2, 3] and [x["local"] for x in d["ranks"]] == [0, 1, 2, 3] and all(x["world"] == 4 and x["lens"] == [128, 128] for x in d["ranks"])
+    # weak scaling (the driver's form): --chains per GPU, contiguous global id ranges; --scaling strong: --chains is the job's total
+    assert all(x["scaling"] == "weak" and x["chains_per_gpu"] == 1 << 20 and x["chain_range"] == [x["rank"] << 20, (x["rank"] + 1) << 20] and x["chains_total"] == 4 << 20 for x in d["ranks"])
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--scaling", "strong"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert all(x["scaling"] == "strong" and x["chains_per_gpu"] == 1 << 18 and x["chain_range"] == [x["rank"] << 18, (x["rank"] + 1) << 18] and x["chains_total"] == 1 << 20 for x in d["ranks"])
+    r = subprocess.run([sys.executable, bench, "--gpus", "3", "--scaling", "strong"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "multiple of --gpus" in r.stderr
     # a rank that dies takes the job down with its exit code instead of leaving the others in a collective
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--bogus-flag"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
