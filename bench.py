@@ -253,9 +253,9 @@ def other_configs(args, p, gc):
     door = os.path.join(ROOT, "scenes", "veachdoor")
     cfgs = [
         dict(name="torus, full BSDF set (Phong, rough dielectric, bitmap texture), max path length 12, LMC (BASELINE.json configs[2])",
-             xml=gc.TORUS, kw=dict(force_diffuse=0, max_depth=12), chains=args.chains, L=12, h2mc=False, warm=40, steps=40),
+             xml=gc.TORUS, kw=dict(force_diffuse=0, max_depth=12), chains=args.chains, L=12, h2mc=False, warm=40, steps=40, lanes_key="torus12"),
         dict(name="veach-door, shipped lmc.xml (area light, textures, max path length 8), LMC (BASELINE.json configs[3], one GPU's shard)",
-             xml=os.path.join(door, "lmc.xml"), kw={}, chains=args.chains, L=8, h2mc=False, warm=40, steps=40),
+             xml=os.path.join(door, "lmc.xml"), kw={}, chains=args.chains, L=8, h2mc=False, warm=40, steps=40, lanes_key="door"),
         dict(name="veach-door, shipped h2mc.xml, H2MC (BASELINE.json configs[4], one GPU's shard)",
              xml=os.path.join(door, "h2mc.xml"), kw={}, chains=args.chains, L=8, h2mc=True, warm=40, steps=40),
     ]
@@ -304,6 +304,10 @@ def other_configs(args, p, gc):
                              "concurrent_launches": "the three step launches share the GPU inside each bracket"},
                 "accept_rate": (s1["accepted"] - s0["accepted"]) / max(steps_total, 1), "large_step_frac": large_steps / max(steps_total, 1),
             })
+            lw = lanes_by_workload().get(c.get("lanes_key"))
+            if lw:
+                out[-1]["lanes_active"] = {"kernels": {k: x["lanes_active"] for k, x in lw["kernels"].items()},
+                                           "source": "REPLAYED from profiles/lanes_by_workload.json (%s): lanes per issued vector instruction, not counted during this run" % lw["source"]}
             if c["h2mc"]:
                 # the pipeline's dominant launch (k_h2_hess) is ARITHMETIC-bound: the HBM fraction above says nothing about it.  Its governing figure -- the share
                 # of a SIMD's cycles in which the vector ALU issues -- needs counters, i.e. its own rocprofv3 --pmc passes: replayed from the committed summary
@@ -317,6 +321,12 @@ def other_configs(args, p, gc):
         except Exception as e:  # noqa: BLE001 -- the headline line must still come out
             out.append({"workload": c["name"], "failed": str(e)[:300]})
     return out
+
+
+def lanes_by_workload():
+    """profiles/lanes_by_workload.json (scripts/lanes_summary.py): lanes active per issued vector instruction of the step launches, by workload"""
+    f = os.path.join(ROOT, "profiles", "lanes_by_workload.json")
+    return json.load(open(f)).get("workloads", {}) if os.path.exists(f) else {}
 
 
 def kernel_source_sha():
@@ -717,6 +727,10 @@ def main_rank(args):
                                       "not counted during this run: counters need their own rocprofv3 passes (scripts/pmc_passes.sh)")
         else:
             roof["traffic"] = None
+        lw = lanes_by_workload().get("torus6")
+        if lw:
+            roof["lanes_active"] = {"kernels": {k: x["lanes_active"] for k, x in lw["kernels"].items()},
+                                    "source": "REPLAYED from profiles/lanes_by_workload.json (%s): lanes per issued vector instruction, not counted during this run" % lw["source"]}
         out = {
             "metric": "MALA chain-steps/sec, torus scene",
             "value": value,
