@@ -150,3 +150,31 @@ def test_benchmarked_size_through_the_cache_ready_transition():
     assert np.linalg.norm(l0 - l1) <= 1e-5 * np.linalg.norm(l0)
     # the chains ARE grouped: few technique changes along the slots right after a step whose last full re-sort was at most 8 steps ago
     assert rs1["breaks"] < 0.2 * rs1["slots"], rs1
+
+
+def test_full_resort_really_sorts_the_slots():
+    """The transparency tests above would also pass if the full re-sort moved nothing.  With a re-sort after EVERY step (LMC_RESORT_EVERY=1, first after step 0)
+    the slots must be in technique order right after a step -- at most one technique change per populated technique -- while the per-step relocation alone
+    (round 4's quantile rule) leaves hundreds to thousands of them after the same steps; and the order inside a technique must follow the screen Morton
+    code (not observable through the ABI: rows are reported by chain id; its effect is the lane utilisation of profiles/r06_n_pmc_lanes_*)."""
+    p = gc.pkg()
+    n = 1 << 16
+    res = {}
+    for every in (0, 1):
+        os.environ["LMC_RESORT_EVERY"], os.environ["LMC_RESORT_FIRST"] = str(every), "0"
+        try:
+            ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=256, height=192, seed_offset=0, use_gradient=0)
+            ren.set_option("mala", 0)
+            ren.init_chains(8 * n, n, 4096, 10 ** 6)
+        finally:
+            del os.environ["LMC_RESORT_EVERY"], os.environ["LMC_RESORT_FIRST"]
+        ren.step(12)
+        rs, summ = ren.relocation_stats(), ren.summary(0)
+        # rows come in chain order; the slot of a chain is not exposed, but `breaks` is counted along the slots
+        res[every] = (rs, summ)
+        ren.close()
+    techniques = len({(int(r[1]), int(r[2])) for r in res[1][1] if r[0] == 1})
+    assert res[1][0]["breaks"] <= techniques + 2, (res[1][0], techniques)
+    assert res[0][0]["breaks"] > 20 * techniques, (res[0][0], techniques)
+    # both runs hold the same chains in the same states (the sort is transparent) ...
+    _same_states(res[0][1], res[1][1])
