@@ -61,7 +61,10 @@ int lmc_scene_params(lmc_ctx *ctx, float *out38);
 /* <dpt> float options by XML name: largestepprob, largestepscale, mala, uniformmixprob, mala-stepsize, mala-gn,
  * perturbstddev, mindepth, h2mc, uselightcoordinatesampling, largestepmultiplexed, samplecache (parsescene.cpp:538-585).  mala / h2mc /
  * samplecache / uselightcoordinatesampling select what the resident chain state and the launch plan are laid out for: the call itself succeeds
- * at any time, but once one of them differs from its value at lmc_chains_init, lmc_chains_step returns -1 until the chains are initialised again */
+ * at any time, but once one of them differs from its value at lmc_chains_init, lmc_chains_step returns -1 until the chains are initialised again.
+ * Back-end switches (no counterpart in the reference): "timing" (per-step HIP events for lmc_step_timing), "overlap" (side streams on / off),
+ * "max-derivatives-depth" (main.cpp:59-60), "resort_every" / "resort_first" (period and first step of the full re-sort of the resident chains by
+ * technique and screen position, device/relocate.hip; default 32 / 4, 0 = off; read at the next lmc_chains_init), "exp_resort" (measurement hook) */
 int lmc_set_option(lmc_ctx *ctx, const char *name, double value);
 /* <dpt> options as parsed: spp, numinitsamples, numchains, directspp, mindepth, maxdepth, largestepprob, largestepscale,
  * mala, h2mc, seedoffset (dptoptions.h:7-34); back-end state: bvh_quantised (the scene's hot launches walk the 64-byte quantised BVH nodes),

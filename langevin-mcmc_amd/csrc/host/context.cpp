@@ -203,6 +203,7 @@ struct lmc_ctx {
     int pendingResort = 0;
     // the periodic full re-sort by (technique, screen Morton code) (relocate.hip): every resortEvery-th step ends with it; 0 = off
     int resortEvery = 0, resortFirst = 0;
+    int resortEveryOpt = -1, resortFirstOpt = -1;  // lmc_set_option "resort_every" / "resort_first" (-1: not set)
     long long stepsSinceInit = 0, resorts = 0;
     DevBuf<unsigned> sortKeys[2];
     DevBuf<int> sortVals[2], sortHist, sortScanSums;
@@ -606,11 +607,8 @@ int lmc_set_option(lmc_ctx *c, const char *name, double v) {
     else if (n == "max-derivatives-depth") c->maxDervDepth = (int)v;  // main.cpp:59-60
     else if (n == "timing") c->timing = v != 0;  // record per-step HIP events for lmc_step_timing / lmc_kernel_timing
     else if (n == "exp_resort") c->pendingResort = (int)v;
-    else if (n == "resort_every") {  // takes effect at the next lmc_chains_init (the sort's buffers are allocated there); LMC_RESORT_EVERY is the environment form
-        char b[32];
-        snprintf(b, sizeof b, "%d", (int)v);
-        setenv("LMC_RESORT_EVERY", b, 1);
-    }  // experiment: the next step ends with a full re-sort of the chains by fine key `v` (relocate.hip k_reloc_finekey)
+    else if (n == "resort_every") c->resortEveryOpt = std::max(0, (int)v);  // period of the full re-sort (relocate.hip); takes effect at the next lmc_chains_init; overrides LMC_RESORT_EVERY
+    else if (n == "resort_first") c->resortFirstOpt = std::max(0, (int)v);
     else throw std::runtime_error("Unknown dpt option:" + n);
     SyncOptions(c);
     return 0;
@@ -1056,6 +1054,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         // a re-sort costs 1.3 ms at 2^20 chains, 1.7 ms while the fill phase's MALA vectors are alive); LMC_RESORT_EVERY=0 switches it off (A/B)
         c->resortEvery = 32;
         if (const char *e = getenv("LMC_RESORT_EVERY")) c->resortEvery = std::max(0, atoi(e));
+        if (c->resortEveryOpt >= 0) c->resortEvery = c->resortEveryOpt;
         // the first one after step resortFirst, then every resortEvery steps.  Every chain's first step is a large step, and so are most of the next few
         // (2^20 chains: 1.05 M, 845 k, 682 k, 553 k, 451 k, 369 k ... large steps in steps 0, 1, 2 ...): an order made before that storm has died down is
         // gone within a step or two.  After it, while a chain's large-step probability is still the unscaled 0.05 (mlt.cpp:96-97: the first 10 % of
@@ -1063,6 +1062,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
         // phase (profiles/r06_l_step_durations_fill_phase_resort16.txt).  LMC_RESORT_FIRST overrides (A/B).
         c->resortFirst = 4;
         if (const char *e = getenv("LMC_RESORT_FIRST")) c->resortFirst = std::max(0, atoi(e));
+        if (c->resortFirstOpt >= 0) c->resortFirst = c->resortFirstOpt;
         if (c->S.opt.h2mc) c->resortEvery = 0;  // the dense Gaussians of an H2MC render live in per-slot buffers that do not move (relocate.hip MemberKey)
         c->stepsSinceInit = 0, c->resorts = 0;
         // per-step relocation by the fine key: measured and not taken -- the lean launch gains 2.5 % (1.12 against 1.15 ms alone), but the radix sort of the step's
