@@ -161,13 +161,11 @@ def test_full_resort_really_sorts_the_slots():
     n = 1 << 16
     res = {}
     for every in (0, 1):
-        os.environ["LMC_RESORT_EVERY"], os.environ["LMC_RESORT_FIRST"] = str(every), "0"
-        try:
-            ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=256, height=192, seed_offset=0, use_gradient=0)
-            ren.set_option("mala", 0)
-            ren.init_chains(8 * n, n, 4096, 10 ** 6)
-        finally:
-            del os.environ["LMC_RESORT_EVERY"], os.environ["LMC_RESORT_FIRST"]
+        ren = p.Renderer(gc.TORUS, force_diffuse=1, max_depth=6, width=256, height=192, seed_offset=0, use_gradient=0)
+        ren.set_option("mala", 0)
+        ren.set_option("resort_every", every)  # the option form of LMC_RESORT_EVERY / LMC_RESORT_FIRST (include/lmc_abi.h)
+        ren.set_option("resort_first", 0)
+        ren.init_chains(8 * n, n, 4096, 10 ** 6)
         ren.step(12)
         rs, summ = ren.relocation_stats(), ren.summary(0)
         # rows come in chain order; the slot of a chain is not exposed, but `breaks` is counted along the slots
