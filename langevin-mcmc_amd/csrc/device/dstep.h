@@ -294,19 +294,14 @@ LMC_D void LargeStepCacheMutate(const DScene &S, const DCache &cache, const Chai
     }
 }
 
-// PREGEN (the large-step launch with wave-shared connections, dlargecoop.h): the proposal path and its contributions were generated before the call
-// (`pre`, `preCount` entries in the chain's sink, the random numbers of the generation drawn from `rng` already)
-template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, int MUX = 0, bool PREGEN = false, class Stk>
+template <bool WITH_LARGE, bool WITH_SMALL, bool WITH_GRAD, int MUX = 0, class Stk>
 LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A, const Film &film, const StepParams &P, int i, int kind, Rng &rng,
-                     GradWork &gw, StepStats &st, Stk &stk, DPath *pre = nullptr, int preCount = 0) {
+                     GradWork &gw, StepStats &st, Stk &stk) {
     const size_t N = A.N;
     int flags = A.flags[i];
     const bool curValid = flags & F_VALID;
     const Contrib cur = LoadContrib(A.curContrib, A.N, i);
-    DPath propStore;
-    DPath *propPtr = &propStore;
-    if constexpr (PREGEN) propPtr = pre;
-    DPath &prop = *propPtr;
+    DPath prop;
     Contrib pc;
     pc.camDepth = pc.lightDepth = 0;
     pc.lsScore = pc.ssScore = 0.f;
@@ -327,8 +322,6 @@ LMC_D void StepChain(const DScene &S, const DCache &cache, const ChainArrays &A,
             const int lgtLength = Clampi(int(rng.Uniform() * float(length + 1)), 0, length);
             const int camLength = length - lgtLength + 1;
             GenerateSubpath(S, camLength, lgtLength, prop, sink, rng, stk);
-        } else if constexpr (PREGEN) {
-            sink.count = preCount;
         } else {
             GeneratePathBidir(S, max(S.opt.minDepth, 3), S.opt.maxDepth, prop, sink, rng, stk);
         }

@@ -50,10 +50,6 @@ void LaunchSetupChains(const lmcd::ChainArrays &A, int chainBegin, long long per
 void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::StepParams &P, hipStream_t s);
 // one of the three step launches (device/step_*.hip): chains of `list` (count read on the device) run one mutation and
 // append themselves to the lists of the next step
-// the large-step launch with a wave's vertex connections shared out over its lanes (step_large_coop.hip, dlargecoop.h); scratch: LargeCoopScratchFloats(N) floats
-size_t LargeCoopScratchFloats(int N);
-void LaunchStepLargeCoop(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list, const int *listCount,
-                         const lmcd::NextLists &next, float *scratch, bool glossy, int gridBlocks, int bvhStackNeed, hipStream_t s);
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);
 void LaunchStepLargeMux(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,

@@ -110,8 +110,6 @@ struct lmc_ctx {
     int maxDervDepth = 8;  // --max-derivatives-depth default, main.cpp:46
     bool useOccFilter = true;  // LMC_OCC_FILTER=0: A/B switch for the existence test in front of the cache query
     int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
-    bool largeCoop = false;     // LMC_LARGE_COOP=1: the large-step launch shares a wave's vertex connections out over its lanes (device/dlargecoop.h)
-    DevBuf<float> largeCoopScratch;
     bool largeLdsStack = true;  // LMC_LARGE_LDS=0: A/B switch for the LDS traversal stack of the large-step launch
     int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256); 128 disturbs the lean launch less (its bracket 2.4 instead of 2.7 ms) but the step and the start-up end 1-2 % later (profiles/r02_j_ab_block_sizes.jsonl)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
@@ -529,7 +527,6 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
     if (const char *e = getenv("LMC_LARGE_LDS")) c->largeLdsStack = atoi(e) != 0;
-    if (const char *e = getenv("LMC_LARGE_COOP")) c->largeCoop = atoi(e) != 0;
     if (const char *e = getenv("LMC_LARGE_BLOCK")) c->largeBlock = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
@@ -1042,9 +1039,6 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     A.initPath = c->initPath.p, A.initContrib = c->initContrib.p, A.initScoreSum = c->initScoreSum.p, A.initLsAll = c->initLsAll.p, A.initCLAll = c->initCLAll.p;
     A.counters = c->counters.p, A.weightSum = c->weightSum.p, A.prof = c->prof.p;
     // Relocation: off for `samplecache` (chain.path is not moved); H2MC renders move only chains without a stored Gaussian (relocate.hip)
-    if (c->largeCoop) c->largeCoopScratch.Alloc(LargeCoopScratchFloats((int)N), false);
-    else
-        c->largeCoopScratch.Free();
     c->relocate = true;
     if (const char *e = getenv("LMC_RELOCATE")) c->relocate = atoi(e) != 0;
     if (sampleCache) c->relocate = false;
@@ -1582,10 +1576,6 @@ StepParams MakeStepParams(const lmc_ctx *c) {
 // which large-step / generic small-step kernel the options in force select (cnt: the three list lengths on the device)
 void LaunchLarge(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sL) {
     const bool mux = c->scene->options.largeStepMultiplexed;
-    if (c->largeCoop && !mux && !c->S.opt.sampleCache && c->largeLdsStack && c->bvhDepth <= BVH_LDS_STACK && c->largeCoopScratch.p) {
-        LaunchStepLargeCoop(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->largeCoopScratch.p, c->S.glossy != 0, c->stepGrid, c->bvhDepth, sL);
-        return;
-    }
     (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
 }
 void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sG) {
