@@ -683,9 +683,15 @@ Rccl &GetRccl() {
     static bool ready = false;  // set only after EVERY required symbol has resolved: a failed first call must not leave a half-filled table behind
     if (ready) return r;
     void *h = nullptr;
+    // LMC_RCCL_LIB: another library with the six entry points (tests/helpers/rccl_stub.cpp: the collectives over host shared memory, so that a job of several
+    // rank PROCESSES can be run on the one GPU of the test tier -- real RCCL refuses two ranks on one device)
+    if (const char *e = getenv("LMC_RCCL_LIB")) {
+        h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) throw std::runtime_error(std::string("LMC_RCCL_LIB: ") + dlerror());
+    }
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!h) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
     Rccl t;

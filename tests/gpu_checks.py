@@ -196,6 +196,17 @@ def host_trans_lib():
     return so
 
 
+def rccl_stub_lib():
+    """Test helper: the six RCCL entry points over host shared memory (tests/helpers/rccl_stub.cpp), for multi-PROCESS jobs on one GPU (LMC_RCCL_LIB)"""
+    import subprocess
+
+    so = os.path.join(ROOT, "tests", "helpers", "librccl_stub.so")
+    src = os.path.join(ROOT, "tests", "helpers", "rccl_stub.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so, "-lrt"], cwd=ROOT)
+    return so
+
+
 def trans_cases(seed=1, n=1 << 20):
     """(mode, x, y) argument sets of the exp / log / pow checks: the BSDFs' ranges and the full float range"""
     rng = np.random.default_rng(seed)
