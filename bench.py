@@ -704,8 +704,12 @@ def main_rank(args):
     p = importlib.import_module("langevin-mcmc_amd")
     from tests import gpu_checks as gc
 
+    oversubscribed = bool(world > p.device_count() and os.environ.get("LMC_BENCH_OVERSUBSCRIBE") and os.environ.get("LMC_RCCL_LIB"))
     if p.device_count() <= local:
-        die("rank %d: local device %d is not visible (%d HIP device(s))" % (rank, local, p.device_count()))
+        if p.device_count() >= 1 and os.environ.get("LMC_BENCH_OVERSUBSCRIBE") and os.environ.get("LMC_RCCL_LIB"):  # test aid (main_spawn): ranks share the devices
+            local, oversubscribed = local % p.device_count(), True
+        else:
+            die("rank %d: local device %d is not visible (%d HIP device(s))" % (rank, local, p.device_count()))
     multi = world > 1 or bool(os.environ.get("LMC_BENCH_FORCE_DIST"))
     head_name = "torus scene, %d persistent chains per GPU, Lambertian-only BSDF, max path length 6 (BASELINE.json configs[1])" % args.chains
     head = rank_job(args, p, gc, boot, rank, world, local, head_name, gc.TORUS, dict(force_diffuse=1, max_depth=6), args.warmup, args.steps, ALGO_BYTES_PER_STEP,
@@ -759,6 +763,8 @@ def main_rank(args):
                 "parallelism": "chains sharded x%d, one process per GPU" % world,
                 "collective": head["multi_gpu"]["collective"] if multi else "none (one GPU)",
                 "rccl_ranks": world if multi else 0,
+                **({"oversubscribed": True} if oversubscribed else {}),
+                **({"rccl_library": os.environ["LMC_RCCL_LIB"] + " (NOT RCCL: a stand-in over host shared memory, tests only)"} if os.environ.get("LMC_RCCL_LIB") else {}),
                 "launch": ("spawned by bench.py, id over a private directory" if boot and boot.kind == "file" else "torch.distributed.run, id over its gloo rendezvous") if multi else "single process",
             },
             "roofline": roof,
@@ -808,7 +814,10 @@ def main_spawn(args):
     if not dry:
         p = importlib.import_module("langevin-mcmc_amd")
         have = p.device_count()
-        if have < args.gpus:
+        # bring-up / test aid ONLY: with a stand-in for RCCL that accepts several ranks per device (LMC_RCCL_LIB, tests/helpers/rccl_stub.cpp) AND
+        # LMC_BENCH_OVERSUBSCRIBE=1 the N rank processes share the visible devices; the line says so (`oversubscribed`, `rccl_library`)
+        stub_ok = have >= 1 and os.environ.get("LMC_BENCH_OVERSUBSCRIBE") and os.environ.get("LMC_RCCL_LIB")
+        if have < args.gpus and not stub_ok:
             die("--gpus %d but only %d HIP device(s) visible to this process: refusing to measure a smaller job under that name "
                 "(RCCL cannot place two ranks on one device; for bring-up on fewer devices: --in-process with LMC_BENCH_OVERSUBSCRIBE=1)" % (args.gpus, have))
     boot_dir = tempfile.mkdtemp(prefix="lmc_bench_")

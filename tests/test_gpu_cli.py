@@ -193,3 +193,30 @@ def test_rank_processes_through_the_rccl_code_path_equal_one_rank(tmp_path, worl
     for x in R:  # the all-reduce: every rank holds the sum of the ranks' films (rank order on the stub, so bit-equal between ranks)
         assert np.array_equal(x["film"], R[0]["film"]) and np.allclose(x["film"], own, rtol=1e-6, atol=1e-9)
     assert np.allclose(R[0]["film"], film1, rtol=1e-4, atol=1e-6)
+
+
+def test_bench_spawned_ranks_end_to_end_with_the_rccl_stand_in():
+    """`python bench.py --gpus 2` -- the form the driver's scaling run takes -- end to end on the one GPU of this tier: two spawned rank processes, the id through
+    the private directory, the library's communicator over tests/helpers/rccl_stub.cpp (LMC_RCCL_LIB + LMC_BENCH_OVERSUBSCRIBE: both ranks on device 0, and the
+    line says so), sharded MLTInit, steps with the per-step exchange, film all-reduce, barriers and max-over-ranks timing through the communicator.  Checks the
+    line's shape and its arithmetic; the numbers themselves mean nothing (two ranks share one GPU through a host-memory transport)."""
+    import json
+    import sys
+
+    p = gc.pkg()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LMC_BENCH_FORCE_DIST", "LMC_BENCH_DRY_RUN", "LMC_BENCH_BOOT")}
+    env.update(LMC_RCCL_LIB=gc.rccl_stub_lib(), LMC_BENCH_OVERSUBSCRIBE="1")
+    argv = [sys.executable, os.path.join(gc.ROOT, "bench.py"), "--gpus", "2", "--chains", "16384", "--steps", "8", "--warmup", "24", "--samples-per-chain", "64", "--init-threads", "2048",
+            "--no-configs", "--no-cpu-baseline", "--no-rmse"]
+    r = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["multi_gpu"]["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert "rccl_library" in d["config"] and (d["config"].get("oversubscribed", False) == (p.device_count() < 2))
+    assert len(d["roofline"]["frac_per_rank"]) == 2 and len(d["multi_gpu"]["per_rank_step_ms"]) == 2 and d["multi_gpu"]["film_sum"] > 0
+    assert d["value"] > 0 and abs(d["value"] - 2 * 16384 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
+    # strong scaling form: the same total over two ranks
+    r = subprocess.run(argv + ["--scaling", "strong"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["config"]["chains_per_gpu"] == 8192 and abs(d["value"] - 16384 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
