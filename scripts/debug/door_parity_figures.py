@@ -22,7 +22,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "torus":  # the torus tests' configurati
         r = gc.run_pair(160, 120, 20000, 256, 20000, 400, 40, max_depth=8, force_diffuse=0, **kw)
         print(json.dumps({"case": name, **{k: r[k] for k in keep if k in r}}), flush=True)
     sys.exit(0)
-for name, scene, grad, og in (("lmc_nograd", DOOR, 0, "reference"), ("lmc_grad_reference", DOOR, 1, "reference"), ("lmc_grad_product", DOOR, 1, "product"), ("h2mc_product", DOOR_H2, 1, "product")):
+cases = (("lmc_nograd", DOOR, 0, "reference"), ("lmc_grad_reference", DOOR, 1, "reference"), ("lmc_grad_product", DOOR, 1, "product"), ("h2mc_product", DOOR_H2, 1, "product"))
+if len(sys.argv) > 1 and sys.argv[1] == "h2only":  # e.g. with LMC_LIB=<the strict build of the Hessian / eigen-solve units> (scripts/build_h2strict.sh)
+    cases = cases[3:] + (("h2mc_torus_product", os.path.join(gc.ROOT, "scenes", "torus", "h2mc.xml"), 1, "product"),)
+for name, scene, grad, og in cases:
     try:
         r = gc.run_pair(160, 90, 40000, 2048, 40000, 400, 60, use_gradient=grad, max_depth=8, scene=scene, force_diffuse=0, oracle_grad=og)
         print(json.dumps({"case": name, **{k: r[k] for k in keep if k in r}}), flush=True)

@@ -361,6 +361,32 @@ def test_h2mc_chain_parity_on_the_strict_build():
         assert abs(strict[k]["final_state_match"] - fast[k]["final_state_match"]) <= 0.0235, (k, strict[k], fast[k])
 
 
+def test_h2mc_chains_exact_on_the_strict_build_with_the_products_hessians():
+    """Round 6: with one sin / cos / acos / atan2 / exp / log / pow and glibc's logf on both sides, what is left between the device's H2MC chains and the oracle's is
+    (a) whose Hessians the oracle uses and (b) the fused arithmetic of the shipped Hessian / eigen-solve units.  Take both away -- the oracle on the product's
+    second-order path program compiled for the host, the device on the STRICT build of h2hess.hip / h2gauss.hip (scripts/build_h2strict.sh, LMC_LIB) -- and the
+    shipped `h2mc.xml` of BOTH scenes runs chain-exact: 2048 chains x 60 mutations, every counter (large steps, accepted, Hessian calls) equal, every final state
+    equal, film 1e-6.  (The shipped build on the same comparison: 97 % / 73 % of the final states, profiles/r06_af_*.)  This pins the whole H2MC step -- Hessian
+    assembly, the round-robin Jacobi eigen-solve, the dense Gaussian and its log-pdf, the streamed re-trace -- bit for bit against the CPU restatement."""
+    import subprocess
+    import sys
+
+    var = os.path.join(gc.ROOT, "langevin-mcmc_amd", "csrc", "_ab", "h2strict", "liblmc_hip.so")
+    if not os.path.exists(var):
+        pytest.skip("strict variant not built (python __graft_entry__.py builds it)")
+    env = dict({k: v for k, v in os.environ.items() if k != "LMC_LIB"}, LMC_LIB=var)
+    r = subprocess.run([sys.executable, os.path.join(gc.ROOT, "scripts", "debug", "door_parity_figures.py"), "h2only"], cwd=gc.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [x["case"] for x in rows] == ["h2mc_product", "h2mc_torus_product"] and not any("error" in x for x in rows), rows
+    for x in rows:
+        so, sg = x["stats_oracle"], x["stats_gpu"]
+        assert x["contribs_gpu"] == x["contribs_oracle"] and x["norm_gpu"] == x["norm_oracle"] and x["init_pss_maxdiff"] == 0.0
+        for k in ("steps", "largeSteps", "accepted", "gradCalls"):
+            assert sg[k] == so[k], (x["case"], k, sg[k], so[k])
+        assert sg["gradCalls"] > 20000 and x["final_state_match"] == 1.0 and x["film_rel_l2"] < 1e-6, (x["case"], x["final_state_match"], x["film_rel_l2"])
+
+
 @pytest.mark.parametrize("diffuse", [1, 0])
 def test_h2mc_per_step_agreement(diffuse):
     """What a single H2MC mutation agrees to, before the divergence of test_h2mc_chain_parity_* compounds: 2048 chains, 6 lock-step
