@@ -1071,3 +1071,36 @@ def test_plain_monte_carlo_estimators_are_pinned_to_the_oracle():
             assert abs(a.mean() - b.mean()) < 3 * sigma + 0.01 * b.mean(), (gy, gx, a.mean(), b.mean(), sigma)
     orc.close()
     ren.close()
+
+
+OPTION_MATRIX = ["mux_lambertian", "mux_arealight_lightcoord", "mux_full_materials", "lightcoord_arealight", "pointlight_full_materials", "samplecache_lambertian", "door_lightcoord",
+                 "plain_mlt_full_materials"]
+
+
+@pytest.mark.parametrize("case", OPTION_MATRIX)
+def test_option_matrix_chain_exact_with_the_products_gradients(case):
+    """Round 6: every <dpt> option that changes the chain loop -- `largestepmultiplexed` (GenerateSubpath, lengthDist), `uselightcoordinatesampling` on the planar
+    area-light scene and on the veach-door scene, `samplecache` (LargeStepCache: cached rows sampled and perturbed, evalPdfCache), the point-light scene with the full
+    material set, plain MLT (mala = 0) -- oracle vs device chain by chain with the oracle drawing its gradients from the product's path program compiled for the
+    host (so that the LOOP is compared, not two gradient implementations; the tests above keep the comparison against the reference's generated programs):
+    EXACT -- contributions, normalization and every init state bit for bit, large steps, accepted steps, gradient calls, cache queries, the cache-ready mask, every
+    chain's final state; film 1e-6 (order of the float atomics).  The cases and their sizes: scripts/debug/option_matrix_parity.py (profiles/r06_ah_*)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("option_matrix_parity", os.path.join(gc.ROOT, "scripts", "debug", "option_matrix_parity.py"))
+    # the script runs its cases at import unless told otherwise: take its table only
+    src = open(spec.origin).read().split("keep = (")[0]
+    ns = {"__file__": spec.origin}
+    exec(compile(src, spec.origin, "exec"), ns)
+    c = ns["CASES"][case]
+    r = gc.run_pair(*c["args"], oracle_grad="product", **c["kw"])
+    assert r["contribs_gpu"] == r["contribs_oracle"] and r["norm_gpu"] == r["norm_oracle"]
+    assert r["init_cl_match"] == 1.0 and r["init_ls_relerr_max"] == 0.0 and r["init_pss_maxdiff"] == 0.0
+    so, sg = r["stats_oracle"], r["stats_gpu"]
+    for k in ("steps", "largeSteps", "accepted", "gradCalls", "cacheQueries", "cacheHits", "resets", "cacheReadyMask"):
+        assert sg[k] == so[k], (k, sg[k], so[k])
+    assert r["final_state_match"] == 1.0 and r["film_rel_l2"] < 1e-6 and r["nonfinite_gpu"] == 0
+    if case == "samplecache_lambertian":
+        assert so["cacheReadyMask"] != 0 and so["cacheQueries"] > 0
+    if case != "plain_mlt_full_materials":
+        assert so["gradCalls"] > 1000
