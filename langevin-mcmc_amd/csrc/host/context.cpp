@@ -233,6 +233,15 @@ struct lmc_ctx {
     bool earlyApply = true;                  // LMC_EARLY_APPLY=0: a single rank also applies its pushes at the end of the step
     int lastCounts[CACHE_SLOTS] = {0, 0, 0, 0}; // ... as last read back, and the steps run since (CacheApplyLaunch)
     long long stepsSinceCounts = 0;
+    // the rows of a dim that is about to fill up, sent to the host behind the apply of the step that is expected to fill it (CacheApplyLaunch): when
+    // the counts say "ready" the rows are there already and the kd-tree build starts at once (the fetch was 0.2 ms of a 1.2 ms transition)
+    float *rowsPinned[CACHE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool rowsPrefetched[CACHE_SLOTS] = {false, false, false, false};
+    int lastDelta[CACHE_SLOTS] = {0, 0, 0, 0};  // rows added per step, as of the last two read-backs
+    // ... and the way up: a dim's kd-tree (nodes, then the point order) in a pinned buffer of its own, so that the copies are queued and the host goes on
+    // (pageable copies made the host wait for the stream, existence-grid builds included, once per dim: 0.3 ms)
+    char *treePinned[CACHE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t treesUpEvent = nullptr;
     bool allCachesReady = false;
     int mutationAtInit = -1;  // (mala, h2mc) the resident chain state was laid out for by lmc_chains_init; lmc_chains_step refuses any other
     bool needGeneric = true;  // some chain may still need the generic small-step launch (gradient / deep cache tree)
@@ -270,6 +279,11 @@ struct lmc_ctx {
             }
         }
         if (hostCounts) (void)hipHostFree(hostCounts);
+        for (float *r : rowsPinned)
+            if (r) (void)hipHostFree(r);
+        for (char *r : treePinned)
+            if (r) (void)hipHostFree(r);
+        if (treesUpEvent) (void)hipEventDestroy(treesUpEvent);
         if (cachePinned) (void)hipHostFree(cachePinned);
         if (cacheStream) (void)hipStreamDestroy(cacheStream);
         if (countsEvent) (void)hipEventDestroy(countsEvent);
@@ -1121,6 +1135,12 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
             cd.gridWords.Alloc((cells + 31) / 32, false), cd.gridCellStart.Alloc(std::min(cells, (size_t)PSS_MAX_SIZE * nbrs) + 1, false), cd.gridIdx.Alloc((size_t)PSS_MAX_SIZE * nbrs, false);
             maxGridCells = std::max(maxGridCells, cells);
             cd.nodes.Alloc(KD_MAX_NODES, false), cd.vind.Alloc(PSS_MAX_SIZE, false);
+            // ... the pinned buffers of the rows' way down and the tree's way up included (hipHostMalloc: 0.1 ms each)
+            const int sl = (d - 6) / 2;
+            if (sl >= 0 && sl < CACHE_SLOTS && d == 6 + 2 * sl) {
+                if (!c->rowsPinned[sl]) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->rowsPinned[sl]), (size_t)PSS_MAX_SIZE * PSS_MAX_LENGTH * sizeof(float)));
+                if (!c->treePinned[sl]) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->treePinned[sl]), (size_t)KD_MAX_NODES * sizeof(KdNode) + (size_t)PSS_MAX_SIZE * sizeof(int)));
+            }
         }
     }
     if (maxGridCells) {
@@ -1130,6 +1150,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     c->cacheCounts.Alloc(CACHE_SLOTS), c->pushTiles.Alloc((N + 1023) / 1024);
     if (!c->hostCounts) HIP_CHECK(hipHostMalloc((void **)&c->hostCounts, CACHE_SLOTS * sizeof(int)));
     if (!c->countsEvent) HIP_CHECK(hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming));
+    if (!c->treesUpEvent) HIP_CHECK(hipEventCreateWithFlags(&c->treesUpEvent, hipEventDisableTiming));
     c->stageLayout = MakePushStageLayout(sampleCache);
     c->pushStage.Alloc((size_t)c->stageLayout.totalFloats), c->pushGather.Alloc(c->world > 1 ? (size_t)c->stageLayout.totalFloats * c->world : 1);
     memset(&c->stageT, 0, sizeof(c->stageT));
@@ -1150,7 +1171,7 @@ void InitPhase4(lmc_ctx *c, InitJob &J) {
     UploadCacheStruct(c);
     c->allCachesReady = false;
     c->stepsSinceCounts = 0;
-    for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = 0;
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = 0, c->lastDelta[sl] = 0, c->rowsPrefetched[sl] = false;
     c->needGeneric = true;
     c->genericTokenOnly = false;
     c->anyDeepCache = false;
@@ -1452,6 +1473,17 @@ static void CacheApplyLaunch(lmc_ctx *c, hipStream_t s) {
     }
     c->countsInFlight = canBeFull;
     LaunchCachePushApply(gathered, (size_t)c->stageLayout.totalFloats, c->world, c->stageLayout, c->pushT, canBeFull ? c->hostCounts : nullptr, s);
+    static const bool prefetch = !getenv("LMC_NO_ROWS_PREFETCH");
+    for (int sl = 0; sl < CACHE_SLOTS && canBeFull && prefetch; sl++) {
+        CacheDimHost &cd = c->cacheDims[6 + 2 * sl];
+        c->rowsPrefetched[sl] = false;
+        // expected to fill in this step at the rate of the last ones (twice the rate, to be on the safe side: a wrong guess costs one copy of 70-140 KB
+        // or, the other way, the fetch after the counts as before)
+        if (!cd.relevant || cd.ready || (long long)c->lastCounts[sl] + 2ll * c->lastDelta[sl] * c->stepsSinceCounts < PSS_MAX_SIZE) continue;
+        if (!c->rowsPinned[sl]) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->rowsPinned[sl]), (size_t)PSS_MAX_SIZE * PSS_MAX_LENGTH * sizeof(float)));
+        HIP_CHECK(hipMemcpyAsync(c->rowsPinned[sl], cd.pss.p, cd.pss.n * sizeof(float), hipMemcpyDeviceToHost, s));
+        c->rowsPrefetched[sl] = true;
+    }
     if (canBeFull) HIP_CHECK(hipEventRecord(c->countsEvent, s));
 }
 // The host half: the counts looked at, the kd-tree and the existence grid of a dim that has just become ready built (stream = the step stream)
@@ -1459,9 +1491,18 @@ static void CacheApplyFinish(lmc_ctx *c) {
     hipStream_t s = c->stream;
     if (!c->countsInFlight) return;
     c->countsInFlight = false;
+    static const bool tlog = getenv("LMC_CACHE_LOG") != nullptr;  // measurement: host time of the transition's parts (stderr)
+    const auto T0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (tlog) fprintf(stderr, "[lmc] cache transition: %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
     HIP_CHECK(hipEventSynchronize(c->countsEvent));
+    mark("counts on the host");
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) {
+        c->lastDelta[sl] = (int)((c->hostCounts[sl] - c->lastCounts[sl] + c->stepsSinceCounts - 1) / std::max(1ll, c->stepsSinceCounts));
+        c->lastCounts[sl] = c->hostCounts[sl];
+    }
     c->stepsSinceCounts = 0;
-    for (int sl = 0; sl < CACHE_SLOTS; sl++) c->lastCounts[sl] = c->hostCounts[sl];
     bool changed = false;
     // the dims that became ready in this step (often two at once: at 2^20 chains dims 10 and 12 fill in the same step): the existence
     // grids are started on the device first, the point rows are fetched, and the kd-trees are built side by side on host threads
@@ -1482,29 +1523,38 @@ static void CacheApplyFinish(lmc_ctx *c) {
     // The pushes of this step are applied (countsEvent above), so nothing on that stream has to wait for anything.
     const bool beside = c->appliedEarly && c->overlap && c->cacheStream && !c->S.opt.sampleCache && !getenv("LMC_NO_CACHE_STREAM");
     hipStream_t cs = beside ? c->cacheStream : s;
-    if (beside) {
-        for (int r = 0; r < numReady; r++) {
-            const DevBuf<float> &b = c->cacheDims[readyDims[r]].pss;
-            ptsOf[r].resize(b.n);
-            HIP_CHECK(hipMemcpyAsync(ptsOf[r].data(), b.p, b.n * sizeof(float), hipMemcpyDeviceToHost, cs));
-        }
-        if (numReady) HIP_CHECK(hipStreamSynchronize(cs));
-    } else if (c->appliedEarly && c->overlap) {
-        for (int r = 0; r < numReady; r++) {
-            const DevBuf<float> &b = c->cacheDims[readyDims[r]].pss;
-            ptsOf[r].resize(b.n);
-            HIP_CHECK(hipMemcpyAsync(ptsOf[r].data(), b.p, b.n * sizeof(float), hipMemcpyDeviceToHost, c->sideStream[0]));
-        }
-        if (numReady) HIP_CHECK(hipStreamSynchronize(c->sideStream[0]));
-    } else {
-        for (int r = 0; r < numReady; r++) ptsOf[r] = c->cacheDims[readyDims[r]].pss.Download();
+    int toFetch = 0;
+    for (int r = 0; r < numReady; r++) {
+        const int sl = (readyDims[r] - 6) / 2;
+        const DevBuf<float> &b = c->cacheDims[readyDims[r]].pss;
+        if (c->rowsPrefetched[sl]) ptsOf[r].assign(c->rowsPinned[sl], c->rowsPinned[sl] + b.n);  // sent behind the apply (CacheApplyLaunch), complete since countsEvent
+        else
+            toFetch++;
     }
+    if (tlog && numReady) fprintf(stderr, "[lmc] cache transition: %d of %d dims' rows were prefetched\n", numReady - toFetch, numReady);
+    if (toFetch == 0) {
+    } else if (beside || (c->appliedEarly && c->overlap)) {
+        hipStream_t fs = beside ? cs : c->sideStream[0];
+        for (int r = 0; r < numReady; r++) {
+            if (!ptsOf[r].empty()) continue;
+            const DevBuf<float> &b = c->cacheDims[readyDims[r]].pss;
+            ptsOf[r].resize(b.n);
+            HIP_CHECK(hipMemcpyAsync(ptsOf[r].data(), b.p, b.n * sizeof(float), hipMemcpyDeviceToHost, fs));
+        }
+        HIP_CHECK(hipStreamSynchronize(fs));
+    } else {
+        for (int r = 0; r < numReady; r++)
+            if (ptsOf[r].empty()) ptsOf[r] = c->cacheDims[readyDims[r]].pss.Download();
+    }
+    for (int sl = 0; sl < CACHE_SLOTS; sl++) c->rowsPrefetched[sl] = false;
+    if (numReady) mark("rows on the host");
     for (int r = 0; r < numReady; r++) {
         CacheDimHost &cd = c->cacheDims[readyDims[r]];
         lmc::ChooseGridCoords(ptsOf[r].data(), PSS_MAX_SIZE, readyDims[r], cd.gridM, cd.gridCoord);
         LaunchBuildCacheGrid(cd.pss.p, PSS_MAX_SIZE, readyDims[r], cd.gridG, cd.gridM, cd.gridCoord, c->gridScratchStart.p, c->gridScratchCursor.p, c->gridScratchWordCount.p, c->gridTileSums.p,
                              cd.gridWords.p, cd.gridCellStart.p, cd.gridIdx.p, cs);
     }
+    if (numReady) mark("grid builds queued");
     {
         std::vector<std::thread> workers;
         std::vector<std::exception_ptr> failed(numReady);  // an exception must not leave a worker thread (std::terminate): re-thrown after the join
@@ -1525,14 +1575,22 @@ static void CacheApplyFinish(lmc_ctx *c) {
         for (auto &f : failed)
             if (f) std::rethrow_exception(f);
     }
+    if (numReady) mark("kd-trees built");
     for (int r = 0; r < numReady; r++) {
         const int d = readyDims[r];
         CacheDimHost &cd = c->cacheDims[d];
         lmc::KdTreeResult &t = treeOf[r];
         if (t.nodes.size() > KD_MAX_NODES) throw std::runtime_error("kd-tree larger than its preallocated node buffer");
-        HIP_CHECK(hipMemcpyAsync(cd.nodes.p, t.nodes.data(), t.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, cs));
-        HIP_CHECK(hipMemcpyAsync(cd.vind.p, t.vind.data(), t.vind.size() * sizeof(int), hipMemcpyHostToDevice, cs));
-        HIP_CHECK(hipStreamSynchronize(cs));  // the pageable copies above must have left the host before the trees go out of scope (beside: the grids are built by then too)
+        {
+            const int sl = (d - 6) / 2;
+            const size_t nodeBytes = t.nodes.size() * sizeof(KdNode), vindBytes = t.vind.size() * sizeof(int);
+            if (!c->treePinned[sl]) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->treePinned[sl]), (size_t)KD_MAX_NODES * sizeof(KdNode) + (size_t)PSS_MAX_SIZE * sizeof(int)));
+            if (vindBytes > (size_t)PSS_MAX_SIZE * sizeof(int)) throw std::runtime_error("kd-tree point order larger than the cache");
+            memcpy(c->treePinned[sl], t.nodes.data(), nodeBytes);
+            memcpy(c->treePinned[sl] + (size_t)KD_MAX_NODES * sizeof(KdNode), t.vind.data(), vindBytes);
+            HIP_CHECK(hipMemcpyAsync(cd.nodes.p, c->treePinned[sl], nodeBytes, hipMemcpyHostToDevice, cs));
+            HIP_CHECK(hipMemcpyAsync(cd.vind.p, c->treePinned[sl] + (size_t)KD_MAX_NODES * sizeof(KdNode), vindBytes, hipMemcpyHostToDevice, cs));
+        }
         DCacheDim &D = c->cacheHost.d[d];
         D.gridWords = c->useOccFilter ? cd.gridWords.p : nullptr, D.gridCellStart = cd.gridCellStart.p, D.gridIdx = cd.gridIdx.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
         for (int k = 0; k < 4; k++) D.gridCoord[k] = cd.gridCoord[k];
@@ -1557,7 +1615,15 @@ static void CacheApplyFinish(lmc_ctx *c) {
         cd.ready = true;
         changed = true;
     }
-    if (changed) UploadCacheStruct(c, beside ? s : nullptr);  // beside: the step's launches are still running and read the struct as it was; `s` is behind all of them (StepPhase1's joins)
+    if (numReady) mark("trees on their way up");
+    if (changed && beside) {  // the next step's launches (stream s and its forks) read the trees and the grids built on the cache stream
+        if (!c->treesUpEvent) HIP_CHECK(hipEventCreateWithFlags(&c->treesUpEvent, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(c->treesUpEvent, cs));
+        HIP_CHECK(hipStreamWaitEvent(s, c->treesUpEvent, 0));
+    }
+    if (changed && !beside) HIP_CHECK(hipStreamSynchronize(s));  // the struct is replaced by a blocking copy below: nothing of this step may still read it
+    if (changed) UploadCacheStruct(c, beside ? s : nullptr);
+    if (numReady) mark("cache struct refreshed");  // beside: the step's launches are still running and read the struct as it was; `s` is behind all of them (StepPhase1's joins)
 }
 
 extern "C++" {
