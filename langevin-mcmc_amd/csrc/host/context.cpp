@@ -126,6 +126,8 @@ struct lmc_ctx {
     static constexpr int H2_MAX_PARTS = 4;
     hipStream_t partStream[H2_MAX_PARTS - 1] = {};  // H2MC: the pipelines of the other parts of the chain population (LaunchGeneric)
     hipEvent_t partFork = nullptr, partJoin[H2_MAX_PARTS - 1] = {};
+    hipEvent_t h2HeadDone[H2_MAX_PARTS] = {};  // H2MC: behind each part's k_h2_begin (the large-step launch can be made to wait for them: LMC_H2_LARGE_AFTER)
+    int h2HeadParts = 0;
     hipEvent_t forkEvent = nullptr, joinEvent[2] = {nullptr, nullptr};
     hipEvent_t packedEvent = nullptr, copiedEvent = nullptr;  // in-process group: this member's stage is complete / this member has copied every stage (ExchangeStagesAsync)
     // in-process group, film merge (lmc_group_film_reduce): staging for the slices pulled from the peers + the peers' weight sums, allocated when the
@@ -285,6 +287,8 @@ struct lmc_ctx {
             if (r) (void)hipHostFree(r);
         if (treesUpEvent) (void)hipEventDestroy(treesUpEvent);
         if (cachePinned) (void)hipHostFree(cachePinned);
+        for (auto e : h2HeadDone)
+            if (e) (void)hipEventDestroy(e);
         if (cacheStream) (void)hipStreamDestroy(cacheStream);
         if (countsEvent) (void)hipEventDestroy(countsEvent);
         for (auto st : partStream)
@@ -1682,9 +1686,23 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
             const int grid = laneGrid / parts + 1;
             HIP_CHECK(hipMemsetAsync(c->h2Bins[h][0].count, 0, 2 * 3 * H2_COUNT_WORDS * sizeof(int), sp));  // both stages' tables of this part are contiguous
             LaunchH2Begin(c->S, c->A, P, H, lists[h], counts[h], grid, sp);
+            // The large-step launch starts behind every part's k_h2_begin: released together with the pipelines it won the race for the machine by microseconds
+            // and the pipelines' first launch -- a memset -- waited 1.5 ms for a slot with everything else behind it (profiles/r06_final_h2mc_timeline_door.txt).
+            // LMC_H2_LARGE_AFTER: 0 = at once (veach-door 88.2 M), 1 = behind the begins (91.3 M), 2 = behind the first Hessian launches too (90.6 M); torus 73.1 / 72.6 / 72.5
+            static const int largeAfter = getenv("LMC_H2_LARGE_AFTER") ? atoi(getenv("LMC_H2_LARGE_AFTER")) : 1;
+            if (largeAfter == 1 && c->overlap) {
+                if (!c->h2HeadDone[h]) HIP_CHECK(hipEventCreateWithFlags(&c->h2HeadDone[h], hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(c->h2HeadDone[h], sp));
+                c->h2HeadParts = h + 1;
+            }
             LaunchBinsCompact(H.bins[0], lists[h], counts[h], grid, sp);
             for (int stage = 0; stage < 2; stage++) {
                 if (!LMC_EXP(P.expFlags, 64)) LaunchH2Hess(H.rec, H.bins[stage], N, c->S.sceneParams, H.hout, c->h2HessGrid, sp);
+                if (stage == 0 && largeAfter == 2 && c->overlap) {
+                    if (!c->h2HeadDone[h]) HIP_CHECK(hipEventCreateWithFlags(&c->h2HeadDone[h], hipEventDisableTiming));
+                    HIP_CHECK(hipEventRecord(c->h2HeadDone[h], sp));
+                    c->h2HeadParts = h + 1;
+                }
                 LaunchH2Gauss(H.bins[stage], N, H.hout, param, P.expFlags, c->A.flags, stage, H.gauss, H.offset, H.px, c->h2GaussGrid, sp);
                 if (stage == 0) {
                     LaunchH2Sample(lists[h], counts[h], N, c->A.flags, H.kind, c->A.curContrib, H.gauss, param.sigma, H.offset, H.py, grid, sp);
@@ -1748,7 +1766,9 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
     const bool genericFirst = c->S.opt.h2mc != 0;
     const bool exchange = !c->allCachesReady && CachePending(c);
     c->appliedEarly = false;
+    c->h2HeadParts = 0;
     auto large = [&] {
+        for (int h = 0; h < c->h2HeadParts; h++) HIP_CHECK(hipStreamWaitEvent(sL, c->h2HeadDone[h], 0));
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[4], sL));
         LaunchLarge(c, film, P, cur, cnt, next, sL);
         if (c->timing) HIP_CHECK(hipEventRecord(ev.e[5], sL));
