@@ -3,6 +3,7 @@
 // steps run in separate, divergence-free launches.  Launch glue is in host/context.cpp.
 #include "dh2coop.h"
 #include "kernels.h"
+#include "upload.h"
 
 #include "ddirect.h"
 #include "dstep.h"
@@ -1035,4 +1036,19 @@ void LaunchBuildLists(const ChainArrays &A, const NextLists &next, int sortPlain
 }
 void LaunchInitLists(int n, int *large, int *counts, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lists, dim3(GridFor(n, 256)), dim3(256), 0, s, n, large, counts);
+}
+
+// upload.h: host -> device words through a kernel (one block per 64 KB of a segment, blockIdx.y = segment)
+__global__ void __launch_bounds__(256) k_upload_segments(UploadSegments U) {
+    const int seg = blockIdx.y, n = U.words[seg];
+    const unsigned *src = U.src[seg];
+    unsigned *dst = U.dst[seg];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) dst[k] = src[k];
+}
+void LaunchUploadSegments(const UploadSegments &U, hipStream_t s) {
+    if (U.count <= 0) return;
+    int most = 0;
+    for (int k = 0; k < U.count; k++) most = max(most, U.words[k]);
+    if (most <= 0) return;
+    hipLaunchKernelGGL(k_upload_segments, dim3(min((most + 255) / 256, 64), U.count), dim3(256), 0, s, U);
 }

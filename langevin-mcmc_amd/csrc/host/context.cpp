@@ -24,6 +24,7 @@
 #include "../../../include/lmc_abi.h"
 #include "../device/drng.h"
 #include "../device/kernels.h"
+#include "../device/upload.h"
 #include "../device/dh2coop.h"
 #include "../device/dh2mc.h"
 #include "accel.h"
@@ -487,7 +488,10 @@ static void UploadCacheStruct(lmc_ctx *c, hipStream_t after = nullptr) {
         // queueing.  The copy has run long before the pinned words are written again: that happens behind a later step's countsEvent, which the
         // device reaches after that step's launches, which wait for this stream (StepPhase1's fork).
         *c->cachePinned = c->cacheHost;
-        HIP_CHECK(hipMemcpyAsync(c->cacheDev.p, c->cachePinned, sizeof(DCache), hipMemcpyHostToDevice, after));
+        static_assert(sizeof(DCache) % 4 == 0, "the struct goes up word by word");
+        lmcd::UploadSegments U;  // as a kernel, not a DMA copy: upload.h
+        U.Add(c->cacheDev.p, c->cachePinned, sizeof(DCache));
+        LaunchUploadSegments(U, after);
         return;
     }
     HIP_CHECK(hipMemcpy(c->cacheDev.p, &c->cacheHost, sizeof(DCache), hipMemcpyHostToDevice));  // in place: the kernels keep the pointer
@@ -1580,6 +1584,8 @@ static void CacheApplyFinish(lmc_ctx *c) {
             if (f) std::rethrow_exception(f);
     }
     if (numReady) mark("kd-trees built");
+    lmcd::UploadSegments treesUp;
+    static_assert(sizeof(KdNode) % 4 == 0 && 2 * CACHE_SLOTS <= lmcd::UPLOAD_MAX_SEGMENTS, "the trees go up word by word, two segments per dim");
     for (int r = 0; r < numReady; r++) {
         const int d = readyDims[r];
         CacheDimHost &cd = c->cacheDims[d];
@@ -1592,8 +1598,8 @@ static void CacheApplyFinish(lmc_ctx *c) {
             if (vindBytes > (size_t)PSS_MAX_SIZE * sizeof(int)) throw std::runtime_error("kd-tree point order larger than the cache");
             memcpy(c->treePinned[sl], t.nodes.data(), nodeBytes);
             memcpy(c->treePinned[sl] + (size_t)KD_MAX_NODES * sizeof(KdNode), t.vind.data(), vindBytes);
-            HIP_CHECK(hipMemcpyAsync(cd.nodes.p, c->treePinned[sl], nodeBytes, hipMemcpyHostToDevice, cs));
-            HIP_CHECK(hipMemcpyAsync(cd.vind.p, c->treePinned[sl] + (size_t)KD_MAX_NODES * sizeof(KdNode), vindBytes, hipMemcpyHostToDevice, cs));
+            treesUp.Add(cd.nodes.p, c->treePinned[sl], nodeBytes);
+            treesUp.Add(cd.vind.p, c->treePinned[sl] + (size_t)KD_MAX_NODES * sizeof(KdNode), vindBytes);
         }
         DCacheDim &D = c->cacheHost.d[d];
         D.gridWords = c->useOccFilter ? cd.gridWords.p : nullptr, D.gridCellStart = cd.gridCellStart.p, D.gridIdx = cd.gridIdx.p, D.gridG = cd.gridG, D.gridM = cd.gridM;
@@ -1619,6 +1625,7 @@ static void CacheApplyFinish(lmc_ctx *c) {
         cd.ready = true;
         changed = true;
     }
+    LaunchUploadSegments(treesUp, cs);  // one launch for all of them, behind the grid builds on the same stream (upload.h)
     if (numReady) mark("trees on their way up");
     if (changed && beside) {  // the next step's launches (stream s and its forks) read the trees and the grids built on the cache stream
         if (!c->treesUpEvent) HIP_CHECK(hipEventCreateWithFlags(&c->treesUpEvent, hipEventDisableTiming));
