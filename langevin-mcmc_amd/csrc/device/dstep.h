@@ -43,22 +43,23 @@ LMC_D void StoreGauss(const ChainArrays &A, int i, int dim, int flags, const Gau
 // gradIn: the state's gradient where the step is run as a pipeline of launches (step_mala_phases.hip), else it is evaluated here.
 // Persistent Chain vectors (mutation.h:28-43) live in HBM: v1, v2, curr_new_v2, prop_new_v1, prop_new_v2, pss,
 // last_pss (g / curr_new_v1 / curr_new_g / prop_new_g / M are write-only or recomputed in the reference).
-// InitGaussianCore: the state given by its technique (camDepth, lgtDepth) and its primary-sample vector `pss` (GetPathPss) -- all the block reads of
-// the path, unless `samplecache` keeps a copy of it or the gradient is evaluated here (`path`, else null: the launches that stream the path, dwalk.h).
 template <bool WITH_GRAD>
-LMC_D void InitGaussianCore(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, int camDepth, int lgtDepth, const float *pss, const DPath *path,
-                            const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st, const float *gradIn = nullptr) {
+LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, const DPath &path,
+                           const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st, const float *gradIn = nullptr) {
     const size_t N = A.N;
-    const int dim = PathDimension(camDepth, lgtDepth);
+    const int dim = PathDimension(path.camDepth, path.lgtDepth);
+    float pss[MAXPSS];
+    for (int k = 0; k < MAXPSS; k++) pss[k] = 0.f;
+    GetPathPss(path, pss);
     for (int k = 0; k < dim; k++) A.chPss[(size_t)k * N + i] = pss[k];  // GetPathPss(path, chain->pss)
     A.pathWeight[i] = sp.lsScore;
-    if (A.chPath && path) {  // chain->path / chain->spContrib, mutation_mala.h:90-91,185-186 (`samplecache`)
-        StorePath(A.chPath, A.N, i, *path);
+    if (A.chPath) {  // chain->path / chain->spContrib, mutation_mala.h:90-91,185-186 (`samplecache`)
+        StorePath(A.chPath, A.N, i, path);
         StoreContrib(A.chContrib, A.N, i, sp);
     }
     const bool inRange = dim >= PSS_MIN_LENGTH && dim <= PSS_MAX_LENGTH;
     const bool ready = inRange && cache.d[dim].ready;
-    const bool haveDerv = P.useGradient && GradAvailable(camDepth, lgtDepth) && camDepth + lgtDepth - 1 <= P.maxDervDepth;
+    const bool haveDerv = P.useGradient && GradAvailable(path.camDepth, path.lgtDepth) && path.camDepth + path.lgtDepth - 1 <= P.maxDervDepth;
     const float ss = S.opt.malaStepsize, shk = S.opt.malaStdDev;
     float M[MAXPSS];
     if (inRange && !ready && haveDerv) {
@@ -69,7 +70,7 @@ LMC_D void InitGaussianCore(const DScene &S, const DCache &cache, const ChainArr
             // ready (NeedsGradient below), so this branch is unreachable there; NaN -> zeroed keeps it defined
             if (gradIn) {  // evaluated by the launch in front of this one (step_mala_phases.hip, gradcoop.hip)
                 for (int k = 0; k < dim; k++) vGrad[k] = gradIn[k];
-            } else if (WITH_GRAD && path && !LMC_EXP(P.expFlags, 4)) ComputeGradient(S, *path, sp, vGrad, gw);
+            } else if (WITH_GRAD && !LMC_EXP(P.expFlags, 4)) ComputeGradient(S, path, sp, vGrad, gw);
             else
                 for (int k = 0; k < dim; k++) vGrad[k] = NAN;
             st.gradCalls++;
@@ -138,14 +139,6 @@ LMC_D void InitGaussianCore(const DScene &S, const DCache &cache, const ChainArr
     } else {
         IsotropicGaussian(dim, shk, g);
     }
-}
-template <bool WITH_GRAD>
-LMC_D void InitGaussianFor(const DScene &S, const DCache &cache, const ChainArrays &A, const StepParams &P, int i, const DPath &path,
-                           const Contrib &sp, bool isProposal, int &flags, Gauss &g, GradWork &gw, StepStats &st, const float *gradIn = nullptr) {
-    float pss[MAXPSS];
-    for (int k = 0; k < MAXPSS; k++) pss[k] = 0.f;
-    GetPathPss(path, pss);
-    InitGaussianCore<WITH_GRAD>(S, cache, A, P, i, path.camDepth, path.lgtDepth, pss, &path, sp, isProposal, flags, g, gw, st, gradIn);
 }
 
 // mlt.cpp:96-97.  Drawn by the launch that precedes the step so that large and small steps can be

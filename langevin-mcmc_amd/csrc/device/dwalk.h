@@ -160,31 +160,6 @@ LMC_D bool PerturbPathStreamed(const DScene &S, const float *cur, float *prop, s
     return ok;
 }
 
-// ---- GetPathPss (path.cpp:2588-2632; dpath.h GetPathPss over a DPath) over an SoA path record: the same words in the same order
-LMC_D int GetPathPssStreamed(const float *buf, size_t N, int i, float *pss) {
-    auto F = [&](int w) { return LdS(&buf[(size_t)w * N + i]); };
-    const int camDepth = __float_as_int(F(PW_CAMDEPTH)), lgtDepth = __float_as_int(F(PW_LGTDEPTH));
-    const int camCount = __float_as_int(F(PW_CAMCOUNT)), lgtCount = __float_as_int(F(PW_LGTCOUNT));
-    int k = 0;
-    if (lgtDepth > 1) {
-        pss[k++] = F(PW_LGTPOS0), pss[k++] = F(PW_LGTPOS1), pss[k++] = F(PW_LGTDIR0), pss[k++] = F(PW_LGTDIR1);
-        for (int d = 0; d < lgtCount; d++) {
-            if (d == lgtCount - 1 && camDepth == 1) return k;
-            if (d == lgtCount - 1) break;
-            pss[k++] = F(VertWord(true, d, 3)), pss[k++] = F(VertWord(true, d, 4));  // rnd0, rnd1
-        }
-    }
-    pss[k++] = F(PW_SCREEN0), pss[k++] = F(PW_SCREEN1);
-    for (int d = 0; d < camCount; d++) {
-        if (d == camCount - 1) {
-            if (lgtDepth == 1) pss[k++] = F(VertWord(false, d, 10)), pss[k++] = F(VertWord(false, d, 11));  // dirRnd0, dirRnd1
-            return k;
-        }
-        pss[k++] = F(VertWord(false, d, 3)), pss[k++] = F(VertWord(false, d, 4));
-    }
-    return k;
-}
-
 // ---- Serialize(scene, path), path.cpp:2497-2586, over an SoA path record (same words, same order as dgrad.h SerializePath over a DPath)
 struct SoAPathView {
     const float *buf;

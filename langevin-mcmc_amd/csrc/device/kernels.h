@@ -78,11 +78,11 @@ void LaunchH2Sample(const int *list, const int *listCount, int N, const int *cha
                     float sigma, float *offsetSoA, float *py, int gridBlocks, hipStream_t s);
 // the gradient steps of the LMC cache-fill phase as a pipeline (device/dh2coop.h MalaPipe; step_mala_phases.hip, gradcoop.hip)
 void LaunchMalaBegin(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::StepParams &P, const lmcd::MalaPipe &M, const int *list,
-                     const int *listCount, int bvhStackNeed, int gridBlocks, hipStream_t s);
+                     const int *listCount, int gridBlocks, hipStream_t s);
 void LaunchMalaMid(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::StepParams &P, const lmcd::MalaPipe &M, const int *list,
                    const int *listCount, int bvhStackNeed, bool glossy, int gridBlocks, hipStream_t s);
 void LaunchMalaFinish(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const lmcd::MalaPipe &M,
-                      const int *list, const int *listCount, int bvhStackNeed, int gridBlocks, hipStream_t s);
+                      const int *list, const int *listCount, int gridBlocks, hipStream_t s);
 void LaunchMalaGrad(const float *rec, const lmcd::H2Bins &bins, int N, const float *scene38 /* host memory: passed by value */, float *gout, int gridBlocks, hipStream_t s);
 // n gradient + Hessian evaluations of the (c,l) path program (the throughput form of the H2MC plugin symbols)
 void LaunchHessBatch(int c, int l, int n, const float *primarySoA, const float *scene, const float *vertSoA, float *logLum, float *gradSoA, float *hessSoA,

@@ -15,7 +15,6 @@
 #define LMC_RNG_JUMP_LDS  // drng.h: the PCG jump constants of this launch live in LDS
 #endif
 #include "dpipe.h"
-#include "dwalk.h"
 
 using namespace lmcd;
 
@@ -28,10 +27,6 @@ __device__ __forceinline__ bool WantsGradient(const DCache &cache, const StepPar
 
 }  // namespace
 
-// STREAMED (all three phases): the state is read from / written to the chain's SoA path buffers word by word (dwalk.h) instead of being held as a
-// DPath in private memory between LoadPath and StorePath -- the form of every render whose tree fits the LDS traversal stack, without
-// `uselightcoordinatesampling` and `samplecache` (MalaStreamed below).  Same words, same arithmetic, same RNG order.
-template <bool STREAMED>
 __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount) {
     if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
@@ -59,16 +54,10 @@ __global__ void __launch_bounds__(64) k_mala_begin(DScene S, const DCache *cache
             }
             int bits = mala ? MS_MALA : 0;
             if (mala && !(flags & F_GAUSS) && WantsGradient(cache, P, c, l, curSs)) {
-                if constexpr (STREAMED) {
-                    const unsigned sig = H2SerializeStreamed(S, SoAPathView{CurPathBuf(A, flags), (size_t)N, i}, M.rec + (size_t)i * H2_REC_WORDS);
-                    t = H2BinIndex(H2TechIndex(c, l), sig);
-                } else {
-                    DPath path;
-                    LoadPath(CurPathBuf(A, flags), N, i, path);
-                    H2Serialize(S, path, M.rec + (size_t)i * H2_REC_WORDS);
-                    t = H2BinIndex(H2TechIndex(c, l), H2MaterialSignature(S, path));
-                }
-                want = true;
+                DPath path;
+                LoadPath(CurPathBuf(A, flags), N, i, path);
+                H2Serialize(S, path, M.rec + (size_t)i * H2_REC_WORDS);
+                want = true, t = H2BinIndex(H2TechIndex(c, l), H2MaterialSignature(S, path));
                 bits |= MS_GRAD_CUR;
             }
             M.step[i] = bits;
@@ -159,86 +148,6 @@ __global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid(DScene S, c
     BlockReduceStats(st, A.counters, A.weightSum, sStats);
 }
 
-// k_mala_mid, streamed: offsets and traversal stack in LDS ([word][lane], the lean kernel's layout), PerturbPathStreamed from the current buffer into
-// the other one, the proposal's record for stage 1 serialised from that buffer
-template <bool GLOSSY>
-__global__ void __launch_bounds__(64, LMC_MALA_MID_WAVES) k_mala_mid_streamed(DScene S, const DCache *cachePtr, ChainArrays A, StepParams P, MalaPipe M, const int *list, const int *listCount,
-                                                                            int stackWords) {
-    if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;
-    LMC_RNG_JUMP_INIT();
-    LMC_MAT_LDS_INIT(S);
-    extern __shared__ int ldsStack[];
-    const DCache &cache = *cachePtr;
-    StepStats st;
-    const int total = *listCount, N = A.N;
-    float *const ldsF = reinterpret_cast<float *>(ldsStack) + threadIdx.x;
-    for (int j0 = blockIdx.x * blockDim.x; j0 < total; j0 += gridDim.x * blockDim.x) {
-        const int j = j0 + threadIdx.x;
-        bool want = false;
-        int t = 0, i = 0;
-        if (j < total) {
-            i = list[j];
-            Rng rng = LoadChainRng(A, P.chainBegin, S.opt.seedOffset, i);
-            int flags = A.flags[i];
-            int bits = M.step[i];
-            const bool mala = bits & MS_MALA;
-            const Contrib cur = LoadContrib(A.curContrib, A.N, i);
-            const int c = cur.camDepth, l = cur.lightDepth;  // the technique of the current state = the depths in its path record
-            const int dim = PathDimension(c, l);
-            const float *curBuf = CurPathBuf(A, flags);
-            float *propBuf = PropPathBuf(A, flags);
-            float offset[MAXPSS];
-            for (int k = 0; k < dim; k++) offset[k] = M.offset[(size_t)k * N + i];
-            GradWork gw{nullptr, 0, 0};
-            if (mala) {
-                if (!(flags & F_BUFFERED)) {  // mutation_mala.h:59-81; the vectors are zero already (dchain.h ClearBuffered)
-                    flags |= F_BUFFERED;
-                    flags &= ~F_QUERIED;
-                }
-                flags |= F_VDIRTY;
-                Gauss cg;
-                if (!(flags & F_GAUSS)) {
-                    float pss[MAXPSS];
-                    for (int k = 0; k < MAXPSS; k++) pss[k] = 0.f;
-                    GetPathPssStreamed(curBuf, (size_t)N, i, pss);
-                    InitGaussianCore<false>(S, cache, A, P, i, c, l, pss, nullptr, cur, false, flags, cg, gw, st, (bits & MS_GRAD_CUR) ? M.gout + (size_t)i * MG_OUT_WORDS : nullptr);
-                    StoreGauss(A, i, dim, flags, cg);
-                    flags = (flags | F_GAUSS) & ~F_GAUSS_ISO;
-                } else {
-                    LoadGauss(S, A, i, dim, flags, cg);
-                }
-                for (int k = 0; k < dim; k++) offset[k] = cg.covL[k] * offset[k] + cg.mean[k];  // GenerateSample, gaussian.cpp:38-55
-                for (int k = 0; k < dim; k++) M.offset[(size_t)k * N + i] = offset[k];
-                M.py[i] = GaussianLogPdf(dim, offset, false, cg);
-            }
-            for (int k = 0; k < dim; k++) ldsF[(stackWords + k) * 64] = offset[k];
-            Contrib pc;
-            pc.camDepth = pc.lightDepth = 0;
-            pc.lsScore = pc.ssScore = 0.f;
-            pc.screenPos = V2{0.f, 0.f};
-            pc.contrib = V3{0.f, 0.f, 0.f};
-            LdsStackT<GLOSSY> stk{ldsStack + threadIdx.x, 64, 0};
-            const bool ok = PerturbPathStreamed(S, curBuf, propBuf, (size_t)N, i, c, l, LdsOffsets{ldsF, 64, stackWords}, rng, stk, pc);
-            if (ok) {
-                bits |= MS_OK;
-                StoreContrib(M.propContrib, N, i, pc);
-                if (mala && WantsGradient(cache, P, c, l, pc.ssScore)) {  // a small step keeps (c, l)
-                    const unsigned sig = H2SerializeStreamed(S, SoAPathView{propBuf, (size_t)N, i}, M.rec + (size_t)i * H2_REC_WORDS);
-                    want = true, t = H2BinIndex(H2TechIndex(c, l), sig);
-                    bits |= MS_GRAD_PROP;
-                }
-            }
-            A.flags[i] = flags;
-            M.step[i] = bits;
-            StoreChainRng(A, i, rng);
-        }
-        H2Enqueue(M.bins[1], N, want, t, j < total ? i : -1);
-    }
-    __shared__ int sStats[9];
-    BlockReduceStats(st, A.counters, A.weightSum, sStats);
-}
-
-template <bool STREAMED>
 __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cachePtr, ChainArrays A, Film film, StepParams P, MalaPipe M, const int *list, const int *listCount) {
     if ((int)(blockIdx.x * blockDim.x) >= *listCount) return;  // a block past the end of the work list: nothing to set up, nothing to do
     LMC_RNG_JUMP_INIT();
@@ -264,21 +173,11 @@ __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cach
         if (bits & MS_OK) {
             pc = LoadContrib(M.propContrib, A.N, i);
             if (mala) {
+                DPath prop;
+                LoadPath(PropPathBuf(A, flags), (int)N, i, prop);
+                const int dim = PathDimension(prop.camDepth, prop.lgtDepth);
                 GradWork gw{nullptr, 0, 0};
-                const float *gradIn = (bits & MS_GRAD_PROP) ? M.gout + (size_t)i * MG_OUT_WORDS : nullptr;
-                int dim;
-                if constexpr (STREAMED) {
-                    dim = PathDimension(pc.camDepth, pc.lightDepth);  // the proposal's record holds these depths (PerturbPathStreamed)
-                    float pss[MAXPSS];
-                    for (int k = 0; k < MAXPSS; k++) pss[k] = 0.f;
-                    GetPathPssStreamed(PropPathBuf(A, flags), N, i, pss);
-                    InitGaussianCore<false>(S, cache, A, P, i, pc.camDepth, pc.lightDepth, pss, nullptr, pc, true, flags, pg, gw, st, gradIn);
-                } else {
-                    DPath prop;
-                    LoadPath(PropPathBuf(A, flags), (int)N, i, prop);
-                    dim = PathDimension(prop.camDepth, prop.lgtDepth);
-                    InitGaussianFor<false>(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st, gradIn);
-                }
+                InitGaussianFor<false>(S, cache, A, P, i, prop, pc, true, flags, pg, gw, st, (bits & MS_GRAD_PROP) ? M.gout + (size_t)i * MG_OUT_WORDS : nullptr);
                 float offset[MAXPSS];
                 for (int k = 0; k < dim; k++) offset[k] = M.offset[(size_t)k * N + i];
                 const float py = M.py[i];
@@ -347,26 +246,13 @@ __global__ void __launch_bounds__(64) k_mala_finish(DScene S, const DCache *cach
     BlockReduceStats(st, A.counters, A.weightSum, sStats);
 }
 
-// the streamed forms (LMC_MALA_GENERIC=1: the DPath forms, for the A/B)
-static bool MalaStreamed(const DScene &S, const ChainArrays &A, int bvhStackNeed) {
-    static const bool generic = getenv("LMC_MALA_GENERIC") != nullptr;
-    return !generic && bvhStackNeed <= BVH_LDS_STACK && !S.opt.useLightCoord && !S.opt.sampleCache && !A.chPath;
-}
-void LaunchMalaBegin(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, const MalaPipe &M, const int *list, const int *listCount, int bvhStackNeed,
-                     int gridBlocks, hipStream_t s) {
-    if (MalaStreamed(S, A, bvhStackNeed)) hipLaunchKernelGGL(k_mala_begin<true>, dim3(gridBlocks), dim3(64), 0, s, S, cache, A, P, M, list, listCount);
-    else
-        hipLaunchKernelGGL(k_mala_begin<false>, dim3(gridBlocks), dim3(64), 0, s, S, cache, A, P, M, list, listCount);
+void LaunchMalaBegin(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, const MalaPipe &M, const int *list, const int *listCount, int gridBlocks,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_mala_begin, dim3(gridBlocks), dim3(64), 0, s, S, cache, A, P, M, list, listCount);
 }
 void LaunchMalaMid(const DScene &S, const DCache *cache, const ChainArrays &A, const StepParams &P, const MalaPipe &M, const int *list, const int *listCount, int bvhStackNeed,
                    bool glossy, int gridBlocks, hipStream_t s) {
-    if (MalaStreamed(S, A, bvhStackNeed)) {
-        const int stackWords = LeanStackWords(bvhStackNeed);
-        const size_t ldsBytes = (size_t)64 * LeanLdsWordsPerThread(stackWords) * sizeof(int);
-        if (glossy) hipLaunchKernelGGL(k_mala_mid_streamed<true>, dim3(gridBlocks), dim3(64), ldsBytes, s, S, cache, A, P, M, list, listCount, stackWords);
-        else
-            hipLaunchKernelGGL(k_mala_mid_streamed<false>, dim3(gridBlocks), dim3(64), ldsBytes, s, S, cache, A, P, M, list, listCount, stackWords);
-    } else if (bvhStackNeed <= BVH_LDS_STACK) {
+    if (bvhStackNeed <= BVH_LDS_STACK) {
         const size_t ldsBytes = (size_t)64 * ((bvhStackNeed + 7) / 8 * 8) * sizeof(int);
         if (glossy) hipLaunchKernelGGL((k_mala_mid<true, true>), dim3(gridBlocks), dim3(64), ldsBytes, s, S, cache, A, P, M, list, listCount);
         else
@@ -378,8 +264,6 @@ void LaunchMalaMid(const DScene &S, const DCache *cache, const ChainArrays &A, c
     }
 }
 void LaunchMalaFinish(const DScene &S, const DCache *cache, const ChainArrays &A, const Film &film, const StepParams &P, const MalaPipe &M, const int *list, const int *listCount,
-                      int bvhStackNeed, int gridBlocks, hipStream_t s) {
-    if (MalaStreamed(S, A, bvhStackNeed)) hipLaunchKernelGGL(k_mala_finish<true>, dim3(gridBlocks), dim3(64), 0, s, S, cache, A, film, P, M, list, listCount);
-    else
-        hipLaunchKernelGGL(k_mala_finish<false>, dim3(gridBlocks), dim3(64), 0, s, S, cache, A, film, P, M, list, listCount);
+                      int gridBlocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_mala_finish, dim3(gridBlocks), dim3(64), 0, s, S, cache, A, film, P, M, list, listCount);
 }

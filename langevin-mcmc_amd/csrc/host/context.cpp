@@ -1729,13 +1729,13 @@ void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, c
         static const int laneGridEnv = getenv("LMC_MALA_LANE_GRID") ? atoi(getenv("LMC_MALA_LANE_GRID")) : 0;
         const int N = (int)c->N, laneGrid = laneGridEnv > 0 ? std::min(laneGridEnv, c->stepGrid * 4) : c->stepGrid * 4;
         const MalaPipe &M = c->MP;  // the bin counts: zero-filled at set-up, zeroed again by k_mala_finish
-        LaunchMalaBegin(c->S, c->cacheDev.p, c->A, P, M, list, n, c->bvhDepth, laneGrid, sG);
+        LaunchMalaBegin(c->S, c->cacheDev.p, c->A, P, M, list, n, laneGrid, sG);
         LaunchBinsCompact(M.bins[0], list, n, laneGrid, sG);
         LaunchMalaGrad(M.rec, M.bins[0], N, c->S.sceneParams, M.gout, c->h2HessGrid, sG);
         LaunchMalaMid(c->S, c->cacheDev.p, c->A, P, M, list, n, c->bvhDepth, c->S.glossy != 0, laneGrid, sG);
         LaunchBinsCompact(M.bins[1], list, n, laneGrid, sG);
         LaunchMalaGrad(M.rec, M.bins[1], N, c->S.sceneParams, M.gout, c->h2HessGrid, sG);
-        LaunchMalaFinish(c->S, c->cacheDev.p, c->A, film, P, M, list, n, c->bvhDepth, laneGrid, sG);
+        LaunchMalaFinish(c->S, c->cacheDev.p, c->A, film, P, M, list, n, laneGrid, sG);
     } else if (c->needGeneric && c->leanGrad && !c->anyDeepCache && !c->S.opt.useLightCoord && !c->S.opt.sampleCache && c->bvhDepth <= BVH_LDS_STACK)
         LaunchStepSmallLeanGrad(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][1].p, cnt + 1, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->genericTokenOnly ? 64 : c->stepGrid * 4, 64, c->bvhDepth, sG);
     else if (c->needGeneric)
