@@ -829,11 +829,16 @@ void ExchangeStagePartC(lmc_ctx *c) {
     for (lmc_ctx *peer : c->group)
         if (peer != c) HIP_CHECK(hipStreamWaitEvent(c->stream, peer->copiedEvent, 0));
 }
+bool RcclEarlyExchange() {
+    static const bool on = !(getenv("LMC_RCCL_EARLY_EXCHANGE") && atoi(getenv("LMC_RCCL_EARLY_EXCHANGE")) == 0);
+    return on;
+}
 void ExchangeStagesAsync(const std::vector<lmc_ctx *> &g, size_t bytes) {
     if (bytes == 0) return;
     if (g.size() == 1) {
         lmc_ctx *c = g[0];
         if (c->world <= 1) return;
+        if (c->appliedEarly) return;  // exchanged and applied behind the pack on the large-step stream (StepPhase1)
         HIP_CHECK(hipSetDevice(c->device));
         RcclCheck(GetRccl().AllGather(c->pushStage.p, c->pushGather.p, bytes, ncclUint8, (ncclComm_t)c->comm, c->stream), "ncclAllGather(cache pushes)");
         return;
@@ -1782,6 +1787,17 @@ bool StepPhase1(lmc_ctx *c, lmc_ctx::StepEvents &ev) {
         if (exchange) {
             CachePack(c, sL);
             if (c->world == 1 && c->earlyApply) CacheApplyLaunch(c, sL), c->appliedEarly = true;
+            // An RCCL rank (one context per process) does the same with the collective in between: the all-gather of the ranks' stages is queued HERE, on the
+            // large-step stream behind the pack, and runs beside the hot launch -- on the step stream it sat behind every launch of the step, with the apply,
+            // the counts' way to the host and the next step's lists behind it (a collective's latency + 1.3 MB per rank, every step of the fill phase).
+            // Every rank reaches this point in every step of the fill phase (`exchange` is a function of the cache's state, which is the same on all of
+            // them), so the collectives of a communicator keep one order: one all-gather per step here, the film's all-reduce at the end on the step stream.
+            // LMC_RCCL_EARLY_EXCHANGE=0: behind the step's launches as before (A/B).  In-process groups keep their event-ordered copies (RunSteps).
+            else if (c->world > 1 && c->group.size() <= 1 && c->comm && c->earlyApply && RcclEarlyExchange() && c->stageLayout.totalFloats > 0) {
+                RcclCheck(GetRccl().AllGather(c->pushStage.p, c->pushGather.p, (size_t)c->stageLayout.totalFloats * sizeof(float), ncclUint8, (ncclComm_t)c->comm, sL),
+                          "ncclAllGather(cache pushes, large-step stream)");
+                CacheApplyLaunch(c, sL), c->appliedEarly = true;
+            }
         }
         // the chains this launch gave a new technique move to the slots of their technique (relocate.hip) -- on this stream, beside the small-step
         // launches, whose chains it does not touch, and behind the pack, which reads the pushes of these very chains (in chain order: A.slotOf)
