@@ -52,10 +52,6 @@ void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 // append themselves to the lists of the next step
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);
-// ... with re-filled lanes (device/dlarge.h): `cursor` = a zeroed word of the work list's counts, `perLane` chains per lane of the waves that take part, the tail of
-// the step run once `retireAt` lanes of a wave have a complete path; false: not available for this scene (tree too deep for the LDS stack), nothing was launched
-bool LaunchStepLargeRefill(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
-                           const int *list, const int *listCount, int *cursor, int retireAt, int perLane, bool glossy, int maxWaves, int bvhStackNeed, hipStream_t s);
 void LaunchStepLargeMux(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);  // step_large_mux.hip
 void LaunchStepLargeCache(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,

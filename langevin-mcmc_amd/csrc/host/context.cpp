@@ -113,8 +113,6 @@ struct lmc_ctx {
     int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
     bool largeLdsStack = true;  // LMC_LARGE_LDS=0: A/B switch for the LDS traversal stack of the large-step launch
     int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256); 128 disturbs the lean launch less (its bracket 2.4 instead of 2.7 ms) but the step and the start-up end 1-2 % later (profiles/r02_j_ab_block_sizes.jsonl)
-    bool largeRefill = true;    // LMC_LARGE_REFILL=0: the plain large-step launch (k_step<large>: one list entry per lane, no re-fill) -- A/B
-    int largeRetireAt = 16, largePerLane = 3;  // LMC_LARGE_RETIRE_AT / LMC_LARGE_PER_LANE (dlarge.h)
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
     bool sortH2mc = true;
@@ -551,9 +549,6 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
     if (const char *e = getenv("LMC_LARGE_LDS")) c->largeLdsStack = atoi(e) != 0;
-    if (const char *e = getenv("LMC_LARGE_REFILL")) c->largeRefill = atoi(e) != 0;
-    if (const char *e = getenv("LMC_LARGE_RETIRE_AT")) c->largeRetireAt = std::min(64, std::max(1, atoi(e)));
-    if (const char *e = getenv("LMC_LARGE_PER_LANE")) c->largePerLane = std::max(1, atoi(e));
     if (const char *e = getenv("LMC_LARGE_BLOCK")) c->largeBlock = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
@@ -1669,10 +1664,6 @@ StepParams MakeStepParams(const lmc_ctx *c) {
 // which large-step / generic small-step kernel the options in force select (cnt: the three list lengths on the device)
 void LaunchLarge(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sL) {
     const bool mux = c->scene->options.largeStepMultiplexed;
-    // the default large step with re-filled lanes (device/dlarge.h); the work list's fourth count word is its cursor (zeroed with the counts, StepPhase1)
-    if (c->largeRefill && !c->S.opt.sampleCache && !mux && c->largeLdsStack &&
-        LaunchStepLargeRefill(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, const_cast<int *>(cnt) + 3, c->largeRetireAt, c->largePerLane, c->S.glossy != 0, c->stepGrid * 4, c->bvhDepth, sL))
-        return;
     (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
 }
 void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sG) {
