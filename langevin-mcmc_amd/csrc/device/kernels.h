@@ -52,16 +52,6 @@ void LaunchFirstKind(const lmcd::DScene &S, const lmcd::DCache *cache, const lmc
 // append themselves to the lists of the next step
 void LaunchStepLarge(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);
-// ... as a wavefront of launches (device/step_large_wf.hip): the list cut into `parts` ranges, each a chain of launches (cut at the camera depths `cuts`, where the chains still
-// alive are compacted into a new list) on a stream of its own; this queues ONE part's chain on `s`.  state: LargeWavefrontStateWords() x N floats, lgt: (light states a path can have) x
-// LargeWavefrontLightWords() x N floats, alive0 / alive1: parts x aliveStride ints each (aliveStride >= the largest part), counts: LargeWavefrontCountWords(parts) ints,
-// zeroed by the caller in front of the parts.  false: not available for this scene (tree too deep for the LDS stack), nothing was launched
-size_t LargeWavefrontStateWords();
-size_t LargeWavefrontLightWords();
-int LargeWavefrontCountWords(int parts);
-bool LaunchStepLargeWavefrontPart(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P, const int *list,
-                                  const int *listCount, float *state, float *lgt, int *alive0, int *alive1, int aliveStride, int *counts, bool glossy, int gridBlocks, int bvhStackNeed,
-                                  int part, int parts, const int *cuts, int numCuts, hipStream_t s);
 void LaunchStepLargeMux(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,
                      const int *list, const int *listCount, const lmcd::NextLists &next, float *gradBuf, int gradStride, bool glossy, int gridBlocks, int bvhStackNeed, int blockThreads, hipStream_t s);  // step_large_mux.hip
 void LaunchStepLargeCache(const lmcd::DScene &S, const lmcd::DCache *cache, const lmcd::ChainArrays &A, const lmcd::Film &film, const lmcd::StepParams &P,

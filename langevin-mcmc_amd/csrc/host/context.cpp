@@ -113,14 +113,6 @@ struct lmc_ctx {
     int gridDims = 4;          // LMC_GRID_DIMS: rank of its grid (3 or 4)
     bool largeLdsStack = true;  // LMC_LARGE_LDS=0: A/B switch for the LDS traversal stack of the large-step launch
     int largeBlock = 64;        // LMC_LARGE_BLOCK: its block size (64, 128 or 256); 128 disturbs the lean launch less (its bracket 2.4 instead of 2.7 ms) but the step and the start-up end 1-2 % later (profiles/r02_j_ab_block_sizes.jsonl)
-    bool largeWavefront = true;  // LMC_LARGE_WAVEFRONT=0: the large steps as ONE launch (k_step<large>: a lane walks a whole path) -- A/B
-    DevBuf<float> wfState, wfLgt;  // the wavefront's walk states and light states (step_large_wf.hip), allocated at the first large-step launch
-    DevBuf<int> wfAlive[2], wfCounts;
-    static constexpr int WF_MAX_PARTS = 8;
-    int wfParts = 1;  // LMC_LARGE_WF_PARTS: ranges of the large-step list, each a chain of launches on its own stream
-    int wfCuts[16] = {1}, wfNumCuts = 1;  // LMC_LARGE_WF_CUTS="1,3": the camera depths at which the live chains are compacted into a new list
-    hipStream_t wfStream[WF_MAX_PARTS - 1] = {};
-    hipEvent_t wfFork = nullptr, wfJoin[WF_MAX_PARTS - 1] = {};
     bool leanGrad = true;      // LMC_LEAN_GRAD=0: the cache-filling launch falls back to k_step<false,true,true,true>
     bool anyDeepCache = false;  // (always false since the LDS search is gone: see DCacheDim::deep)
     bool sortH2mc = true;
@@ -302,11 +294,6 @@ struct lmc_ctx {
         if (countsEvent) (void)hipEventDestroy(countsEvent);
         for (auto st : partStream)
             if (st) (void)hipStreamDestroy(st);
-        for (auto st : wfStream)
-            if (st) (void)hipStreamDestroy(st);
-        if (wfFork) (void)hipEventDestroy(wfFork);
-        for (auto e : wfJoin)
-            if (e) (void)hipEventDestroy(e);
         for (auto e : {partFork, partJoin[0], partJoin[1], partJoin[2], forkEvent, joinEvent[0], joinEvent[1], packedEvent, copiedEvent, filmReadyEvent, sliceReducedEvent, weightsCopiedEvent})
             if (e) (void)hipEventDestroy(e);
         for (auto st : sideStream)
@@ -550,13 +537,10 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
             HIP_CHECK(hipStreamCreateWithPriority(&c->sideStream[k], hipStreamNonBlocking, m > 0 ? hi : m < 0 ? lo : 0));
         }
         for (auto &ps : c->partStream) HIP_CHECK(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
-        for (auto &ws : c->wfStream) HIP_CHECK(hipStreamCreateWithPriority(&ws, hipStreamNonBlocking, modeL > 0 ? hi : modeL < 0 ? lo : 0));  // the large-step wavefront's other parts
         HIP_CHECK(hipStreamCreateWithPriority(&c->cacheStream, hipStreamNonBlocking, mode > 0 ? hi : mode < 0 ? lo : 0));
         HIP_CHECK(hipHostMalloc((void **)&c->cachePinned, sizeof(DCache), hipHostMallocDefault));
     }
     HIP_CHECK(hipEventCreateWithFlags(&c->partFork, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&c->wfFork, hipEventDisableTiming));
-    for (auto &e : c->wfJoin) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->partJoin) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     for (auto &e : c->joinEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -565,18 +549,6 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
     if (const char *e = getenv("LMC_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("LMC_OCC_FILTER")) c->useOccFilter = atoi(e) != 0;
     if (const char *e = getenv("LMC_LARGE_LDS")) c->largeLdsStack = atoi(e) != 0;
-    if (const char *e = getenv("LMC_LARGE_WAVEFRONT")) c->largeWavefront = atoi(e) != 0;
-    if (const char *e = getenv("LMC_LARGE_WF_CUTS")) {
-        c->wfNumCuts = 0;
-        for (const char *q = e; *q && c->wfNumCuts < 16;) {
-            char *end = nullptr;
-            const long v = strtol(q, &end, 10);
-            if (end == q) break;
-            if (v > 0) c->wfCuts[c->wfNumCuts++] = (int)v;
-            q = *end ? end + 1 : end;
-        }
-    }
-    if (const char *e = getenv("LMC_LARGE_WF_PARTS")) c->wfParts = std::min((int)lmc_ctx::WF_MAX_PARTS, std::max(1, atoi(e)));
     if (const char *e = getenv("LMC_LARGE_BLOCK")) c->largeBlock = atoi(e) == 64 ? 64 : atoi(e) == 128 ? 128 : 256;
     if (const char *e = getenv("LMC_PROF")) c->profileLean = atoi(e) != 0;
     if (const char *e = getenv("LMC_LEAN_GRAD")) c->leanGrad = atoi(e) != 0;
@@ -1692,28 +1664,6 @@ StepParams MakeStepParams(const lmc_ctx *c) {
 // which large-step / generic small-step kernel the options in force select (cnt: the three list lengths on the device)
 void LaunchLarge(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sL) {
     const bool mux = c->scene->options.largeStepMultiplexed;
-    // the default large step as a wavefront of launches (device/step_large_wf.hip): the list's parts on streams of their own, forked from and joined into sL
-    if (c->largeWavefront && !c->S.opt.sampleCache && !mux && c->largeLdsStack && c->bvhDepth <= lmcd::BVH_LDS_STACK) {
-        const int parts = c->overlap ? c->wfParts : 1;
-        const size_t N = c->N;
-        const int aliveStride = (int)((N + parts - 1) / parts) + 64;
-        if (c->wfState.n != LargeWavefrontStateWords() * N || c->wfAlive[0].n != (size_t)aliveStride * parts) {  // (first use after an init: WarmStepLaunches, on the initialising thread)
-            const size_t lgtStates = c->S.opt.maxDepth == -1 ? lmcd::MAXD : (size_t)std::max(1, std::min(c->S.opt.maxDepth - 1, lmcd::MAXD));
-            c->wfState.Alloc(LargeWavefrontStateWords() * N, false), c->wfLgt.Alloc(lgtStates * LargeWavefrontLightWords() * N, false);
-            c->wfAlive[0].Alloc((size_t)aliveStride * parts, false), c->wfAlive[1].Alloc((size_t)aliveStride * parts, false), c->wfCounts.Alloc(LargeWavefrontCountWords(lmc_ctx::WF_MAX_PARTS));
-        }
-        HIP_CHECK(hipMemsetAsync(c->wfCounts.p, 0, LargeWavefrontCountWords(parts) * sizeof(int), sL));
-        if (parts > 1) HIP_CHECK(hipEventRecord(c->wfFork, sL));
-        for (int p = 0; p < parts; p++) {
-            hipStream_t sp = p == 0 ? sL : c->wfStream[p - 1];
-            if (p > 0) HIP_CHECK(hipStreamWaitEvent(sp, c->wfFork, 0));
-            LaunchStepLargeWavefrontPart(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, c->wfState.p, c->wfLgt.p, c->wfAlive[0].p, c->wfAlive[1].p, aliveStride, c->wfCounts.p,
-                                         c->S.glossy != 0, c->stepGrid * 4, c->bvhDepth, p, parts, c->wfCuts, c->wfNumCuts, sp);
-            if (p > 0) HIP_CHECK(hipEventRecord(c->wfJoin[p - 1], sp));
-        }
-        for (int p = 1; p < parts; p++) HIP_CHECK(hipStreamWaitEvent(sL, c->wfJoin[p - 1], 0));
-        return;
-    }
     (c->S.opt.sampleCache ? LaunchStepLargeCache : mux ? LaunchStepLargeMux : LaunchStepLarge)(c->S, c->cacheDev.p, c->A, film, P, c->lists[cur][0].p, cnt + 0, next, c->gradBuf.p, c->gradStride, c->S.glossy != 0, c->stepGrid, c->largeLdsStack ? c->bvhDepth : 1 << 30, c->largeBlock, sL);
 }
 void LaunchGeneric(lmc_ctx *c, const Film &film, const StepParams &P, int cur, const int *cnt, const NextLists &next, hipStream_t sG) {
