@@ -154,13 +154,14 @@ def test_dpt_amd_shards_the_chains_over_a_device_list(tmp_path):
     assert r.returncode == 2 and "visible" in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_rank_processes_through_the_rccl_code_path_equal_one_rank(tmp_path, world):
+@pytest.mark.parametrize("world,early", [(2, "1"), (3, "1"), (2, "0")])
+def test_rank_processes_through_the_rccl_code_path_equal_one_rank(tmp_path, world, early):
     """VERDICT r5 missing #1 / weak: `lmc_comm_init -> ncclAllGather / ncclAllReduce` had only ever run with ONE rank.  Real RCCL refuses two ranks on one device,
     so here `world` rank PROCESSES on the one GPU bind tests/helpers/rccl_stub.cpp through LMC_RCCL_LIB (the six entry points over host shared memory) and run the
     library's rank code path exactly as bench.py's spawned ranks do: communicator from the 128-byte id, COLLECTIVE lmc_chains_init (sharded MLTInit: three
     all-gathers), 40 steps through the cache-fill phase (one all-gather of the cache pushes per step), lmc_film_allreduce, the driver's scalar all-reduce and
-    barrier.  Against ONE rank holding all the chains -- EXACT: normalization, every init state, the cache-ready mask, every counter, every final state; the
+    barrier.  `early`: LMC_RCCL_EARLY_EXCHANGE -- the per-step all-gather + apply queued on the large-step stream behind the pack (1, the default) or behind the
+    step's launches on the step stream (0).  Against ONE rank holding all the chains -- EXACT: normalization, every init state, the cache-ready mask, every counter, every final state; the
     all-reduced film on every rank = the sum of the ranks' own films = the one-rank film up to the order of the float atomics."""
     import json
     import sys
@@ -174,7 +175,7 @@ def test_rank_processes_through_the_rccl_code_path_equal_one_rank(tmp_path, worl
     one.step(steps)
     st1, fin1, film1 = one.stats(), one.summary(0), one.film()
     one.close()
-    env = dict(os.environ, LMC_RCCL_LIB=stub)
+    env = dict(os.environ, LMC_RCCL_LIB=stub, LMC_RCCL_EARLY_EXCHANGE=early)
     worker = os.path.join(gc.ROOT, "tests", "helpers", "rank_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), str(n), str(steps), str(ninit), str(streams)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
