@@ -376,7 +376,7 @@ LMC_D int VisitInner(const DScene &S, int cur, V3 org, V3 invd, float tnear, flo
 // one loop a wave executed both bodies on almost every iteration (profiles/r01_d: 5270 vector-memory instructions per
 // wave-step for ~800 per lane).  A leaf's triangles (up to four) are fetched in one round and tested in leaf order.
 template <class Stk>
-LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stk &stk, int hint = -1) {
+LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar, float &tHit, Stk &stk, int hint = -1, bool hintOnly = false) {  // hintOnly: measurement switch LMC_EXP_NOTRAV (dstep_params.h)
     if (S.numNodes == 0) return -1;
     V3 invd{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
     stk.Reset();
@@ -394,6 +394,10 @@ LMC_D int BvhIntersect(const DScene &S, V3 org, V3 dir, float tnear, float tfar,
         if (TriTest(p0, e1, e2, org, dir, tnear, tfar, t)) best = hint, bestT = t;
     }
 #endif
+    if (hintOnly) {
+        tHit = bestT;
+        return best;
+    }
     int cur = 0;  // root is an inner node
 #if defined(LMC_TRAV_SPEC) && defined(__HIP_DEVICE_COMPILE__)
     // A/B build ("speculative" while-while): the wave leaves the inner-node loop as soon as fewer than LMC_TRAV_SPEC of its lanes

@@ -28,9 +28,9 @@ struct SurfHit {
 
 // path.cpp:91-103 = scene.cpp:106-126 (BVH) + TriangleMesh::Intersect (recompute from primID)
 template <class Stk>
-LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float tfar, SurfHit &hit, Isect &isect, Stk &stk, int hint = -1) {
+LMC_D bool IntersectSurface(const DScene &S, V3 org, V3 dir, float tnear, float tfar, SurfHit &hit, Isect &isect, Stk &stk, int hint = -1, bool hintOnly = false) {
     float tB;
-    int id = BvhIntersect(S, org, dir, tnear, tfar, tB, stk, hint);
+    int id = BvhIntersect(S, org, dir, tnear, tfar, tB, stk, hint, hintOnly);
     if (id < 0) return false;
     TriData T = S.tris[id];  // the whole record at once: by value, and pinned (dscene.h LMC_PIN) -- hipcc fetched the normals and the st / material words
                              // where they are first used, two more dependent round trips per hit

@@ -231,19 +231,37 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
 #pragma unroll
         for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
         bool any = false;
-        for (int j = s0; j < s1; j++) {
-            const float2 *row = reinterpret_cast<const float2 *>(C.pts + (size_t)C.gridIdx[j] * dim);
-            float d = 0.f;  // same arithmetic, same order as the leaf scan of the search
+#ifndef LMC_QUERY_BATCH
+#define LMC_QUERY_BATCH 4
+#endif
+        // LMC_QUERY_BATCH candidates per round: their row indices in flight together, then their rows together (indices clamped, the surplus slots repeat the
+        // last candidate).  A third to a half of the queries land in a non-empty cell, cells near the states' clusters list tens of candidates, and one candidate
+        // at a time was two dependent fetches each -- the wave runs the loop of its longest lane: 11 % of the lean kernel (profiles/r06_bj_*: LMC_EXP_QUERY_STOP=2)
+        for (int j = s0; j < s1; j += LMC_QUERY_BATCH) {
+            int id[LMC_QUERY_BATCH];
 #pragma unroll
-            for (int k = 0; k < MD / 2; ++k)
-                if (2 * k < dim) {
-                    const float2 p = row[k];
-                    const float diff0 = q[2 * k] - p.x;
-                    d += diff0 * diff0;
-                    const float diff1 = q[2 * k + 1] - p.y;
-                    d += diff1 * diff1;
-                }
-            any = any || d < radiusSq;
+            for (int b = 0; b < LMC_QUERY_BATCH; b++) id[b] = C.gridIdx[min(j + b, s1 - 1)];
+            float2 pr[LMC_QUERY_BATCH][MD / 2];
+#pragma unroll
+            for (int b = 0; b < LMC_QUERY_BATCH; b++) {
+                const float2 *row = reinterpret_cast<const float2 *>(C.pts + (size_t)id[b] * dim);
+#pragma unroll
+                for (int k = 0; k < MD / 2; ++k) pr[b][k] = row[min(k, dim / 2 - 1)];
+            }
+#pragma unroll
+            for (int b = 0; b < LMC_QUERY_BATCH; b++) {
+                float d = 0.f;  // same arithmetic, same order as the leaf scan of the search
+#pragma unroll
+                for (int k = 0; k < MD / 2; ++k)
+                    if (2 * k < dim) {
+                        const float2 p = pr[b][k];
+                        const float diff0 = q[2 * k] - p.x;
+                        d += diff0 * diff0;
+                        const float diff1 = q[2 * k + 1] - p.y;
+                        d += diff1 * diff1;
+                    }
+                any = any || d < radiusSq;
+            }
         }
         if (!any) return;
     }
@@ -571,7 +589,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 #ifndef LMC_PROF_FINE
             prof.Mark(PR_VERTEX_LOAD);
 #endif
-            const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk, sv.tri);  // sv.tri: the current state's triangle, tried first (dscene.h)
+            const bool hitSurface = IntersectSurface(S, org, dir, tnear, tfar, hit, isect, stk, sv.tri, LMC_EXP(P.expFlags, 1024));  // sv.tri: the current state's triangle, tried first (dscene.h)
 #if LMC_MAT_CARRY
             // the vertex's material by the index the hit record carried (dshade.h SurfHit::material), not through S.tris[tri].material again.  (Requesting the
             // record HERE, so that it travels while ConvertMIS and the draws run, was measured too: -1.4 % -- eight more registers live across that code,
@@ -588,11 +606,11 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 ConvertMIS(S, depth, lgtLight, org, dir, lps);
                 if (depth == lgtCount - 1 && c == 1) {
                     ok = ConnectToCamera(S, depth, lps, sv, pc, stk, occ);
-                    StoreVertex(prop, N, i, true, depth, sv);
+                    if (!LMC_EXP(P.expFlags, 2048)) StoreVertex(prop, N, i, true, depth, sv);
                     break;
                 }
                 if (depth == lgtCount - 1) {
-                    StoreVertex(prop, N, i, true, depth, sv);
+                    if (!LMC_EXP(P.expFlags, 2048)) StoreVertex(prop, N, i, true, depth, sv);
                     lastLgt = sv;
                     BeginCamera();
                     depth = 0;
@@ -607,7 +625,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 #else
                 if (!BSDFSampling<true, true, Stk::kGlossy>(S, lps, sv, lps, dir, bsdfContrib)) break;
 #endif
-                StoreVertex(prop, N, i, true, depth, sv);
+                if (!LMC_EXP(P.expFlags, 2048)) StoreVertex(prop, N, i, true, depth, sv);
                 lps.throughput = lps.throughput * sv.rrWeight;
                 org = lps.isect.position;
                 depth++;
@@ -623,7 +641,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 #endif
                 const int light = HitLightOf(S, hitSurface, hit);
                 if (light >= 0) ok = HandleHitLight(S, depth, light, hitSurface, dir, screenPos, cps, envPrim, pc);
-                StoreVertex(prop, N, i, false, depth, sv);
+                if (!LMC_EXP(P.expFlags, 2048)) StoreVertex(prop, N, i, false, depth, sv);
 #ifdef LMC_PROF_FINE
                 prof.Mark(PR_ISO);
 #endif
@@ -648,7 +666,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
                 } else {
                     ok = ConnectVertex(S, depth, lgtCount - 1, lps, lastLgt, cps, sv, screenPos, pc, stk, occ);
                 }
-                StoreVertex(prop, N, i, false, depth, sv);
+                if (!LMC_EXP(P.expFlags, 2048)) StoreVertex(prop, N, i, false, depth, sv);
 #ifdef LMC_PROF_FINE
                 prof.Mark(PR_VERTEX_LOAD);
 #endif
@@ -663,7 +681,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
 #else
             if (!BSDFSampling<false, true, Stk::kGlossy>(S, cps, sv, cps, dir, bsdfContrib)) break;
 #endif
-            StoreVertex(prop, N, i, false, depth, sv);
+            if (!LMC_EXP(P.expFlags, 2048)) StoreVertex(prop, N, i, false, depth, sv);
             cps.throughput = cps.throughput * sv.rrWeight;
             org = cps.isect.position;
             tnear = c_IsectEpsilon;
@@ -674,7 +692,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
     }
     prof.Mark(PR_LOOP_EXIT);  // the last segment's vertex work: connection strategy / emitter hit
     // the one shadow ray of the step (scene.cpp:128-149), cast after its strategy has been evaluated
-    if (ok && occ.pending) ok = !Occluded(S, occ.org, occ.dir, occ.dist, stk);
+    if (ok && occ.pending && !LMC_EXP(P.expFlags, 1024)) ok = !Occluded(S, occ.org, occ.dir, occ.dist, stk);
     prof.Mark(PR_SHADOW);
 
     // ---- proposal Gaussian + acceptance probability (mutation_mala.h:174-267)
