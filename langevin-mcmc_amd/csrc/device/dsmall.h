@@ -109,11 +109,11 @@ struct PssSink {
 // The query point is read from the caller's LDS words here, not handed over as a private array: an array whose address escapes into a call lives in
 // scratch memory, and the caller -- the hot path, in which 99.98 % of the queries end at the existence test -- paid twelve scratch stores (and the
 // reloads of the spilled LDS addresses they were filled from) per query for it (hipcc -S of the round-4 kernel).
-__device__ __noinline__ int KdRadiusSearchRare(const DCacheDim &C, int dim, const float *ldsQ, int ldsStride, float radiusSq, int *idx, float *dist) {
+__device__ __noinline__ int KdRadiusSearchRare(const DCacheDim &C, int dim, const float *ldsQ, int ldsStride, float radiusSq, int knn, int *idx, float *dist) {
     float q[MD];
 #pragma unroll
     for (int k = 0; k < MD; k++) q[k] = k < dim ? ldsQ[k * ldsStride] : 0.f;
-    return KdRadiusSearch(C, dim, q, radiusSq, 5, idx, dist);
+    return KdRadiusSearch(C, dim, q, radiusSq, knn, idx, dist);
 }
 
 // Where the moment vectors (v1, v2) behind a state's Gaussian come from (mutation_mala.h:131-164 and :224-257, cache /
@@ -219,6 +219,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
     if (LMC_EXP(P.expFlags, 256)) return;  // LMC_EXP_QUERY_STOP=1 (measurement): the query ends before its cell is computed
     const DCacheDim &C = cache.d[dim];
     const float radiusSq = dim * (PSS_QUERY_DIST * PSS_QUERY_DIST);
+    int knnStop = 5;
     if (C.gridWords) {  // exact existence test (dchain.h): no candidate within the radius => query() finds nothing
         int cell = 0;
         for (int k = 0; k < C.gridM; k++) cell = cell * C.gridG + CacheGridCell(L.Q(C.gridCoord[k]), C.gridG);
@@ -231,6 +232,8 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
 #pragma unroll
         for (int k = 0; k < MD; k++) q[k] = k < dim ? L.Q(k) : 0.f;
         bool any = false;
+        int nMatch = 0, oneIdx = 0;  // the candidates within the radius: how many, and (if one) which
+        float oneD = 0.f;
 #ifndef LMC_QUERY_BATCH
 #define LMC_QUERY_BATCH 4
 #endif
@@ -261,13 +264,33 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
                         d += diff1 * diff1;
                     }
                 any = any || d < radiusSq;
+                if (j + b < s1 && d < radiusSq) nMatch++, oneIdx = id[b], oneD = d;
             }
         }
         if (!any) return;
+#ifndef LMC_QUERY_ALWAYS_SEARCH
+        // The cell's candidates are a superset of the rows within the radius and each was measured with the search's own arithmetic: if exactly ONE lies within it,
+        // the search (unsorted, traversal order, dchain.h KdRadiusSearch) can only return that row with that distance -- and need not run.  It is a serial walk of
+        // one lane through a tree whose planes prune little in 6-12 dimensions: ~0.1 ms, and although only ~20 queries of a launch get this far, one of their waves
+        // is nearly always among the launch's last, so the search was the TAIL of the lean launch: 9 % of it, 7 % of the step (profiles/r06_bo_*, r06_bq_*;
+        // LMC_QUERY_ALWAYS_SEARCH: A/B build).  Two or more rows within the radius: their order is the tree's, the search runs.
+        if (nMatch == 1) {
+            st.cacheHits++;
+            vs.mode = VS_BLEND;
+            vs.nMatches = 1;
+            vs.idx[0] = oneIdx;
+            vs.w[0] = inverse(oneD * oneD + 1e-6f);
+            vs.sum_w += vs.w[0];
+            return;
+        }
+        knnStop = min(nMatch, 5);
+#endif
     }
     float dist[5];
     int idx[5];  // not vs.idx: an array handed to the search by address lives in private memory, and with it would the whole of vs
-    const int n = KdRadiusSearchRare(C, dim, &L.Q(0), L.stride, radiusSq, idx, dist);
+    // (the search stops at its knn-th match, nanoflann.hpp:256-262 as modified by the reference: 5 -- or, when the existence test has COUNTED the rows within the radius,
+    // that count: the matches lie in the leaves the walk reaches first, everything behind its last match is backtracking that finds nothing)
+    const int n = KdRadiusSearchRare(C, dim, &L.Q(0), L.stride, radiusSq, knnStop, idx, dist);
     if (n > 0) {  // global_cache.h:106-123
         st.cacheHits++;
         vs.mode = VS_BLEND;
@@ -449,6 +472,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             }
             const GradState gs{cur, c, l, curSs, false, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, curLs, flags, L, vs, st, gs, LMC_EXP(P.expFlags, 2));
+            if (LMC_EXP(P.expFlags, 4096) && (vs.mode == VS_REUSE || vs.mode == VS_BLEND)) vs.mode = VS_ISOTROPIC;  // LMC_EXP_NOREUSE (measurement): a found neighbour is not used
             if (vs.mode == VS_BLEND) flags = (flags | F_QUERIED) & ~F_VSYNC;  // the blend rewrote chain->v1 / v2
             if (vs.wrotePss || vs.mode == VS_BLEND || vs.mode == VS_GRAD) flags |= F_VDIRTY;
             flags |= F_GAUSS;
@@ -704,6 +728,7 @@ LMC_D void SmallStepLean(const DScene &S, const DCache &cache, const ChainArrays
             VSource vs;
             const GradState gs{prop, c, l, pc.ssScore, true, workBuf, workStride, workSlot};
             PrepareGaussianLean<WITH_GRAD>(S, cache, A, P, i, dim, pc.lsScore, flags, L, vs, st, gs, LMC_EXP(P.expFlags, 2));
+            if (LMC_EXP(P.expFlags, 4096) && (vs.mode == VS_REUSE || vs.mode == VS_BLEND)) vs.mode = VS_ISOTROPIC;
 #ifdef LMC_PROF_FINE
             prof.Mark(PR_RESET);
 #endif
