@@ -274,7 +274,7 @@ LMC_D void PrepareGaussianLean(const DScene &S, const DCache &cache, const Chain
         // one lane through a tree whose planes prune little in 6-12 dimensions: ~0.1 ms, and although only ~20 queries of a launch get this far, one of their waves
         // is nearly always among the launch's last, so the search was the TAIL of the lean launch: 9 % of it, 7 % of the step (profiles/r06_bo_*, r06_bq_*;
         // LMC_QUERY_ALWAYS_SEARCH: A/B build).  Two or more rows within the radius: their order is the tree's, the search runs.
-        if (nMatch == 1 || LMC_EXP(P.expFlags, 8192)) {  // (LMC_EXP_NOSEARCH, measurement: the last counted row stands in for the search's answer whatever the count)
+        if (nMatch == 1) {
             st.cacheHits++;
             vs.mode = VS_BLEND;
             vs.nMatches = 1;

@@ -14,7 +14,7 @@ struct StepParams {
     // such a variable is set): 1 = no film splats in the lean kernel (LMC_EXP_NOSPLAT), 2 = no cache queries (LMC_EXP_NOQUERY), 256 / 512 = the
     // query cut short before its cell / after its occupancy word (LMC_EXP_QUERY_STOP=1|2), 4 = no gradient program (LMC_EXP_NOGRAD), 8 = no
     // statistics reduction (LMC_EXP_NOSTATS), 16 / 32 / 64 = H2MC without the Hessian program / the eigen-solve / the Hessian launch, 1024 = the lean kernel's rays
-    // test the state's own triangle only: no tree walk, no shadow ray (LMC_EXP_NOTRAV), 2048 = ... does not store the proposal's vertices (LMC_EXP_NOSTORE), 4096 = a neighbour the cache query found (or a re-used one) is not used: isotropic (LMC_EXP_NOREUSE), 8192 = the exact search never runs: with several rows within the radius the last counted one stands in (LMC_EXP_NOSEARCH)
+    // test the state's own triangle only: no tree walk, no shadow ray (LMC_EXP_NOTRAV), 2048 = ... does not store the proposal's vertices (LMC_EXP_NOSTORE), 4096 = a neighbour the cache query found (or a re-used one) is not used: isotropic (LMC_EXP_NOREUSE)
     int expFlags;
     // lengthDist of the multiplexed large step (mlt.h:99, mutation_large.h:45-47,90-101): PiecewiseConstant1D over the per-length
     // score sums of MLTInit (distribution.h:8-60); lengthCount = 0 unless `largestepmultiplexed` is set

@@ -564,7 +564,7 @@ lmc_ctx *lmc_create(const lmc_scene_desc *desc) {
             const char *name;
             int one, two;
         } sw[] = {{"LMC_EXP_NOSPLAT", 1, 1}, {"LMC_EXP_NOQUERY", 2, 2}, {"LMC_EXP_QUERY_STOP", 256, 512}, {"LMC_EXP_NOGRAD", 4, 4}, {"LMC_EXP_NOSTATS", 8, 8},
-                  {"LMC_EXP_NOHESS", 16, 16}, {"LMC_EXP_NOEIGEN", 32, 32}, {"LMC_EXP_NOHESSLAUNCH", 64, 64}, {"LMC_EXP_NOTRAV", 1024, 1024}, {"LMC_EXP_NOSTORE", 2048, 2048}, {"LMC_EXP_NOREUSE", 4096, 4096}, {"LMC_EXP_NOSEARCH", 8192, 8192}};
+                  {"LMC_EXP_NOHESS", 16, 16}, {"LMC_EXP_NOEIGEN", 32, 32}, {"LMC_EXP_NOHESSLAUNCH", 64, 64}, {"LMC_EXP_NOTRAV", 1024, 1024}, {"LMC_EXP_NOSTORE", 2048, 2048}, {"LMC_EXP_NOREUSE", 4096, 4096}};
         for (const auto &w : sw) {
             const char *e = getenv(w.name);
             if (!e || atoi(e) == 0) continue;
